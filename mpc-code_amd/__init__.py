@@ -1,0 +1,30 @@
+"""MI355X-native batched linear MPC: the hot path of CPCLAB-UNIPI/MPC-code behind a C-ABI.
+
+Layout
+------
+``exfile``   run an unmodified Ex-style problem file without CasADi -> namespace
+``problem``  namespace -> numeric :class:`LinearMPCProblem` (DARE, bounds, estimator gains)
+``capi``     ctypes binding of ``include/mpc_amd.h`` (``libmpc_amd.so``, hand-written HIP, gfx950)
+``driver``   the closed loop of the reference's ``MPC_code.py:485-875`` over a batch of instances
+``shard``    batch partition across ranks + the all-gather of u* (``torch.distributed``: RCCL / gloo)
+``csrc/``    the HIP kernels and the C-ABI
+
+Nothing here imports ``oracle/`` - that directory is test infrastructure.
+"""
+import os as _os
+
+PKG_DIR = _os.path.dirname(_os.path.abspath(__file__))
+EXAMPLES_DIR = _os.path.join(PKG_DIR, "examples")
+
+from .exfile import load_exfile, DEFAULTS  # noqa: E402,F401
+from .problem import LinearMPCProblem, UnsupportedProblem, problem_from_namespace  # noqa: E402,F401
+
+
+def load_problem(path, overrides=None):
+    """Ex-style file -> :class:`LinearMPCProblem`."""
+    ns = load_exfile(path, overrides)
+    return problem_from_namespace(ns)
+
+
+def example_path(name):
+    return _os.path.join(EXAMPLES_DIR, name)

@@ -1,0 +1,816 @@
+/*
+ * ORACLE (test infrastructure, never shipped): plain-C restatement of the linear-MPC hot path of
+ * CPCLAB-UNIPI/MPC-code.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load the library built from this file; the product (mpc-code_amd/) never links or calls it.
+ *
+ * PARITY STATUS: unpinned against the reference implementation (CasADi/IPOPT are absent from
+ * /root/reference and from this image, and the reference ships no tests or golden vectors - see the
+ * header of oracle/mpc_oracle.py).  This file is pinned instead against oracle/mpc_oracle.py (dense
+ * KKT interior point + exact active-set polish + KKT certificates + LQR known answer) and against
+ * oracle/riccati_np.py (the same algorithm, vectorised NumPy) by tests/test_oracle_c.py.
+ *
+ * What it restates (reference file:line):
+ *   orc_ocp_solve     one solver(...) call on the NLP of opt_dyn        Control_Calc.py:20-260,
+ *                     with the glue of the driver                       MPC_code.py:733-805
+ *   orc_target_solve  one solver_ss(...) call on the NLP of opt_ss      Target_Calc.py:20-161, MPC_code.py:693-718
+ *   orc_kf_update     kalman() / kalss()                                Estimator.py:263-311 / :231-261
+ *   orc_closed_loop   the loop body                                     MPC_code.py:485-827
+ *   model / plant     defF_model / defF_p (matrix case)                 Utilities.py:135-155,208-244 / :45-49,88-91
+ *
+ * Algorithm ("RPDIP"): Mehrotra predictor-corrector primal-dual interior point on the stage-form QP,
+ * Newton systems solved by a Riccati recursion in closed-loop (Joseph) form; constants identical to
+ * oracle/riccati_np.py.  Runtime dimensions, scalar loops, one instance at a time; OpenMP over the batch.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXN 8   /* stage state (model state + previous input when the cost is on Delta-u) */
+#define MAXM 4
+#define MAXY 8
+#define MAXD 8
+#define MAXV (MAXN + MAXM)
+#define MAXH 128 /* horizon */
+#define MAXC (MAXN + MAXM + MAXY) /* target rows */
+#define MAXE (MAXN + MAXD)        /* estimator state */
+
+/* algorithm constants - keep in sync with oracle/riccati_np.py */
+#define MU0 1.0
+#define S_MIN 1.0
+#define TAU 0.995
+#define TOL_STAT 1e-9
+#define TOL_STAT_ACC 1e-6
+#define STALL_MAX 2
+#define TOL_FEAS 1e-9
+#define TOL_C 1e-9
+#define TOL_MU 1e-12
+#define MU_FLOOR 1e-13
+#define S_FLOOR 1e-11
+#define BOUND_RELAX 1e-8
+#define INFEAS_Z 1e10
+
+enum { ST_SOLVED = 0, ST_MAXITER = 1, ST_INFEASIBLE = 2 };
+
+/* Problem in the reference's own terms; all matrices row-major, bounds +-INFINITY when absent. */
+typedef struct {
+    int32_t nx, nu, ny, nd, nxp, N, du_form, duss_form, y_bounded, estimator /*0 none,1 kal,2 kalss*/, max_iter;
+    const double *A, *B, *C, *Bd, *Cd, *fx_const, *fy_const;
+    const double *Ap, *Bp, *Cp;
+    const double *Q, *R, *P, *Qss, *Rss;
+    const double *umin, *umax, *xmin, *xmax, *ymin, *ymax;
+    const double *umin_ss, *umax_ss, *xmin_ss, *xmax_ss, *ymin_ss, *ymax_ss;
+    const double *dmin, *dmax;            /* NULL when absent */
+    const double *Q_kf, *R_kf, *K;        /* estimator data */
+} orc_problem;
+
+static double dmax2(double a, double b) { return a > b ? a : b; }
+static double dmin2(double a, double b) { return a < b ? a : b; }
+
+/* ------------------------------------------------------------------------------------------------
+ * stage form (see the docstring of oracle/riccati_np.py)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, m, N;
+    double A[MAXN][MAXN], B[MAXN][MAXM], Q[MAXN][MAXN], M[MAXN][MAXM], R[MAXM][MAXM], Pf[MAXN][MAXN];
+    double ulo[MAXM], uhi[MAXM], zlo_m[MAXN], zhi_m[MAXN], zlo_e[MAXN], zhi_e[MAXN];
+} stage_t;
+
+static void build_stage(const orc_problem *p, stage_t *s)
+{
+    int n0 = p->nx, m = p->nu, n = p->du_form ? n0 + m : n0;
+    memset(s, 0, sizeof(*s));
+    s->n = n; s->m = m; s->N = p->N;
+    for (int i = 0; i < n0; i++) {
+        for (int j = 0; j < n0; j++) { s->A[i][j] = p->A[i * n0 + j]; s->Q[i][j] = p->Q[i * n0 + j]; s->Pf[i][j] = p->P[i * n0 + j]; }
+        for (int j = 0; j < m; j++) s->B[i][j] = p->B[i * m + j];
+        s->zlo_m[i] = s->zlo_e[i] = p->xmin[i];
+        s->zhi_m[i] = s->zhi_e[i] = p->xmax[i];
+    }
+    for (int i = 0; i < m; i++) {
+        for (int j = 0; j < m; j++) s->R[i][j] = p->R[i * m + j];
+        s->ulo[i] = p->umin[i]; s->uhi[i] = p->umax[i];
+    }
+    if (p->du_form) {            /* z = [x; u_prev], Control_Calc.py:163-166,180-181 */
+        for (int i = 0; i < m; i++) {
+            s->B[n0 + i][i] = 1.0;
+            for (int j = 0; j < m; j++) { s->Q[n0 + i][n0 + j] = p->R[i * m + j]; s->M[n0 + i][j] = -p->R[i * m + j]; }
+            s->zlo_m[n0 + i] = s->zlo_e[n0 + i] = -INFINITY;
+            s->zhi_m[n0 + i] = s->zhi_e[n0 + i] = INFINITY;
+        }
+    }
+}
+
+typedef struct {
+    double z0[MAXN], zr[MAXN], ur[MAXM], c[MAXN], us[MAXM];
+    double zlo_m[MAXN], zhi_m[MAXN];
+    int ok0;
+} inst_t;
+
+static int build_inst(const orc_problem *p, const stage_t *s, const double *xhat, const double *xs, const double *us,
+                      const double *dhat, const double *u_prev, inst_t *q)
+{
+    int n0 = p->nx, m = p->nu, nd = p->nd, ny = p->ny;
+    memset(q, 0, sizeof(*q));
+    for (int i = 0; i < n0; i++) {
+        double c = p->fx_const[i];
+        for (int j = 0; j < nd; j++) c += p->Bd[i * nd + j] * dhat[j];
+        q->c[i] = c; q->z0[i] = xhat[i]; q->zr[i] = xs[i];
+    }
+    for (int i = 0; i < m; i++) { q->us[i] = us[i]; q->ur[i] = p->du_form ? 0.0 : us[i]; }
+    if (p->du_form) for (int i = 0; i < m; i++) { q->z0[n0 + i] = u_prev[i]; q->zr[n0 + i] = 0.0; q->c[n0 + i] = 0.0; }
+    for (int i = 0; i < s->n; i++) { q->zlo_m[i] = s->zlo_m[i]; q->zhi_m[i] = s->zhi_m[i]; }
+    q->ok0 = 1;
+    if (p->y_bounded) {
+        for (int i = 0; i < ny; i++) {
+            double e = p->fy_const[i], y0, sc = 0.0; int idx = -1, cnt = 0;
+            for (int j = 0; j < nd; j++) e += p->Cd[i * nd + j] * dhat[j];
+            y0 = e;
+            for (int j = 0; j < n0; j++) {
+                double cij = p->C[i * n0 + j];
+                y0 += cij * xhat[j];
+                if (cij != 0.0) { idx = j; sc = cij; cnt++; }
+            }
+            if (cnt != 1) return -1;          /* general output rows: not supported */
+            /* stage-0 row: pure feasibility test with IPOPT's bound relaxation (Control_Calc.py:128-151) */
+            double rl = BOUND_RELAX * dmax2(1.0, fabs(p->ymin[i])), rh = BOUND_RELAX * dmax2(1.0, fabs(p->ymax[i]));
+            if (!(y0 >= p->ymin[i] - rl) || !(y0 <= p->ymax[i] + rh)) q->ok0 = 0;
+            double a = (p->ymin[i] - e) / sc, b = (p->ymax[i] - e) / sc;
+            double lo = sc > 0 ? a : b, hi = sc > 0 ? b : a;
+            q->zlo_m[idx] = dmax2(q->zlo_m[idx], lo);
+            q->zhi_m[idx] = dmin2(q->zhi_m[idx], hi);
+        }
+    }
+    return 0;
+}
+
+/* per-bound complementarity measure, <= 1 means converged */
+static double comp_measure(double s, double l)
+{
+    return dmin2(dmin2(s, l) / TOL_C, s * l / TOL_MU);
+}
+
+typedef struct {
+    double u[MAXH][MAXM], z[MAXH + 1][MAXN];
+    double s_lo[MAXH][MAXV], s_hi[MAXH][MAXV], l_lo[MAXH][MAXV], l_hi[MAXH][MAXV];
+    double lo[MAXH][MAXV], hi[MAXH][MAXV];
+    double r_lo[MAXH][MAXV], r_hi[MAXH][MAXV], sig[MAXH][MAXV];
+    double gz[MAXH + 1][MAXN], gu[MAXH][MAXM];
+    double K[MAXH][MAXM][MAXN], Li[MAXH][MAXM][MAXM], Acl[MAXH][MAXN][MAXN];
+    double rc_lo[MAXH][MAXV], rc_hi[MAXH][MAXV];
+    double d_u[MAXH][MAXM], d_z[MAXH + 1][MAXN];
+    double ds_lo[MAXH][MAXV], ds_hi[MAXH][MAXV], dl_lo[MAXH][MAXV], dl_hi[MAXH][MAXV];
+    unsigned char fl[MAXH][MAXV], fh[MAXH][MAXV];
+} work_t;
+
+/* symmetric positive definite inverse of an m x m matrix by Cholesky (m <= MAXM) */
+static int spd_inverse(int m, double L[MAXM][MAXM], double out[MAXM][MAXM])
+{
+    double c[MAXM][MAXM];
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j <= i; j++) {
+            double a = L[i][j];
+            for (int k = 0; k < j; k++) a -= c[i][k] * c[j][k];
+            if (i == j) { if (!(a > 0.0)) return -1; c[i][i] = sqrt(a); }
+            else c[i][j] = a / c[j][j];
+        }
+    for (int col = 0; col < m; col++) {         /* solve c c' x = e_col */
+        double y[MAXM];
+        for (int i = 0; i < m; i++) {
+            double a = (i == col) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) a -= c[i][k] * y[k];
+            y[i] = a / c[i][i];
+        }
+        for (int i = m - 1; i >= 0; i--) {
+            double a = y[i];
+            for (int k = i + 1; k < m; k++) a -= c[k][i] * out[k][col];
+            out[i][col] = a / c[i][i];
+        }
+    }
+    return 0;
+}
+
+/* Newton step for complementarity residuals rc (work->rc_*): fills d_u, d_z, ds_*, dl_* */
+static void newton_solve(const stage_t *s, work_t *w)
+{
+    int n = s->n, m = s->m, N = s->N, nv = n + m;
+    double pv[MAXN], kff[MAXH][MAXM], hh[MAXH][MAXV];
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < nv; i++)
+            hh[k][i] = (-w->rc_hi[k][i] + w->l_hi[k][i] * w->r_hi[k][i]) / w->s_hi[k][i]
+                     + (w->rc_lo[k][i] + w->l_lo[k][i] * w->r_lo[k][i]) / w->s_lo[k][i];
+    /* backward: p_N = gradient wrt z_N (with its h); p_k = q_z,k + Acl_k' p_{k+1} + K_k' q_u,k */
+    for (int i = 0; i < n; i++) pv[i] = w->gz[N][i] + hh[N - 1][m + i];
+    for (int k = N - 1; k >= 0; k--) {
+        double qu[MAXM], psi[MAXM], pn[MAXN];
+        for (int i = 0; i < m; i++) qu[i] = w->gu[k][i] + hh[k][i];
+        for (int i = 0; i < m; i++) { double a = qu[i]; for (int j = 0; j < n; j++) a += s->B[j][i] * pv[j]; psi[i] = a; }
+        for (int i = 0; i < m; i++) { double a = 0.0; for (int j = 0; j < m; j++) a += w->Li[k][i][j] * psi[j]; kff[k][i] = -a; }
+        if (k > 0) {
+            for (int i = 0; i < n; i++) {
+                double a = w->gz[k][i] + hh[k - 1][m + i];
+                for (int j = 0; j < n; j++) a += w->Acl[k][j][i] * pv[j];
+                for (int j = 0; j < m; j++) a += w->K[k][j][i] * qu[j];
+                pn[i] = a;
+            }
+            for (int i = 0; i < n; i++) pv[i] = pn[i];
+        }
+    }
+    /* forward */
+    for (int i = 0; i < n; i++) w->d_z[0][i] = 0.0;
+    for (int k = 0; k < N; k++) {
+        for (int i = 0; i < m; i++) { double a = kff[k][i]; for (int j = 0; j < n; j++) a += w->K[k][i][j] * w->d_z[k][j]; w->d_u[k][i] = a; }
+        for (int i = 0; i < n; i++) {
+            double a = 0.0;
+            for (int j = 0; j < n; j++) a += s->A[i][j] * w->d_z[k][j];
+            for (int j = 0; j < m; j++) a += s->B[i][j] * w->d_u[k][j];
+            w->d_z[k + 1][i] = a;
+        }
+        for (int i = 0; i < nv; i++) {
+            double dv = i < m ? w->d_u[k][i] : w->d_z[k + 1][i - m];
+            double dsh = w->fh[k][i] ? -w->r_hi[k][i] - dv : 0.0, dsl = w->fl[k][i] ? w->r_lo[k][i] + dv : 0.0;
+            w->ds_hi[k][i] = dsh; w->ds_lo[k][i] = dsl;
+            w->dl_hi[k][i] = w->fh[k][i] ? (-w->rc_hi[k][i] - w->l_hi[k][i] * dsh) / w->s_hi[k][i] : 0.0;
+            w->dl_lo[k][i] = w->fl[k][i] ? (-w->rc_lo[k][i] - w->l_lo[k][i] * dsl) / w->s_lo[k][i] : 0.0;
+        }
+    }
+}
+
+static double max_step(const stage_t *s, const work_t *w)
+{
+    int nv = s->n + s->m; double a = 1.0;
+    for (int k = 0; k < s->N; k++)
+        for (int i = 0; i < nv; i++) {
+            if (w->ds_lo[k][i] < 0) a = dmin2(a, -w->s_lo[k][i] / w->ds_lo[k][i]);
+            if (w->ds_hi[k][i] < 0) a = dmin2(a, -w->s_hi[k][i] / w->ds_hi[k][i]);
+            if (w->dl_lo[k][i] < 0) a = dmin2(a, -w->l_lo[k][i] / w->dl_lo[k][i]);
+            if (w->dl_hi[k][i] < 0) a = dmin2(a, -w->l_hi[k][i] / w->dl_hi[k][i]);
+        }
+    return a;
+}
+
+/* one OCP; returns status; res[3] = {stationarity, bound residual, mean complementarity} */
+static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w, int *iters_out, double *res)
+{
+    const int n = s->n, m = s->m, N = s->N, nv = n + m;
+    double ncon = 0.0;
+    res[0] = res[1] = res[2] = 0.0;
+    *iters_out = 0;
+    if (!q->ok0) return ST_INFEASIBLE;
+    /* bounds per block k = (u_k, z_{k+1}) */
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < nv; i++) {
+            double lo = i < m ? s->ulo[i] : (k < N - 1 ? q->zlo_m[i - m] : s->zlo_e[i - m]);
+            double hi = i < m ? s->uhi[i] : (k < N - 1 ? q->zhi_m[i - m] : s->zhi_e[i - m]);
+            w->fl[k][i] = isfinite(lo) ? 1 : 0; w->fh[k][i] = isfinite(hi) ? 1 : 0;
+            w->lo[k][i] = w->fl[k][i] ? lo : 0.0; w->hi[k][i] = w->fh[k][i] ? hi : 0.0;
+            ncon += w->fl[k][i] + w->fh[k][i];
+        }
+    /* initial point: u = us pushed into the interior of its box, z simulated */
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < m; i++) {
+            double lo = s->ulo[i], hi = s->uhi[i], push, v = q->us[i];
+            if (isfinite(lo) && isfinite(hi)) push = 0.1 * (hi - lo);
+            else push = 0.1 * dmax2(1.0, fabs(isfinite(lo) ? lo : (isfinite(hi) ? hi : 0.0)));
+            if (isfinite(lo)) v = dmax2(v, lo + push);
+            if (isfinite(hi)) v = dmin2(v, hi - push);
+            w->u[k][i] = v;
+        }
+    for (int i = 0; i < n; i++) w->z[0][i] = q->z0[i];
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < n; i++) {
+            double a = q->c[i];
+            for (int j = 0; j < n; j++) a += s->A[i][j] * w->z[k][j];
+            for (int j = 0; j < m; j++) a += s->B[i][j] * w->u[k][j];
+            w->z[k + 1][i] = a;
+        }
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < nv; i++) {
+            double v = i < m ? w->u[k][i] : w->z[k + 1][i - m];
+            w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], S_MIN) : 1.0;
+            w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, S_MIN) : 1.0;
+            w->l_lo[k][i] = w->fl[k][i] ? MU0 / w->s_lo[k][i] : 0.0;
+            w->l_hi[k][i] = w->fh[k][i] ? MU0 / w->s_hi[k][i] : 0.0;
+        }
+    double gscale = 1.0; int stall = 0;
+    for (int it = 0;; it++) {
+        /* ---- residuals, barrier weights, gradients ------------------------------------------ */
+        double mu = 0.0, res_p = 0.0, cres = 0.0, lmax = 0.0;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < nv; i++) {
+                double v = i < m ? w->u[k][i] : w->z[k + 1][i - m];
+                w->r_lo[k][i] = w->fl[k][i] ? v - w->s_lo[k][i] - w->lo[k][i] : 0.0;
+                w->r_hi[k][i] = w->fh[k][i] ? v + w->s_hi[k][i] - w->hi[k][i] : 0.0;
+                mu += w->s_lo[k][i] * w->l_lo[k][i] + w->s_hi[k][i] * w->l_hi[k][i];
+                w->sig[k][i] = w->l_lo[k][i] / w->s_lo[k][i] + w->l_hi[k][i] / w->s_hi[k][i];
+                res_p = dmax2(res_p, dmax2(fabs(w->r_lo[k][i]), fabs(w->r_hi[k][i])));
+                cres = dmax2(cres, dmax2(comp_measure(w->s_lo[k][i], w->l_lo[k][i]), comp_measure(w->s_hi[k][i], w->l_hi[k][i])));
+                lmax = dmax2(lmax, dmax2(w->l_lo[k][i], w->l_hi[k][i]));
+            }
+        mu /= dmax2(ncon, 1.0);
+        for (int k = 0; k <= N; k++) {
+            double dz[MAXN], du[MAXM];
+            for (int i = 0; i < n; i++) dz[i] = w->z[k][i] - q->zr[i];
+            if (k < N) for (int i = 0; i < m; i++) du[i] = w->u[k][i] - q->ur[i];
+            for (int i = 0; i < n; i++) {
+                double a = 0.0;
+                if (k < N) { for (int j = 0; j < n; j++) a += s->Q[i][j] * dz[j]; for (int j = 0; j < m; j++) a += s->M[i][j] * du[j]; }
+                else for (int j = 0; j < n; j++) a += s->Pf[i][j] * dz[j];
+                if (k >= 1) a += w->l_hi[k - 1][m + i] - w->l_lo[k - 1][m + i];
+                w->gz[k][i] = a;
+            }
+            if (k < N) for (int i = 0; i < m; i++) {
+                double a = 0.0;
+                for (int j = 0; j < m; j++) a += s->R[i][j] * du[j];
+                for (int j = 0; j < n; j++) a += s->M[j][i] * dz[j];
+                w->gu[k][i] = a + w->l_hi[k][i] - w->l_lo[k][i];
+            }
+        }
+        /* adjoint recursion and stationarity residual */
+        double pi[MAXN], res_s = 0.0;
+        for (int i = 0; i < n; i++) pi[i] = w->gz[N][i];
+        for (int k = N - 1; k >= 0; k--) {
+            double pn[MAXN];
+            for (int i = 0; i < m; i++) { double a = w->gu[k][i]; for (int j = 0; j < n; j++) a += s->B[j][i] * pi[j]; res_s = dmax2(res_s, fabs(a)); }
+            for (int i = 0; i < n; i++) { double a = w->gz[k][i]; for (int j = 0; j < n; j++) a += s->A[j][i] * pi[j]; pn[i] = a; }
+            for (int i = 0; i < n; i++) pi[i] = pn[i];
+        }
+        if (it == 0) gscale = dmax2(1.0, res_s);
+        res[0] = res_s; res[1] = res_p; res[2] = mu;
+        *iters_out = it;
+        int ok_cp = (cres <= 1.0) && (res_p <= TOL_FEAS);
+        stall = ok_cp ? stall + 1 : 0;
+        if (ok_cp && (res_s <= TOL_STAT * gscale || (stall > STALL_MAX && res_s <= TOL_STAT_ACC * gscale))) return ST_SOLVED;
+        if (lmax > INFEAS_Z * gscale || !isfinite(mu)) return ST_INFEASIBLE;
+        if (it == max_iter) return ST_MAXITER;
+        /* ---- factorisation: Riccati in closed-loop (Joseph) form ----------------------------- */
+        double P[MAXN][MAXN];
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) P[i][j] = s->Pf[i][j] + (i == j ? w->sig[N - 1][m + i] : 0.0);
+        for (int k = N - 1; k >= 0; k--) {
+            double PB[MAXN][MAXM], Lam[MAXM][MAXM], Psi[MAXM][MAXN], PA[MAXN][MAXN];
+            for (int i = 0; i < n; i++) {
+                for (int j = 0; j < m; j++) { double a = 0.0; for (int l = 0; l < n; l++) a += P[i][l] * s->B[l][j]; PB[i][j] = a; }
+                for (int j = 0; j < n; j++) { double a = 0.0; for (int l = 0; l < n; l++) a += P[i][l] * s->A[l][j]; PA[i][j] = a; }
+            }
+            for (int i = 0; i < m; i++) {
+                for (int j = 0; j < m; j++) { double a = s->R[i][j] + (i == j ? w->sig[k][i] : 0.0); for (int l = 0; l < n; l++) a += s->B[l][i] * PB[l][j]; Lam[i][j] = a; }
+                for (int j = 0; j < n; j++) { double a = s->M[j][i]; for (int l = 0; l < n; l++) a += s->B[l][i] * PA[l][j]; Psi[i][j] = a; }
+            }
+            for (int i = 0; i < m; i++) for (int j = 0; j < i; j++) { double a = 0.5 * (Lam[i][j] + Lam[j][i]); Lam[i][j] = Lam[j][i] = a; }
+            if (spd_inverse(m, Lam, w->Li[k]) != 0) return ST_INFEASIBLE;
+            for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) { double a = 0.0; for (int l = 0; l < m; l++) a += w->Li[k][i][l] * Psi[l][j]; w->K[k][i][j] = -a; }
+            for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { double a = s->A[i][j]; for (int l = 0; l < m; l++) a += s->B[i][l] * w->K[k][l][j]; w->Acl[k][i][j] = a; }
+            if (k > 0) {
+                double T[MAXN][MAXN], RK[MAXM][MAXN], Pn[MAXN][MAXN];
+                for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { double a = 0.0; for (int l = 0; l < n; l++) a += P[i][l] * w->Acl[k][l][j]; T[i][j] = a; }
+                for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) { double a = w->sig[k][i] * w->K[k][i][j]; for (int l = 0; l < m; l++) a += s->R[i][l] * w->K[k][l][j]; RK[i][j] = a; }
+                for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {
+                    double a = s->Q[i][j] + (i == j ? w->sig[k - 1][m + i] : 0.0);
+                    for (int l = 0; l < n; l++) a += w->Acl[k][l][i] * T[l][j];
+                    for (int l = 0; l < m; l++) a += w->K[k][l][i] * RK[l][j];
+                    for (int l = 0; l < m; l++) a += s->M[i][l] * w->K[k][l][j] + w->K[k][l][i] * s->M[j][l];
+                    Pn[i][j] = a;
+                }
+                for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) P[i][j] = 0.5 * (Pn[i][j] + Pn[j][i]);
+            }
+        }
+        /* ---- predictor ------------------------------------------------------------------------ */
+        for (int k = 0; k < N; k++) for (int i = 0; i < nv; i++) {
+            w->rc_lo[k][i] = w->fl[k][i] ? w->s_lo[k][i] * w->l_lo[k][i] : 0.0;
+            w->rc_hi[k][i] = w->fh[k][i] ? w->s_hi[k][i] * w->l_hi[k][i] : 0.0;
+        }
+        newton_solve(s, w);
+        double a_aff = max_step(s, w), mu_aff = 0.0;
+        for (int k = 0; k < N; k++) for (int i = 0; i < nv; i++)
+            mu_aff += (w->s_lo[k][i] + a_aff * w->ds_lo[k][i]) * (w->l_lo[k][i] + a_aff * w->dl_lo[k][i])
+                    + (w->s_hi[k][i] + a_aff * w->ds_hi[k][i]) * (w->l_hi[k][i] + a_aff * w->dl_hi[k][i]);
+        mu_aff /= dmax2(ncon, 1.0);
+        double sigma = mu > 0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+        double sm = dmax2(sigma * mu, MU_FLOOR);
+        /* ---- corrector ------------------------------------------------------------------------ */
+        for (int k = 0; k < N; k++) for (int i = 0; i < nv; i++) {
+            w->rc_lo[k][i] = w->fl[k][i] ? w->s_lo[k][i] * w->l_lo[k][i] - dmax2(sm, w->l_lo[k][i] * S_FLOOR) + w->ds_lo[k][i] * w->dl_lo[k][i] : 0.0;
+            w->rc_hi[k][i] = w->fh[k][i] ? w->s_hi[k][i] * w->l_hi[k][i] - dmax2(sm, w->l_hi[k][i] * S_FLOOR) + w->ds_hi[k][i] * w->dl_hi[k][i] : 0.0;
+        }
+        newton_solve(s, w);
+        double a = dmin2(1.0, TAU * max_step(s, w));
+        for (int k = 0; k < N; k++) {
+            for (int i = 0; i < m; i++) w->u[k][i] += a * w->d_u[k][i];
+            for (int i = 0; i < n; i++) w->z[k + 1][i] += a * w->d_z[k + 1][i];
+            for (int i = 0; i < nv; i++) {
+                w->s_lo[k][i] += a * w->ds_lo[k][i]; w->s_hi[k][i] += a * w->ds_hi[k][i];
+                w->l_lo[k][i] += a * w->dl_lo[k][i]; w->l_hi[k][i] += a * w->dl_hi[k][i];
+            }
+        }
+    }
+}
+
+int orc_ocp_solve(const orc_problem *p, int Bsz, const double *xhat, const double *xs, const double *us,
+                  const double *dhat, const double *u_prev, double *u0, double *x1, int32_t *status,
+                  int32_t *iters, double *res, double *w_out)
+{
+    stage_t st;
+    if (p->nx + (p->du_form ? p->nu : 0) > MAXN || p->nu > MAXM || p->N > MAXH || p->ny > MAXY || p->nd > MAXD) return -2;
+    build_stage(p, &st);
+    int err = 0;
+#pragma omp parallel
+    {
+        work_t *w = (work_t *)malloc(sizeof(work_t));
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < Bsz; b++) {
+            inst_t q; int it; double r3[3];
+            int n0 = p->nx, m = p->nu;
+            if (build_inst(p, &st, xhat + b * n0, xs + b * n0, us + b * m, dhat + b * p->nd, u_prev + b * m, &q) != 0) {
+#pragma omp atomic write
+                err = -3;
+                continue;
+            }
+            int stt = rpdip_one(&st, &q, p->max_iter, w, &it, r3);
+            status[b] = stt; if (iters) iters[b] = it;
+            if (res) { res[3 * b] = r3[0]; res[3 * b + 1] = r3[1]; res[3 * b + 2] = r3[2]; }
+            if (stt != ST_INFEASIBLE) {
+                for (int i = 0; i < m; i++) u0[b * m + i] = w->u[0][i];
+                for (int i = 0; i < n0; i++) x1[b * n0 + i] = w->z[1][i];
+                if (w_out) {                     /* opt_dyn layout [x0,u0,...,x_N] (Control_Calc.py:31-37) */
+                    double *wo = w_out + (size_t)b * (n0 * (p->N + 1) + m * p->N);
+                    for (int k = 0; k <= p->N; k++) {
+                        for (int i = 0; i < n0; i++) wo[k * (n0 + m) + i] = w->z[k][i];
+                        if (k < p->N) for (int i = 0; i < m; i++) wo[k * (n0 + m) + n0 + i] = w->u[k][i];
+                    }
+                }
+            }
+        }
+        free(w);
+    }
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * target problem in null-space coordinates (see riccati_np.target_data)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, m, q, nr, nc;
+    double Ep[MAXV][MAXN], Z[MAXV][MAXM], CZx[MAXY][MAXM], Hr[MAXM][MAXM], W[MAXC][MAXM], lo[MAXC], hi[MAXC];
+} target_t;
+
+static int build_target(const orc_problem *p, target_t *t)
+{
+    int n = p->nx, m = p->nu, q = p->ny, nv = n + m;
+    double a[MAXV][MAXN], Qf[MAXV][MAXV], Rm[MAXV][MAXN];
+    memset(t, 0, sizeof(*t));
+    t->n = n; t->m = m; t->q = q; t->nr = m; t->nc = nv + q;
+    /* a = [A-I, B]'  (nv x n) */
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) a[j][i] = p->A[i * n + j] - (i == j ? 1.0 : 0.0);
+        for (int j = 0; j < m; j++) a[n + j][i] = p->B[i * m + j];
+    }
+    /* Householder QR: a = Qf Rm */
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Qf[i][j] = (i == j);
+    for (int i = 0; i < nv; i++) for (int j = 0; j < n; j++) Rm[i][j] = a[i][j];
+    double rmax = 0.0;
+    for (int k = 0; k < n; k++) {
+        double v[MAXV], nrm = 0.0;
+        for (int i = k; i < nv; i++) nrm += Rm[i][k] * Rm[i][k];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) return -1;
+        double alpha = Rm[k][k] > 0 ? -nrm : nrm, vn = 0.0;
+        for (int i = 0; i < nv; i++) v[i] = i < k ? 0.0 : Rm[i][k];
+        v[k] -= alpha;
+        for (int i = k; i < nv; i++) vn += v[i] * v[i];
+        if (vn > 0.0) {
+            for (int j = 0; j < n; j++) { double d = 0.0; for (int i = k; i < nv; i++) d += v[i] * Rm[i][j]; d *= 2.0 / vn; for (int i = k; i < nv; i++) Rm[i][j] -= d * v[i]; }
+            for (int j = 0; j < nv; j++) { double d = 0.0; for (int i = k; i < nv; i++) d += Qf[j][i] * v[i]; d *= 2.0 / vn; for (int i = k; i < nv; i++) Qf[j][i] -= d * v[i]; }
+        }
+    }
+    for (int k = 0; k < n; k++) rmax = dmax2(rmax, fabs(Rm[k][k]));
+    for (int k = 0; k < n; k++) if (fabs(Rm[k][k]) < 1e-12 * rmax) return -1;
+    /* Ep = Q1 R^-T : solve for each row r of Q1: x R' = Q1[r,:]  ->  forward substitution on R' (lower) */
+    for (int r = 0; r < nv; r++)
+        for (int j = 0; j < n; j++) t->Ep[r][j] = 0.0;
+    /* R^-T = (R')^-1 ; Ep[r][c] = sum_j Q1[r][j] * Rinv'[j][c], Rinv' = inverse of R' */
+    double Rt_inv[MAXN][MAXN];
+    for (int c = 0; c < n; c++) {            /* column c of (R')^-1: solve R' x = e_c, R' lower: R'[i][j]=Rm[j][i] */
+        for (int i = 0; i < n; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) s -= Rm[j][i] * Rt_inv[j][c];
+            Rt_inv[i][c] = s / Rm[i][i];
+        }
+    }
+    for (int r = 0; r < nv; r++) for (int c = 0; c < n; c++) { double s = 0.0; for (int j = 0; j < n; j++) s += Qf[r][j] * Rt_inv[j][c]; t->Ep[r][c] = s; }
+    for (int r = 0; r < nv; r++) for (int c = 0; c < m; c++) t->Z[r][c] = Qf[r][n + c];
+    for (int i = 0; i < q; i++) for (int c = 0; c < m; c++) { double s = 0.0; for (int j = 0; j < n; j++) s += p->C[i * n + j] * t->Z[j][c]; t->CZx[i][c] = s; }
+    for (int a1 = 0; a1 < m; a1++) for (int b1 = 0; b1 < m; b1++) {
+        double s = 0.0;
+        for (int i = 0; i < q; i++) for (int j = 0; j < q; j++) s += t->CZx[i][a1] * p->Qss[i * q + j] * t->CZx[j][b1];
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) s += t->Z[n + i][a1] * p->Rss[i * m + j] * t->Z[n + j][b1];
+        t->Hr[a1][b1] = s;
+    }
+    for (int a1 = 0; a1 < m; a1++) for (int b1 = 0; b1 < a1; b1++) { double s = 0.5 * (t->Hr[a1][b1] + t->Hr[b1][a1]); t->Hr[a1][b1] = t->Hr[b1][a1] = s; }
+    for (int r = 0; r < nv; r++) for (int c = 0; c < m; c++) t->W[r][c] = t->Z[r][c];
+    for (int r = 0; r < q; r++) for (int c = 0; c < m; c++) t->W[nv + r][c] = t->CZx[r][c];
+    for (int i = 0; i < n; i++) { t->lo[i] = p->xmin_ss[i]; t->hi[i] = p->xmax_ss[i]; }
+    for (int i = 0; i < m; i++) { t->lo[n + i] = p->umin_ss[i]; t->hi[n + i] = p->umax_ss[i]; }
+    for (int i = 0; i < q; i++) { t->lo[nv + i] = p->ymin_ss[i]; t->hi[nv + i] = p->ymax_ss[i]; }
+    return 0;
+}
+
+static int target_one(const orc_problem *p, const target_t *t, const double *usp, const double *ysp, const double *dhat,
+                      const double *us_prev, double *xs, double *us, double *ys, int *iters_out)
+{
+    const int n = t->n, m = t->m, q = t->q, nr = t->nr, nc = t->nc, nv = n + m, nd = p->nd;
+    double cx[MAXN], e[MAXY], vp[MAXV], yp[MAXY], gr[MAXM], w0[MAXC], y[MAXM];
+    double s_lo[MAXC], s_hi[MAXC], l_lo[MAXC], l_hi[MAXC], lo[MAXC], hi[MAXC], r_lo[MAXC], r_hi[MAXC];
+    unsigned char fl[MAXC], fh[MAXC];
+    for (int i = 0; i < n; i++) { double a = p->fx_const[i]; for (int j = 0; j < nd; j++) a += p->Bd[i * nd + j] * dhat[j]; cx[i] = a; }
+    for (int i = 0; i < q; i++) { double a = p->fy_const[i]; for (int j = 0; j < nd; j++) a += p->Cd[i * nd + j] * dhat[j]; e[i] = a; }
+    for (int r = 0; r < nv; r++) { double a = 0.0; for (int j = 0; j < n; j++) a -= t->Ep[r][j] * cx[j]; vp[r] = a; }
+    for (int i = 0; i < q; i++) { double a = e[i]; for (int j = 0; j < n; j++) a += p->C[i * n + j] * vp[j]; yp[i] = a; }
+    const double *uref = p->duss_form ? us_prev : usp;
+    for (int c = 0; c < nr; c++) {
+        double a = 0.0;
+        for (int i = 0; i < q; i++) { double qi = 0.0; for (int j = 0; j < q; j++) qi += p->Qss[i * q + j] * (yp[j] - ysp[j]); a += qi * t->CZx[i][c]; }
+        for (int i = 0; i < m; i++) { double ri = 0.0; for (int j = 0; j < m; j++) ri += p->Rss[i * m + j] * (vp[n + j] - uref[j]); a += ri * t->Z[n + i][c]; }
+        gr[c] = a;
+    }
+    for (int r = 0; r < nv; r++) w0[r] = vp[r];
+    for (int r = 0; r < q; r++) w0[nv + r] = yp[r];
+    double ncon = 0.0;
+    for (int r = 0; r < nc; r++) { fl[r] = isfinite(t->lo[r]); fh[r] = isfinite(t->hi[r]); lo[r] = fl[r] ? t->lo[r] : 0.0; hi[r] = fh[r] ? t->hi[r] : 0.0; ncon += fl[r] + fh[r]; }
+    /* start at the unconstrained minimiser */
+    double Hi[MAXM][MAXM], Hc[MAXM][MAXM];
+    for (int i = 0; i < nr; i++) for (int j = 0; j < nr; j++) Hc[i][j] = t->Hr[i][j];
+    if (spd_inverse(nr, Hc, Hi) != 0) return -1;
+    for (int i = 0; i < nr; i++) { double a = 0.0; for (int j = 0; j < nr; j++) a += Hi[i][j] * gr[j]; y[i] = -a; }
+    for (int r = 0; r < nc; r++) {
+        double v = w0[r]; for (int c = 0; c < nr; c++) v += t->W[r][c] * y[c];
+        s_lo[r] = fl[r] ? dmax2(v - lo[r], S_MIN) : 1.0; s_hi[r] = fh[r] ? dmax2(hi[r] - v, S_MIN) : 1.0;
+        l_lo[r] = fl[r] ? MU0 / s_lo[r] : 0.0; l_hi[r] = fh[r] ? MU0 / s_hi[r] : 0.0;
+    }
+    double gscale = 1.0; int stall = 0, status = -1;
+    for (int c = 0; c < nr; c++) gscale = dmax2(gscale, fabs(gr[c]));
+    for (int it = 0;; it++) {
+        double mu = 0.0, res_p = 0.0, res_s = 0.0, cres = 0.0, lmax = 0.0, grad[MAXM], sig[MAXC];
+        for (int r = 0; r < nc; r++) {
+            double v = w0[r]; for (int c = 0; c < nr; c++) v += t->W[r][c] * y[c];
+            r_lo[r] = fl[r] ? v - s_lo[r] - lo[r] : 0.0; r_hi[r] = fh[r] ? v + s_hi[r] - hi[r] : 0.0;
+            mu += s_lo[r] * l_lo[r] + s_hi[r] * l_hi[r];
+            sig[r] = l_lo[r] / s_lo[r] + l_hi[r] / s_hi[r];
+            res_p = dmax2(res_p, dmax2(fabs(r_lo[r]), fabs(r_hi[r])));
+            cres = dmax2(cres, dmax2(comp_measure(s_lo[r], l_lo[r]), comp_measure(s_hi[r], l_hi[r])));
+            lmax = dmax2(lmax, dmax2(l_lo[r], l_hi[r]));
+        }
+        mu /= dmax2(ncon, 1.0);
+        for (int c = 0; c < nr; c++) {
+            double a = gr[c]; for (int j = 0; j < nr; j++) a += t->Hr[c][j] * y[j];
+            for (int r = 0; r < nc; r++) a += (l_hi[r] - l_lo[r]) * t->W[r][c];
+            grad[c] = a; res_s = dmax2(res_s, fabs(a));
+        }
+        *iters_out = it;
+        int ok_cp = (cres <= 1.0) && (res_p <= TOL_FEAS);
+        stall = ok_cp ? stall + 1 : 0;
+        if (ok_cp && (res_s <= TOL_STAT * gscale || (stall > STALL_MAX && res_s <= TOL_STAT_ACC * gscale))) { status = ST_SOLVED; break; }
+        if (lmax > INFEAS_Z * gscale || !isfinite(mu)) { status = ST_INFEASIBLE; break; }
+        if (it == p->max_iter) { status = ST_MAXITER; break; }
+        double Ht[MAXM][MAXM], Hti[MAXM][MAXM];
+        for (int i = 0; i < nr; i++) for (int j = 0; j < nr; j++) { double a = t->Hr[i][j]; for (int r = 0; r < nc; r++) a += sig[r] * t->W[r][i] * t->W[r][j]; Ht[i][j] = a; }
+        if (spd_inverse(nr, Ht, Hti) != 0) { status = ST_INFEASIBLE; break; }
+        double dy[MAXM], ds_lo[MAXC], ds_hi[MAXC], dl_lo[MAXC], dl_hi[MAXC], rc_lo[MAXC], rc_hi[MAXC];
+        double a_aff = 1.0, mu_aff = 0.0, sm = 0.0, alpha = 1.0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int r = 0; r < nc; r++) {
+                if (pass == 0) { rc_lo[r] = fl[r] ? s_lo[r] * l_lo[r] : 0.0; rc_hi[r] = fh[r] ? s_hi[r] * l_hi[r] : 0.0; }
+                else {
+                    rc_lo[r] = fl[r] ? s_lo[r] * l_lo[r] - dmax2(sm, l_lo[r] * S_FLOOR) + ds_lo[r] * dl_lo[r] : 0.0;
+                    rc_hi[r] = fh[r] ? s_hi[r] * l_hi[r] - dmax2(sm, l_hi[r] * S_FLOOR) + ds_hi[r] * dl_hi[r] : 0.0;
+                }
+            }
+            double rhs[MAXM];
+            for (int c = 0; c < nr; c++) {
+                double a = grad[c];
+                for (int r = 0; r < nc; r++) {
+                    double h = (-rc_hi[r] + l_hi[r] * r_hi[r]) / s_hi[r] + (rc_lo[r] + l_lo[r] * r_lo[r]) / s_lo[r];
+                    a += h * t->W[r][c];
+                }
+                rhs[c] = a;
+            }
+            for (int i = 0; i < nr; i++) { double a = 0.0; for (int j = 0; j < nr; j++) a += Hti[i][j] * rhs[j]; dy[i] = -a; }
+            double amax = 1.0;
+            for (int r = 0; r < nc; r++) {
+                double dv = 0.0; for (int c = 0; c < nr; c++) dv += t->W[r][c] * dy[c];
+                ds_hi[r] = fh[r] ? -r_hi[r] - dv : 0.0; ds_lo[r] = fl[r] ? r_lo[r] + dv : 0.0;
+                dl_hi[r] = fh[r] ? (-rc_hi[r] - l_hi[r] * ds_hi[r]) / s_hi[r] : 0.0;
+                dl_lo[r] = fl[r] ? (-rc_lo[r] - l_lo[r] * ds_lo[r]) / s_lo[r] : 0.0;
+                if (ds_lo[r] < 0) amax = dmin2(amax, -s_lo[r] / ds_lo[r]);
+                if (ds_hi[r] < 0) amax = dmin2(amax, -s_hi[r] / ds_hi[r]);
+                if (dl_lo[r] < 0) amax = dmin2(amax, -l_lo[r] / dl_lo[r]);
+                if (dl_hi[r] < 0) amax = dmin2(amax, -l_hi[r] / dl_hi[r]);
+            }
+            if (pass == 0) {
+                a_aff = amax;
+                for (int r = 0; r < nc; r++) mu_aff += (s_lo[r] + a_aff * ds_lo[r]) * (l_lo[r] + a_aff * dl_lo[r]) + (s_hi[r] + a_aff * ds_hi[r]) * (l_hi[r] + a_aff * dl_hi[r]);
+                mu_aff /= dmax2(ncon, 1.0);
+                double sg = mu > 0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+                sm = dmax2(sg * mu, MU_FLOOR);
+            } else alpha = dmin2(1.0, TAU * amax);
+        }
+        for (int c = 0; c < nr; c++) y[c] += alpha * dy[c];
+        for (int r = 0; r < nc; r++) { s_lo[r] += alpha * ds_lo[r]; s_hi[r] += alpha * ds_hi[r]; l_lo[r] += alpha * dl_lo[r]; l_hi[r] += alpha * dl_hi[r]; }
+    }
+    for (int r = 0; r < nv; r++) { double a = vp[r]; for (int c = 0; c < nr; c++) a += t->Z[r][c] * y[c]; if (r < n) xs[r] = a; else us[r - n] = a; }
+    for (int i = 0; i < q; i++) { double a = e[i]; for (int j = 0; j < n; j++) a += p->C[i * n + j] * xs[j]; ys[i] = a; }
+    return status;
+}
+
+int orc_target_solve(const orc_problem *p, int Bsz, const double *usp, const double *ysp, const double *xsp,
+                     const double *dhat, const double *us_prev, double *xs, double *us, double *ys,
+                     int32_t *status, int32_t *iters)
+{
+    target_t t; (void)xsp;
+    if (p->nx > MAXN || p->nu > MAXM || p->ny > MAXY || p->nd > MAXD) return -2;
+    if (build_target(p, &t) != 0) return -4;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < Bsz; b++) {
+        int it = 0;
+        int st = target_one(p, &t, usp + b * p->nu, ysp + b * p->ny, dhat + b * p->nd, us_prev + b * p->nu,
+                            xs + b * p->nx, us + b * p->nu, ys + b * p->ny, &it);
+        status[b] = st; if (iters) iters[b] = it;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * estimator
+ * ---------------------------------------------------------------------------------------------- */
+static void est_mats(const orc_problem *p, double Aa[MAXE][MAXE], double Ca[MAXY][MAXE])
+{
+    int n = p->nx, nd = p->nd, ne = n + nd, q = p->ny;
+    for (int i = 0; i < ne; i++) for (int j = 0; j < ne; j++) Aa[i][j] = (i == j);
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) Aa[i][j] = p->A[i * n + j]; for (int j = 0; j < nd; j++) Aa[i][n + j] = p->Bd[i * nd + j]; }
+    for (int i = 0; i < q; i++) { for (int j = 0; j < n; j++) Ca[i][j] = p->C[i * n + j]; for (int j = 0; j < nd; j++) Ca[i][n + j] = p->Cd[i * nd + j]; }
+}
+
+/* xi [ne], P [ne*ne] in/out; innov = y - yhat */
+static void kalman_one(const orc_problem *p, double Aa[MAXE][MAXE], double Ca[MAXY][MAXE], double *xi, double *P, const double *innov)
+{
+    int ne = p->nx + p->nd, q = p->ny;
+    double PCt[MAXE][MAXY], S[MAXY][MAXY], Lc[MAXY][MAXY], K[MAXE][MAXY], Pc[MAXE][MAXE], T[MAXE][MAXE];
+    for (int i = 0; i < ne; i++) for (int j = 0; j < q; j++) { double a = 0.0; for (int l = 0; l < ne; l++) a += P[i * ne + l] * Ca[j][l]; PCt[i][j] = a; }
+    for (int i = 0; i < q; i++) for (int j = 0; j < q; j++) { double a = p->R_kf[i * q + j]; for (int l = 0; l < ne; l++) a += Ca[i][l] * PCt[l][j]; S[i][j] = a; }
+    /* K S = PCt  (Estimator.py:297) - S symmetric positive definite: Cholesky */
+    for (int i = 0; i < q; i++) for (int j = 0; j <= i; j++) {
+        double a = 0.5 * (S[i][j] + S[j][i]);
+        for (int l = 0; l < j; l++) a -= Lc[i][l] * Lc[j][l];
+        if (i == j) Lc[i][i] = sqrt(a); else Lc[i][j] = a / Lc[j][j];
+    }
+    for (int r = 0; r < ne; r++) {
+        double yv[MAXY];
+        for (int i = 0; i < q; i++) { double a = PCt[r][i]; for (int l = 0; l < i; l++) a -= Lc[i][l] * yv[l]; yv[i] = a / Lc[i][i]; }
+        for (int i = q - 1; i >= 0; i--) { double a = yv[i]; for (int l = i + 1; l < q; l++) a -= Lc[l][i] * K[r][l]; K[r][i] = a / Lc[i][i]; }
+    }
+    /* P_corr = (I - K C) P  (:300) */
+    for (int i = 0; i < ne; i++) for (int j = 0; j < ne; j++) {
+        double a = P[i * ne + j];
+        for (int l = 0; l < q; l++) { double kc = K[i][l]; double cp = 0.0; for (int r = 0; r < ne; r++) cp += Ca[l][r] * P[r * ne + j]; a -= kc * cp; }
+        Pc[i][j] = a;
+    }
+    for (int i = 0; i < ne; i++) { double a = 0.0; for (int l = 0; l < q; l++) a += K[i][l] * innov[l]; xi[i] += a; }   /* :303-306 */
+    /* P_plus = A P_corr A' + Q  (:309) */
+    for (int i = 0; i < ne; i++) for (int j = 0; j < ne; j++) { double a = 0.0; for (int l = 0; l < ne; l++) a += Aa[i][l] * Pc[l][j]; T[i][j] = a; }
+    for (int i = 0; i < ne; i++) for (int j = 0; j < ne; j++) { double a = p->Q_kf[i * ne + j]; for (int l = 0; l < ne; l++) a += T[i][l] * Aa[j][l]; P[i * ne + j] = a; }
+}
+
+int orc_kf_update(const orc_problem *p, int Bsz, const double *y, const double *yhat, double *xi, double *P)
+{
+    int ne = p->nx + p->nd, q = p->ny;
+    double Aa[MAXE][MAXE], Ca[MAXY][MAXE];
+    if (ne > MAXE || q > MAXY) return -2;
+    est_mats(p, Aa, Ca);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < Bsz; b++) {
+        double innov[MAXY];
+        for (int i = 0; i < q; i++) innov[i] = y[b * q + i] - yhat[b * q + i];
+        if (p->estimator == 1) kalman_one(p, Aa, Ca, xi + b * ne, P + (size_t)b * ne * ne, innov);
+        else if (p->estimator == 2)
+            for (int i = 0; i < ne; i++) { double a = 0.0; for (int l = 0; l < q; l++) a += p->K[i * q + l] * innov[l]; xi[b * ne + i] += a; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * closed loop, MPC_code.py:485-827.  State arrays are in/out; schedules are [nsteps][.] shared by the batch.
+ * Logs (optional, may be NULL) are [nsteps][B][.].
+ * ---------------------------------------------------------------------------------------------- */
+int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
+                    double *x /*[B][nxp]*/, double *xhat /*[B][nx]*/, double *dhat /*[B][nd]*/, double *Pk /*[B][ne*ne] or NULL*/,
+                    double *u /*[B][nu]*/, double *xs /*[B][nx]*/, double *us /*[B][nu]*/,
+                    const double *ysp, const double *usp, const double *xsp, const double *pxp, const double *pyp,
+                    double *U_log, double *XHAT_log, double *XS_log, double *US_log, double *YS_log, double *XP_log, double *DHAT_log,
+                    int32_t *st_dyn_log, int32_t *st_ss_log, int32_t *it_dyn_log, int32_t *it_ss_log, int nthreads)
+{
+    stage_t st; target_t tg;
+    const int n = p->nx, m = p->nu, q = p->ny, nd = p->nd, nxp = p->nxp, ne = n + nd;
+    double Aa[MAXE][MAXE], Ca[MAXY][MAXE];
+    if (p->nx + (p->du_form ? p->nu : 0) > MAXN || m > MAXM || p->N > MAXH || q > MAXY || nd > MAXD) return -2;
+    build_stage(p, &st);
+    if (build_target(p, &tg) != 0) return -4;
+    est_mats(p, Aa, Ca);
+    int err = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        work_t *w = (work_t *)malloc(sizeof(work_t));
+#pragma omp for schedule(dynamic, 4)
+        for (int b = 0; b < Bsz; b++) {
+            double *xb = x + b * nxp, *xh = xhat + b * n, *dh = dhat + b * nd, *ub = u + b * m, *xsb = xs + b * n, *usb = us + b * m;
+            for (int k = 0; k < nsteps; k++) {
+                size_t lb = (size_t)k * Bsz + b;
+                if (XP_log) memcpy(XP_log + lb * nxp, xb, sizeof(double) * nxp);
+                if (XHAT_log) memcpy(XHAT_log + lb * n, xh, sizeof(double) * n);
+                /* yhat = Fy_model(xhat, dhat) (:524); y = Fy_p(x) + pyp (:534) */
+                double xi[MAXE], innov[MAXY];
+                for (int i = 0; i < q; i++) {
+                    double yh = p->fy_const[i], yy = pyp[k * q + i];
+                    for (int j = 0; j < n; j++) yh += p->C[i * n + j] * xh[j];
+                    for (int j = 0; j < nd; j++) yh += p->Cd[i * nd + j] * dh[j];
+                    for (int j = 0; j < nxp; j++) yy += p->Cp[i * nxp + j] * xb[j];
+                    innov[i] = yy - yh;
+                }
+                for (int i = 0; i < n; i++) xi[i] = xh[i];
+                for (int i = 0; i < nd; i++) xi[n + i] = dh[i];
+                if (p->estimator == 1) kalman_one(p, Aa, Ca, xi, Pk + (size_t)b * ne * ne, innov);
+                else if (p->estimator == 2)
+                    for (int i = 0; i < ne; i++) { double a = 0.0; for (int l = 0; l < q; l++) a += p->K[i * q + l] * innov[l]; xi[i] += a; }
+                for (int i = 0; i < n; i++) xh[i] = xi[i];
+                for (int i = 0; i < nd; i++) { double d = xi[n + i]; if (p->dmin) d = dmin2(dmax2(d, p->dmin[i]), p->dmax[i]); dh[i] = d; }   /* :660-665 */
+                if (DHAT_log) memcpy(DHAT_log + lb * nd, dh, sizeof(double) * nd);
+                /* target (:693-718): keep the previous one when infeasible */
+                double xs_n[MAXN], us_n[MAXM], ys_n[MAXY]; int it_ss = 0;
+                int sss = target_one(p, &tg, usp + k * m, ysp + k * q, dh, usb, xs_n, us_n, ys_n, &it_ss);
+                (void)xsp;
+                if (sss != ST_INFEASIBLE) { memcpy(xsb, xs_n, sizeof(double) * n); memcpy(usb, us_n, sizeof(double) * m); }
+                if (XS_log) memcpy(XS_log + lb * n, xsb, sizeof(double) * n);
+                if (US_log) memcpy(US_log + lb * m, usb, sizeof(double) * m);
+                if (YS_log) for (int i = 0; i < q; i++) {                        /* :730 */
+                    double a = p->fy_const[i];
+                    for (int j = 0; j < n; j++) a += p->C[i * n + j] * xsb[j];
+                    for (int j = 0; j < nd; j++) a += p->Cd[i * nd + j] * dh[j];
+                    YS_log[lb * q + i] = a;
+                }
+                /* OCP (:733-805) */
+                inst_t qi; int it_dyn = 0; double r3[3];
+                if (build_inst(p, &st, xh, xsb, usb, dh, ub, &qi) != 0) {
+#pragma omp atomic write
+                    err = -3;
+                    break;
+                }
+                int sd = rpdip_one(&st, &qi, p->max_iter, w, &it_dyn, r3);
+                if (sd != ST_INFEASIBLE) {
+                    for (int i = 0; i < m; i++) ub[i] = w->u[0][i];              /* :798 */
+                    for (int i = 0; i < n; i++) xh[i] = w->z[1][i];              /* :799 */
+                } else {                                                          /* :804-805 */
+                    double xn[MAXN];
+                    for (int i = 0; i < n; i++) {
+                        double a = p->fx_const[i];
+                        for (int j = 0; j < n; j++) a += p->A[i * n + j] * xh[j];
+                        for (int j = 0; j < m; j++) a += p->B[i * m + j] * ub[j];
+                        for (int j = 0; j < nd; j++) a += p->Bd[i * nd + j] * dh[j];
+                        xn[i] = a;
+                    }
+                    memcpy(xh, xn, sizeof(double) * n);
+                }
+                if (U_log) memcpy(U_log + lb * m, ub, sizeof(double) * m);
+                if (st_dyn_log) st_dyn_log[lb] = sd;
+                if (st_ss_log) st_ss_log[lb] = sss;
+                if (it_dyn_log) it_dyn_log[lb] = it_dyn;
+                if (it_ss_log) it_ss_log[lb] = it_ss;
+                /* plant (:816) */
+                double xn[MAXN];
+                for (int i = 0; i < nxp; i++) {
+                    double a = pxp[k * nxp + i];
+                    for (int j = 0; j < nxp; j++) a += p->Ap[i * nxp + j] * xb[j];
+                    for (int j = 0; j < m; j++) a += p->Bp[i * m + j] * ub[j];
+                    xn[i] = a;
+                }
+                memcpy(xb, xn, sizeof(double) * nxp);
+            }
+        }
+        free(w);
+    }
+    return err;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
