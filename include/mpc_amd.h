@@ -1,0 +1,161 @@
+/*
+ * mpc_amd.h - C-ABI of the MI355X-native batched linear MPC solver (libmpc_amd.so).
+ *
+ * Drop-in boundary for the hot path of CPCLAB-UNIPI/MPC-code.  The reference has no FFI; its only
+ * seam is the CasADi nlpsol function object.  Each entry point below names the
+ * reference call it replaces.  All reference line numbers are in /root/reference.
+ *
+ * Conventions
+ *   - every array is caller-owned, contiguous float64 (int32 for status / iteration words);
+ *   - host arrays are batch-major [B][k] (one row per instance), matrices row-major;
+ *   - absent bounds are +-INFINITY; optional pointers may be NULL where stated;
+ *   - every function returns 0 on success and a negative code on error, mpc_last_error() then holds a
+ *     message (thread-local).  Nothing falls back to a CPU path: without a usable GPU the create call fails.
+ *   - status words: 0 solved, 1 iteration limit (accepted by the reference, MPC_code.py:714,786),
+ *     2 infeasible (== IPOPT 'Infeasible_Problem_Detected': the driver holds u / the target).
+ *   - one host thread drives a handle; calls are blocking unless stated (mpc_loop_run is asynchronous).
+ */
+#ifndef MPC_AMD_H
+#define MPC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_STATUS_SOLVED 0
+#define MPC_STATUS_MAXITER 1
+#define MPC_STATUS_INFEASIBLE 2
+
+#define MPC_EST_NONE 0
+#define MPC_EST_KALMAN 1 /* time-varying Kalman filter, Estimator.py:263-311 */
+#define MPC_EST_FIXED_GAIN 2 /* steady-state KF / Luenberger, Estimator.py:231-261 */
+
+typedef struct mpc_handle mpc_handle;
+
+/*
+ * Numeric problem: what the reference builds symbolically once per run -
+ * defF_model (Utilities.py:102-245), defF_p (:21-100), defFss_obj (:267-321), defF_obj (:323-381),
+ * defVfin (:383-420; P is the DARE solution the caller computes with the same SciPy call, :409),
+ * opt_ss (Target_Calc.py:20-161), opt_dyn (Control_Calc.py:20-260), Kkalss (Estimator.py:103-229).
+ */
+typedef struct mpc_lin_desc {
+    int32_t nx, nu, ny, nd, nxp; /* MPC_code.py:31-35 */
+    int32_t N;                   /* horizon */
+    int32_t du_form;             /* cost on u_k - u_{k-1} with weight R (the Ex-file's S), Control_Calc.py:163-166,180-181 */
+    int32_t duss_form;           /* target cost on us - us_prev, Target_Calc.py:121-122 */
+    int32_t y_bounded;           /* the g1 rows exist (yFree False), Control_Calc.py:60-63,150-151 */
+    int32_t estimator;           /* MPC_EST_* */
+    int32_t max_iter;            /* ipopt.max_iter = Sol_itmax, MPC_code.py:262-263 */
+    int32_t device;              /* HIP device ordinal */
+    /* model x+ = A x + B u + Bd d + fx_const, y = C x + Cd d + fy_const (Utilities.py:135-155,208-244) */
+    const double *A, *B, *C, *Bd, *Cd, *fx_const, *fy_const;
+    /* plant xp+ = Ap xp + Bp u + pxp, y = Cp xp + pyp (Utilities.py:45-49,88-91) */
+    const double *Ap, *Bp, *Cp;
+    /* weights: stage Q [nx,nx], R [nu,nu], terminal P [nx,nx]; target Qss [ny,ny], Rss [nu,nu] */
+    const double *Q, *R, *P, *Qss, *Rss;
+    /* bounds of the dynamic problem (Control_Calc.py:213-252) and of the target problem (Target_Calc.py:127-134) */
+    const double *umin, *umax, *xmin, *xmax, *ymin, *ymax;
+    const double *umin_ss, *umax_ss, *xmin_ss, *xmax_ss, *ymin_ss, *ymax_ss;
+    const double *dmin, *dmax; /* saturation of the disturbance estimate, MPC_code.py:660-665; NULL = none */
+    /* estimator data: Q_kf,R_kf [nx+nd]^2,[ny]^2 for MPC_EST_KALMAN; K [nx+nd,ny] for MPC_EST_FIXED_GAIN */
+    const double *Q_kf, *R_kf, *K;
+} mpc_lin_desc;
+
+/* Replaces the construction nlpsol('solver','ipopt',...) of Control_Calc.py:256-258 and
+ * Target_Calc.py:157-159 (and their bound vectors, :260 / :161).  Fails if no gfx950 device is usable,
+ * if the dimensions have no compiled kernel, or if [A-I, B] is rank deficient. */
+int mpc_lin_create(const mpc_lin_desc *desc, mpc_handle **out);
+void mpc_destroy(mpc_handle *h);
+const char *mpc_last_error(void);
+
+/*
+ * One solver(lbx,ubx,x0,p,lbg,ubg) call per instance, MPC_code.py:776-781, with the driver's glue:
+ * x_0 fixed to xhat (:734), parameters par[0:13] = xhat,xs,us,dhat,u_prev (:772, Control_Calc.py:44-48),
+ * read-out u* = w[nx:nx+nu], xhat+ = w[nx+nu:2nx+nu] (:798-799).
+ *   px, py    time-varying model parameters [B][N][nx|ny]; must be NULL (def_px/def_py are a later scope row)
+ *   w_out     optional [B][nx*(N+1)+nu*N]: primal optimum in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37)
+ *   u_out [B][nu], xnext_out [B][nx]: untouched for instances with status 2
+ *   kkt_res   optional [B][3]: stationarity, bound residual, mean complementarity at the returned point
+ */
+int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
+                  const double *dhat, const double *u_prev, const double *px, const double *py,
+                  double *w_out, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
+                  double *kkt_res);
+
+/* One solver_ss(...) call per instance, MPC_code.py:693-718 (par_ss = usp,ysp,xsp,dhat,us_prev, :693). */
+int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, const double *ysp, const double *xsp,
+                     const double *dhat, const double *us_prev, double *xs, double *us, double *ys,
+                     int32_t *status, int32_t *iters);
+
+/* defEstimator(...) -> kalman() / kalss(), MPC_code.py:577-650, Estimator.py:231-311.
+ * xi = [xhat; dhat] [B][nx+nd] in/out; P [B][(nx+nd)^2] in/out (ignored for MPC_EST_FIXED_GAIN, may be NULL).
+ * The predicted output Fy_model(xhat, dhat) (MPC_code.py:524) is formed inside. */
+int mpc_kf_update(mpc_handle *h, int32_t B, const double *y, double *xi_inout, double *P_inout);
+
+/*
+ * The closed loop MPC_code.py:485-827 for B instances that share the problem and the schedules and differ
+ * in their state.  Step order: measure (:524-534) -> estimate (:577-650) -> target (:693-718) -> OCP
+ * (:733-805) -> plant (:813-816).  State lives in HBM inside the handle between calls.
+ *
+ *   mpc_loop_set_state   upload [B][.] arrays: x_p [nxp], xhat [nx], dhat [nd], P [(nx+nd)^2] (NULL unless
+ *                        MPC_EST_KALMAN), u [nu], xs [nx], us [nu] (first step: xs = x0_m, us = u0, :682-684)
+ *   mpc_loop_set_schedule per-step values shared by the batch, [nsteps][.]: ysp,usp,xsp = defSP(t) (:677-680),
+ *                        pxp = def_pxp(t), pyp = def_pyp(t) (:512-515)
+ *   mpc_loop_run         advance steps k0 .. k0+nsteps-1 of the schedule; asynchronous on the handle's stream
+ *   mpc_loop_sync        wait for it
+ *   mpc_loop_get_state   download the state (any pointer may be NULL)
+ *   mpc_loop_get_log     download one log, [nsteps][B][dim] float64 ("U","X_HAT","XS","US","YS","Xp","D_HAT")
+ *                        or [nsteps][B] int32 ("STATUS_DYN","STATUS_SS","ITERS_DYN","ITERS_SS") - the
+ *                        reference's result arrays, MPC_code.py:877-895
+ */
+#define MPC_LOG_NONE 0
+#define MPC_LOG_U 1   /* only U and the status / iteration words */
+#define MPC_LOG_ALL 2
+int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32_t log_level);
+int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double *xhat, const double *dhat,
+                       const double *P, const double *u, const double *xs, const double *us);
+int mpc_loop_get_state(mpc_handle *h, double *x_p, double *xhat, double *dhat, double *P, double *u,
+                       double *xs, double *us);
+int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double *ysp, const double *usp,
+                          const double *xsp, const double *pxp, const double *pyp);
+int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps);
+int mpc_loop_sync(mpc_handle *h);
+int mpc_loop_get_log(mpc_handle *h, const char *name, void *out);
+
+/* Convenience wrapper with host buffers only (set_state, set_schedule, run, sync, get_state):
+ * the fused equivalent of calling the three solvers nsteps times from MPC_code.py's loop. */
+int mpc_closed_loop(mpc_handle *h, int32_t B, int32_t nsteps, double *x_p, double *xhat, double *dhat,
+                    double *P, double *u, double *xs, double *us, const double *ysp, const double *usp,
+                    const double *xsp, const double *pxp, const double *pyp, double *U_log /* [nsteps][B][nu] or NULL */);
+
+/*
+ * Measurement and integration hooks.
+ *   mpc_last_kernel_ms   HIP-event time (ms) of the kernels of the last mpc_loop_run / solve call, measured
+ *                        on the handle's stream; n_launches receives the number of launches it covers
+ *   mpc_stream           the hipStream_t the handle launches on (for callers that order their own work)
+ *   mpc_dev_ptr          device address of a resident array: state "x_p","xhat","dhat","P","u","xs","us"
+ *                        (layout [dim][Bpad], instance index fastest) or a log ("U", ... layout
+ *                        [step][dim][Bpad]); *bpad receives the padded batch stride
+ *   mpc_pack_u           gather u of the last step into a dense [B][nu] device buffer owned by the caller
+ *                        (what a rank hands to the all-gather of u*)
+ */
+float mpc_last_kernel_ms(mpc_handle *h, int32_t *n_launches);
+void *mpc_stream(mpc_handle *h);
+void *mpc_dev_ptr(mpc_handle *h, const char *name, int64_t *bpad);
+int mpc_pack_u(mpc_handle *h, void *dst_dev /* [B][nu] float64 */);
+/* device-to-device copy of steps [k0,k0+nsteps) of a float64 log, layout [step][dim][Bpad], into dst_dev
+ * (asynchronous on the handle's stream) - the send buffer of the end-of-run all-gather of U */
+int mpc_pack_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, void *dst_dev);
+
+/* Tunables (0 / negative = keep default): instances per workgroup and steps fused into one launch. */
+int mpc_set_option(mpc_handle *h, const char *name, double value);
+
+/* Library self-description: "gfx950;dims=3/2/3/3/3/0,4/2/2/2/4/1;..." */
+const char *mpc_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_AMD_H */

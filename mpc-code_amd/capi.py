@@ -1,0 +1,282 @@
+"""ctypes binding of ``include/mpc_amd.h`` - the only way Python reaches the HIP solver.
+
+``Solver(problem)`` is the counterpart of the reference's solver construction
+(``opt_ss`` + ``opt_dyn`` + estimator set-up, reference ``MPC_code.py:300,331-363``); its methods are
+the per-step calls of the loop (``solver_ss(...)`` ``:704-709``, ``solver(...)`` ``:776-781``,
+``defEstimator(...)`` ``:577-650``) over a batch of instances.
+
+There is no fallback: if ``libmpc_amd.so`` is missing or no HIP device is usable, construction
+raises :class:`MpcAmdError`.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from . import PKG_DIR
+
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmpc_amd.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2
+LOG_NONE, LOG_U, LOG_ALL = 0, 1, 2
+_EST = {"none": 0, "kal": 1, "kalss": 2}
+
+_dp = ct.POINTER(ct.c_double)
+_ip = ct.POINTER(ct.c_int32)
+
+
+class MpcAmdError(RuntimeError):
+    pass
+
+
+class _Desc(ct.Structure):
+    _fields_ = [(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "N", "du_form", "duss_form", "y_bounded",
+                                          "estimator", "max_iter", "device")] + \
+               [(k, _dp) for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp",
+                                   "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax",
+                                   "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss",
+                                   "dmin", "dmax", "Q_kf", "R_kf", "K")]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile ``csrc/mpc_amd.hip`` for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp")] + \
+           [os.path.join(os.path.dirname(PKG_DIR), "include", "mpc_amd.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ct.CDLL:
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MpcAmdError(f"{path} not found: build it with mpc_code_amd.capi.build_library() (needs hipcc); "
+                          "there is no CPU fallback")
+    lib = ct.CDLL(path)
+    lib.mpc_last_error.restype = ct.c_char_p
+    lib.mpc_build_info.restype = ct.c_char_p
+    lib.mpc_last_kernel_ms.restype = ct.c_float
+    lib.mpc_last_kernel_ms.argtypes = [ct.c_void_p, _ip]
+    lib.mpc_stream.restype = ct.c_void_p
+    lib.mpc_stream.argtypes = [ct.c_void_p]
+    lib.mpc_dev_ptr.restype = ct.c_void_p
+    lib.mpc_dev_ptr.argtypes = [ct.c_void_p, ct.c_char_p, ct.POINTER(ct.c_int64)]
+    lib.mpc_destroy.restype = None
+    lib.mpc_destroy.argtypes = [ct.c_void_p]
+    lib.mpc_lin_create.argtypes = [ct.POINTER(_Desc), ct.POINTER(ct.c_void_p)]
+    lib.mpc_set_option.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_double]
+    lib.mpc_pack_u.argtypes = [ct.c_void_p, ct.c_void_p]
+    lib.mpc_pack_log.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.c_int32, ct.c_void_p]
+    lib.mpc_loop_alloc.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]
+    lib.mpc_loop_run.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32]
+    lib.mpc_loop_sync.argtypes = [ct.c_void_p]
+    lib.mpc_loop_get_log.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_void_p]
+    lib.mpc_loop_set_state.argtypes = [ct.c_void_p] + [_dp] * 7
+    lib.mpc_loop_get_state.argtypes = [ct.c_void_p] + [_dp] * 7
+    lib.mpc_loop_set_schedule.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5
+    lib.mpc_ocp_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 7 + [_dp, _dp, _dp, _ip, _ip, _dp]
+    lib.mpc_target_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5 + [_dp, _dp, _dp, _ip, _ip]
+    lib.mpc_kf_update.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp, _dp]
+    lib.mpc_closed_loop.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32] + [_dp] * 13
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update",
+           "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_run",
+           "mpc_loop_sync", "mpc_loop_get_log", "mpc_closed_loop", "mpc_last_kernel_ms", "mpc_stream", "mpc_dev_ptr",
+           "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_build_info")
+
+
+def _c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+class Solver:
+    """A problem resident on one GPU.  ``problem`` is a :class:`LinearMPCProblem`."""
+
+    def __init__(self, problem, device: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        self.p = p = problem
+        self._keep = {}
+        d = _Desc()
+        d.nx, d.nu, d.ny, d.nd, d.nxp, d.N = p.nx, p.nu, p.ny, p.nd, p.nxp, p.N
+        d.du_form, d.duss_form, d.y_bounded = int(p.DUForm), int(p.DUssForm), int(p.y_bounded)
+        d.estimator, d.max_iter, d.device = _EST[p.estimator], int(p.max_iter), int(device)
+        for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp", "Q", "R", "P", "Qss", "Rss",
+                  "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss",
+                  "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf", "K"):
+            v = getattr(p, k)
+            if v is None:
+                setattr(d, k, None)
+            else:
+                a = _c(v)
+                if a.size == 0:
+                    a = np.zeros(1)
+                self._keep[k] = a
+                setattr(d, k, _p(a))
+        self.h = ct.c_void_p()
+        rc = self.lib.mpc_lin_create(ct.byref(d), ct.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise MpcAmdError(f"mpc_lin_create failed ({rc}): {self.lib.mpc_last_error().decode()}")
+        self._loop_B = 0
+        self._loop_steps = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MpcAmdError(f"{what} failed ({rc}): {self.lib.mpc_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_info(self) -> str:
+        return self.lib.mpc_build_info().decode()
+
+    def set_option(self, name: str, value: float):
+        self._chk(self.lib.mpc_set_option(self.h, name.encode(), float(value)), "mpc_set_option")
+
+    def last_kernel_ms(self):
+        n = ct.c_int32(0)
+        ms = self.lib.mpc_last_kernel_ms(self.h, ct.byref(n))
+        return float(ms), int(n.value)
+
+    def stream(self) -> int:
+        return int(self.lib.mpc_stream(self.h) or 0)
+
+    def dev_ptr(self, name: str):
+        bp = ct.c_int64(0)
+        ptr = self.lib.mpc_dev_ptr(self.h, name.encode(), ct.byref(bp))
+        return (int(ptr) if ptr else 0), int(bp.value)
+
+    def pack_u(self, dst_ptr: int):
+        self._chk(self.lib.mpc_pack_u(self.h, ct.c_void_p(dst_ptr)), "mpc_pack_u")
+
+    def pack_log(self, name: str, k0: int, nsteps: int, dst_ptr: int):
+        self._chk(self.lib.mpc_pack_log(self.h, name.encode(), int(k0), int(nsteps), ct.c_void_p(dst_ptr)), "mpc_pack_log")
+
+    # ------------------------------------------------------------------ per-step calls
+    def ocp_solve(self, xhat, xs, us, dhat, u_prev, want_w=False):
+        """``solver(...)`` of MPC_code.py:776-781 for a batch; returns dict(u0, x1, status, iters, res[, w])."""
+        p = self.p
+        xhat = _c(np.atleast_2d(xhat)); B = xhat.shape[0]
+        xs, us = _c(xs, (B, p.nx)), _c(us, (B, p.nu))
+        dhat, u_prev = _c(dhat, (B, p.nd)), _c(u_prev, (B, p.nu))
+        u0 = np.full((B, p.nu), np.nan); x1 = np.full((B, p.nx), np.nan)
+        st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); res = np.zeros((B, 3))
+        w = np.full((B, p.nw), np.nan) if want_w else None
+        self._chk(self.lib.mpc_ocp_solve(self.h, B, _p(xhat), _p(xs), _p(us), _p(dhat) if p.nd else None, _p(u_prev),
+                                         None, None, _p(w), _p(u0), _p(x1), _pi(st), _pi(it), _p(res)), "mpc_ocp_solve")
+        return dict(u0=u0, x1=x1, status=st, iters=it, res=res, w=w)
+
+    def target_solve(self, usp, ysp, xsp, dhat, us_prev):
+        """``solver_ss(...)`` of MPC_code.py:704-709 for a batch; returns dict(xs, us, ys, status, iters)."""
+        p = self.p
+        dhat = _c(np.atleast_2d(dhat)); B = dhat.shape[0]
+        usp, ysp, xsp, us_prev = _c(usp, (B, p.nu)), _c(ysp, (B, p.ny)), _c(xsp, (B, p.nx)), _c(us_prev, (B, p.nu))
+        xs = np.zeros((B, p.nx)); us = np.zeros((B, p.nu)); ys = np.zeros((B, p.ny))
+        st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
+        self._chk(self.lib.mpc_target_solve(self.h, B, _p(usp), _p(ysp), _p(xsp), _p(dhat) if p.nd else None, _p(us_prev),
+                                            _p(xs), _p(us), _p(ys), _pi(st), _pi(it)), "mpc_target_solve")
+        return dict(xs=xs, us=us, ys=ys, status=st, iters=it)
+
+    def kf_update(self, y, xi, P=None):
+        """``defEstimator(...)`` of MPC_code.py:577-650; returns (xi_corrected, P_plus)."""
+        p = self.p
+        xi = _c(np.atleast_2d(xi)).copy(); B = xi.shape[0]
+        y = _c(y, (B, p.ny))
+        ne = p.nx + p.nd
+        Pk = _c(P, (B, ne, ne)).copy() if P is not None else None
+        self._chk(self.lib.mpc_kf_update(self.h, B, _p(y), _p(xi), _p(Pk)), "mpc_kf_update")
+        return xi, Pk
+
+    # ------------------------------------------------------------------ resident closed loop
+    def loop_alloc(self, B: int, max_steps: int, log_level: int = LOG_ALL):
+        self._chk(self.lib.mpc_loop_alloc(self.h, int(B), int(max_steps), int(log_level)), "mpc_loop_alloc")
+        self._loop_B, self._loop_steps, self._loop_log = int(B), int(max_steps), int(log_level)
+
+    def loop_set_state(self, x_p, xhat, dhat=None, P=None, u=None, xs=None, us=None):
+        p, B = self.p, self._loop_B
+        ne = p.nx + p.nd
+        x_p, xhat = _c(x_p, (B, p.nxp)), _c(xhat, (B, p.nx))
+        dhat = _c(p.dhat0 if dhat is None else dhat, (B, p.nd)) if p.nd else None
+        u = _c(p.u0 if u is None else u, (B, p.nu))
+        xs = xhat.copy() if xs is None else _c(xs, (B, p.nx))       # MPC_code.py:682-684
+        us = u.copy() if us is None else _c(us, (B, p.nu))
+        Pk = None
+        if p.estimator == "kal":
+            Pk = _c(p.P0 if P is None else P, (B, ne, ne))
+        self._chk(self.lib.mpc_loop_set_state(self.h, _p(x_p), _p(xhat), _p(dhat), _p(Pk), _p(u), _p(xs), _p(us)),
+                  "mpc_loop_set_state")
+
+    def loop_get_state(self):
+        p, B = self.p, self._loop_B
+        ne = p.nx + p.nd
+        out = dict(x_p=np.zeros((B, p.nxp)), xhat=np.zeros((B, p.nx)), dhat=np.zeros((B, p.nd)) if p.nd else None,
+                   P=np.zeros((B, ne, ne)) if p.estimator == "kal" else None, u=np.zeros((B, p.nu)),
+                   xs=np.zeros((B, p.nx)), us=np.zeros((B, p.nu)))
+        self._chk(self.lib.mpc_loop_get_state(self.h, *(_p(out[k]) for k in ("x_p", "xhat", "dhat", "P", "u", "xs", "us"))),
+                  "mpc_loop_get_state")
+        return out
+
+    def loop_set_schedule(self, sched, nsteps=None):
+        nsteps = len(sched["ysp"]) if nsteps is None else nsteps
+        self._sched_keep = {k: _c(v) for k, v in sched.items()}
+        s = self._sched_keep
+        self._chk(self.lib.mpc_loop_set_schedule(self.h, int(nsteps), _p(s["ysp"]), _p(s["usp"]), _p(s.get("xsp")),
+                                                 _p(s.get("pxp")), _p(s.get("pyp"))), "mpc_loop_set_schedule")
+        self._sched_n = int(nsteps)
+
+    def loop_run(self, k0: int, nsteps: int):
+        self._chk(self.lib.mpc_loop_run(self.h, int(k0), int(nsteps)), "mpc_loop_run")
+
+    def loop_sync(self):
+        self._chk(self.lib.mpc_loop_sync(self.h), "mpc_loop_sync")
+
+    def loop_get_log(self, name: str):
+        p, B, ns = self.p, self._loop_B, self._sched_n
+        dims = dict(U=p.nu, X_HAT=p.nx, XS=p.nx, US=p.nu, YS=p.ny, Xp=p.nxp, D_HAT=p.nd)
+        if name in dims:
+            out = np.zeros((ns, B, dims[name]))
+        else:
+            out = np.zeros((ns, B), np.int32)
+        self._chk(self.lib.mpc_loop_get_log(self.h, name.encode(), out.ctypes.data_as(ct.c_void_p)), "mpc_loop_get_log")
+        return out

@@ -1,0 +1,922 @@
+// libmpc_amd.so - hand-written HIP (gfx950) implementation of include/mpc_amd.h.
+//
+// Host side: turns the reference-level problem description into the stage form / null-space form the
+// kernels use, owns all device memory, launches on one stream per handle, times launches with HIP events.
+// Device side: mpc_device.hpp.  No PyTorch, no CUDA-compat layer, no CPU fallback: every entry point
+// fails loudly when the device path is unavailable.
+#include "../../include/mpc_amd.h"
+#include "mpc_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mpc;
+
+// ---------------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(x)                                                                                       \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) return fail(-10, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *mpc_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------------
+// compiled dimension sets: NX, NU, NY, ND, NXP, DU
+// ---------------------------------------------------------------------------------------------------
+#ifndef MPC_DIM_LIST
+#define MPC_DIM_LIST(X) \
+    X(3, 2, 3, 3, 3, 0) /* Ex_LMPC_CSTR */ \
+    X(4, 2, 2, 2, 4, 1) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */ \
+    X(2, 1, 1, 1, 2, 0) /* double integrator (tests: LQR known answer) */ \
+    X(2, 1, 1, 1, 2, 1)
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// kernels.  Device arrays are structure-of-arrays [dim][Bs], instance index fastest.
+// ---------------------------------------------------------------------------------------------------
+struct OcpArgs {
+    const double *xhat, *xs, *us, *dhat, *u_prev;   // in
+    double *u_out, *xnext_out, *res;                // out ([nu][Bs], [nx][Bs], [3][Bs])
+    int32_t *status, *iters;
+    double *ws;                                     // workspace rows
+    int B; size_t Bs;
+};
+
+template <int NX, int NU, int NY, int ND, bool DU>
+__global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ Pp, OcpArgs a)
+{
+    constexpr int NS = NX + (DU ? NU : 0);
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    double xhat[NX], xs[NX], us[NU], up[NU], dh[ND > 0 ? ND : 1];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { xhat[i] = a.xhat[i * a.Bs + b]; xs[i] = a.xs[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { us[i] = a.us[i * a.Bs + b]; up[i] = a.u_prev[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
+    OcpInst<NS, NU> q;
+    build_inst<NX, NU, NY, ND, DU>(P, xhat, xs, us, dh, up, q);
+    Ws ws{a.ws, a.Bs, P.N, b};
+    double u0[NU], z1[NS], res[3];
+    int it;
+    const int st = rpdip_lane<NS, NU, DU>(P, q, ws, P.max_iter, u0, z1, res, it);
+    a.status[b] = st; a.iters[b] = it;
+    MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
+    if (st != kInfeasible) {
+        MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * a.Bs + b] = u0[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) a.xnext_out[i * a.Bs + b] = z1[i];
+    }
+}
+
+struct TargetArgs {
+    const double *usp, *ysp, *dhat, *us_prev;
+    double *xs, *us, *ys;
+    int32_t *status, *iters;
+    int B; size_t Bs;
+};
+
+template <int NX, int NU, int NY, int ND>
+__global__ __launch_bounds__(64) void target_kernel(const DevProblem *__restrict__ Pp, TargetArgs a)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    double usp[NU], ysp[NY], dh[ND > 0 ? ND : 1], usprev[NU], xs[NX], us[NU], ys[NY];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { usp[i] = a.usp[i * a.Bs + b]; usprev[i] = a.us_prev[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[i * a.Bs + b];
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
+    int it;
+    const int st = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, usprev, xs, us, ys, it);
+    a.status[b] = st; a.iters[b] = it;
+    MPC_UNROLL for (int i = 0; i < NX; i++) a.xs[i * a.Bs + b] = xs[i];
+    MPC_UNROLL for (int i = 0; i < NU; i++) a.us[i * a.Bs + b] = us[i];
+    MPC_UNROLL for (int i = 0; i < NY; i++) a.ys[i * a.Bs + b] = ys[i];
+}
+
+struct KfArgs {
+    const double *y; double *xi, *Pk;
+    int B; size_t Bs;
+};
+
+template <int NX, int NY, int ND>
+__global__ __launch_bounds__(64) void kf_kernel(const DevProblem *__restrict__ Pp, KfArgs a)
+{
+    constexpr int NE = NX + ND;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    double xi[NE], innov[NY];
+    MPC_UNROLL for (int i = 0; i < NE; i++) xi[i] = a.xi[i * a.Bs + b];
+    MPC_UNROLL for (int i = 0; i < NY; i++) {       // yhat = Fy_model(xhat, dhat), MPC_code.py:524
+        double yh = P.fyc[i];
+        MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+        innov[i] = a.y[i * a.Bs + b] - yh;
+    }
+    if (P.estimator == MPC_EST_KALMAN) {
+        double Pk[NE][NE];
+        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * a.Bs + b]; }
+        kalman_lane<NE, NY>(P, xi, Pk, innov);
+        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * a.Bs + b] = Pk[i][j]; }
+    } else if (P.estimator == MPC_EST_FIXED_GAIN) {
+        MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+    }
+    MPC_UNROLL for (int i = 0; i < NE; i++) a.xi[i * a.Bs + b] = xi[i];
+}
+
+// The closed loop, MPC_code.py:485-827: `nsteps` consecutive steps per launch, state read from / written
+// back to HBM once per launch.
+struct LoopArgs {
+    double *x, *xhat, *dhat, *Pk, *u, *xs, *us;      // state [dim][Bs]
+    const double *ysp, *usp, *pxp, *pyp;             // schedules [step][dim], already offset to k0
+    double *U, *XHAT, *XS, *US, *YS, *XP, *DHAT;     // logs [step][dim][Bs] offset to k0, or nullptr
+    int32_t *st_dyn, *st_ss, *it_dyn, *it_ss;        // logs [step][Bs] offset to k0, or nullptr
+    double *ws;
+    int B, nsteps; size_t Bs;
+};
+
+template <int NX, int NU, int NY, int ND, int NXP, bool DU>
+__global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__ Pp, LoopArgs a)
+{
+    constexpr int NS = NX + (DU ? NU : 0), NE = NX + ND;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    const size_t Bs = a.Bs;
+    double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
+    MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
+    Ws ws{a.ws, Bs, P.N, b};
+    for (int k = 0; k < a.nsteps; k++) {
+        if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
+        if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
+        // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
+        if (P.estimator != MPC_EST_NONE) {
+            double xi[NE], innov[NY];
+            MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
+            MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double yh = P.fyc[i], yy = a.pyp[k * NY + i];
+                MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+                MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
+                innov[i] = yy - yh;
+            }
+            if (P.estimator == MPC_EST_KALMAN) {
+                double Pk[NE][NE];
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
+                kalman_lane<NE, NY>(P, xi, Pk, innov);
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+            } else {
+                MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
+            MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
+        }
+        if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) a.DHAT[((size_t)k * ND + i) * Bs + b] = dh[i]; }
+        // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
+        double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
+        MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
+        MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
+        int it_ss;
+        const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss);
+        if (st_ss != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
+        }
+        if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XS[((size_t)k * NX + i) * Bs + b] = xs[i]; }
+        if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) a.US[((size_t)k * NU + i) * Bs + b] = us[i]; }
+        if (a.YS) {   // ys = Fy_model(xs, us, dhat), MPC_code.py:730
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double v = P.fyc[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Cm[i][j] * xs[j];
+                MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Cd[i][j] * dh[j];
+                a.YS[((size_t)k * NY + i) * Bs + b] = v;
+            }
+        }
+        // ---- OCP (MPC_code.py:733-805) -------------------------------------------------------------
+        OcpInst<NS, NU> q;
+        build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
+        double u0[NU], z1[NS], res[3];
+        int it_dyn;
+        const int st_dyn = rpdip_lane<NS, NU, DU>(P, q, ws, P.max_iter, u0, z1, res, it_dyn);
+        if (st_dyn != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = u0[i];          // :798
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
+        } else {                                                           // :804-805 hold u, propagate the model
+            double xn[NX];
+            MPC_UNROLL for (int i = 0; i < NX; i++) {
+                double v = P.fxc[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Am[i][j] * xh[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bm[i][j] * u[j];
+                MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Bd[i][j] * dh[j];
+                xn[i] = v;
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xn[i];
+        }
+        if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) a.U[((size_t)k * NU + i) * Bs + b] = u[i]; }
+        if (a.st_dyn) { a.st_dyn[(size_t)k * Bs + b] = st_dyn; a.st_ss[(size_t)k * Bs + b] = st_ss; a.it_dyn[(size_t)k * Bs + b] = it_dyn; a.it_ss[(size_t)k * Bs + b] = it_ss; }
+        // ---- plant (MPC_code.py:813-816) -----------------------------------------------------------
+        {
+            double xn[NXP];
+            MPC_UNROLL for (int i = 0; i < NXP; i++) {
+                double v = a.pxp[k * NXP + i];
+                MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
+                xn[i] = v;
+            }
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = xn[i];
+        }
+    }
+    MPC_UNROLL for (int i = 0; i < NXP; i++) a.x[i * Bs + b] = x[i];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { a.xhat[i * Bs + b] = xh[i]; a.xs[i * Bs + b] = xs[i]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { a.u[i * Bs + b] = u[i]; a.us[i * Bs + b] = us[i]; }
+}
+
+// dense [B][nu] copy of u for the all-gather of u* 
+__global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__ dst, int B, size_t Bs, int nu)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int i = 0; i < nu; i++) dst[(size_t)b * nu + i] = u[i * Bs + b];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------
+struct Launchers {
+    void (*ocp)(const DevProblem *, OcpArgs, hipStream_t);
+    void (*target)(const DevProblem *, TargetArgs, hipStream_t);
+    void (*kf)(const DevProblem *, KfArgs, hipStream_t);
+    void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
+    int ws_rows;
+};
+
+template <int NX, int NU, int NY, int ND, int NXP, bool DU>
+static Launchers make_launchers()
+{
+    Launchers l;
+    l.ocp = [](const DevProblem *p, OcpArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel<NX, NU, NY, ND, DU>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.ws_rows = WsLayout<NX + (DU ? NU : 0), NU>::ROWS;
+    return l;
+}
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t n)
+    {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct mpc_handle {
+    DevProblem hp;              // host copy
+    DevProblem *dp = nullptr;   // device copy
+    Launchers L;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false; int n_launches = 0;
+    int steps_per_launch = 1;
+    // per-call scratch (solve API)
+    DevBuf scratch, ws;
+    // loop state
+    int B = 0; size_t Bs = 0; int max_steps = 0, log_level = 0, sched_steps = 0, last_k0 = 0, last_n = 0;
+    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, sch, logs, logi;
+    std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
+};
+
+static size_t pad64(size_t b) { return (b + 63) / 64 * 64; }
+
+// host [B][d] -> SoA staging [d][Bs]
+static void to_soa(const double *src, int B, int d, size_t Bs, double *dst)
+{
+    for (int i = 0; i < d; i++) {
+        double *row = dst + (size_t)i * Bs;
+        for (int b = 0; b < B; b++) row[b] = src[(size_t)b * d + i];
+        for (size_t b = B; b < Bs; b++) row[b] = 0.0;
+    }
+}
+static void from_soa(const double *src, int B, int d, size_t Bs, double *dst)
+{
+    for (int i = 0; i < d; i++) {
+        const double *row = src + (size_t)i * Bs;
+        for (int b = 0; b < B; b++) dst[(size_t)b * d + i] = row[b];
+    }
+}
+
+// Householder QR of [A-I, B]' and the reduced target problem
+static int build_target(const mpc_lin_desc *d, DevProblem &P)
+{
+    const int n = d->nx, m = d->nu, q = d->ny, nv = n + m;
+    double Qf[kMaxV][kMaxV], Rm[kMaxV][kMaxN];
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Qf[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) Rm[j][i] = d->A[i * n + j] - (i == j ? 1.0 : 0.0);
+        for (int j = 0; j < m; j++) Rm[n + j][i] = d->B[i * m + j];
+    }
+    for (int k = 0; k < n; k++) {
+        double v[kMaxV], nrm = 0.0, vn = 0.0;
+        for (int i = k; i < nv; i++) nrm += Rm[i][k] * Rm[i][k];
+        nrm = std::sqrt(nrm);
+        if (nrm == 0.0) return -1;
+        const double alpha = Rm[k][k] > 0 ? -nrm : nrm;
+        for (int i = 0; i < nv; i++) v[i] = i < k ? 0.0 : Rm[i][k];
+        v[k] -= alpha;
+        for (int i = k; i < nv; i++) vn += v[i] * v[i];
+        if (vn > 0.0) {
+            for (int j = 0; j < n; j++) { double s = 0.0; for (int i = k; i < nv; i++) s += v[i] * Rm[i][j]; s *= 2.0 / vn; for (int i = k; i < nv; i++) Rm[i][j] -= s * v[i]; }
+            for (int j = 0; j < nv; j++) { double s = 0.0; for (int i = k; i < nv; i++) s += Qf[j][i] * v[i]; s *= 2.0 / vn; for (int i = k; i < nv; i++) Qf[j][i] -= s * v[i]; }
+        }
+    }
+    double rmax = 0.0;
+    for (int k = 0; k < n; k++) rmax = std::fmax(rmax, std::fabs(Rm[k][k]));
+    for (int k = 0; k < n; k++) if (std::fabs(Rm[k][k]) < 1e-12 * rmax) return -1;
+    double Rti[kMaxN][kMaxN];
+    for (int c = 0; c < n; c++)
+        for (int i = 0; i < n; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) s -= Rm[j][i] * Rti[j][c];
+            Rti[i][c] = s / Rm[i][i];
+        }
+    for (int r = 0; r < nv; r++) for (int c = 0; c < n; c++) { double s = 0.0; for (int j = 0; j < n; j++) s += Qf[r][j] * Rti[j][c]; P.Ep[r][c] = s; }
+    for (int r = 0; r < nv; r++) for (int c = 0; c < m; c++) P.Zn[r][c] = Qf[r][n + c];
+    for (int i = 0; i < q; i++) for (int c = 0; c < m; c++) { double s = 0.0; for (int j = 0; j < n; j++) s += d->C[i * n + j] * P.Zn[j][c]; P.CZx[i][c] = s; }
+    for (int a = 0; a < m; a++) for (int b = 0; b < m; b++) {
+        double s = 0.0;
+        for (int i = 0; i < q; i++) for (int j = 0; j < q; j++) s += P.CZx[i][a] * d->Qss[i * q + j] * P.CZx[j][b];
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) s += P.Zn[n + i][a] * d->Rss[i * m + j] * P.Zn[n + j][b];
+        P.Hr[a][b] = s;
+    }
+    for (int a = 0; a < m; a++) for (int b = 0; b < a; b++) { const double s = 0.5 * (P.Hr[a][b] + P.Hr[b][a]); P.Hr[a][b] = P.Hr[b][a] = s; }
+    for (int r = 0; r < nv; r++) for (int c = 0; c < m; c++) P.W[r][c] = P.Zn[r][c];
+    for (int r = 0; r < q; r++) for (int c = 0; c < m; c++) P.W[nv + r][c] = P.CZx[r][c];
+    for (int i = 0; i < n; i++) { P.tlo[i] = d->xmin_ss[i]; P.thi[i] = d->xmax_ss[i]; }
+    for (int i = 0; i < m; i++) { P.tlo[n + i] = d->umin_ss[i]; P.thi[n + i] = d->umax_ss[i]; }
+    for (int i = 0; i < q; i++) { P.tlo[nv + i] = d->ymin_ss[i]; P.thi[nv + i] = d->ymax_ss[i]; }
+    for (int i = 0; i < q; i++) for (int j = 0; j < q; j++) P.Qss[i][j] = d->Qss[i * q + j];
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) P.Rss[i][j] = d->Rss[i * m + j];
+    // the reduced Hessian must be positive definite (unique target)
+    if (m == 1) { if (!(P.Hr[0][0] > 0)) return -2; }
+    else {
+        double c[kMaxM][kMaxM];
+        for (int i = 0; i < m; i++) for (int j = 0; j <= i; j++) {
+            double a = P.Hr[i][j];
+            for (int k = 0; k < j; k++) a -= c[i][k] * c[j][k];
+            if (i == j) { if (!(a > 0)) return -2; c[i][i] = std::sqrt(a); } else c[i][j] = a / c[j][j];
+        }
+    }
+    return 0;
+}
+
+static int build_problem(const mpc_lin_desc *d, DevProblem &P)
+{
+    std::memset(&P, 0, sizeof(P));
+    const int n0 = d->nx, m = d->nu, q = d->ny, nd = d->nd, nxp = d->nxp;
+    P.nx = n0; P.nu = m; P.ny = q; P.nd = nd; P.nxp = nxp; P.N = d->N;
+    P.du_form = d->du_form; P.duss_form = d->duss_form; P.y_bounded = d->y_bounded; P.estimator = d->estimator;
+    P.max_iter = d->max_iter > 0 ? d->max_iter : 100;
+    for (int i = 0; i < n0; i++) {
+        for (int j = 0; j < n0; j++) { P.A[i][j] = P.Am[i][j] = d->A[i * n0 + j]; P.Q[i][j] = d->Q[i * n0 + j]; P.Pf[i][j] = d->P[i * n0 + j]; }
+        for (int j = 0; j < m; j++) P.B[i][j] = P.Bm[i][j] = d->B[i * m + j];
+        for (int j = 0; j < nd; j++) P.Bd[i][j] = d->Bd[i * nd + j];
+        P.fxc[i] = d->fx_const ? d->fx_const[i] : 0.0;
+        P.zlo_m[i] = P.zlo_e[i] = d->xmin[i]; P.zhi_m[i] = P.zhi_e[i] = d->xmax[i];
+    }
+    for (int i = 0; i < m; i++) {
+        for (int j = 0; j < m; j++) P.R[i][j] = d->R[i * m + j];
+        P.ulo[i] = d->umin[i]; P.uhi[i] = d->umax[i];
+    }
+    if (d->du_form) {   // z = [x; u_prev]  (Control_Calc.py:163-166,180-181)
+        for (int i = 0; i < m; i++) {
+            P.B[n0 + i][i] = 1.0;
+            for (int j = 0; j < m; j++) { P.Q[n0 + i][n0 + j] = d->R[i * m + j]; P.M[n0 + i][j] = -d->R[i * m + j]; }
+            P.zlo_m[n0 + i] = P.zlo_e[n0 + i] = -INFINITY; P.zhi_m[n0 + i] = P.zhi_e[n0 + i] = INFINITY;
+        }
+    }
+    for (int i = 0; i < q; i++) {
+        for (int j = 0; j < n0; j++) P.Cm[i][j] = d->C[i * n0 + j];
+        for (int j = 0; j < nd; j++) P.Cd[i][j] = d->Cd[i * nd + j];
+        for (int j = 0; j < nxp; j++) P.Cp[i][j] = d->Cp[i * nxp + j];
+        P.fyc[i] = d->fy_const ? d->fy_const[i] : 0.0;
+        P.ymin[i] = d->ymin[i]; P.ymax[i] = d->ymax[i];
+        P.ymap_idx[i] = 0; P.ymap_scale[i] = 1.0;
+    }
+    for (int i = 0; i < nxp; i++) {
+        for (int j = 0; j < nxp; j++) P.Ap[i][j] = d->Ap[i * nxp + j];
+        for (int j = 0; j < m; j++) P.Bp[i][j] = d->Bp[i * m + j];
+    }
+    if (d->y_bounded) {
+        for (int i = 0; i < q; i++) {
+            int cnt = 0;
+            for (int j = 0; j < n0; j++) if (d->C[i * n0 + j] != 0.0) { P.ymap_idx[i] = j; P.ymap_scale[i] = d->C[i * n0 + j]; cnt++; }
+            if (cnt != 1) return fail(-3, "output bound row %d of C has %d non-zero entries: general output rows are not implemented", i, cnt);
+        }
+    }
+    P.has_dsat = (d->dmin && d->dmax) ? 1 : 0;
+    for (int i = 0; i < nd; i++) { P.dmin[i] = d->dmin ? d->dmin[i] : -INFINITY; P.dmax[i] = d->dmax ? d->dmax[i] : INFINITY; }
+    const int ne = n0 + nd;
+    for (int i = 0; i < ne; i++) P.Aa[i][i] = 1.0;
+    for (int i = 0; i < n0; i++) { for (int j = 0; j < n0; j++) P.Aa[i][j] = d->A[i * n0 + j]; for (int j = 0; j < nd; j++) P.Aa[i][n0 + j] = d->Bd[i * nd + j]; }
+    for (int i = 0; i < q; i++) { for (int j = 0; j < n0; j++) P.Ca[i][j] = d->C[i * n0 + j]; for (int j = 0; j < nd; j++) P.Ca[i][n0 + j] = d->Cd[i * nd + j]; }
+    if (d->estimator == MPC_EST_KALMAN) {
+        if (!d->Q_kf || !d->R_kf) return fail(-3, "MPC_EST_KALMAN needs Q_kf and R_kf");
+        for (int i = 0; i < ne; i++) for (int j = 0; j < ne; j++) P.Qkf[i][j] = d->Q_kf[i * ne + j];
+        for (int i = 0; i < q; i++) for (int j = 0; j < q; j++) P.Rkf[i][j] = d->R_kf[i * q + j];
+    } else if (d->estimator == MPC_EST_FIXED_GAIN) {
+        if (!d->K) return fail(-3, "MPC_EST_FIXED_GAIN needs K");
+        for (int i = 0; i < ne; i++) for (int j = 0; j < q; j++) P.Kfix[i][j] = d->K[i * q + j];
+    }
+    const int rc = build_target(d, P);
+    if (rc == -1) return fail(-4, "[A-I, B] is rank deficient: no steady state for arbitrary disturbances");
+    if (rc == -2) return fail(-4, "reduced Hessian of the target problem is not positive definite");
+    return 0;
+}
+
+extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
+{
+    if (!d || !out) return fail(-1, "null argument");
+    *out = nullptr;
+    const int ns = d->nx + (d->du_form ? d->nu : 0);
+    if (d->nx < 1 || d->nu < 1 || ns > kMaxN || d->nu > kMaxM || d->ny > kMaxY || d->nd > kMaxD || d->nxp > kMaxN || d->N < 2 || d->N > 512)
+        return fail(-2, "dimensions out of range (stage state <= %d, nu <= %d, ny <= %d, nd <= %d, 2 <= N <= 512)", kMaxN, kMaxM, kMaxY, kMaxD);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(-11, "no HIP device: the MI355X path is required (there is no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev) return fail(-11, "device %d out of range (have %d)", d->device, ndev);
+    mpc_handle *h = new mpc_handle();
+    bool found = false;
+#define MPC_TRY_DIM(NX, NU, NY, ND, NXP, DU)                                                                  \
+    if (!found && d->nx == NX && d->nu == NU && d->ny == NY && d->nd == ND && d->nxp == NXP && (d->du_form != 0) == (DU != 0)) { \
+        h->L = make_launchers<NX, NU, NY, ND, NXP, (DU != 0)>();                                              \
+        found = true;                                                                                         \
+    }
+    MPC_DIM_LIST(MPC_TRY_DIM)
+#undef MPC_TRY_DIM
+    if (!found) {
+        delete h;
+        return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, d->du_form, mpc_build_info());
+    }
+    int rc = build_problem(d, h->hp);
+    if (rc != 0) { delete h; return rc; }
+    h->device = d->device;
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->dp, sizeof(DevProblem));
+    if (e == hipSuccess) e = hipMemcpy(h->dp, &h->hp, sizeof(DevProblem), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { const int c = fail(-10, "device set-up failed: %s", hipGetErrorString(e)); mpc_destroy(h); return c; }
+    *out = h;
+    return 0;
+}
+
+extern "C" void mpc_destroy(mpc_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->sch, &h->logs, &h->logi}) b->release();
+    if (h->dp) (void)hipFree(h->dp);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char *mpc_build_info(void)
+{
+    static std::string s;
+    if (s.empty()) {
+        s = "gfx950;mapping=instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
+#define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU ",";
+        MPC_DIM_LIST(MPC_INFO_DIM)
+#undef MPC_INFO_DIM
+        s.pop_back();
+    }
+    return s.c_str();
+}
+
+extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
+{
+    if (!h || !name) return fail(-1, "null argument");
+    if (!std::strcmp(name, "steps_per_launch")) { h->steps_per_launch = value >= 1 ? (int)value : 1; return 0; }
+    return fail(-1, "unknown option '%s'", name);
+}
+
+extern "C" void *mpc_stream(mpc_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+extern "C" float mpc_last_kernel_ms(mpc_handle *h, int32_t *n_launches)
+{
+    if (!h || !h->timed) return -1.0f;
+    float ms = -1.0f;
+    (void)hipSetDevice(h->device);
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0f;
+    if (n_launches) *n_launches = h->n_launches;
+    return ms;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-call solvers with host buffers
+// ---------------------------------------------------------------------------------------------------
+static int ensure_ws(mpc_handle *h, size_t Bs)
+{
+    return h->ws.ensure((size_t)h->L.ws_rows * h->hp.N * Bs * sizeof(double));
+}
+
+extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
+                             const double *dhat, const double *u_prev, const double *px, const double *py,
+                             double *w_out, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
+                             double *kkt_res)
+{
+    if (!h || B < 1 || !xhat || !xs || !us || !u_prev || !u_out || !xnext_out || !status) return fail(-1, "null argument");
+    if (px || py) return fail(-6, "time-varying px/py (def_px/def_py) are not implemented");
+    const DevProblem &P = h->hp;
+    if (P.nd > 0 && !dhat) return fail(-1, "dhat is required when nd > 0");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t Bs = pad64(B);
+    const int nx = P.nx, nu = P.nu, nd = P.nd;
+    // layout of the scratch buffer (doubles): in: xhat xs us dhat u_prev | out: u x1 res | ints: status iters
+    const size_t n_in = (size_t)(2 * nx + 2 * nu + nd) * Bs, n_out = (size_t)(nu + nx + 3) * Bs;
+    const size_t bytes = (n_in + n_out) * sizeof(double) + 2 * Bs * sizeof(int32_t);
+    if (h->scratch.ensure(bytes)) return -10;
+    if (ensure_ws(h, Bs)) return -10;
+    std::vector<double> stage(n_in + n_out);
+    double *sp = stage.data();
+    to_soa(xhat, B, nx, Bs, sp); to_soa(xs, B, nx, Bs, sp + (size_t)nx * Bs); to_soa(us, B, nu, Bs, sp + (size_t)2 * nx * Bs);
+    if (nd) to_soa(dhat, B, nd, Bs, sp + (size_t)(2 * nx + nu) * Bs);
+    to_soa(u_prev, B, nu, Bs, sp + (size_t)(2 * nx + nu + nd) * Bs);
+    double *d = (double *)h->scratch.p;
+    HIP_TRY(hipMemcpyAsync(d, sp, n_in * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    OcpArgs a;
+    a.xhat = d; a.xs = d + (size_t)nx * Bs; a.us = d + (size_t)2 * nx * Bs; a.dhat = d + (size_t)(2 * nx + nu) * Bs;
+    a.u_prev = d + (size_t)(2 * nx + nu + nd) * Bs;
+    a.u_out = d + n_in; a.xnext_out = a.u_out + (size_t)nu * Bs; a.res = a.xnext_out + (size_t)nx * Bs;
+    a.status = (int32_t *)(d + n_in + n_out); a.iters = a.status + Bs;
+    a.ws = (double *)h->ws.p; a.B = B; a.Bs = Bs;
+    HIP_TRY(hipMemsetAsync(a.u_out, 0, n_out * sizeof(double), h->stream));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    h->L.ocp(h->dp, a, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true; h->n_launches = 1;
+    std::vector<int32_t> ist(2 * Bs);
+    HIP_TRY(hipMemcpyAsync(sp + n_in, a.u_out, n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ist.data(), a.status, 2 * Bs * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const double *o = sp + n_in;
+    for (int b = 0; b < B; b++) {
+        status[b] = ist[b];
+        if (iters) iters[b] = ist[Bs + b];
+        if (ist[b] != kInfeasible) {
+            for (int i = 0; i < nu; i++) u_out[(size_t)b * nu + i] = o[(size_t)i * Bs + b];
+            for (int i = 0; i < nx; i++) xnext_out[(size_t)b * nx + i] = o[(size_t)(nu + i) * Bs + b];
+        }
+        if (kkt_res) for (int i = 0; i < 3; i++) kkt_res[(size_t)b * 3 + i] = o[(size_t)(nu + nx + i) * Bs + b];
+    }
+    if (w_out) {   // primal trajectory in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) from the workspace
+        const int N = P.N, ns = nx + (P.du_form ? nu : 0), nv = ns + nu, nxu = nx + nu;
+        std::vector<double> wsh((size_t)nv * N * Bs);
+        HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));   // rows U then Z
+        for (int b = 0; b < B; b++) {
+            if (ist[b] == kInfeasible) continue;
+            double *w = w_out + (size_t)b * (nx * (N + 1) + nu * N);
+            for (int i = 0; i < nx; i++) w[i] = xhat[(size_t)b * nx + i];
+            for (int k = 0; k < N; k++) {
+                for (int i = 0; i < nu; i++) w[k * nxu + nx + i] = wsh[((size_t)i * N + k) * Bs + b];
+                for (int i = 0; i < nx; i++) w[(k + 1) * nxu + i] = wsh[((size_t)(nu + i) * N + k) * Bs + b];
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, const double *ysp, const double *xsp,
+                                const double *dhat, const double *us_prev, double *xs, double *us, double *ys,
+                                int32_t *status, int32_t *iters)
+{
+    (void)xsp;   // the reference passes xsp but Fss_obj never uses dx for matrix-defined costs (Utilities.py:299-313)
+    if (!h || B < 1 || !usp || !ysp || !us_prev || !xs || !us || !ys || !status) return fail(-1, "null argument");
+    const DevProblem &P = h->hp;
+    if (P.nd > 0 && !dhat) return fail(-1, "dhat is required when nd > 0");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t Bs = pad64(B);
+    const int nx = P.nx, nu = P.nu, ny = P.ny, nd = P.nd;
+    const size_t n_in = (size_t)(2 * nu + ny + nd) * Bs, n_out = (size_t)(nx + nu + ny) * Bs;
+    if (h->scratch.ensure((n_in + n_out) * sizeof(double) + 2 * Bs * sizeof(int32_t))) return -10;
+    std::vector<double> stage(n_in + n_out);
+    double *sp = stage.data();
+    to_soa(usp, B, nu, Bs, sp); to_soa(ysp, B, ny, Bs, sp + (size_t)nu * Bs);
+    if (nd) to_soa(dhat, B, nd, Bs, sp + (size_t)(nu + ny) * Bs);
+    to_soa(us_prev, B, nu, Bs, sp + (size_t)(nu + ny + nd) * Bs);
+    double *d = (double *)h->scratch.p;
+    HIP_TRY(hipMemcpyAsync(d, sp, n_in * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    TargetArgs a;
+    a.usp = d; a.ysp = d + (size_t)nu * Bs; a.dhat = d + (size_t)(nu + ny) * Bs; a.us_prev = d + (size_t)(nu + ny + nd) * Bs;
+    a.xs = d + n_in; a.us = a.xs + (size_t)nx * Bs; a.ys = a.us + (size_t)nu * Bs;
+    a.status = (int32_t *)(d + n_in + n_out); a.iters = a.status + Bs; a.B = B; a.Bs = Bs;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    h->L.target(h->dp, a, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true; h->n_launches = 1;
+    std::vector<int32_t> ist(2 * Bs);
+    HIP_TRY(hipMemcpyAsync(sp + n_in, a.xs, n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ist.data(), a.status, 2 * Bs * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    from_soa(sp + n_in, B, nx, Bs, xs); from_soa(sp + n_in + (size_t)nx * Bs, B, nu, Bs, us);
+    from_soa(sp + n_in + (size_t)(nx + nu) * Bs, B, ny, Bs, ys);
+    for (int b = 0; b < B; b++) { status[b] = ist[b]; if (iters) iters[b] = ist[Bs + b]; }
+    return 0;
+}
+
+extern "C" int mpc_kf_update(mpc_handle *h, int32_t B, const double *y, double *xi, double *Pk)
+{
+    if (!h || B < 1 || !y || !xi) return fail(-1, "null argument");
+    const DevProblem &P = h->hp;
+    if (P.estimator == MPC_EST_NONE) return fail(-7, "the problem has no estimator");
+    if (P.estimator == MPC_EST_KALMAN && !Pk) return fail(-1, "P is required for MPC_EST_KALMAN");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t Bs = pad64(B);
+    const int ne = P.nx + P.nd, ny = P.ny;
+    const bool kal = P.estimator == MPC_EST_KALMAN;
+    const size_t n_all = (size_t)(ny + ne + (kal ? ne * ne : 0)) * Bs;
+    if (h->scratch.ensure(n_all * sizeof(double))) return -10;
+    std::vector<double> stage(n_all);
+    double *sp = stage.data();
+    to_soa(y, B, ny, Bs, sp); to_soa(xi, B, ne, Bs, sp + (size_t)ny * Bs);
+    if (kal) to_soa(Pk, B, ne * ne, Bs, sp + (size_t)(ny + ne) * Bs);
+    double *d = (double *)h->scratch.p;
+    HIP_TRY(hipMemcpyAsync(d, sp, n_all * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    KfArgs a{d, d + (size_t)ny * Bs, d + (size_t)(ny + ne) * Bs, B, Bs};
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    h->L.kf(h->dp, a, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true; h->n_launches = 1;
+    HIP_TRY(hipMemcpyAsync(sp, d, n_all * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    from_soa(sp + (size_t)ny * Bs, B, ne, Bs, xi);
+    if (kal) from_soa(sp + (size_t)(ny + ne) * Bs, B, ne * ne, Bs, Pk);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// resident closed loop
+// ---------------------------------------------------------------------------------------------------
+static const char *kLogD[] = {"U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT"};
+static const char *kLogI[] = {"STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"};
+
+extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32_t log_level)
+{
+    if (!h || B < 1 || max_steps < 1) return fail(-1, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const DevProblem &P = h->hp;
+    const size_t Bs = pad64(B);
+    const int ne = P.nx + P.nd;
+    if (h->st_x.ensure((size_t)P.nxp * Bs * 8) || h->st_xhat.ensure((size_t)P.nx * Bs * 8) || h->st_dhat.ensure((size_t)(P.nd ? P.nd : 1) * Bs * 8) ||
+        h->st_P.ensure((size_t)ne * ne * Bs * 8) || h->st_u.ensure((size_t)P.nu * Bs * 8) || h->st_xs.ensure((size_t)P.nx * Bs * 8) ||
+        h->st_us.ensure((size_t)P.nu * Bs * 8))
+        return -10;
+    if (ensure_ws(h, Bs)) return -10;
+    const int sdim = P.ny + P.nu + P.nxp + P.ny;   // ysp usp pxp pyp
+    if (h->sch.ensure((size_t)max_steps * sdim * 8)) return -10;
+    h->log_off.clear();
+    size_t off = 0;
+    const int dims[] = {P.nu, P.nx, P.nx, P.nu, P.ny, P.nxp, P.nd};
+    for (int i = 0; i < 7; i++) {
+        const bool on = log_level >= MPC_LOG_ALL || (log_level >= MPC_LOG_U && i == 0);
+        if (on && dims[i] > 0) { h->log_off[kLogD[i]] = {off, dims[i]}; off += (size_t)max_steps * dims[i] * Bs; }
+    }
+    if (h->logs.ensure(off ? off * 8 : 8)) return -10;
+    if (log_level >= MPC_LOG_U) {
+        for (int i = 0; i < 4; i++) h->log_off[kLogI[i]] = {(size_t)i * max_steps * Bs, 0};
+        if (h->logi.ensure((size_t)4 * max_steps * Bs * 4)) return -10;
+    }
+    h->B = B; h->Bs = Bs; h->max_steps = max_steps; h->log_level = log_level; h->sched_steps = 0;
+    return 0;
+}
+
+static int up_state(mpc_handle *h, DevBuf &buf, const double *src, int d)
+{
+    if (!src || d == 0) return 0;
+    std::vector<double> st((size_t)d * h->Bs);
+    to_soa(src, h->B, d, h->Bs, st.data());
+    HIP_TRY(hipMemcpyAsync(buf.p, st.data(), st.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+static int down_state(mpc_handle *h, DevBuf &buf, double *dst, int d)
+{
+    if (!dst || d == 0) return 0;
+    std::vector<double> st((size_t)d * h->Bs);
+    HIP_TRY(hipMemcpyAsync(st.data(), buf.p, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    from_soa(st.data(), h->B, d, h->Bs, dst);
+    return 0;
+}
+
+extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double *xhat, const double *dhat,
+                                  const double *Pk, const double *u, const double *xs, const double *us)
+{
+    if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
+    HIP_TRY(hipSetDevice(h->device));
+    const DevProblem &P = h->hp;
+    const int ne = P.nx + P.nd;
+    if (P.estimator == MPC_EST_KALMAN && !Pk) {
+        // a fresh filter needs a covariance; refuse to guess
+        // (the reference falls back to zeros when P0 is absent, MPC_code.py:455-458: pass zeros explicitly)
+    }
+    int rc = 0;
+    rc |= up_state(h, h->st_x, x_p, P.nxp); rc |= up_state(h, h->st_xhat, xhat, P.nx); rc |= up_state(h, h->st_dhat, dhat, P.nd);
+    rc |= up_state(h, h->st_P, Pk, ne * ne); rc |= up_state(h, h->st_u, u, P.nu); rc |= up_state(h, h->st_xs, xs, P.nx);
+    rc |= up_state(h, h->st_us, us, P.nu);
+    return rc ? -10 : 0;
+}
+
+extern "C" int mpc_loop_get_state(mpc_handle *h, double *x_p, double *xhat, double *dhat, double *Pk, double *u,
+                                  double *xs, double *us)
+{
+    if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
+    HIP_TRY(hipSetDevice(h->device));
+    const DevProblem &P = h->hp;
+    const int ne = P.nx + P.nd;
+    int rc = 0;
+    rc |= down_state(h, h->st_x, x_p, P.nxp); rc |= down_state(h, h->st_xhat, xhat, P.nx); rc |= down_state(h, h->st_dhat, dhat, P.nd);
+    rc |= down_state(h, h->st_P, Pk, ne * ne); rc |= down_state(h, h->st_u, u, P.nu); rc |= down_state(h, h->st_xs, xs, P.nx);
+    rc |= down_state(h, h->st_us, us, P.nu);
+    return rc ? -10 : 0;
+}
+
+extern "C" int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double *ysp, const double *usp,
+                                     const double *xsp, const double *pxp, const double *pyp)
+{
+    (void)xsp;
+    if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
+    if (nsteps < 1 || nsteps > h->max_steps) return fail(-1, "nsteps %d exceeds the allocated %d", nsteps, h->max_steps);
+    if (!ysp || !usp) return fail(-1, "ysp and usp are required");
+    HIP_TRY(hipSetDevice(h->device));
+    const DevProblem &P = h->hp;
+    const size_t ms = h->max_steps;
+    std::vector<double> st(ms * (P.ny + P.nu + P.nxp + P.ny), 0.0);
+    double *a = st.data(), *b = a + ms * P.ny, *c = b + ms * P.nu, *e = c + ms * P.nxp;
+    std::memcpy(a, ysp, sizeof(double) * nsteps * P.ny);
+    std::memcpy(b, usp, sizeof(double) * nsteps * P.nu);
+    if (pxp) std::memcpy(c, pxp, sizeof(double) * nsteps * P.nxp);
+    if (pyp) std::memcpy(e, pyp, sizeof(double) * nsteps * P.ny);
+    HIP_TRY(hipMemcpy(h->sch.p, st.data(), st.size() * 8, hipMemcpyHostToDevice));
+    h->sched_steps = nsteps;
+    return 0;
+}
+
+extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
+{
+    if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
+    if (k0 < 0 || nsteps < 1 || k0 + nsteps > h->sched_steps) return fail(-1, "steps [%d,%d) outside the schedule of %d steps", k0, k0 + nsteps, h->sched_steps);
+    HIP_TRY(hipSetDevice(h->device));
+    const DevProblem &P = h->hp;
+    const size_t Bs = h->Bs, ms = h->max_steps;
+    const double *sch = (const double *)h->sch.p;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    int launches = 0;
+    for (int k = k0; k < k0 + nsteps; k += h->steps_per_launch) {
+        const int n = std::min(h->steps_per_launch, k0 + nsteps - k);
+        LoopArgs a;
+        a.x = (double *)h->st_x.p; a.xhat = (double *)h->st_xhat.p; a.dhat = (double *)h->st_dhat.p; a.Pk = (double *)h->st_P.p;
+        a.u = (double *)h->st_u.p; a.xs = (double *)h->st_xs.p; a.us = (double *)h->st_us.p;
+        a.ysp = sch + (size_t)k * P.ny; a.usp = sch + ms * P.ny + (size_t)k * P.nu;
+        a.pxp = sch + ms * (P.ny + P.nu) + (size_t)k * P.nxp; a.pyp = sch + ms * (P.ny + P.nu + P.nxp) + (size_t)k * P.ny;
+        auto dl = [&](const char *nm) -> double * {
+            auto it = h->log_off.find(nm);
+            if (it == h->log_off.end()) return nullptr;
+            return (double *)h->logs.p + it->second.first + (size_t)k * it->second.second * Bs;
+        };
+        a.U = dl("U"); a.XHAT = dl("X_HAT"); a.XS = dl("XS"); a.US = dl("US"); a.YS = dl("YS"); a.XP = dl("Xp"); a.DHAT = dl("D_HAT");
+        if (h->log_level >= MPC_LOG_U) {
+            int32_t *li = (int32_t *)h->logi.p;
+            a.st_dyn = li + (size_t)k * Bs; a.st_ss = li + ms * Bs + (size_t)k * Bs; a.it_dyn = li + 2 * ms * Bs + (size_t)k * Bs; a.it_ss = li + 3 * ms * Bs + (size_t)k * Bs;
+        } else a.st_dyn = a.st_ss = a.it_dyn = a.it_ss = nullptr;
+        a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
+        h->L.loop(h->dp, a, h->stream);
+        launches++;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true; h->n_launches = launches; h->last_k0 = k0; h->last_n = nsteps;
+    return 0;
+}
+
+extern "C" int mpc_loop_sync(mpc_handle *h)
+{
+    if (!h) return fail(-1, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int mpc_loop_get_log(mpc_handle *h, const char *name, void *out)
+{
+    if (!h || !name || !out) return fail(-1, "null argument");
+    auto it = h->log_off.find(name);
+    if (it == h->log_off.end()) return fail(-8, "log '%s' was not enabled in mpc_loop_alloc", name);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t Bs = h->Bs; const int B = h->B, ns = h->sched_steps;
+    if (it->second.second > 0) {
+        const int d = it->second.second;
+        std::vector<double> st((size_t)ns * d * Bs);
+        HIP_TRY(hipMemcpy(st.data(), (double *)h->logs.p + it->second.first, st.size() * 8, hipMemcpyDeviceToHost));
+        double *o = (double *)out;
+        for (int k = 0; k < ns; k++) from_soa(st.data() + (size_t)k * d * Bs, B, d, Bs, o + (size_t)k * B * d);
+    } else {
+        std::vector<int32_t> st((size_t)ns * Bs);
+        HIP_TRY(hipMemcpy(st.data(), (int32_t *)h->logi.p + it->second.first, st.size() * 4, hipMemcpyDeviceToHost));
+        int32_t *o = (int32_t *)out;
+        for (int k = 0; k < ns; k++) for (int b = 0; b < B; b++) o[(size_t)k * B + b] = st[(size_t)k * Bs + b];
+    }
+    return 0;
+}
+
+extern "C" void *mpc_dev_ptr(mpc_handle *h, const char *name, int64_t *bpad)
+{
+    if (!h || !name) return nullptr;
+    if (bpad) *bpad = (int64_t)h->Bs;
+    const std::string n(name);
+    if (n == "x_p") return h->st_x.p;
+    if (n == "xhat") return h->st_xhat.p;
+    if (n == "dhat") return h->st_dhat.p;
+    if (n == "P") return h->st_P.p;
+    if (n == "u") return h->st_u.p;
+    if (n == "xs") return h->st_xs.p;
+    if (n == "us") return h->st_us.p;
+    auto it = h->log_off.find(n);
+    if (it == h->log_off.end()) return nullptr;
+    if (it->second.second > 0) return (double *)h->logs.p + it->second.first;
+    return (int32_t *)h->logi.p + it->second.first;
+}
+
+extern "C" int mpc_pack_u(mpc_handle *h, void *dst_dev)
+{
+    if (!h || h->B == 0 || !dst_dev) return fail(-1, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(pack_u_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (const double *)h->st_u.p, (double *)dst_dev, h->B, h->Bs, h->hp.nu);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mpc_pack_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, void *dst_dev)
+{
+    if (!h || h->B == 0 || !name || !dst_dev) return fail(-1, "bad argument");
+    auto it = h->log_off.find(name);
+    if (it == h->log_off.end() || it->second.second == 0) return fail(-8, "float64 log '%s' was not enabled in mpc_loop_alloc", name);
+    if (k0 < 0 || nsteps < 1 || k0 + nsteps > h->max_steps) return fail(-1, "steps out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t row = (size_t)it->second.second * h->Bs;
+    HIP_TRY(hipMemcpyAsync(dst_dev, (double *)h->logs.p + it->second.first + (size_t)k0 * row, (size_t)nsteps * row * 8, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+extern "C" int mpc_closed_loop(mpc_handle *h, int32_t B, int32_t nsteps, double *x_p, double *xhat, double *dhat,
+                               double *Pk, double *u, double *xs, double *us, const double *ysp, const double *usp,
+                               const double *xsp, const double *pxp, const double *pyp, double *U_log)
+{
+    if (!h) return fail(-1, "null handle");
+    int rc;
+    if (h->B != B || h->max_steps < nsteps || (U_log && h->log_level < MPC_LOG_U))
+        if ((rc = mpc_loop_alloc(h, B, nsteps, U_log ? MPC_LOG_U : MPC_LOG_NONE))) return rc;
+    if ((rc = mpc_loop_set_state(h, x_p, xhat, dhat, Pk, u, xs, us))) return rc;
+    if ((rc = mpc_loop_set_schedule(h, nsteps, ysp, usp, xsp, pxp, pyp))) return rc;
+    if ((rc = mpc_loop_run(h, 0, nsteps))) return rc;
+    if ((rc = mpc_loop_sync(h))) return rc;
+    if ((rc = mpc_loop_get_state(h, x_p, xhat, dhat, Pk, u, xs, us))) return rc;
+    if (U_log && (rc = mpc_loop_get_log(h, "U", U_log))) return rc;
+    return 0;
+}

@@ -1,0 +1,71 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+REF = "/root/reference"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def gpu_available():
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+    except OSError:
+        return False
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import mpc_code_amd
+    return mpc_code_amd
+
+
+@pytest.fixture(scope="session")
+def cstr(pkg):
+    return pkg.load_problem(pkg.example_path("cstr_lmpc.py"))
+
+
+@pytest.fixture(scope="session")
+def wb(pkg):
+    return pkg.load_problem(pkg.example_path("wood_berry_lmpc.py"))
+
+
+@pytest.fixture(scope="session")
+def oracle_c():
+    import oracle_c as oc
+    oc.build()
+    return oc
+
+
+@pytest.fixture(scope="session")
+def solver_factory(pkg):
+    """Solver on cuda:0 - the HIP path, loudly required for -m gpu tests."""
+    from mpc_code_amd import capi
+    made = []
+
+    def make(problem):
+        s = capi.Solver(problem, device=0)
+        made.append(s)
+        return s
+
+    yield make
+    for s in made:
+        s.close()
+
+
+def bench_x0(B, seed=20250614):
+    """Initial states of BASELINE.md section 3: x0 ~ U([-0.5,0.5] x [-8,8] x [-5,5])."""
+    rng = np.random.default_rng(seed)
+    return rng.uniform([-0.5, -8.0, -5.0], [0.5, 8.0, 5.0], size=(B, 3))
