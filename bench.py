@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: closed-loop MPC steps/s over a batch, LMPC-CSTR, N=50 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one closed-loop step (estimator + target + OCP + plant, reference MPC_code.py:485-827)
+of every instance of the per-GPU batch.  Workload at N=1: BASELINE.json configs[1] - the shipped
+Ex_LMPC_CSTR problem, batch 4096 initial states drawn as BASELINE.md section 3 says.  For N>1 the driver
+launches this file once per GPU under torch.distributed.run; each rank owns its own 4096 instances
+(weak scaling), the only exchange is the all-gather of the optimal controls U at the end of the
+timed region (RCCL).  PyTorch is used for rendezvous, barrier, the collective and device-wide
+synchronisation only; the solver is libmpc_amd.so through ctypes.
+
+The timed region holds exactly K steps from t = 0 with all inputs resident in HBM; the W warm-up
+steps run before it from the same initial state, which is then restored (untimed).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the fused closed-loop kernel against HBM with the
+algorithmic bytes of DESIGN.md section 6 (this path is latency / fp64-issue bound, not HBM bound);
+`cpu_baseline` times oracle/mpc_oracle.c (a C port of the same algorithm - the reference's own
+CasADi/IPOPT path cannot run here) on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 4096
+SEED = 20250614
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def alg_bytes_per_step(p) -> int:
+    """Algorithmic HBM bytes per closed-loop step per instance (SURVEY.md 8d without warm start)."""
+    ne = p.nx + p.nd
+    n_in = p.nxp + p.nx + p.nd + (ne * ne if p.estimator == "kal" else 0) + p.nu + (p.ny + p.nu + p.nx) + (p.nx + p.nu)
+    n_out = p.nxp + p.nx + p.nd + (ne * ne if p.estimator == "kal" else 0) + p.nu + p.nx + p.nu + p.ny
+    return 8 * (n_in + n_out)
+
+
+def cpu_baseline(problem, x0, target_seconds=12.0):
+    """Time the oracle's C restatement on the host cores over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    oc = oracle_c.OracleC(problem)
+    nthr = oc.max_threads()
+    nb, ns = min(64, len(x0)), 10
+    t0 = time.perf_counter(); oc.closed_loop(ns, x0[:nb], x0[:nb], logs=False); t1 = time.perf_counter() - t0
+    rate = nb * ns / max(t1, 1e-6)
+    ns2 = 25
+    nb2 = int(min(len(x0), max(64, target_seconds * rate / ns2)))
+    t0 = time.perf_counter(); oc.closed_loop(ns2, x0[:nb2], x0[:nb2], logs=False); t2 = time.perf_counter() - t0
+    return dict(value=nb2 * ns2 / t2, unit="steps/s", cores=nthr, kind="port",
+                sample=f"{nb2} instances x {ns2} closed-loop steps from t=0 of the same workload, oracle/mpc_oracle.c "
+                       f"(C Riccati-PDIP, gcc -O2 -fopenmp, {nthr} threads, {t2:.1f} s); the reference's CasADi/IPOPT path is not installable")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="instances per GPU (default: BASELINE configs[1])")
+    ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    K, W, B = args.steps, args.warmup, args.batch
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import mpc_code_amd as m
+    from mpc_code_amd import capi
+    prob = m.load_problem(m.example_path("cstr_lmpc.py"))
+    capi.build_library()
+    solver = capi.Solver(prob, device=local_rank)
+    solver.set_option("steps_per_launch", args.steps_per_launch)
+
+    # synthetic initial states: the same generator for the whole job, each rank takes its block
+    rng = np.random.default_rng(SEED)
+    x0_all = rng.uniform([-0.5, -8.0, -5.0], [0.5, 8.0, 5.0], size=(B * world, 3))
+    x0 = x0_all[rank * B:(rank + 1) * B]
+    nsched = max(K, W, 1)
+    sched = prob.schedules(nsched)
+    solver.loop_alloc(B, nsched, capi.LOG_U)
+    solver.loop_set_schedule(sched)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # gather buffers for U: [K][nu][Bpad] per rank
+    _, bpad = solver.dev_ptr("U")
+    send = torch.empty((K, prob.nu, bpad), dtype=torch.float64, device="cuda")
+    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    # warm-up (untimed), then restore the initial state
+    solver.loop_set_state(x0, x0)
+    if W > 0:
+        solver.loop_run(0, W)
+        solver.loop_sync()
+    if world > 1:
+        dist.all_gather_into_tensor(recv, send)
+    solver.loop_set_state(x0, x0)
+
+    barrier()
+    t0 = time.perf_counter()
+    solver.loop_run(0, K)
+    solver.pack_log("U", 0, K, send.data_ptr())
+    solver.loop_sync()
+    if world > 1:
+        dist.all_gather_into_tensor(recv, send)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kernel_ms, n_launch = solver.last_kernel_ms()
+
+    if rank == 0:
+        st = solver.loop_get_log("STATUS_DYN")[:K]
+        it = solver.loop_get_log("ITERS_DYN")[:K]
+        steps_total = B * world * K
+        per_launch_s = kernel_ms * 1e-3 / max(n_launch, 1)
+        steps_per_launch = B * K / max(n_launch, 1)
+        ab = alg_bytes_per_step(prob)
+        achieved = ab * steps_per_launch / per_launch_s / 1e9
+        out = {
+            "metric": "closed-loop MPC steps/sec over batch, LMPC-CSTR N=50",
+            "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Ex_LMPC_CSTR (nx=3,nu=2,ny=3,nd=3), N=50, batch=%d per GPU, x0~U([-0.5,0.5]x[-8,8]x[-5,5]) seed %d, "
+                                   "closed loop from t=0: Kalman filter + target QP + OCP (Riccati-PDIP) + plant per step" % (B, SEED),
+                       "batch_per_gpu": B, "horizon": prob.N, "steps_per_launch": args.steps_per_launch,
+                       "parallelism": "instances sharded over %d GPU(s), all-gather of U at the end" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "loop_kernel<3,2,3,3,3,false>", "launches": n_launch,
+                         "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
+                         "note": "latency / fp64-issue bound by construction (SURVEY.md 8d); the workspace traffic stays in L2/MALL"},
+            "solver": {"mean_iters": float(it[st != 2].mean()) if (st != 2).any() else None, "max_iters": int(it.max()),
+                       "frac_solved": float((st == 0).mean()), "frac_maxiter": float((st == 1).mean()),
+                       "frac_infeasible_hold": float((st == 2).mean())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, x0)
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""The closed loop of the reference's ``MPC_code.py:485-875`` over a batch of instances, on the GPU.
+
+``run_closed_loop`` is what "python MPC_code.py" does after its set-up section, for B instances
+that share the Ex-file and differ in their initial state; the result arrays carry the reference's
+names (``MPC_code.py:877-895``): ``U, X_HAT, XS, US, YS, Xp, D_HAT`` plus the solver status /
+iteration words per step.  Two modes:
+
+* ``fused=True``  - ``mpc_loop_run``: one kernel launch advances all instances one or more steps
+  (estimator, target, OCP, plant fused), state resident in HBM.
+* ``fused=False`` - the reference's own call sequence, one C-ABI call per solver per step
+  (``mpc_kf_update``, ``mpc_target_solve``, ``mpc_ocp_solve``) with the glue of ``MPC_code.py:524-816``
+  in NumPy.  Slower (host round trips) but it is the literal drop-in for the three call sites.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import capi
+from .shard import allgather_rows, shard_bounds
+
+
+def _bcast(v, B, d):
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(-1, d) if np.ndim(v) > 1 else np.asarray(v, dtype=np.float64), (B, d)))
+
+
+def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[capi.Solver] = None,
+                    fused: bool = True, device: int = 0, gather: bool = False, total: Optional[int] = None) -> Dict[str, np.ndarray]:
+    p = problem
+    nsteps = p.Nsim if nsteps is None else int(nsteps)
+    x0_p = p.x0_p[None] if x0_p is None else np.atleast_2d(x0_p)
+    x0_m = p.x0_m[None] if x0_m is None else np.atleast_2d(x0_m)
+    B = x0_p.shape[0]
+    own = solver is None
+    s = capi.Solver(p, device=device) if own else solver
+    try:
+        sched = p.schedules(nsteps)
+        if fused:
+            s.loop_alloc(B, nsteps, capi.LOG_ALL)
+            s.loop_set_state(x0_p, x0_m)
+            s.loop_set_schedule(sched)
+            s.loop_run(0, nsteps)
+            s.loop_sync()
+            out = {k: s.loop_get_log(k) for k in ("U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT", "STATUS_DYN",
+                                                  "STATUS_SS", "ITERS_DYN", "ITERS_SS") if not (k == "D_HAT" and p.nd == 0)}
+        else:
+            out = _stepwise(p, s, x0_p, x0_m, nsteps, sched)
+    finally:
+        if own:
+            s.close()
+    if gather:
+        out = {k: np.moveaxis(allgather_rows(np.moveaxis(v, 1, 0), total if total is not None else B), 0, 1) for k, v in out.items()}
+    return out
+
+
+def _stepwise(p, s, x0_p, x0_m, nsteps, sched):
+    """The reference's call sequence, MPC_code.py:519-816, with each solver call going through the C-ABI."""
+    B, n = x0_p.shape[0], p.nx
+    x, xhat = x0_p.copy(), x0_m.copy()
+    u = _bcast(p.u0, B, p.nu).copy(); dhat = _bcast(p.dhat0, B, p.nd).copy() if p.nd else np.zeros((B, 0))
+    Pk = np.broadcast_to(p.P0, (B,) + p.P0.shape).copy() if p.estimator == "kal" else None
+    us_k, xs_k = u.copy(), x0_m.copy()                                   # :682-684
+    keys = ("U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS")
+    log = {k: [] for k in keys}
+    for k in range(nsteps):
+        log["Xp"].append(x.copy()); log["X_HAT"].append(xhat.copy())      # :519-520
+        y = x @ p.Cp.T + sched["pyp"][k]                                  # :534
+        if p.estimator != "none":
+            xi, Pk = s.kf_update(y, np.hstack([xhat, dhat]), Pk)          # :577-650
+            xhat, dhat = xi[:, :n].copy(), xi[:, n:].copy()
+            if p.dmin is not None:
+                dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)       # :660-665
+        log["D_HAT"].append(dhat.copy())
+        t = s.target_solve(sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_k)   # :704-709
+        ok = (t["status"] != capi.STATUS_INFEASIBLE)[:, None]
+        xs_k = np.where(ok, t["xs"], xs_k); us_k = np.where(ok, t["us"], us_k)               # :714-718
+        log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy())
+        log["YS"].append(xs_k @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0))      # :730
+        o = s.ocp_solve(xhat, xs_k, us_k, dhat, u)                                           # :776-781
+        ok = (o["status"] != capi.STATUS_INFEASIBLE)[:, None]
+        hold = xhat @ p.A.T + u @ p.B.T + p.fx_const + (dhat @ p.Bd.T if p.nd else 0.0)      # :804-805
+        u = np.where(ok, o["u0"], u); xhat = np.where(ok, o["x1"], hold)                     # :798-799
+        log["U"].append(u.copy())
+        log["STATUS_DYN"].append(o["status"]); log["STATUS_SS"].append(t["status"])
+        log["ITERS_DYN"].append(o["iters"]); log["ITERS_SS"].append(t["iters"])
+        x = x @ p.Ap.T + u @ p.Bp.T + sched["pxp"][k]                                        # :816
+    return {k: np.array(v) for k, v in log.items()}
