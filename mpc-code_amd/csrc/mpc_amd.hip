@@ -74,10 +74,13 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
     OcpInst<NS, NU> q;
     build_inst<NX, NU, NY, ND, DU>(P, xhat, xs, us, dh, up, q);
-    Ws ws{a.ws, a.Bs, P.N, b};
+    StageConst<NS, NU> C;
+    load_stage_const<NS, NU, DU>(P, C);
+    constexpr int SL = BlkLayout<NS, NU>::SLOTS;
+    Ws ws{(double2 *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64 + threadIdx.x, P.N, SL};
     double u0[NU], z1[NS], res[3];
     int it;
-    const int st = rpdip_lane<NS, NU, DU>(P, q, ws, P.max_iter, u0, z1, res, it);
+    const int st = rpdip_lane<NS, NU, DU>(P, C, q, ws, P.max_iter, u0, z1, res, it);
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
@@ -165,7 +168,10 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
     MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
     MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
-    Ws ws{a.ws, Bs, P.N, b};
+    StageConst<NS, NU> C;
+    load_stage_const<NS, NU, DU>(P, C);
+    constexpr int SL = BlkLayout<NS, NU>::SLOTS;
+    Ws ws{(double2 *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64 + threadIdx.x, P.N, SL};
     for (int k = 0; k < a.nsteps; k++) {
         if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
         if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
         double u0[NU], z1[NS], res[3];
         int it_dyn;
-        const int st_dyn = rpdip_lane<NS, NU, DU>(P, q, ws, P.max_iter, u0, z1, res, it_dyn);
+        const int st_dyn = rpdip_lane<NS, NU, DU>(P, C, q, ws, P.max_iter, u0, z1, res, it_dyn);
         if (st_dyn != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = u0[i];          // :798
             MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
@@ -279,7 +285,7 @@ static Launchers make_launchers()
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
-    l.ws_rows = WsLayout<NX + (DU ? NU : 0), NU>::ROWS;
+    l.ws_rows = 2 * BlkLayout<NX + (DU ? NU : 0), NU>::SLOTS;   // doubles per instance per block
     return l;
 }
 
@@ -549,7 +555,7 @@ extern "C" float mpc_last_kernel_ms(mpc_handle *h, int32_t *n_launches)
 // ---------------------------------------------------------------------------------------------------
 static int ensure_ws(mpc_handle *h, size_t Bs)
 {
-    return h->ws.ensure((size_t)h->L.ws_rows * h->hp.N * Bs * sizeof(double));
+    return h->ws.ensure((size_t)h->L.ws_rows * (h->hp.N + 2) * Bs * sizeof(double));   // +2 guard blocks per wave
 }
 
 extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
@@ -604,15 +610,17 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     }
     if (w_out) {   // primal trajectory in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) from the workspace
         const int N = P.N, ns = nx + (P.du_form ? nu : 0), nv = ns + nu, nxu = nx + nu;
-        std::vector<double> wsh((size_t)nv * N * Bs);
-        HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));   // rows U then Z
+        const int slots = h->L.ws_rows / 2, slotU = 4 * nv, slotZ = slotU + (nu + 1) / 2;
+        std::vector<double> wsh((size_t)h->L.ws_rows * (N + 2) * Bs);
+        HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));
+        auto at = [&](int b, int k, int slot, int comp) { return wsh[((((size_t)(b / 64) * (N + 2) + k + 1) * slots + slot) * 64 + (b % 64)) * 2 + comp]; };
         for (int b = 0; b < B; b++) {
             if (ist[b] == kInfeasible) continue;
             double *w = w_out + (size_t)b * (nx * (N + 1) + nu * N);
             for (int i = 0; i < nx; i++) w[i] = xhat[(size_t)b * nx + i];
             for (int k = 0; k < N; k++) {
-                for (int i = 0; i < nu; i++) w[k * nxu + nx + i] = wsh[((size_t)i * N + k) * Bs + b];
-                for (int i = 0; i < nx; i++) w[(k + 1) * nxu + i] = wsh[((size_t)(nu + i) * N + k) * Bs + b];
+                for (int i = 0; i < nu; i++) w[k * nxu + nx + i] = at(b, k, slotU + i / 2, i % 2);
+                for (int i = 0; i < nx; i++) w[(k + 1) * nxu + i] = at(b, k, slotZ + i / 2, i % 2);
             }
         }
     }

@@ -2,8 +2,8 @@
 //
 // Everything here is templated on the problem dimensions so that every small-matrix loop is fully
 // unrolled into fp64 FMAs on registers; the only memory traffic is the per-instance workspace of the
-// OCP (structure-of-arrays, instance index fastest => every wave access is a contiguous 512-byte row)
-// and the problem constants, which are wave-uniform and therefore come through the scalar cache.
+// OCP (wave-tiled: every access of a wave is one contiguous 1-KiB global_load/store_dwordx4) and the
+// problem constants (wave-uniform: scalar cache, the hot ones pinned in VGPRs).
 //
 // Reference semantics (file:line in /root/reference):
 //   rpdip_lane    solver(...) on the NLP of opt_dyn        Control_Calc.py:20-260 + MPC_code.py:733-805
@@ -66,47 +66,94 @@ __device__ __forceinline__ double comp_measure(double s, double l)
     return dmin(dmin(s, l) * (1.0 / kTolC), s * l * (1.0 / kTolMu));
 }
 
-// ---- OCP workspace: rows of N*Bs doubles, addressed (row, block k, instance b) ----------------------
+// accurate reciprocal without the IEEE division sequence: v_rcp_f64 + two Newton steps (~1 ulp for normal x)
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    return r;
+}
+// raw v_rcp_f64 (about 2^-27 relative): only for step-length ratio tests, which keep a 0.5 % margin anyway
+__device__ __forceinline__ double frcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
+
+// keep a wave-uniform constant in a VGPR (stops the compiler from parking it in - and spilling - SGPRs)
+__device__ __forceinline__ double vreg(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// ---- OCP workspace --------------------------------------------------------------
+// One wave owns a contiguous slab; inside it block k (u_k, z_{k+1} and everything attached to them) is a
+// run of SLOTS double2 "slots", each slot holding 64 lanes x 2 doubles = 1 KiB, so that every access of a
+// wave is one fully coalesced global_load/store_dwordx4 at a compile-time offset from a scalar base.
 template <int NS, int NU>
-struct WsLayout {
+struct BlkLayout {
     static constexpr int NV = NS + NU;
-    static constexpr int U = 0, Z = NU, SLO = NV, SHI = 2 * NV, LLO = 3 * NV, LHI = 4 * NV, PLO = 5 * NV, PHI = 6 * NV,
-                         DU = 7 * NV, DZ = 7 * NV + NU, K = 8 * NV, LI = K + NU * NS, KFF = LI + NU * (NU + 1) / 2,
-                         ROWS = KFF + NU;
+    static constexpr int S = 0, L = NV, P = 2 * NV, IS = 3 * NV;   // pair slots {lo, hi}, one per bounded variable
+    static constexpr int U = 4 * NV, Z = U + (NU + 1) / 2, DU = Z + (NS + 1) / 2, DZ = DU + (NU + 1) / 2,
+                         KFF = DZ + (NS + 1) / 2, K = KFF + (NU + 1) / 2, LI = K + (NU * NS + 1) / 2,
+                         SLOTS = LI + (NU * (NU + 1) / 2 + 1) / 2;
 };
 
 struct Ws {
-    double *base; size_t Bs; int N; int b;
-    __device__ __forceinline__ double &at(int row, int k) const { return base[((size_t)row * N + k) * Bs + b]; }
+    double2 *slab;   // wave slab + lane, pointing at block 0; blocks -1 and N exist as guard blocks
+    int N, slots;
+    __device__ __forceinline__ double2 *blk(int k) const { return slab + (ptrdiff_t)k * slots * 64; }
 };
 
-// symmetric positive definite inverse, n x n, in place (full storage), by Cholesky; returns false if not PD
-template <int n>
-__device__ __forceinline__ bool spd_inverse(double (&a)[n][n])
+template <int CNT>
+__device__ __forceinline__ void ld_field(const double2 *blk, int slot0, double (&out)[CNT])
 {
-    double c[n][n];
+    MPC_UNROLL for (int j = 0; j < (CNT + 1) / 2; j++) {
+        const double2 v = blk[(slot0 + j) * 64];
+        out[2 * j] = v.x;
+        if (2 * j + 1 < CNT) out[2 * j + 1 < CNT ? 2 * j + 1 : 0] = v.y;
+    }
+}
+template <int CNT>
+__device__ __forceinline__ void st_field(double2 *blk, int slot0, const double (&in)[CNT])
+{
+    MPC_UNROLL for (int j = 0; j < (CNT + 1) / 2; j++) {
+        double2 v;
+        v.x = in[2 * j];
+        v.y = (2 * j + 1 < CNT) ? in[2 * j + 1 < CNT ? 2 * j + 1 : 0] : 0.0;
+        blk[(slot0 + j) * 64] = v;
+    }
+}
+
+// symmetric inverse by LDL' with reciprocal pivots (no sqrt, no IEEE division); false if a pivot is not > 0
+template <int n>
+__device__ __forceinline__ bool sym_inverse(double (&a)[n][n])
+{
+    double l[n][n], d[n], dinv[n];
     bool ok = true;
-    MPC_UNROLL for (int i = 0; i < n; i++) {
-        MPC_UNROLL for (int j = 0; j <= i; j++) {
+    MPC_UNROLL for (int j = 0; j < n; j++) {
+        double dj = a[j][j];
+        MPC_UNROLL for (int k = 0; k < j; k++) dj -= l[j][k] * l[j][k] * d[k];
+        ok = ok && (dj > 0.0);
+        d[j] = dj;
+        dinv[j] = frcp(dj);
+        MPC_UNROLL for (int i = j + 1; i < n; i++) {
             double v = a[i][j];
-            MPC_UNROLL for (int k = 0; k < j; k++) v -= c[i][k] * c[j][k];
-            if (i == j) { ok = ok && (v > 0.0); c[i][i] = sqrt(v); }
-            else c[i][j] = v / c[j][j];
+            MPC_UNROLL for (int k = 0; k < j; k++) v -= l[i][k] * l[j][k] * d[k];
+            l[i][j] = v * dinv[j];
         }
     }
-    double ci[n];
-    MPC_UNROLL for (int i = 0; i < n; i++) ci[i] = 1.0 / c[i][i];
-    MPC_UNROLL for (int col = 0; col < n; col++) {
+    MPC_UNROLL for (int col = 0; col < n; col++) {      // inverse = L^-T D^-1 L^-1, column by column
         double y[n];
         MPC_UNROLL for (int i = 0; i < n; i++) {
             double v = (i == col) ? 1.0 : 0.0;
-            MPC_UNROLL for (int k = 0; k < i; k++) v -= c[i][k] * y[k];
-            y[i] = v * ci[i];
+            MPC_UNROLL for (int k = 0; k < i; k++) v -= l[i][k] * y[k];
+            y[i] = v;
         }
         MPC_UNROLL for (int i = n - 1; i >= 0; i--) {
-            double v = y[i];
-            MPC_UNROLL for (int k = i + 1; k < n; k++) v -= c[k][i] * a[k][col];
-            a[i][col] = v * ci[i];
+            double v = y[i] * dinv[i];
+            MPC_UNROLL for (int k = i + 1; k < n; k++) v -= l[k][i] * a[k][col];
+            a[i][col] = v;
         }
     }
     return ok;
@@ -163,73 +210,89 @@ __device__ __forceinline__ void build_inst(const DevProblem &P, const double (&x
 //   F1 (forward)   predictor direction, step length, second-order products
 //   B2 (backward)  corrector rhs
 //   F2 (forward)   corrector direction, step length
+// Every sweep loads block k-1 / k+1 while it computes block k (software prefetch: one wave per SIMD has
+// nobody else to hide its memory latency behind).
 // Returns the status; u0/z1 receive the first input / next state of the final iterate.
 // --------------------------------------------------------------------------------------------------------
+template <int NS, int NU>
+struct StageConst {      // the hot constants, held in VGPRs
+    double A[NS][NS], B[NS][NU], Q[NS][NS], M[NS][NU], R[NU][NU], Pf[NS][NS];
+};
+
 template <int NS, int NU, bool HASM>
-__device__ int rpdip_lane(const DevProblem &P, const OcpInst<NS, NU> &q, const Ws &ws, int max_iter,
-                          double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
+__device__ __forceinline__ void load_stage_const(const DevProblem &P, StageConst<NS, NU> &C)
 {
-    using L = WsLayout<NS, NU>;
+    MPC_UNROLL for (int i = 0; i < NS; i++) {
+        MPC_UNROLL for (int j = 0; j < NS; j++) { C.A[i][j] = vreg(P.A[i][j]); C.Q[i][j] = vreg(P.Q[i][j]); C.Pf[i][j] = vreg(P.Pf[i][j]); }
+        MPC_UNROLL for (int j = 0; j < NU; j++) { C.B[i][j] = vreg(P.B[i][j]); C.M[i][j] = HASM ? vreg(P.M[i][j]) : 0.0; }
+    }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) C.R[i][j] = vreg(P.R[i][j]); }
+}
+
+template <int NS, int NU, bool HASM>
+__device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, const OcpInst<NS, NU> &q, const Ws &ws,
+                          int max_iter, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
+{
+    using L = BlkLayout<NS, NU>;
     constexpr int NV = NS + NU;
     const int N = ws.N;
     res[0] = res[1] = res[2] = 0.0;
     iters = 0;
     if (!q.ok0) return kInfeasible;
 
-    // bounds: u box, z box (mid stages / last stage); fl/fh say which are finite
-    double blo_u[NU], bhi_u[NU];
-    bool fl_u[NU], fh_u[NU], fl_zm[NS], fh_zm[NS], fl_ze[NS], fh_ze[NS];
+    // bounds of block k = (u_k, z_{k+1}): mid blocks and the last one; absent bounds are masked
+    double lo_m[NV], hi_m[NV], lo_e[NV], hi_e[NV];
+    bool fl_m[NV], fh_m[NV], fl_e[NV], fh_e[NV];
     double ncon = 0.0;
-    MPC_UNROLL for (int i = 0; i < NU; i++) {
-        blo_u[i] = P.ulo[i]; bhi_u[i] = P.uhi[i]; fl_u[i] = fin(blo_u[i]); fh_u[i] = fin(bhi_u[i]);
-        ncon += (double)N * ((fl_u[i] ? 1 : 0) + (fh_u[i] ? 1 : 0));
-    }
-    MPC_UNROLL for (int i = 0; i < NS; i++) {
-        fl_zm[i] = fin(q.zlo_m[i]); fh_zm[i] = fin(q.zhi_m[i]); fl_ze[i] = fin(P.zlo_e[i]); fh_ze[i] = fin(P.zhi_e[i]);
-        ncon += (double)(N - 1) * ((fl_zm[i] ? 1 : 0) + (fh_zm[i] ? 1 : 0)) + (fl_ze[i] ? 1 : 0) + (fh_ze[i] ? 1 : 0);
+    MPC_UNROLL for (int i = 0; i < NV; i++) {
+        const double lm = i < NU ? P.ulo[i < NU ? i : 0] : q.zlo_m[i >= NU ? i - NU : 0], hm = i < NU ? P.uhi[i < NU ? i : 0] : q.zhi_m[i >= NU ? i - NU : 0];
+        const double le = i < NU ? P.ulo[i < NU ? i : 0] : P.zlo_e[i >= NU ? i - NU : 0], he = i < NU ? P.uhi[i < NU ? i : 0] : P.zhi_e[i >= NU ? i - NU : 0];
+        fl_m[i] = fin(lm); fh_m[i] = fin(hm); fl_e[i] = fin(le); fh_e[i] = fin(he);
+        lo_m[i] = fl_m[i] ? lm : 0.0; hi_m[i] = fh_m[i] ? hm : 0.0; lo_e[i] = fl_e[i] ? le : 0.0; hi_e[i] = fh_e[i] ? he : 0.0;
+        ncon += (double)(N - 1) * ((fl_m[i] ? 1 : 0) + (fh_m[i] ? 1 : 0)) + (fl_e[i] ? 1 : 0) + (fh_e[i] ? 1 : 0);
     }
     const double inv_ncon = 1.0 / dmax(ncon, 1.0);
-
-#define MPC_BOUNDS(k, i, lo, hi, fl, fh)                                                           \
-    double lo, hi; bool fl, fh;                                                                    \
-    if (i < NU) { lo = blo_u[i < NU ? i : 0]; hi = bhi_u[i < NU ? i : 0]; fl = fl_u[i < NU ? i : 0]; fh = fh_u[i < NU ? i : 0]; } \
-    else if (k < N - 1) { lo = q.zlo_m[i >= NU ? i - NU : 0]; hi = q.zhi_m[i >= NU ? i - NU : 0]; fl = fl_zm[i >= NU ? i - NU : 0]; fh = fh_zm[i >= NU ? i - NU : 0]; } \
-    else { lo = P.zlo_e[i >= NU ? i - NU : 0]; hi = P.zhi_e[i >= NU ? i - NU : 0]; fl = fl_ze[i >= NU ? i - NU : 0]; fh = fh_ze[i >= NU ? i - NU : 0]; } \
-    if (!fl) lo = 0.0;                                                                             \
-    if (!fh) hi = 0.0;
+#define MPC_BOUNDS(k, i, lo, hi, fl, fh)                                   \
+    const bool last_##i = (k) == N - 1;                                    \
+    const double lo = last_##i ? lo_e[i] : lo_m[i], hi = last_##i ? hi_e[i] : hi_m[i]; \
+    const bool fl = last_##i ? fl_e[i] : fl_m[i], fh = last_##i ? fh_e[i] : fh_m[i];
 
     // ---- initial point: u = us pushed inside its box, z simulated, slacks >= kSMin -------------------
     {
-        double uinit[NU], z[NS];
+        double uinit[NU], z[NS], zero_u[NU], zero_z[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             const double lo = P.ulo[i], hi = P.uhi[i];
+            const bool fl = fin(lo), fh = fin(hi);
             double push, v = q.us[i];
-            if (fl_u[i] && fh_u[i]) push = 0.1 * (hi - lo);
-            else push = 0.1 * dmax(1.0, fabs(fl_u[i] ? lo : (fh_u[i] ? hi : 0.0)));
-            if (fl_u[i]) v = dmax(v, lo + push);
-            if (fh_u[i]) v = dmin(v, hi - push);
-            uinit[i] = v;
+            if (fl && fh) push = 0.1 * (hi - lo);
+            else push = 0.1 * dmax(1.0, fabs(fl ? lo : (fh ? hi : 0.0)));
+            if (fl) v = dmax(v, lo + push);
+            if (fh) v = dmin(v, hi - push);
+            uinit[i] = v; zero_u[i] = 0.0;
         }
-        MPC_UNROLL for (int i = 0; i < NS; i++) z[i] = q.z0[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { z[i] = q.z0[i]; zero_z[i] = 0.0; }
         for (int k = 0; k < N; k++) {
+            double2 *b = ws.blk(k);
             double zn[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = q.c[i];
-                MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[i][j] * z[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) a += P.B[i][j] * uinit[j];
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * z[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * uinit[j];
                 zn[i] = a;
             }
             MPC_UNROLL for (int i = 0; i < NS; i++) z[i] = zn[i];
             MPC_UNROLL for (int i = 0; i < NV; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
                 const double v = i < NU ? uinit[i < NU ? i : 0] : z[i >= NU ? i - NU : 0];
-                const double sl = fl ? dmax(v - lo, kSMin) : 1.0, sh = fh ? dmax(hi - v, kSMin) : 1.0;
-                ws.at(L::SLO + i, k) = sl; ws.at(L::SHI + i, k) = sh;
-                ws.at(L::LLO + i, k) = fl ? kMu0 / sl : 0.0; ws.at(L::LHI + i, k) = fh ? kMu0 / sh : 0.0;
-                ws.at(L::PLO + i, k) = 0.0; ws.at(L::PHI + i, k) = 0.0;
-                if (i < NU) { ws.at(L::U + i, k) = v; ws.at(L::DU + i, k) = 0.0; }
-                else { ws.at(L::Z + (i - NU), k) = v; ws.at(L::DZ + (i - NU), k) = 0.0; }
+                double2 sv, lv, iv, pz;
+                sv.x = fl ? dmax(v - lo, kSMin) : 1.0; sv.y = fh ? dmax(hi - v, kSMin) : 1.0;
+                iv.x = frcp(sv.x); iv.y = frcp(sv.y);
+                lv.x = fl ? kMu0 * iv.x : 0.0; lv.y = fh ? kMu0 * iv.y : 0.0;
+                pz.x = 0.0; pz.y = 0.0;
+                b[(L::S + i) * 64] = sv; b[(L::L + i) * 64] = lv; b[(L::IS + i) * 64] = iv; b[(L::P + i) * 64] = pz;
             }
+            st_field<NU>(b, L::U, uinit); st_field<NS>(b, L::Z, z);
+            st_field<NU>(b, L::DU, zero_u); st_field<NS>(b, L::DZ, zero_z);
         }
     }
 
@@ -242,33 +305,50 @@ __device__ int rpdip_lane(const DevProblem &P, const OcpInst<NS, NU> &q, const W
         bool pd_ok = true;
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             pi[i] = 0.0; pcar[i] = 0.0;
-            MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = P.Pf[i][j];
+            MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = C.Pf[i][j];
         }
         MPC_UNROLL for (int i = 0; i < NU; i++) unext_dev[i] = 0.0;
         double ublk[NU], zblk[NS];
+        const bool upd = alpha != 0.0;
+        struct B1Blk { double2 s[NV], l[NV], p[NV], is[NV]; double u[NU], z[NS], du[NU], dz[NS]; };
+        auto load_b1 = [&](int k, B1Blk &d) {
+            const double2 *b = ws.blk(k);
+            MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; }
+            ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z);
+            if (upd) {
+                MPC_UNROLL for (int i = 0; i < NV; i++) { d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                ld_field<NU>(b, L::DU, d.du); ld_field<NS>(b, L::DZ, d.dz);
+            }
+        };
+        B1Blk cur;
+        load_b1(N - 1, cur);
         for (int k = N - 1; k >= 0; k--) {
+            double2 *b = ws.blk(k);
             double sig[NV], dlm[NV], haff[NV];
-            MPC_UNROLL for (int i = 0; i < NU; i++) ublk[i] = ws.at(L::U + i, k);
-            MPC_UNROLL for (int i = 0; i < NS; i++) zblk[i] = ws.at(L::Z + i, k);
+            // ---- phase A: apply the previous step to block k, residuals and barrier weights -----------
+            MPC_UNROLL for (int i = 0; i < NU; i++) ublk[i] = cur.u[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) zblk[i] = cur.z[i];
             MPC_UNROLL for (int i = 0; i < NV; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
                 double v = i < NU ? ublk[i < NU ? i : 0] : zblk[i >= NU ? i - NU : 0];
-                const double dv = i < NU ? ws.at(L::DU + (i < NU ? i : 0), k) : ws.at(L::DZ + (i >= NU ? i - NU : 0), k);
-                double sl = ws.at(L::SLO + i, k), sh = ws.at(L::SHI + i, k), ll = ws.at(L::LLO + i, k), lh = ws.at(L::LHI + i, k);
-                if (alpha != 0.0) {   // apply the step of the previous iteration
-                    const double plo = ws.at(L::PLO + i, k), phi = ws.at(L::PHI + i, k);
+                double sl = cur.s[i].x, sh = cur.s[i].y, ll = cur.l[i].x, lh = cur.l[i].y;
+                if (upd) {   // apply the step of the previous iteration
+                    const double dv = i < NU ? cur.du[i < NU ? i : 0] : cur.dz[i >= NU ? i - NU : 0];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
-                    const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + phi : 0.0;
-                    const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + plo : 0.0;
+                    const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + cur.p[i].y : 0.0;
+                    const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + cur.p[i].x : 0.0;
                     const double dsh = fh ? -rh - dv : 0.0, dsl = fl ? rl + dv : 0.0;
-                    const double dlh = fh ? (-rch - lh * dsh) / sh : 0.0, dll = fl ? (-rcl - ll * dsl) / sl : 0.0;
+                    const double dlh = fh ? (-rch - lh * dsh) * cur.is[i].y : 0.0, dll = fl ? (-rcl - ll * dsl) * cur.is[i].x : 0.0;
                     sl += alpha * dsl; sh += alpha * dsh; ll += alpha * dll; lh += alpha * dlh; v += alpha * dv;
-                    ws.at(L::SLO + i, k) = sl; ws.at(L::SHI + i, k) = sh; ws.at(L::LLO + i, k) = ll; ws.at(L::LHI + i, k) = lh;
-                    if (i < NU) { ublk[i < NU ? i : 0] = v; ws.at(L::U + (i < NU ? i : 0), k) = v; }
-                    else { zblk[i >= NU ? i - NU : 0] = v; ws.at(L::Z + (i >= NU ? i - NU : 0), k) = v; }
+                    if (i < NU) ublk[i < NU ? i : 0] = v; else zblk[i >= NU ? i - NU : 0] = v;
                 }
                 const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
-                const double isl = 1.0 / sl, ish = 1.0 / sh;
+                const double isl = frcp(sl), ish = frcp(sh);
+                if (upd) {
+                    double2 t; t.x = sl; t.y = sh; b[(L::S + i) * 64] = t;
+                    t.x = ll; t.y = lh; b[(L::L + i) * 64] = t;
+                    t.x = isl; t.y = ish; b[(L::IS + i) * 64] = t;
+                }
                 mu_sum += sl * ll + sh * lh;
                 sig[i] = ll * isl + lh * ish;
                 dlm[i] = lh - ll;
@@ -277,92 +357,98 @@ __device__ int rpdip_lane(const DevProblem &P, const OcpInst<NS, NU> &q, const W
                 cres = dmax(cres, dmax(comp_measure(sl, ll), comp_measure(sh, lh)));
                 lmax = dmax(lmax, dmax(ll, lh));
             }
-            // gradients of the current point (cost + bound multipliers)
+            if (upd) { st_field<NU>(b, L::U, ublk); st_field<NS>(b, L::Z, zblk); }
+            // ---- prefetch block k-1 into the (now dead) buffer; it lands while phase B computes ---------
+            load_b1(k - 1, cur);     // k-1 = -1 is a guard block
+            // ---- phase B: Riccati step.  P_{k+1} completed with the barrier weights of z_{k+1} -----------
+            MPC_UNROLL for (int i = 0; i < NS; i++) Pm[i][i] += sig[NU + i];
+            double PB[NS][NU], PA[NS][NS], Lam[NU][NU], Psi[NU][NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * C.B[l][j]; PB[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * C.A[l][j]; PA[i][j] = a; }
+            }
+            MPC_UNROLL for (int i = 0; i < NU; i++) {
+                MPC_UNROLL for (int j = 0; j <= i; j++) { double a = C.R[i][j] + (i == j ? sig[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += C.B[l][i] * PB[l][j]; Lam[i][j] = a; Lam[j][i] = a; }
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = HASM ? C.M[j][i] : 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += C.B[l][i] * PA[l][j]; Psi[i][j] = a; }
+            }
+            pd_ok = sym_inverse<NU>(Lam) && pd_ok;     // Lam now holds Li
+            double Kk[NU][NS], Acl[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a += Lam[i][l] * Psi[l][j]; Kk[i][j] = -a; } }
+            {
+                double kflat[NU * NS], liflat[NU * (NU + 1) / 2];
+                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) kflat[i * NS + j] = Kk[i][j]; }
+                int c = 0;
+                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { liflat[c] = Lam[i][j]; c++; } }
+                st_field<NU * NS>(b, L::K, kflat); st_field<NU * (NU + 1) / 2>(b, L::LI, liflat);
+            }
+            if (k > 0) {
+                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = C.A[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += C.B[i][l] * Kk[l][j]; Acl[i][j] = a; } }
+                // closed-loop (Joseph) form: P_k = Q + Acl' P Acl + K' Rt K + M K + K' M'  (no cancellation)
+                double T[NS][NS], RK[NU][NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * Acl[l][j]; T[i][j] = a; } }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = sig[i] * Kk[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += C.R[i][l] * Kk[l][j]; RK[i][j] = a; } }
+                MPC_UNROLL for (int i = 0; i < NS; i++) {
+                    MPC_UNROLL for (int j = 0; j <= i; j++) {      // symmetric in exact arithmetic: lower triangle, mirrored
+                        double a = C.Q[i][j];
+                        MPC_UNROLL for (int l = 0; l < NS; l++) a += Acl[l][i] * T[l][j];
+                        MPC_UNROLL for (int l = 0; l < NU; l++) a += Kk[l][i] * RK[l][j];
+                        if (HASM) { MPC_UNROLL for (int l = 0; l < NU; l++) a += C.M[i][l] * Kk[l][j] + Kk[l][i] * C.M[j][l]; }
+                        Pm[i][j] = a; Pm[j][i] = a;
+                    }
+                }
+            }
+            // ---- gradients of the current point (cost + bound multipliers), adjoint, predictor rhs --------
             double dz1[NS], du[NU], gz1[NS], gu[NU];
             MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = zblk[i] - q.zr[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = ublk[i] - q.ur[i];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = dlm[NU + i];
-                if (k == N - 1) { MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Pf[i][j] * dz1[j]; }
+                if (k == N - 1) { MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Pf[i][j] * dz1[j]; }
                 else {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Q[i][j] * dz1[j];
-                    if (HASM) { MPC_UNROLL for (int j = 0; j < NU; j++) a += P.M[i][j] * unext_dev[j]; }
+                    MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Q[i][j] * dz1[j];
+                    if (HASM) { MPC_UNROLL for (int j = 0; j < NU; j++) a += C.M[i][j] * unext_dev[j]; }
                 }
                 gz1[i] = a;
             }
             MPC_UNROLL for (int i = 0; i < NU; i++) {
                 double a = dlm[i];
-                MPC_UNROLL for (int j = 0; j < NU; j++) a += P.R[i][j] * du[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) a += C.R[i][j] * du[j];
                 gu[i] = a;
             }
-            if (HASM) {   // M'(z_k - zr): z_k is block k-1 (or z0)
+            if (HASM) {   // M'(z_k - zr): z_k lives in block k-1 (just prefetched, not yet updated) or is z0
                 double zk[NS];
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    double zv = k > 0 ? ws.at(L::Z + i, k - 1) : q.z0[i];
-                    if (k > 0 && alpha != 0.0) zv += alpha * ws.at(L::DZ + i, k - 1);   // not yet updated in memory
+                    double zv = k > 0 ? cur.z[i] : q.z0[i];
+                    if (k > 0 && upd) zv += alpha * cur.dz[i];
                     zk[i] = zv - q.zr[i];
                 }
-                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) gu[i] += P.M[j][i] * zk[j]; }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) gu[i] += C.M[j][i] * zk[j]; }
             }
             // adjoint pi_{k+1} = gz_{k+1} + A' pi_{k+2};  stationarity residual r_u,k = gu_k + B' pi_{k+1}
             {
                 double pn[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = gz1[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[j][i] * pi[j]; pn[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = gz1[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pi[j]; pn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = pn[i];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.B[j][i] * pi[j]; res_s = dmax(res_s, fabs(a)); }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pi[j]; res_s = dmax(res_s, fabs(a)); }
             }
-            // Riccati: P_{k+1} completed with the barrier weights of z_{k+1}
-            MPC_UNROLL for (int i = 0; i < NS; i++) Pm[i][i] += sig[NU + i];
-            double PB[NS][NU], PA[NS][NS], Lam[NU][NU], Psi[NU][NS];
-            MPC_UNROLL for (int i = 0; i < NS; i++) {
-                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * P.B[l][j]; PB[i][j] = a; }
-                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * P.A[l][j]; PA[i][j] = a; }
-            }
-            MPC_UNROLL for (int i = 0; i < NU; i++) {
-                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = P.R[i][j] + (i == j ? sig[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += P.B[l][i] * PB[l][j]; Lam[i][j] = a; }
-                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = HASM ? P.M[j][i] : 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += P.B[l][i] * PA[l][j]; Psi[i][j] = a; }
-            }
-            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Lam[i][j] + Lam[j][i]); Lam[i][j] = a; Lam[j][i] = a; } }
-            pd_ok = spd_inverse<NU>(Lam) && pd_ok;     // Lam now holds Li
-            double Kk[NU][NS], Acl[NS][NS];
-            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a += Lam[i][l] * Psi[l][j]; Kk[i][j] = -a; ws.at(L::K + i * NS + j, k) = -a; } }
-            {
-                int c = 0;
-                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { ws.at(L::LI + c, k) = Lam[i][j]; c++; } }
-            }
-            // predictor rhs
             double pv[NS], qu[NU];
             MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = gz1[i] + haff[NU + i] + pcar[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) qu[i] = gu[i] + haff[i];
             {
-                double psi[NU];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.B[j][i] * pv[j]; psi[i] = a; }
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Lam[i][j] * psi[j]; ws.at(L::KFF + i, k) = -a; }
-            }
-            if (k > 0) {
-                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = P.A[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += P.B[i][l] * Kk[l][j]; Acl[i][j] = a; } }
-                // closed-loop (Joseph) form: P_k = Q + Acl' P Acl + K' Rt K + M K + K' M'  (no cancellation)
-                double T[NS][NS], RK[NU][NS], Pn[NS][NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * Acl[l][j]; T[i][j] = a; } }
-                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = sig[i] * Kk[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += P.R[i][l] * Kk[l][j]; RK[i][j] = a; } }
-                MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) {
-                        double a = P.Q[i][j];
-                        MPC_UNROLL for (int l = 0; l < NS; l++) a += Acl[l][i] * T[l][j];
-                        MPC_UNROLL for (int l = 0; l < NU; l++) a += Kk[l][i] * RK[l][j];
-                        if (HASM) { MPC_UNROLL for (int l = 0; l < NU; l++) a += P.M[i][l] * Kk[l][j] + Kk[l][i] * P.M[j][l]; }
-                        Pn[i][j] = a;
+                double psi[NU], kff[NU];
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Lam[i][j] * psi[j]; kff[i] = -a; }
+                st_field<NU>(b, L::KFF, kff);
+                if (k > 0) {     // p_k carry = Acl' pv + K' qu = A' pv + K' psi
+                    double pn[NS];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) {
+                        double a = 0.0;
+                        MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
+                        MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j][i] * psi[j];
+                        pn[i] = a;
                     }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) pcar[i] = pn[i];
                 }
-                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = 0.5 * (Pn[i][j] + Pn[j][i]); }
-                double pn[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    double a = 0.0;
-                    MPC_UNROLL for (int j = 0; j < NS; j++) a += Acl[j][i] * pv[j];
-                    MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j][i] * qu[j];
-                    pn[i] = a;
-                }
-                MPC_UNROLL for (int i = 0; i < NS; i++) pcar[i] = pn[i];
             }
             MPC_UNROLL for (int i = 0; i < NU; i++) unext_dev[i] = du[i];
         }
@@ -380,137 +466,173 @@ __device__ int rpdip_lane(const DevProblem &P, const OcpInst<NS, NU> &q, const W
         if (it == max_iter) { status = kMaxIter; break; }
 
         // ======================= sweep F1 (forward): predictor ======================================
-        double a_aff = 1.0, s1 = 0.0, s2 = 0.0;
+        double m_aff = 1.0, s1 = 0.0, s2 = 0.0;      // m = max(1, max_i -d_i/x_i); step to the boundary = 1/m
         {
+            struct F1Blk { double2 s[NV], l[NV], is[NV]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
+            auto load_f1 = [&](int k, F1Blk &d) {
+                const double2 *b = ws.blk(k);
+                MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
+            };
+            F1Blk c1;
+            load_f1(0, c1);
             double dz[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
-                double ddu[NU], dzn[NS];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = ws.at(L::KFF + i, k); MPC_UNROLL for (int j = 0; j < NS; j++) a += ws.at(L::K + i * NS + j, k) * dz[j]; ddu[i] = a; }
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += P.B[i][j] * ddu[j]; dzn[i] = a; }
+                double2 *b = ws.blk(k);
+                const double2 *nb = ws.blk(k + 1);      // block N is a guard block; every field is reloaded in place
+                double ddu[NU], dzn[NS];                 // right after its last use (rolling prefetch, no second buffer)
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = c1.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += c1.K[i * NS + j] * dz[j]; ddu[i] = a; }
+                ld_field<NU>(nb, L::KFF, c1.kff); ld_field<NU * NS>(nb, L::K, c1.K);
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
                 MPC_UNROLL for (int i = 0; i < NV; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
-                    const double v = i < NU ? ws.at(L::U + (i < NU ? i : 0), k) : ws.at(L::Z + (i >= NU ? i - NU : 0), k);
+                    const double v = i < NU ? c1.u[i < NU ? i : 0] : c1.z[i >= NU ? i - NU : 0];
                     const double dv = i < NU ? ddu[i < NU ? i : 0] : dz[i >= NU ? i - NU : 0];
-                    const double sl = ws.at(L::SLO + i, k), sh = ws.at(L::SHI + i, k), ll = ws.at(L::LLO + i, k), lh = ws.at(L::LHI + i, k);
+                    const double sl = c1.s[i].x, sh = c1.s[i].y, ll = c1.l[i].x, lh = c1.l[i].y, isl = c1.is[i].x, ish = c1.is[i].y;
+                    c1.s[i] = nb[(L::S + i) * 64]; c1.l[i] = nb[(L::L + i) * 64]; c1.is[i] = nb[(L::IS + i) * 64];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
                     const double dsh = fh ? -rh - dv : 0.0, dsl = fl ? rl + dv : 0.0;
-                    const double dlh = fh ? (-sh * lh - lh * dsh) / sh : 0.0, dll = fl ? (-sl * ll - ll * dsl) / sl : 0.0;
-                    if (dsl < 0.0) a_aff = dmin(a_aff, -sl / dsl);
-                    if (dsh < 0.0) a_aff = dmin(a_aff, -sh / dsh);
-                    if (dll < 0.0) a_aff = dmin(a_aff, -ll / dll);
-                    if (dlh < 0.0) a_aff = dmin(a_aff, -lh / dlh);
+                    // rc = s*l:  dl = -l - l*ds/s,  -dl/l = 1 + ds/s
+                    const double qh = dsh * ish, ql = dsl * isl;
+                    const double dlh = fh ? -lh - lh * qh : 0.0, dll = fl ? -ll - ll * ql : 0.0;
+                    m_aff = dmax(m_aff, dmax(-ql, -qh));
+                    if (fl) m_aff = dmax(m_aff, 1.0 + ql);
+                    if (fh) m_aff = dmax(m_aff, 1.0 + qh);
                     s1 += sl * dll + ll * dsl + sh * dlh + lh * dsh;
                     s2 += dsl * dll + dsh * dlh;
-                    ws.at(L::PLO + i, k) = dsl * dll; ws.at(L::PHI + i, k) = dsh * dlh;
+                    double2 t; t.x = dsl * dll; t.y = dsh * dlh;
+                    b[(L::P + i) * 64] = t;
                 }
+                ld_field<NU>(nb, L::U, c1.u); ld_field<NS>(nb, L::Z, c1.z);
             }
         }
         {
+            const double a_aff = frcp(m_aff);
             const double mu_aff = (mu_sum + a_aff * s1 + a_aff * a_aff * s2) * inv_ncon;
-            const double rat = mu > 0.0 ? mu_aff / mu : 0.0;
+            const double rat = mu > 0.0 ? mu_aff * frcp(mu) : 0.0;
             sm = dmax(rat * rat * rat * mu, kMuFloor);
         }
         // ======================= sweep B2 (backward): corrector rhs ================================
         {
-            double pc[NS], und[NU];
+            struct B2Blk { double2 s[NV], l[NV], p[NV], is[NV]; double u[NU], z[NS], K[NU * NS], li[NU * (NU + 1) / 2]; };
+            auto load_b2 = [&](int k, B2Blk &d) {
+                const double2 *b = ws.blk(k);
+                MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU * NS>(b, L::K, d.K); ld_field<NU * (NU + 1) / 2>(b, L::LI, d.li);
+            };
+            B2Blk c2;
+            load_b2(N - 1, c2);
+            double pc[NS], und[NU], zprev[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
             MPC_UNROLL for (int i = 0; i < NU; i++) und[i] = 0.0;
             for (int k = N - 1; k >= 0; k--) {
-                double hcc[NV], dlm[NV], ub[NU], zb[NS];
-                MPC_UNROLL for (int i = 0; i < NU; i++) ub[i] = ws.at(L::U + i, k);
-                MPC_UNROLL for (int i = 0; i < NS; i++) zb[i] = ws.at(L::Z + i, k);
+                double2 *b = ws.blk(k);
+                const double2 *nb = ws.blk(k - 1);       // block -1 is a guard block
+                double hcc[NV], dlm[NV];
                 MPC_UNROLL for (int i = 0; i < NV; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
-                    const double v = i < NU ? ub[i < NU ? i : 0] : zb[i >= NU ? i - NU : 0];
-                    const double sl = ws.at(L::SLO + i, k), sh = ws.at(L::SHI + i, k), ll = ws.at(L::LLO + i, k), lh = ws.at(L::LHI + i, k);
+                    const double v = i < NU ? c2.u[i < NU ? i : 0] : c2.z[i >= NU ? i - NU : 0];
+                    const double sl = c2.s[i].x, sh = c2.s[i].y, ll = c2.l[i].x, lh = c2.l[i].y;
+                    const double plo = c2.p[i].x, phi = c2.p[i].y, isl = c2.is[i].x, ish = c2.is[i].y;
+                    c2.s[i] = nb[(L::S + i) * 64]; c2.l[i] = nb[(L::L + i) * 64]; c2.p[i] = nb[(L::P + i) * 64]; c2.is[i] = nb[(L::IS + i) * 64];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
-                    const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + ws.at(L::PHI + i, k) : 0.0;
-                    const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + ws.at(L::PLO + i, k) : 0.0;
-                    hcc[i] = (-rch + lh * rh) / sh + (rcl + ll * rl) / sl;
+                    const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + phi : 0.0;
+                    const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + plo : 0.0;
+                    hcc[i] = (-rch + lh * rh) * ish + (rcl + ll * rl) * isl;
                     dlm[i] = lh - ll;
                 }
                 double dz1[NS], du[NU], pv[NS], qu[NU];
-                MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = zb[i] - q.zr[i];
-                MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = ub[i] - q.ur[i];
+                MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = c2.z[i] - q.zr[i];
+                MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = c2.u[i] - q.ur[i];
+                ld_field<NU>(nb, L::U, c2.u); ld_field<NS>(nb, L::Z, c2.z);
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
                     double a = dlm[NU + i] + hcc[NU + i] + pc[i];
-                    if (k == N - 1) { MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Pf[i][j] * dz1[j]; }
+                    if (k == N - 1) { MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Pf[i][j] * dz1[j]; }
                     else {
-                        MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Q[i][j] * dz1[j];
-                        if (HASM) { MPC_UNROLL for (int j = 0; j < NU; j++) a += P.M[i][j] * und[j]; }
+                        MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Q[i][j] * dz1[j];
+                        if (HASM) { MPC_UNROLL for (int j = 0; j < NU; j++) a += C.M[i][j] * und[j]; }
                     }
                     pv[i] = a;
                 }
                 MPC_UNROLL for (int i = 0; i < NU; i++) {
                     double a = dlm[i] + hcc[i];
-                    MPC_UNROLL for (int j = 0; j < NU; j++) a += P.R[i][j] * du[j];
+                    MPC_UNROLL for (int j = 0; j < NU; j++) a += C.R[i][j] * du[j];
                     qu[i] = a;
                 }
-                if (HASM) {
-                    double zk[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) zk[i] = (k > 0 ? ws.at(L::Z + i, k - 1) : q.z0[i]) - q.zr[i];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) qu[i] += P.M[j][i] * zk[j]; }
-                }
-                double Li[NU][NU], Kk[NU][NS];
+                double Li[NU][NU], Kk[NU * NS];
                 {
                     int c = 0;
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { const double a = ws.at(L::LI + c, k); Li[i][j] = a; Li[j][i] = a; c++; } }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { Li[i][j] = c2.li[c]; Li[j][i] = c2.li[c]; c++; } }
+                    MPC_UNROLL for (int i = 0; i < NU * NS; i++) Kk[i] = c2.K[i];
                 }
-                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Kk[i][j] = ws.at(L::K + i * NS + j, k); }
+                ld_field<NU * NS>(nb, L::K, c2.K); ld_field<NU * (NU + 1) / 2>(nb, L::LI, c2.li);
+                if (HASM) {      // M'(z_k - zr): z_k is block k-1 (just requested) or z0 - used last so the load has time
+                    MPC_UNROLL for (int i = 0; i < NS; i++) zprev[i] = (k > 0 ? c2.z[i] : q.z0[i]) - q.zr[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) qu[i] += C.M[j][i] * zprev[j]; }
+                }
                 {
-                    double psi[NU];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.B[j][i] * pv[j]; psi[i] = a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; ws.at(L::KFF + i, k) = -a; }
-                }
-                if (k > 0) {
-                    double pn[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) {
-                        double a = 0.0;
-                        MPC_UNROLL for (int j = 0; j < NS; j++) {
-                            double acl = P.A[j][i];
-                            MPC_UNROLL for (int l = 0; l < NU; l++) acl += P.B[j][l] * Kk[l][i];
-                            a += acl * pv[j];
+                    double psi[NU], kff[NU];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
+                    st_field<NU>(b, L::KFF, kff);
+                    if (k > 0) {     // p_k carry = Acl' pv + K' qu = A' pv + K' psi
+                        double pn[NS];
+                        MPC_UNROLL for (int i = 0; i < NS; i++) {
+                            double a = 0.0;
+                            MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
+                            MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j * NS + i] * psi[j];
+                            pn[i] = a;
                         }
-                        MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j][i] * qu[j];
-                        pn[i] = a;
+                        MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = pn[i];
                     }
-                    MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = pn[i];
                 }
                 MPC_UNROLL for (int i = 0; i < NU; i++) und[i] = du[i];
             }
         }
         // ======================= sweep F2 (forward): corrector direction ============================
-        double a_max = 1.0e300;
+        double m_cc = 1.0;
         {
+            struct F2Blk { double2 s[NV], l[NV], p[NV], is[NV]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
+            auto load_f2 = [&](int k, F2Blk &d) {
+                const double2 *b = ws.blk(k);
+                MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
+            };
+            F2Blk c3;
+            load_f2(0, c3);
             double dz[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
+                double2 *b = ws.blk(k);
+                const double2 *nb = ws.blk(k + 1);
                 double ddu[NU], dzn[NS];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = ws.at(L::KFF + i, k); MPC_UNROLL for (int j = 0; j < NS; j++) a += ws.at(L::K + i * NS + j, k) * dz[j]; ddu[i] = a; }
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += P.B[i][j] * ddu[j]; dzn[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = c3.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += c3.K[i * NS + j] * dz[j]; ddu[i] = a; }
+                ld_field<NU>(nb, L::KFF, c3.kff); ld_field<NU * NS>(nb, L::K, c3.K);
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
-                MPC_UNROLL for (int i = 0; i < NU; i++) ws.at(L::DU + i, k) = ddu[i];
-                MPC_UNROLL for (int i = 0; i < NS; i++) ws.at(L::DZ + i, k) = dz[i];
+                st_field<NU>(b, L::DU, ddu); st_field<NS>(b, L::DZ, dz);
                 MPC_UNROLL for (int i = 0; i < NV; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
-                    const double v = i < NU ? ws.at(L::U + (i < NU ? i : 0), k) : ws.at(L::Z + (i >= NU ? i - NU : 0), k);
+                    const double v = i < NU ? c3.u[i < NU ? i : 0] : c3.z[i >= NU ? i - NU : 0];
                     const double dv = i < NU ? ddu[i < NU ? i : 0] : dz[i >= NU ? i - NU : 0];
-                    const double sl = ws.at(L::SLO + i, k), sh = ws.at(L::SHI + i, k), ll = ws.at(L::LLO + i, k), lh = ws.at(L::LHI + i, k);
+                    const double sl = c3.s[i].x, sh = c3.s[i].y, ll = c3.l[i].x, lh = c3.l[i].y, isl = c3.is[i].x, ish = c3.is[i].y;
+                    const double plo = c3.p[i].x, phi = c3.p[i].y;
+                    c3.s[i] = nb[(L::S + i) * 64]; c3.l[i] = nb[(L::L + i) * 64]; c3.p[i] = nb[(L::P + i) * 64]; c3.is[i] = nb[(L::IS + i) * 64];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
-                    const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + ws.at(L::PHI + i, k) : 0.0;
-                    const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + ws.at(L::PLO + i, k) : 0.0;
+                    const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + phi : 0.0;
+                    const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + plo : 0.0;
                     const double dsh = fh ? -rh - dv : 0.0, dsl = fl ? rl + dv : 0.0;
-                    const double dlh = fh ? (-rch - lh * dsh) / sh : 0.0, dll = fl ? (-rcl - ll * dsl) / sl : 0.0;
-                    if (dsl < 0.0) a_max = dmin(a_max, -sl / dsl);
-                    if (dsh < 0.0) a_max = dmin(a_max, -sh / dsh);
-                    if (dll < 0.0) a_max = dmin(a_max, -ll / dll);
-                    if (dlh < 0.0) a_max = dmin(a_max, -lh / dlh);
+                    const double dlh = fh ? (-rch - lh * dsh) * ish : 0.0, dll = fl ? (-rcl - ll * dsl) * isl : 0.0;
+                    m_cc = dmax(m_cc, dmax(-dsl * isl, -dsh * ish));
+                    if (fl) m_cc = dmax(m_cc, -dll * frcp_approx(ll));
+                    if (fh) m_cc = dmax(m_cc, -dlh * frcp_approx(lh));
                 }
+                ld_field<NU>(nb, L::U, c3.u); ld_field<NS>(nb, L::Z, c3.z);
             }
         }
-        alpha = dmin(1.0, kTau * dmin(a_max, 1.0));
+        alpha = kTau * frcp(m_cc);
     }
 #undef MPC_BOUNDS
     return status;
@@ -552,7 +674,7 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
     {
         double Hi[NR][NR];
         MPC_UNROLL for (int i = 0; i < NR; i++) { MPC_UNROLL for (int j = 0; j < NR; j++) Hi[i][j] = P.Hr[i][j]; }
-        spd_inverse<NR>(Hi);
+        sym_inverse<NR>(Hi);
         MPC_UNROLL for (int i = 0; i < NR; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NR; j++) a += Hi[i][j] * gr[j]; y[i] = -a; }
     }
     MPC_UNROLL for (int r = 0; r < NC; r++) {
@@ -587,7 +709,7 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
         if (it == P.max_iter) { status = kMaxIter; break; }
         double Ht[NR][NR];
         MPC_UNROLL for (int i = 0; i < NR; i++) { MPC_UNROLL for (int j = 0; j < NR; j++) { double a = P.Hr[i][j]; MPC_UNROLL for (int r = 0; r < NC; r++) a += sig[r] * P.W[r][i] * P.W[r][j]; Ht[i][j] = a; } }
-        if (!spd_inverse<NR>(Ht)) { status = kInfeasible; break; }
+        if (!sym_inverse<NR>(Ht)) { status = kInfeasible; break; }
         double dy[NR], ds_lo[NC], ds_hi[NC], dl_lo[NC], dl_hi[NC];
         double sm = 0.0, alpha = 1.0;
         MPC_UNROLL for (int pass = 0; pass < 2; pass++) {
@@ -643,7 +765,7 @@ __device__ void kalman_lane(const DevProblem &P, double (&xi)[NE], double (&Pk)[
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += Pk[i][l] * P.Ca[j][l]; PCt[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = P.Rkf[i][j]; MPC_UNROLL for (int l = 0; l < NE; l++) a += P.Ca[i][l] * PCt[l][j]; S[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (S[i][j] + S[j][i]); S[i][j] = a; S[j][i] = a; } }
-    spd_inverse<NY>(S);                                   // K = P C' S^-1   (Estimator.py:297)
+    sym_inverse<NY>(S);                                   // K = P C' S^-1   (Estimator.py:297)
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) a += PCt[i][l] * S[l][j]; K[i][j] = a; } }
     double CP[NY][NE], Pc[NE][NE], T[NE][NE];
     MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += P.Ca[i][l] * Pk[l][j]; CP[i][j] = a; } }

@@ -1,0 +1,124 @@
+"""Pin the oracle: known answers, KKT certificates, independent solvers, golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import mpc_oracle as o
+import riccati_np as rn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_lqr_known_answer(cstr):
+    """No active bound, P = DARE  =>  u0* = us + K (xhat - xs) for any N."""
+    K = o.lqr_gain(cstr)
+    assert np.allclose(K, [[1.457547e-2, -3.157928e-4, 7.022363e-4], [-1.439759e-4, -1.051276e-5, 2.850066]], rtol=2e-6)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        xs, us, d = np.zeros(3), np.zeros(2), np.zeros(3)
+        xh = rng.uniform(-0.05, 0.05, 3) * [1, 10, 1]
+        r = o.ocp_solve(cstr, xh, xs, us, d, us)
+        assert r["status"] == 0 and o.kkt_max(r["res"]) < 1e-9
+        assert np.allclose(r["u0"], us + K @ (xh - xs), atol=1e-9)
+
+
+def test_dense_ipm_against_scipy_trust_constr(cstr):
+    """Independent third opinion on a short-horizon instance with active bounds."""
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+    import copy
+    p = copy.copy(cstr); p.N = 6
+    xh, xs, us, d = np.array([0.3, 6.0, 2.0]), np.zeros(3), np.zeros(2), np.zeros(3)
+    H, g, E, e, G, lo, hi = o.ocp_qp(p, xh, xs, us, d, us)
+    r = o.ocp_solve_exact(p, xh, xs, us, d, us)
+    assert r["status"] == 0 and r["exact"] and o.kkt_max(r["res"]) < 1e-10
+    sol = minimize(lambda w: 0.5 * w @ H @ w + g @ w, r["w"] * 0, jac=lambda w: H @ w + g, hess=lambda w: H, method="trust-constr",
+                   constraints=[LinearConstraint(E, e, e), LinearConstraint(G, lo, hi)], options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+    assert np.abs(sol.x[3:5] - r["u0"]).max() < 1e-5
+    assert (0.5 * r["w"] @ H @ r["w"] + g @ r["w"]) <= sol.fun + 1e-9
+
+
+def test_shipped_initial_state_is_infeasible(cstr):
+    """xhat = [3,3,3]: x_1[1] >= 12.3 > 10 whatever u; HiGHS agrees."""
+    xh = np.full(3, 3.0)
+    H, g, E, e, G, lo, hi = o.ocp_qp(cstr, xh, xh, np.zeros(2), np.zeros(3), np.zeros(2))
+    assert not o.lp_feasible(E, e, G, lo, hi)
+    assert o.ocp_solve(cstr, xh, xh, np.zeros(2), np.zeros(3), np.zeros(2))["status"] == 2
+    sd = rn.stage_data(cstr)
+    r = rn.rpdip_solve(sd, rn.instance_data(cstr, sd, xh, xh, np.zeros(2), np.zeros(3), np.zeros(2)))
+    assert r["status"][0] == 2 and r["iters"][0] < 20
+
+
+def test_infeasibility_labels_match_highs(cstr):
+    rng = np.random.default_rng(7)
+    x0 = 3 + rng.uniform(-1, 1, size=(60, 3))
+    z3, z2 = np.zeros((60, 3)), np.zeros((60, 2))
+    sd = rn.stage_data(cstr)
+    r = rn.rpdip_solve(sd, rn.instance_data(cstr, sd, x0, z3, z2, z3, z2))
+    for i in range(60):
+        H, g, E, e, G, lo, hi = o.ocp_qp(cstr, x0[i], z3[i], z2[i], z3[i], z2[i])
+        assert (r["status"][i] != 2) == o.lp_feasible(E, e, G, lo, hi), i
+    assert (r["status"] == 1).sum() == 0 and r["iters"].max() < 40
+
+
+@pytest.mark.parametrize("name", ["cstr_shipped", "wb_shipped", "cstr_box"])
+def test_golden_vectors_certify_themselves(name, cstr, wb):
+    """Re-derive the KKT residual of every solved golden OCP from the stated QP (no solver involved)."""
+    p = wb if name.startswith("wb") else cstr
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    nst, nin = g["U"].shape[:2]
+    checked = 0
+    for k in range(0, nst, max(1, nst // 12)):
+        for i in range(min(nin, 4)):
+            if g["STATUS_DYN"][k, i] != 0 or not g["KKT_DYN"][k, i] < 1e-9:
+                continue
+            r = o.ocp_solve_exact(p, g["XHAT_C"][k, i], g["XS"][k, i], g["US"][k, i], g["D_HAT"][k, i], g["U_PREV"][k, i])
+            assert r["status"] == 0 and o.kkt_max(r["res"]) < 1e-9
+            assert np.abs(r["u0"] - g["U"][k, i]).max() < 1e-9
+            checked += 1
+    assert checked >= 8
+
+
+@pytest.mark.parametrize("name", ["cstr_shipped", "wb_shipped", "cstr_box"])
+def test_riccati_restatement_reproduces_golden_ocps(name, cstr, wb):
+    """The structure-exploiting algorithm (NumPy statement) hits the exact optimum of every certified golden OCP."""
+    p = wb if name.startswith("wb") else cstr
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sh = g["U"].shape[:2]
+    flat = lambda a: a.reshape((sh[0] * sh[1],) + a.shape[2:])
+    sd = rn.stage_data(p)
+    r = rn.rpdip_solve(sd, rn.instance_data(p, sd, flat(g["XHAT_C"]), flat(g["XS"]), flat(g["US"]), flat(g["D_HAT"]), flat(g["U_PREV"])))
+    st, kkt = flat(g["STATUS_DYN"]), flat(g["KKT_DYN"])
+    assert np.array_equal(r["status"] == 2, st == 2)
+    ok = (st == 0) & (kkt < 1e-9)
+    err = np.abs(r["u0"] - flat(g["U"]))[ok].max(axis=1)
+    assert ok.sum() > 0.8 * (st == 0).sum()
+    assert err.max() < 1e-6 and np.median(err) < 1e-8, (err.max(), np.median(err))      # tolerance: DESIGN.md section 5
+    assert (r["status"][ok] == 0).all()
+
+
+def test_target_restatement_matches_dense_exact(cstr, wb):
+    rng = np.random.default_rng(3)
+    for p in (cstr, wb):
+        td = rn.target_data(p)
+        d = rng.uniform(-0.3, 0.3, size=(12, p.nd)) * (10 if p is cstr else 1)
+        ysp = np.array([0.2, 0, 0]) if p is cstr else np.array([1.0, -1.0])
+        usp, xsp, usprev = np.zeros(p.nu), np.zeros(p.nx), np.zeros((12, p.nu))
+        r = rn.target_solve(p, td, usp, ysp, xsp, d, usprev)
+        for i in range(12):
+            q = o.target_solve_exact(p, usp, ysp, xsp, d[i], usprev[i])
+            assert q["status"] == r["status"][i]
+            if q["status"] == 0 and q["exact"]:
+                assert np.abs(q["xs"] - r["xs"][i]).max() < 1e-6 and np.abs(q["us"] - r["us"][i]).max() < 1e-6
+
+
+def test_kalman_matches_textbook_form(cstr):
+    rng = np.random.default_rng(5)
+    xi = rng.normal(size=6); Pm = cstr.P0 + 1e-3 * np.eye(6); y = rng.normal(size=3)
+    yhat = cstr.C @ xi[:3] + cstr.Cd @ xi[3:]
+    a, b = o.kalman(cstr, xi, Pm, y, yhat)
+    Aa, Ca = cstr.aug_estimator_matrices()
+    K = Pm @ Ca.T @ np.linalg.inv(Ca @ Pm @ Ca.T + cstr.R_kf)
+    assert np.allclose(a, xi + K @ (y - yhat)) and np.allclose(b, Aa @ (Pm - K @ Ca @ Pm) @ Aa.T + cstr.Q_kf)
+    a2, b2 = rn.kalman_batch(cstr, xi[None], Pm[None], y[None], yhat[None])
+    assert np.allclose(a2[0], a) and np.allclose(b2[0], b)
