@@ -61,7 +61,7 @@ struct OcpArgs {
     int B; size_t Bs;
 };
 
-template <int NX, int NU, int NY, int ND, bool DU>
+template <int NX, int NU, int NY, int ND, bool DU, int NC, bool MASKED>
 __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ Pp, OcpArgs a)
 {
     constexpr int NS = NX + (DU ? NU : 0);
@@ -76,11 +76,11 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     build_inst<NX, NU, NY, ND, DU>(P, xhat, xs, us, dh, up, q);
     StageConst<NS, NU> C;
     load_stage_const<NS, NU, DU>(P, C);
-    constexpr int SL = BlkLayout<NS, NU>::SLOTS;
+    constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
     Ws ws{(double2 *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64 + threadIdx.x, P.N, SL};
     double u0[NU], z1[NS], res[3];
     int it;
-    const int st = rpdip_lane<NS, NU, DU>(P, C, q, ws, P.max_iter, u0, z1, res, it);
+    const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, u0, z1, res, it);
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
@@ -155,7 +155,7 @@ struct LoopArgs {
     int B, nsteps; size_t Bs;
 };
 
-template <int NX, int NU, int NY, int ND, int NXP, bool DU>
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NC, bool MASKED>
 __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__ Pp, LoopArgs a)
 {
     constexpr int NS = NX + (DU ? NU : 0), NE = NX + ND;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
     StageConst<NS, NU> C;
     load_stage_const<NS, NU, DU>(P, C);
-    constexpr int SL = BlkLayout<NS, NU>::SLOTS;
+    constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
     Ws ws{(double2 *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64 + threadIdx.x, P.N, SL};
     for (int k = 0; k < a.nsteps; k++) {
         if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
         double u0[NU], z1[NS], res[3];
         int it_dyn;
-        const int st_dyn = rpdip_lane<NS, NU, DU>(P, C, q, ws, P.max_iter, u0, z1, res, it_dyn);
+        const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, u0, z1, res, it_dyn);
         if (st_dyn != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = u0[i];          // :798
             MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
@@ -274,19 +274,32 @@ struct Launchers {
     void (*target)(const DevProblem *, TargetArgs, hipStream_t);
     void (*kf)(const DevProblem *, KfArgs, hipStream_t);
     void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
-    int ws_rows;
+    int ws_rows, nc;
 };
 
-template <int NX, int NU, int NY, int ND, int NXP, bool DU>
-static Launchers make_launchers()
+// bound modes: which variant of the OCP kernels a problem may use (cheapest first)
+enum { kBoundsAllFinite = 1, kBoundsInputsOnly = 2, kBoundsGeneric = 0 };
+
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NC, bool MASKED>
+static Launchers make_launchers_mode()
 {
     Launchers l;
-    l.ocp = [](const DevProblem *p, OcpArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel<NX, NU, NY, ND, DU>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.ocp = [](const DevProblem *p, OcpArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel<NX, NU, NY, ND, DU, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
-    l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
-    l.ws_rows = 2 * BlkLayout<NX + (DU ? NU : 0), NU>::SLOTS;   // doubles per instance per block
+    l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.ws_rows = 2 * BlkLayout<NX + (DU ? NU : 0), NU, NC>::SLOTS;   // doubles per instance per block
+    l.nc = NC;
     return l;
+}
+
+template <int NX, int NU, int NY, int ND, int NXP, bool DU>
+static Launchers make_launchers(int mode)
+{
+    constexpr int NS = NX + (DU ? NU : 0);
+    if (mode == kBoundsAllFinite) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NS + NU, false>();
+    if (mode == kBoundsInputsOnly) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NU, false>();
+    return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NS + NU, true>();
 }
 
 struct DevBuf {
@@ -467,6 +480,22 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
     return 0;
 }
 
+// cheapest kernel variant the bounds allow: every bounded variable two-sided finite => no masks at all
+static int bound_mode(const mpc_lin_desc *d)
+{
+    bool u_all = true, x_all = true, x_none = true;
+    for (int i = 0; i < d->nu; i++) u_all = u_all && std::isfinite(d->umin[i]) && std::isfinite(d->umax[i]);
+    for (int i = 0; i < d->nx; i++) {
+        const bool lo = std::isfinite(d->xmin[i]), hi = std::isfinite(d->xmax[i]);
+        x_all = x_all && lo && hi; x_none = x_none && !lo && !hi;
+    }
+    bool y_any = false;
+    if (d->y_bounded) for (int i = 0; i < d->ny; i++) y_any = y_any || std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]);
+    if (u_all && x_all && !d->du_form) return kBoundsAllFinite;        // Delta-u form carries unbounded u_prev states
+    if (u_all && x_none && !y_any) return kBoundsInputsOnly;
+    return kBoundsGeneric;
+}
+
 extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
 {
     if (!d || !out) return fail(-1, "null argument");
@@ -481,7 +510,7 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
     bool found = false;
 #define MPC_TRY_DIM(NX, NU, NY, ND, NXP, DU)                                                                  \
     if (!found && d->nx == NX && d->nu == NU && d->ny == NY && d->nd == ND && d->nxp == NXP && (d->du_form != 0) == (DU != 0)) { \
-        h->L = make_launchers<NX, NU, NY, ND, NXP, (DU != 0)>();                                              \
+        h->L = make_launchers<NX, NU, NY, ND, NXP, (DU != 0)>(bound_mode(d));                                 \
         found = true;                                                                                         \
     }
     MPC_DIM_LIST(MPC_TRY_DIM)
@@ -610,7 +639,7 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     }
     if (w_out) {   // primal trajectory in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) from the workspace
         const int N = P.N, ns = nx + (P.du_form ? nu : 0), nv = ns + nu, nxu = nx + nu;
-        const int slots = h->L.ws_rows / 2, slotU = 4 * nv, slotZ = slotU + (nu + 1) / 2;
+        const int slots = h->L.ws_rows / 2, slotU = 4 * h->L.nc, slotZ = slotU + (nu + 1) / 2; (void)nv;
         std::vector<double> wsh((size_t)h->L.ws_rows * (N + 2) * Bs);
         HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));
         auto at = [&](int b, int k, int slot, int comp) { return wsh[((((size_t)(b / 64) * (N + 2) + k + 1) * slots + slot) * 64 + (b % 64)) * 2 + comp]; };

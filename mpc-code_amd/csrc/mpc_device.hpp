@@ -90,11 +90,11 @@ __device__ __forceinline__ double vreg(double x)
 // One wave owns a contiguous slab; inside it block k (u_k, z_{k+1} and everything attached to them) is a
 // run of SLOTS double2 "slots", each slot holding 64 lanes x 2 doubles = 1 KiB, so that every access of a
 // wave is one fully coalesced global_load/store_dwordx4 at a compile-time offset from a scalar base.
-template <int NS, int NU>
+template <int NS, int NU, int NC>
 struct BlkLayout {
     static constexpr int NV = NS + NU;
-    static constexpr int S = 0, L = NV, P = 2 * NV, IS = 3 * NV;   // pair slots {lo, hi}, one per bounded variable
-    static constexpr int U = 4 * NV, Z = U + (NU + 1) / 2, DU = Z + (NS + 1) / 2, DZ = DU + (NU + 1) / 2,
+    static constexpr int S = 0, L = NC, P = 2 * NC, IS = 3 * NC;   // pair slots {lo, hi}, one per bounded variable
+    static constexpr int U = 4 * NC, Z = U + (NU + 1) / 2, DU = Z + (NS + 1) / 2, DZ = DU + (NU + 1) / 2,
                          KFF = DZ + (NS + 1) / 2, K = KFF + (NU + 1) / 2, LI = K + (NU * NS + 1) / 2,
                          SLOTS = LI + (NU * (NU + 1) / 2 + 1) / 2;
 };
@@ -229,33 +229,38 @@ __device__ __forceinline__ void load_stage_const(const DevProblem &P, StageConst
     MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) C.R[i][j] = vreg(P.R[i][j]); }
 }
 
-template <int NS, int NU, bool HASM>
+// NC = number of bounded variables per block (NU: inputs only, NS+NU: inputs and states); MASKED = some of
+// those bounds may be absent (+-inf).  The host picks the cheapest variant the problem allows.
+template <int NS, int NU, bool HASM, int NC, bool MASKED>
 __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, const OcpInst<NS, NU> &q, const Ws &ws,
                           int max_iter, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
 {
-    using L = BlkLayout<NS, NU>;
+    using L = BlkLayout<NS, NU, NC>;
     constexpr int NV = NS + NU;
+    static_assert(NC == NU || NC == NV, "bounded variables: inputs, or inputs and states");
     const int N = ws.N;
     res[0] = res[1] = res[2] = 0.0;
     iters = 0;
     if (!q.ok0) return kInfeasible;
 
-    // bounds of block k = (u_k, z_{k+1}): mid blocks and the last one; absent bounds are masked
-    double lo_m[NV], hi_m[NV], lo_e[NV], hi_e[NV];
-    bool fl_m[NV], fh_m[NV], fl_e[NV], fh_e[NV];
+    // bounds of block k = (u_k, z_{k+1}).  cur_lo/cur_hi hold the bounds of the block being processed: the
+    // sweeps switch them between "mid" (k < N-1) and "end" (k = N-1) once per sweep instead of selecting per block.
+    double lo_m[NC], hi_m[NC], lo_e[NC], hi_e[NC], cur_lo[NC], cur_hi[NC];
+    bool fl_m[NC], fh_m[NC], fl_e[NC], fh_e[NC], cur_fl[NC], cur_fh[NC];
     double ncon = 0.0;
-    MPC_UNROLL for (int i = 0; i < NV; i++) {
+    MPC_UNROLL for (int i = 0; i < NC; i++) {
         const double lm = i < NU ? P.ulo[i < NU ? i : 0] : q.zlo_m[i >= NU ? i - NU : 0], hm = i < NU ? P.uhi[i < NU ? i : 0] : q.zhi_m[i >= NU ? i - NU : 0];
         const double le = i < NU ? P.ulo[i < NU ? i : 0] : P.zlo_e[i >= NU ? i - NU : 0], he = i < NU ? P.uhi[i < NU ? i : 0] : P.zhi_e[i >= NU ? i - NU : 0];
-        fl_m[i] = fin(lm); fh_m[i] = fin(hm); fl_e[i] = fin(le); fh_e[i] = fin(he);
+        fl_m[i] = MASKED ? fin(lm) : true; fh_m[i] = MASKED ? fin(hm) : true; fl_e[i] = MASKED ? fin(le) : true; fh_e[i] = MASKED ? fin(he) : true;
         lo_m[i] = fl_m[i] ? lm : 0.0; hi_m[i] = fh_m[i] ? hm : 0.0; lo_e[i] = fl_e[i] ? le : 0.0; hi_e[i] = fh_e[i] ? he : 0.0;
         ncon += (double)(N - 1) * ((fl_m[i] ? 1 : 0) + (fh_m[i] ? 1 : 0)) + (fl_e[i] ? 1 : 0) + (fh_e[i] ? 1 : 0);
     }
     const double inv_ncon = 1.0 / dmax(ncon, 1.0);
+    auto use_mid = [&]() { MPC_UNROLL for (int i = 0; i < NC; i++) { cur_lo[i] = lo_m[i]; cur_hi[i] = hi_m[i]; cur_fl[i] = fl_m[i]; cur_fh[i] = fh_m[i]; } };
+    auto use_end = [&]() { MPC_UNROLL for (int i = 0; i < NC; i++) { cur_lo[i] = lo_e[i]; cur_hi[i] = hi_e[i]; cur_fl[i] = fl_e[i]; cur_fh[i] = fh_e[i]; } };
 #define MPC_BOUNDS(k, i, lo, hi, fl, fh)                                   \
-    const bool last_##i = (k) == N - 1;                                    \
-    const double lo = last_##i ? lo_e[i] : lo_m[i], hi = last_##i ? hi_e[i] : hi_m[i]; \
-    const bool fl = last_##i ? fl_e[i] : fl_m[i], fh = last_##i ? fh_e[i] : fh_m[i];
+    const double lo = cur_lo[i], hi = cur_hi[i];                           \
+    const bool fl = MASKED ? cur_fl[i] : true, fh = MASKED ? cur_fh[i] : true;
 
     // ---- initial point: u = us pushed inside its box, z simulated, slacks >= kSMin -------------------
     {
@@ -271,7 +276,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             uinit[i] = v; zero_u[i] = 0.0;
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) { z[i] = q.z0[i]; zero_z[i] = 0.0; }
+        use_mid();
         for (int k = 0; k < N; k++) {
+            if (k == N - 1) use_end();
             double2 *b = ws.blk(k);
             double zn[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
@@ -281,7 +288,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 zn[i] = a;
             }
             MPC_UNROLL for (int i = 0; i < NS; i++) z[i] = zn[i];
-            MPC_UNROLL for (int i = 0; i < NV; i++) {
+            MPC_UNROLL for (int i = 0; i < NC; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
                 const double v = i < NU ? uinit[i < NU ? i : 0] : z[i >= NU ? i - NU : 0];
                 double2 sv, lv, iv, pz;
@@ -310,25 +317,28 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         MPC_UNROLL for (int i = 0; i < NU; i++) unext_dev[i] = 0.0;
         double ublk[NU], zblk[NS];
         const bool upd = alpha != 0.0;
-        struct B1Blk { double2 s[NV], l[NV], p[NV], is[NV]; double u[NU], z[NS], du[NU], dz[NS]; };
+        struct B1Blk { double2 s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], du[NU], dz[NS]; };
         auto load_b1 = [&](int k, B1Blk &d) {
             const double2 *b = ws.blk(k);
-            MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; }
+            MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; }
             ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z);
             if (upd) {
-                MPC_UNROLL for (int i = 0; i < NV; i++) { d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::DU, d.du); ld_field<NS>(b, L::DZ, d.dz);
             }
         };
         B1Blk cur;
         load_b1(N - 1, cur);
+        use_end();
         for (int k = N - 1; k >= 0; k--) {
+            if (k == N - 2) use_mid();
             double2 *b = ws.blk(k);
             double sig[NV], dlm[NV], haff[NV];
+            MPC_UNROLL for (int i = NC; i < NV; i++) { sig[i] = 0.0; dlm[i] = 0.0; haff[i] = 0.0; }
             // ---- phase A: apply the previous step to block k, residuals and barrier weights -----------
             MPC_UNROLL for (int i = 0; i < NU; i++) ublk[i] = cur.u[i];
             MPC_UNROLL for (int i = 0; i < NS; i++) zblk[i] = cur.z[i];
-            MPC_UNROLL for (int i = 0; i < NV; i++) {
+            MPC_UNROLL for (int i = 0; i < NC; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
                 double v = i < NU ? ublk[i < NU ? i : 0] : zblk[i >= NU ? i - NU : 0];
                 double sl = cur.s[i].x, sh = cur.s[i].y, ll = cur.l[i].x, lh = cur.l[i].y;
@@ -357,7 +367,10 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 cres = dmax(cres, dmax(comp_measure(sl, ll), comp_measure(sh, lh)));
                 lmax = dmax(lmax, dmax(ll, lh));
             }
-            if (upd) { st_field<NU>(b, L::U, ublk); st_field<NS>(b, L::Z, zblk); }
+            if (upd) {
+                MPC_UNROLL for (int i = NC; i < NV; i++) zblk[i >= NU ? i - NU : 0] += alpha * cur.dz[i >= NU ? i - NU : 0];   // unbounded states
+                st_field<NU>(b, L::U, ublk); st_field<NS>(b, L::Z, zblk);
+            }
             // ---- prefetch block k-1 into the (now dead) buffer; it lands while phase B computes ---------
             load_b1(k - 1, cur);     // k-1 = -1 is a guard block
             // ---- phase B: Riccati step.  P_{k+1} completed with the barrier weights of z_{k+1} -----------
@@ -468,17 +481,19 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         // ======================= sweep F1 (forward): predictor ======================================
         double m_aff = 1.0, s1 = 0.0, s2 = 0.0;      // m = max(1, max_i -d_i/x_i); step to the boundary = 1/m
         {
-            struct F1Blk { double2 s[NV], l[NV], is[NV]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
+            struct F1Blk { double2 s[NC], l[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f1 = [&](int k, F1Blk &d) {
                 const double2 *b = ws.blk(k);
-                MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
             };
             F1Blk c1;
             load_f1(0, c1);
+            use_mid();
             double dz[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
+                if (k == N - 1) use_end();
                 double2 *b = ws.blk(k);
                 const double2 *nb = ws.blk(k + 1);      // block N is a guard block; every field is reloaded in place
                 double ddu[NU], dzn[NS];                 // right after its last use (rolling prefetch, no second buffer)
@@ -486,7 +501,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 ld_field<NU>(nb, L::KFF, c1.kff); ld_field<NU * NS>(nb, L::K, c1.K);
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
-                MPC_UNROLL for (int i = 0; i < NV; i++) {
+                MPC_UNROLL for (int i = 0; i < NC; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
                     const double v = i < NU ? c1.u[i < NU ? i : 0] : c1.z[i >= NU ? i - NU : 0];
                     const double dv = i < NU ? ddu[i < NU ? i : 0] : dz[i >= NU ? i - NU : 0];
@@ -516,22 +531,25 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         }
         // ======================= sweep B2 (backward): corrector rhs ================================
         {
-            struct B2Blk { double2 s[NV], l[NV], p[NV], is[NV]; double u[NU], z[NS], K[NU * NS], li[NU * (NU + 1) / 2]; };
+            struct B2Blk { double2 s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], K[NU * NS], li[NU * (NU + 1) / 2]; };
             auto load_b2 = [&](int k, B2Blk &d) {
                 const double2 *b = ws.blk(k);
-                MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU * NS>(b, L::K, d.K); ld_field<NU * (NU + 1) / 2>(b, L::LI, d.li);
             };
             B2Blk c2;
             load_b2(N - 1, c2);
+            use_end();
             double pc[NS], und[NU], zprev[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
             MPC_UNROLL for (int i = 0; i < NU; i++) und[i] = 0.0;
             for (int k = N - 1; k >= 0; k--) {
+                if (k == N - 2) use_mid();
                 double2 *b = ws.blk(k);
                 const double2 *nb = ws.blk(k - 1);       // block -1 is a guard block
                 double hcc[NV], dlm[NV];
-                MPC_UNROLL for (int i = 0; i < NV; i++) {
+                MPC_UNROLL for (int i = NC; i < NV; i++) { hcc[i] = 0.0; dlm[i] = 0.0; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
                     const double v = i < NU ? c2.u[i < NU ? i : 0] : c2.z[i >= NU ? i - NU : 0];
                     const double sl = c2.s[i].x, sh = c2.s[i].y, ll = c2.l[i].x, lh = c2.l[i].y;
@@ -594,17 +612,19 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         // ======================= sweep F2 (forward): corrector direction ============================
         double m_cc = 1.0;
         {
-            struct F2Blk { double2 s[NV], l[NV], p[NV], is[NV]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
+            struct F2Blk { double2 s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f2 = [&](int k, F2Blk &d) {
                 const double2 *b = ws.blk(k);
-                MPC_UNROLL for (int i = 0; i < NV; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
             };
             F2Blk c3;
             load_f2(0, c3);
+            use_mid();
             double dz[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
+                if (k == N - 1) use_end();
                 double2 *b = ws.blk(k);
                 const double2 *nb = ws.blk(k + 1);
                 double ddu[NU], dzn[NS];
@@ -613,7 +633,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
                 st_field<NU>(b, L::DU, ddu); st_field<NS>(b, L::DZ, dz);
-                MPC_UNROLL for (int i = 0; i < NV; i++) {
+                MPC_UNROLL for (int i = 0; i < NC; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
                     const double v = i < NU ? c3.u[i < NU ? i : 0] : c3.z[i >= NU ? i - NU : 0];
                     const double dv = i < NU ? ddu[i < NU ? i : 0] : dz[i >= NU ? i - NU : 0];

@@ -76,7 +76,7 @@ def plant_fy(p, xp, pyp):
 # ----------------------------------------------------------------------------------------
 # dense QP data in the reference's own layouts
 # ----------------------------------------------------------------------------------------
-def ocp_qp(p, xhat, xs, us, dhat, u_prev):
+def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
     """QP of ``opt_dyn`` in its own variable order w=[x0,u0,...,x_{N-1},u_{N-1},x_N].
 
     Returns ``H, g, E, e, G, lo, hi``:  min 1/2 w'Hw + g'w  s.t.  E w = e,  lo <= G w <= hi.
@@ -84,6 +84,8 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev):
     Inequality rows: variable bounds on x_1..x_N, u_0..u_{N-1} (:248-252; x_0 is fixed by
     ``w_lb[0:nx]=w_ub[0:nx]=xhat``, MPC_code.py:734, so its bound rows are dropped), then the
     ``g1`` rows ``ymin <= C x_k + Cd d + .. <= ymax`` for k=0..N-1 (:130,150-151,229-230).
+    ``drop_stage0_rows`` leaves out the k=0 rows: they constrain the given x_0, i.e. they are a feasibility
+    test that :func:`ocp_solve` makes up front with IPOPT's bound relaxation.
     """
     n, m, N = p.nx, p.nu, p.N
     nxu = n + m
@@ -136,7 +138,7 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev):
                 rows.append(row); lo.append(p.umin[i]); hi.append(p.umax[i])
     if p.y_bounded:
         yc = p.fy_const + (p.Cd @ dhat if p.nd else 0.0)
-        for k in range(N):
+        for k in range(1 if drop_stage0_rows else 0, N):
             for i in range(p.ny):
                 if np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i]):
                     row = np.zeros(nw); row[ix(k)] = p.C[i]
@@ -312,7 +314,7 @@ def ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=1e-11):
     (Control_Calc.py:128-151): if ``C xhat + ..`` violates [ymin,ymax] the problem is infeasible
     whatever u is - reported as status 2 before any iteration.
     """
-    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev)
+    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True)
     n, m = p.nx, p.nu
     if p.y_bounded:
         y0 = model_fy(p, xhat, dhat)
@@ -376,7 +378,8 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, u0=None, dhat0=None, P0=None, s
     x0_m_fixed = np.array(p.x0_m if x0_m is None else x0_m, dtype=float)
     us_k, xs_k = u.copy(), x0_m_fixed.copy()                    # MPC_code.py:682-684
     log = {k: [] for k in ("Xp", "X_HAT", "Yp", "Y_HAT", "D_HAT", "XS", "US", "YS", "U",
-                           "STATUS_SS", "STATUS_DYN", "KKT_DYN", "KKT_SS", "ITERS_DYN", "XHAT_C", "U_PREV")}
+                           "STATUS_SS", "STATUS_DYN", "KKT_DYN", "KKT_SS", "ITERS_DYN", "XHAT_C", "U_PREV",
+                           "EXACT_DYN", "EXACT_SS")}
     n = p.nx
     for k in range(nsteps):
         log["Xp"].append(x.copy()); log["X_HAT"].append(xhat.copy())
@@ -399,6 +402,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, u0=None, dhat0=None, P0=None, s
         log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy())
         log["YS"].append(model_fy(p, xs_k, dhat))
         log["STATUS_SS"].append(t["status"]); log["KKT_SS"].append(kkt_max(t["res"]))
+        log["EXACT_SS"].append(bool(t.get("exact", False)))
         o = ocp(p, xhat, xs_k, us_k, dhat, u, tol=tol)
         if o["status"] != STATUS_INFEASIBLE:
             u, xhat = o["u0"].copy(), o["x1"].copy()             # MPC_code.py:798-799
@@ -406,7 +410,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, u0=None, dhat0=None, P0=None, s
             xhat = model_fx(p, xhat, u, dhat)                    # MPC_code.py:804-805
         log["U"].append(u.copy()); log["STATUS_DYN"].append(o["status"])
         log["KKT_DYN"].append(kkt_max(o["res"]) if o["res"] else np.nan)
-        log["ITERS_DYN"].append(o["iters"])
+        log["ITERS_DYN"].append(o["iters"]); log["EXACT_DYN"].append(bool(o.get("exact", False)))
         x = plant_fx(p, x, u, sched["pxp"][k])                   # MPC_code.py:816
     return {k: np.array(v) for k, v in log.items()}
 
@@ -459,7 +463,7 @@ def ocp_solve_exact(p, xhat, xs, us, dhat, u_prev, tol=1e-11):
     r["exact"] = False
     if r["status"] != STATUS_SOLVED:
         return r
-    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev)
+    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True)
     pol = qp_polish(H, g, E, e, G, lo, hi, r["w"], r["z_lo"], r["z_hi"])
     if pol is not None:
         n, m = p.nx, p.nu

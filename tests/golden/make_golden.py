@@ -12,6 +12,10 @@ them with oracle.mpc_oracle.kkt_residual without trusting any solver.
   cstr_box.npz       24 instances from the benchmark's initial-state box, 12 steps each
 Each file: per step the inputs of the OCP (XHAT_C, XS, US, D_HAT, U_PREV), its outputs (U, X_NEXT via
 X_HAT of the next step), status words, KKT residuals, and the loop logs under the reference's names.
+EXACT_DYN / EXACT_SS mark the rows whose active-set polish verified (complementarity exactly zero, primal and
+dual feasibility checked): only those are exact optima.  A small KKT residual alone is not a certificate of a
+small primal error when bounds are degenerate (s* = l* = 0): there the error of an interior-point answer goes
+like the square root of its complementarity residual.
 """
 import os
 import sys
