@@ -20,7 +20,7 @@ import numpy as np
 from . import PKG_DIR
 
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmpc_amd.so")
+LIB_PATH = os.environ.get("MPC_AMD_LIB") or os.path.join(CSRC, "libmpc_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2

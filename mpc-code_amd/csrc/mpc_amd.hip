@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     StageConst<NS, NU> C;
     load_stage_const<NS, NU, DU>(P, C);
     constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
-    Ws ws{(double2 *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64 + threadIdx.x, P.N, SL};
+    Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
     double u0[NU], z1[NS], res[3];
     int it;
     const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, u0, z1, res, it);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     StageConst<NS, NU> C;
     load_stage_const<NS, NU, DU>(P, C);
     constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
-    Ws ws{(double2 *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64 + threadIdx.x, P.N, SL};
+    Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
     for (int k = 0; k < a.nsteps; k++) {
         if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
         if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }

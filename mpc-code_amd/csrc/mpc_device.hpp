@@ -58,8 +58,8 @@ struct DevProblem {
 
 #define MPC_UNROLL _Pragma("unroll")
 
-__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
-__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64, one instruction
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ bool fin(double a) { return fabs(a) < 1.0e300; }
 __device__ __forceinline__ double comp_measure(double s, double l)
 {
@@ -88,7 +88,7 @@ __device__ __forceinline__ double vreg(double x)
 
 // ---- OCP workspace --------------------------------------------------------------
 // One wave owns a contiguous slab; inside it block k (u_k, z_{k+1} and everything attached to them) is a
-// run of SLOTS double2 "slots", each slot holding 64 lanes x 2 doubles = 1 KiB, so that every access of a
+// run of SLOTS v2d "slots", each slot holding 64 lanes x 2 doubles = 1 KiB, so that every access of a
 // wave is one fully coalesced global_load/store_dwordx4 at a compile-time offset from a scalar base.
 template <int NS, int NU, int NC>
 struct BlkLayout {
@@ -99,26 +99,34 @@ struct BlkLayout {
                          SLOTS = LI + (NU * (NU + 1) / 2 + 1) / 2;
 };
 
+// A block pointer is a wave-uniform base plus the lane index; the pointer is explicitly in the global address
+// space so that accesses are global_load/store_dwordx4 with immediate offsets.
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) v2d gv2d;
+struct BlkPtr {
+    gv2d *base; int lane;
+    __device__ __forceinline__ gv2d &operator[](int i) const { return base[i + lane]; }
+};
 struct Ws {
-    double2 *slab;   // wave slab + lane, pointing at block 0; blocks -1 and N exist as guard blocks
-    int N, slots;
-    __device__ __forceinline__ double2 *blk(int k) const { return slab + (ptrdiff_t)k * slots * 64; }
+    gv2d *slab;   // wave slab (uniform), pointing at block 0; blocks -1 and N exist as guard blocks
+    int N, slots, lane;
+    __device__ __forceinline__ BlkPtr blk(int k) const { return BlkPtr{slab + (ptrdiff_t)k * slots * 64, lane}; }
 };
 
 template <int CNT>
-__device__ __forceinline__ void ld_field(const double2 *blk, int slot0, double (&out)[CNT])
+__device__ __forceinline__ void ld_field(const BlkPtr blk, int slot0, double (&out)[CNT])
 {
     MPC_UNROLL for (int j = 0; j < (CNT + 1) / 2; j++) {
-        const double2 v = blk[(slot0 + j) * 64];
+        const v2d v = blk[(slot0 + j) * 64];
         out[2 * j] = v.x;
         if (2 * j + 1 < CNT) out[2 * j + 1 < CNT ? 2 * j + 1 : 0] = v.y;
     }
 }
 template <int CNT>
-__device__ __forceinline__ void st_field(double2 *blk, int slot0, const double (&in)[CNT])
+__device__ __forceinline__ void st_field(const BlkPtr blk, int slot0, const double (&in)[CNT])
 {
     MPC_UNROLL for (int j = 0; j < (CNT + 1) / 2; j++) {
-        double2 v;
+        v2d v;
         v.x = in[2 * j];
         v.y = (2 * j + 1 < CNT) ? in[2 * j + 1 < CNT ? 2 * j + 1 : 0] : 0.0;
         blk[(slot0 + j) * 64] = v;
@@ -279,7 +287,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         use_mid();
         for (int k = 0; k < N; k++) {
             if (k == N - 1) use_end();
-            double2 *b = ws.blk(k);
+            const BlkPtr b = ws.blk(k);
             double zn[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = q.c[i];
@@ -291,7 +299,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NC; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
                 const double v = i < NU ? uinit[i < NU ? i : 0] : z[i >= NU ? i - NU : 0];
-                double2 sv, lv, iv, pz;
+                v2d sv, lv, iv, pz;
                 sv.x = fl ? dmax(v - lo, kSMin) : 1.0; sv.y = fh ? dmax(hi - v, kSMin) : 1.0;
                 iv.x = frcp(sv.x); iv.y = frcp(sv.y);
                 lv.x = fl ? kMu0 * iv.x : 0.0; lv.y = fh ? kMu0 * iv.y : 0.0;
@@ -317,9 +325,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         MPC_UNROLL for (int i = 0; i < NU; i++) unext_dev[i] = 0.0;
         double ublk[NU], zblk[NS];
         const bool upd = alpha != 0.0;
-        struct B1Blk { double2 s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], du[NU], dz[NS]; };
+        struct B1Blk { v2d s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], du[NU], dz[NS]; };
         auto load_b1 = [&](int k, B1Blk &d) {
-            const double2 *b = ws.blk(k);
+            const BlkPtr b = ws.blk(k);
             MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; }
             ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z);
             if (upd) {
@@ -332,7 +340,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         use_end();
         for (int k = N - 1; k >= 0; k--) {
             if (k == N - 2) use_mid();
-            double2 *b = ws.blk(k);
+            const BlkPtr b = ws.blk(k);
             double sig[NV], dlm[NV], haff[NV];
             MPC_UNROLL for (int i = NC; i < NV; i++) { sig[i] = 0.0; dlm[i] = 0.0; haff[i] = 0.0; }
             // ---- phase A: apply the previous step to block k, residuals and barrier weights -----------
@@ -355,7 +363,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
                 const double isl = frcp(sl), ish = frcp(sh);
                 if (upd) {
-                    double2 t; t.x = sl; t.y = sh; b[(L::S + i) * 64] = t;
+                    v2d t; t.x = sl; t.y = sh; b[(L::S + i) * 64] = t;
                     t.x = ll; t.y = lh; b[(L::L + i) * 64] = t;
                     t.x = isl; t.y = ish; b[(L::IS + i) * 64] = t;
                 }
@@ -481,9 +489,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         // ======================= sweep F1 (forward): predictor ======================================
         double m_aff = 1.0, s1 = 0.0, s2 = 0.0;      // m = max(1, max_i -d_i/x_i); step to the boundary = 1/m
         {
-            struct F1Blk { double2 s[NC], l[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
+            struct F1Blk { v2d s[NC], l[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f1 = [&](int k, F1Blk &d) {
-                const double2 *b = ws.blk(k);
+                const BlkPtr b = ws.blk(k);
                 MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
             };
@@ -494,8 +502,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
                 if (k == N - 1) use_end();
-                double2 *b = ws.blk(k);
-                const double2 *nb = ws.blk(k + 1);      // block N is a guard block; every field is reloaded in place
+                const BlkPtr b = ws.blk(k);
+                const BlkPtr nb = ws.blk(k + 1);      // block N is a guard block; every field is reloaded in place
                 double ddu[NU], dzn[NS];                 // right after its last use (rolling prefetch, no second buffer)
                 MPC_UNROLL for (int i = 0; i < NU; i++) { double a = c1.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += c1.K[i * NS + j] * dz[j]; ddu[i] = a; }
                 ld_field<NU>(nb, L::KFF, c1.kff); ld_field<NU * NS>(nb, L::K, c1.K);
@@ -517,7 +525,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                     if (fh) m_aff = dmax(m_aff, 1.0 + qh);
                     s1 += sl * dll + ll * dsl + sh * dlh + lh * dsh;
                     s2 += dsl * dll + dsh * dlh;
-                    double2 t; t.x = dsl * dll; t.y = dsh * dlh;
+                    v2d t; t.x = dsl * dll; t.y = dsh * dlh;
                     b[(L::P + i) * 64] = t;
                 }
                 ld_field<NU>(nb, L::U, c1.u); ld_field<NS>(nb, L::Z, c1.z);
@@ -531,9 +539,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         }
         // ======================= sweep B2 (backward): corrector rhs ================================
         {
-            struct B2Blk { double2 s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], K[NU * NS], li[NU * (NU + 1) / 2]; };
+            struct B2Blk { v2d s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], K[NU * NS], li[NU * (NU + 1) / 2]; };
             auto load_b2 = [&](int k, B2Blk &d) {
-                const double2 *b = ws.blk(k);
+                const BlkPtr b = ws.blk(k);
                 MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU * NS>(b, L::K, d.K); ld_field<NU * (NU + 1) / 2>(b, L::LI, d.li);
             };
@@ -545,8 +553,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NU; i++) und[i] = 0.0;
             for (int k = N - 1; k >= 0; k--) {
                 if (k == N - 2) use_mid();
-                double2 *b = ws.blk(k);
-                const double2 *nb = ws.blk(k - 1);       // block -1 is a guard block
+                const BlkPtr b = ws.blk(k);
+                const BlkPtr nb = ws.blk(k - 1);       // block -1 is a guard block
                 double hcc[NV], dlm[NV];
                 MPC_UNROLL for (int i = NC; i < NV; i++) { hcc[i] = 0.0; dlm[i] = 0.0; }
                 MPC_UNROLL for (int i = 0; i < NC; i++) {
@@ -612,9 +620,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         // ======================= sweep F2 (forward): corrector direction ============================
         double m_cc = 1.0;
         {
-            struct F2Blk { double2 s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
+            struct F2Blk { v2d s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f2 = [&](int k, F2Blk &d) {
-                const double2 *b = ws.blk(k);
+                const BlkPtr b = ws.blk(k);
                 MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
             };
@@ -625,8 +633,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
                 if (k == N - 1) use_end();
-                double2 *b = ws.blk(k);
-                const double2 *nb = ws.blk(k + 1);
+                const BlkPtr b = ws.blk(k);
+                const BlkPtr nb = ws.blk(k + 1);
                 double ddu[NU], dzn[NS];
                 MPC_UNROLL for (int i = 0; i < NU; i++) { double a = c3.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += c3.K[i * NS + j] * dz[j]; ddu[i] = a; }
                 ld_field<NU>(nb, L::KFF, c3.kff); ld_field<NU * NS>(nb, L::K, c3.K);

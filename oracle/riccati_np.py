@@ -35,6 +35,9 @@ TOL_MU = 1e-12     # ... or s*l <= TOL_MU (degenerate bounds, s* = l* = 0, conve
 MU_FLOOR = 1e-13   # the centring target sigma*mu is never below this ...
 S_FLOOR = 1e-11    # ... nor below l*S_FLOOR: no slack is driven under S_FLOOR (keeps l/s bounded)
 BOUND_RELAX = 1e-8 # relaxation of the stage-0 output rows (constraints on a given quantity)
+POLISH_AT = (1, 5, 9, 13)  # interior-point iteration counts after which an active-set polish is attempted
+POLISH_W = 1e8     # augmented-Lagrangian weight on the active bounds of the polish
+POLISH_TOL = 1e-9  # polish accepted if bound violation, negative multipliers and the last correction are below this
 INFEAS_Z = 1e10    # dual blow-up threshold (times max(1,|g|)): infeasible problem
 STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2
 
@@ -117,7 +120,7 @@ def instance_data(p, sd, xhat, xs, us, dhat, u_prev):
                 us=us.copy())
 
 
-def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None):
+def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False):
     """Batched Mehrotra predictor-corrector with Riccati KKT solves.  Returns dict of [B,..] arrays."""
     A, Bm, Q, M, R, Pf = sd["A"], sd["B"], sd["Q"], sd["M"], sd["R"], sd["Pf"]
     n, m, N = sd["n"], sd["m"], sd["N"]
@@ -156,6 +159,7 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None):
     active = inst["ok0"].copy()
     gscale = None
     stall = np.zeros(Bsz, dtype=np.int64)
+    polished = np.zeros(Bsz, dtype=bool)
     res_out = np.zeros((Bsz, 3))
     K = np.empty((Bsz, N, m, n)); Linv = np.empty((Bsz, N, m, m)); Acl = np.empty((Bsz, N, n, n))
 
@@ -189,6 +193,12 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None):
         lmax = np.maximum(l_lo.max(axis=(1, 2)), l_hi.max(axis=(1, 2)))
         bad = active & ((lmax > INFEAS_Z * gscale) | ~np.isfinite(mu))
         status[bad] = STATUS_INFEASIBLE; iters[bad] = it; active &= ~bad
+        if polish and it in POLISH_AT and active.any():
+            pu, pz, pok, pres = _polish(sd, inst, lo_f, hi_f, fl, fh, u, z, s_lo, s_hi, l_lo, l_hi)
+            acc = active & pok
+            u = np.where(acc[:, None, None], pu, u); z = np.where(acc[:, None, None], pz, z)
+            status[acc] = STATUS_SOLVED; iters[acc] = it; polished[acc] = True; active &= ~acc
+            res_out[acc] = pres[acc]
         if verbose:
             print(it, "active", active.sum(), "res", res_s.max(), res_p.max(), mu.max())
         if trace is not None:
@@ -263,7 +273,69 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None):
     status[left] = STATUS_MAXITER; iters[left] = max_iter
     status[~inst["ok0"]] = STATUS_INFEASIBLE; iters[~inst["ok0"]] = 0
     return dict(u=u, z=z, u0=u[:, 0].copy(), z1=z[:, 1].copy(), status=status, iters=iters, res=res_out,
-                l_lo=l_lo, l_hi=l_hi, s_lo=s_lo, s_hi=s_hi)
+                l_lo=l_lo, l_hi=l_hi, s_lo=s_lo, s_hi=s_hi, polished=polished)
+
+
+def _polish(sd, inst, lo_f, hi_f, fl, fh, u, z, s_lo, s_hi, l_lo, l_hi):
+    """Active-set polish of an interior-point iterate - EXPERIMENT, off by default, not in the C / HIP code
+    (it makes the easy majority exact after one interior-point iteration, but the regime that
+    dominates the benchmark - a long arc riding a state bound with geometrically decaying multipliers - neither
+    polishes nor survives primal-dual active-set updates, and at 4096 instances per GPU the slowest lane sets the pace).
+
+    Guess the active set from the iterate (a bound is active when its multiplier exceeds its slack), solve the
+    equality-constrained QP on it with an augmented-Lagrangian weight POLISH_W and the interior-point multipliers
+    as first estimate - one Riccati factorisation, two solves with a multiplier update in between - and VERIFY the
+    result: every bound satisfied, every active multiplier non-negative, second correction negligible.  A verified
+    point satisfies the KKT conditions with zero complementarity: it is the exact optimum.  Returns
+    (u, z, ok[B], res[B,3]); the caller keeps the interior-point iterate where ok is False.
+    """
+    A, Bm, Q, M, R, Pf = sd["A"], sd["B"], sd["Q"], sd["M"], sd["R"], sd["Pf"]
+    n, m, N = sd["n"], sd["m"], sd["N"]
+    zr, ur = inst["zr"], inst["ur"]
+    Bsz = u.shape[0]
+    a_lo = fl & (l_lo > s_lo); a_hi = fh & (l_hi > s_hi)
+    lam_lo = np.where(a_lo, l_lo, 0.0); lam_hi = np.where(a_hi, l_hi, 0.0)
+    wgt = POLISH_W * (a_lo.astype(float) + a_hi.astype(float))
+    K = np.empty((Bsz, N, m, n)); Linv = np.empty((Bsz, N, m, m)); Acl = np.empty((Bsz, N, n, n))
+    Pn = np.broadcast_to(Pf, (Bsz, n, n)) + _diag(wgt[:, N - 1, m:])
+    for k in range(N - 1, -1, -1):
+        PB = Pn @ Bm
+        Lam = R + _diag(wgt[:, k, :m]) + Bm.T @ PB
+        Psi = M.T + np.swapaxes(PB, 1, 2) @ A
+        Li = np.linalg.inv(Lam); Linv[:, k] = Li; K[:, k] = -Li @ Psi; Acl[:, k] = A + Bm @ K[:, k]
+        if k > 0:
+            Kk = K[:, k]; Rt = R + _diag(wgt[:, k, :m]); MK = M @ Kk
+            Pn = (Q + _diag(wgt[:, k - 1, m:]) + np.swapaxes(Acl[:, k], 1, 2) @ Pn @ Acl[:, k]
+                  + np.swapaxes(Kk, 1, 2) @ Rt @ Kk + MK + np.swapaxes(MK, 1, 2))
+            Pn = 0.5 * (Pn + np.swapaxes(Pn, 1, 2))
+    u = u.copy(); z = z.copy()
+    dlast = np.zeros(Bsz)
+    for _ in range(2):
+        v = np.concatenate([u, z[:, 1:]], axis=2)
+        al = np.where(a_lo, -lam_lo + POLISH_W * (v - lo_f), 0.0) + np.where(a_hi, lam_hi + POLISH_W * (v - hi_f), 0.0)
+        dz = z - zr[:, None, :]; du = u - ur[:, None, :]
+        gz = np.empty((Bsz, N + 1, n)); gu = np.empty((Bsz, N, m))
+        gz[:, :N] = dz[:, :N] @ Q.T + du @ M.T; gz[:, N] = dz[:, N] @ Pf.T
+        gu[:] = du @ R.T + dz[:, :N] @ M
+        gz[:, 1:] += al[:, :, m:]; gu += al[:, :, :m]
+        kff = np.empty((Bsz, N, m)); pv = gz[:, N].copy()
+        for k in range(N - 1, -1, -1):
+            psi = gu[:, k] + pv @ Bm
+            kff[:, k] = -np.einsum("bij,bj->bi", Linv[:, k], psi)
+            pv = gz[:, k] + np.einsum("bji,bj->bi", Acl[:, k], pv) + np.einsum("bji,bj->bi", K[:, k], gu[:, k])
+        d_z = np.zeros((Bsz, N + 1, n)); d_u = np.empty((Bsz, N, m))
+        for k in range(N):
+            d_u[:, k] = np.einsum("bij,bj->bi", K[:, k], d_z[:, k]) + kff[:, k]
+            d_z[:, k + 1] = d_z[:, k] @ A.T + d_u[:, k] @ Bm.T
+        u = u + d_u; z = z + d_z
+        v = np.concatenate([u, z[:, 1:]], axis=2)
+        lam_lo = np.where(a_lo, lam_lo - POLISH_W * (v - lo_f), 0.0); lam_hi = np.where(a_hi, lam_hi + POLISH_W * (v - hi_f), 0.0)
+        dlast = np.maximum(np.abs(d_u).max(axis=(1, 2)), np.abs(d_z).max(axis=(1, 2)))
+    viol = np.maximum(np.where(fl, lo_f - v, -np.inf), np.where(fh, v - hi_f, -np.inf)).max(axis=(1, 2))
+    dneg = np.minimum(np.where(a_lo, lam_lo, np.inf), np.where(a_hi, lam_hi, np.inf)).min(axis=(1, 2))
+    ok = (viol <= POLISH_TOL) & (dneg >= -POLISH_TOL) & (dlast <= POLISH_TOL) & np.isfinite(dlast)
+    res = np.stack([dlast, np.maximum(viol, 0.0), np.zeros(Bsz)], axis=1)
+    return u, z, ok, res
 
 
 def _comp(s, l):
