@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
     double u0[NU], z1[NS], res[3];
     int it;
-    const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, u0, z1, res, it);
+    const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, u0, z1, res, it);
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
@@ -151,6 +151,7 @@ struct LoopArgs {
     const double *ysp, *usp, *pxp, *pyp;             // schedules [step][dim], already offset to k0
     double *U, *XHAT, *XS, *US, *YS, *XP, *DHAT;     // logs [step][dim][Bs] offset to k0, or nullptr
     int32_t *st_dyn, *st_ss, *it_dyn, *it_ss;        // logs [step][Bs] offset to k0, or nullptr
+    int32_t *ws_valid;                               // [Bs] 1 if the workspace holds a solved OCP of the previous step
     double *ws;
     int B, nsteps; size_t Bs;
 };
@@ -172,7 +173,13 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     load_stage_const<NS, NU, DU>(P, C);
     constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
     Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
+    bool ws_valid = a.ws_valid[b] != 0;
     for (int k = 0; k < a.nsteps; k++) {
+        // data of the previous step, for the warm-start test: prediction of xhat, dhat, target
+        double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU];
+        MPC_UNROLL for (int i = 0; i < NX; i++) { xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) dh_prev[i] = dh[i];
+        MPC_UNROLL for (int i = 0; i < NU; i++) us_prev[i] = us[i];
         if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
         if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
         // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
@@ -223,7 +230,13 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
         double u0[NU], z1[NS], res[3];
         int it_dyn;
-        const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, u0, z1, res, it_dyn);
+        double delta = 0.0;
+        MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - xh_pred[i]), fabs(xs[i] - xs_prev[i])));
+        MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
+        MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
+        const bool warm = ws_valid && delta <= kWsDelta;
+        const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, u0, z1, res, it_dyn);
+        ws_valid = st_dyn == kSolved;
         if (st_dyn != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = u0[i];          // :798
             MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
@@ -256,6 +269,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     MPC_UNROLL for (int i = 0; i < NX; i++) { a.xhat[i * Bs + b] = xh[i]; a.xs[i * Bs + b] = xs[i]; }
     MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
     MPC_UNROLL for (int i = 0; i < NU; i++) { a.u[i * Bs + b] = u[i]; a.us[i * Bs + b] = us[i]; }
+    a.ws_valid[b] = ws_valid ? 1 : 0;
 }
 
 // dense [B][nu] copy of u for the all-gather of u* 
@@ -329,7 +343,7 @@ struct mpc_handle {
     DevBuf scratch, ws;
     // loop state
     int B = 0; size_t Bs = 0; int max_steps = 0, log_level = 0, sched_steps = 0, last_k0 = 0, last_n = 0;
-    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, sch, logs, logi;
+    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
@@ -538,7 +552,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->sch, &h->logs, &h->logi}) b->release();
+    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -741,8 +755,9 @@ extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32
     const int ne = P.nx + P.nd;
     if (h->st_x.ensure((size_t)P.nxp * Bs * 8) || h->st_xhat.ensure((size_t)P.nx * Bs * 8) || h->st_dhat.ensure((size_t)(P.nd ? P.nd : 1) * Bs * 8) ||
         h->st_P.ensure((size_t)ne * ne * Bs * 8) || h->st_u.ensure((size_t)P.nu * Bs * 8) || h->st_xs.ensure((size_t)P.nx * Bs * 8) ||
-        h->st_us.ensure((size_t)P.nu * Bs * 8))
+        h->st_us.ensure((size_t)P.nu * Bs * 8) || h->st_flag.ensure(Bs * 4))
         return -10;
+    HIP_TRY(hipMemset(h->st_flag.p, 0, Bs * 4));
     if (ensure_ws(h, Bs)) return -10;
     const int sdim = P.ny + P.nu + P.nxp + P.ny;   // ysp usp pxp pyp
     if (h->sch.ensure((size_t)max_steps * sdim * 8)) return -10;
@@ -796,6 +811,9 @@ extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double
     rc |= up_state(h, h->st_x, x_p, P.nxp); rc |= up_state(h, h->st_xhat, xhat, P.nx); rc |= up_state(h, h->st_dhat, dhat, P.nd);
     rc |= up_state(h, h->st_P, Pk, ne * ne); rc |= up_state(h, h->st_u, u, P.nu); rc |= up_state(h, h->st_xs, xs, P.nx);
     rc |= up_state(h, h->st_us, us, P.nu);
+    // a new state invalidates the warm start: the next OCP of every instance starts cold
+    HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, h->Bs * 4, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return rc ? -10 : 0;
 }
 
@@ -861,6 +879,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
             int32_t *li = (int32_t *)h->logi.p;
             a.st_dyn = li + (size_t)k * Bs; a.st_ss = li + ms * Bs + (size_t)k * Bs; a.it_dyn = li + 2 * ms * Bs + (size_t)k * Bs; a.it_ss = li + 3 * ms * Bs + (size_t)k * Bs;
         } else a.st_dyn = a.st_ss = a.it_dyn = a.it_ss = nullptr;
+        a.ws_valid = (int32_t *)h->st_flag.p;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
         h->L.loop(h->dp, a, h->stream);
         launches++;

@@ -32,6 +32,9 @@ constexpr double kMuFloor = 1e-13;    // centring target never below this
 constexpr double kSFloor = 1e-11;     // ... nor below l*kSFloor
 constexpr double kBoundRelax = 1e-8;  // relaxation of the stage-0 output rows
 constexpr double kInfeasZ = 1e10;     // dual blow-up => infeasible
+constexpr double kWsDelta = 1e-2;     // closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
+constexpr double kWsSMin = 1e-6;      // ... minimum slack
+constexpr double kWsMu = 1e-8;        // ... minimum complementarity product
 
 constexpr int kMaxN = 8, kMaxM = 4, kMaxY = 8, kMaxD = 8, kMaxV = kMaxN + kMaxM, kMaxC = kMaxN + kMaxM + kMaxY,
               kMaxE = kMaxN + kMaxD;
@@ -241,7 +244,7 @@ __device__ __forceinline__ void load_stage_const(const DevProblem &P, StageConst
 // those bounds may be absent (+-inf).  The host picks the cheapest variant the problem allows.
 template <int NS, int NU, bool HASM, int NC, bool MASKED>
 __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, const OcpInst<NS, NU> &q, const Ws &ws,
-                          int max_iter, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
+                          int max_iter, bool warm, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
 {
     using L = BlkLayout<NS, NU, NC>;
     constexpr int NV = NS + NU;
@@ -270,9 +273,13 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
     const double lo = cur_lo[i], hi = cur_hi[i];                           \
     const bool fl = MASKED ? cur_fl[i] : true, fh = MASKED ? cur_fh[i] : true;
 
-    // ---- initial point: u = us pushed inside its box, z simulated, slacks >= kSMin -------------------
+    // ---- initial point ---------------------------------------------------------------------------------
+    // cold: u = us pushed inside its box, slacks >= kSMin, multipliers kMu0/s.
+    // warm (per lane; closed loop only): the final iterate of the previous step, which is
+    // still in this instance's workspace, shifted by one stage: u clipped to its box, slacks >= kWsSMin,
+    // multipliers max(previous, kWsMu/s).  z is simulated from the new initial state in both cases.
     {
-        double uinit[NU], z[NS], zero_u[NU], zero_z[NS];
+        double ucold[NU], z[NS], zero_u[NU], zero_z[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             const double lo = P.ulo[i], hi = P.uhi[i];
             const bool fl = fin(lo), fh = fin(hi);
@@ -281,32 +288,46 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             else push = 0.1 * dmax(1.0, fabs(fl ? lo : (fh ? hi : 0.0)));
             if (fl) v = dmax(v, lo + push);
             if (fh) v = dmin(v, hi - push);
-            uinit[i] = v; zero_u[i] = 0.0;
+            ucold[i] = v; zero_u[i] = 0.0;
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) { z[i] = q.z0[i]; zero_z[i] = 0.0; }
         use_mid();
         for (int k = 0; k < N; k++) {
             if (k == N - 1) use_end();
             const BlkPtr b = ws.blk(k);
+            const BlkPtr src = ws.blk(k + 1 < N ? k + 1 : k);      // previous step's block k+1 (read before block k is written)
+            double uk[NU], uprev[NU];
+            v2d lprev[NC];
+            ld_field<NU>(src, L::U, uprev);
+            MPC_UNROLL for (int i = 0; i < NC; i++) lprev[i] = src[(L::L + i) * 64];
+            MPC_UNROLL for (int i = 0; i < NU; i++) {
+                double v = uprev[i];
+                if (fin(P.ulo[i])) v = dmax(v, P.ulo[i]);
+                if (fin(P.uhi[i])) v = dmin(v, P.uhi[i]);
+                uk[i] = warm ? v : ucold[i];
+            }
             double zn[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = q.c[i];
                 MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * z[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * uinit[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * uk[j];
                 zn[i] = a;
             }
             MPC_UNROLL for (int i = 0; i < NS; i++) z[i] = zn[i];
             MPC_UNROLL for (int i = 0; i < NC; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
-                const double v = i < NU ? uinit[i < NU ? i : 0] : z[i >= NU ? i - NU : 0];
+                const double v = i < NU ? uk[i < NU ? i : 0] : z[i >= NU ? i - NU : 0];
+                const double smin = warm ? kWsSMin : kSMin;
                 v2d sv, lv, iv, pz;
-                sv.x = fl ? dmax(v - lo, kSMin) : 1.0; sv.y = fh ? dmax(hi - v, kSMin) : 1.0;
+                sv.x = fl ? dmax(v - lo, smin) : 1.0; sv.y = fh ? dmax(hi - v, smin) : 1.0;
                 iv.x = frcp(sv.x); iv.y = frcp(sv.y);
-                lv.x = fl ? kMu0 * iv.x : 0.0; lv.y = fh ? kMu0 * iv.y : 0.0;
+                const double llo = warm ? dmax(lprev[i].x, kWsMu * iv.x) : kMu0 * iv.x;
+                const double lhi = warm ? dmax(lprev[i].y, kWsMu * iv.y) : kMu0 * iv.y;
+                lv.x = fl ? llo : 0.0; lv.y = fh ? lhi : 0.0;
                 pz.x = 0.0; pz.y = 0.0;
                 b[(L::S + i) * 64] = sv; b[(L::L + i) * 64] = lv; b[(L::IS + i) * 64] = iv; b[(L::P + i) * 64] = pz;
             }
-            st_field<NU>(b, L::U, uinit); st_field<NS>(b, L::Z, z);
+            st_field<NU>(b, L::U, uk); st_field<NS>(b, L::Z, z);
             st_field<NU>(b, L::DU, zero_u); st_field<NS>(b, L::DZ, zero_z);
         }
     }

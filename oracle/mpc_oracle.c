@@ -52,6 +52,9 @@
 #define S_FLOOR 1e-11
 #define BOUND_RELAX 1e-8
 #define INFEAS_Z 1e10
+#define WS_DELTA 1e-2 /* warm start: used when (xhat-prediction, dhat, xs, us) moved less than this since the last step */
+#define WS_SMIN 1e-6  /* warm start: minimum slack */
+#define WS_MU 1e-8    /* warm start: minimum complementarity product */
 
 enum { ST_SOLVED = 0, ST_MAXITER = 1, ST_INFEASIBLE = 2 };
 
@@ -253,7 +256,9 @@ static double max_step(const stage_t *s, const work_t *w)
 }
 
 /* one OCP; returns status; res[3] = {stationarity, bound residual, mean complementarity} */
-static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w, int *iters_out, double *res)
+/* warm != 0: w->u, w->l_lo, w->l_hi still hold the final iterate of the previous closed-loop step of this instance;
+ * start from it shifted by one stage instead of the cold start. */
+static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w, int *iters_out, double *res, int warm)
 {
     const int n = s->n, m = s->m, N = s->N, nv = n + m;
     double ncon = 0.0;
@@ -269,14 +274,21 @@ static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w,
             w->lo[k][i] = w->fl[k][i] ? lo : 0.0; w->hi[k][i] = w->fh[k][i] ? hi : 0.0;
             ncon += w->fl[k][i] + w->fh[k][i];
         }
-    /* initial point: u = us pushed into the interior of its box, z simulated */
+    /* initial point: u = us pushed into the interior of its box (cold), or the previous solution shifted by one
+     * stage and clipped to the box (warm); z simulated */
     for (int k = 0; k < N; k++)
         for (int i = 0; i < m; i++) {
             double lo = s->ulo[i], hi = s->uhi[i], push, v = q->us[i];
-            if (isfinite(lo) && isfinite(hi)) push = 0.1 * (hi - lo);
-            else push = 0.1 * dmax2(1.0, fabs(isfinite(lo) ? lo : (isfinite(hi) ? hi : 0.0)));
-            if (isfinite(lo)) v = dmax2(v, lo + push);
-            if (isfinite(hi)) v = dmin2(v, hi - push);
+            if (warm) {
+                v = w->u[k + 1 < N ? k + 1 : k][i];
+                if (isfinite(lo)) v = dmax2(v, lo);
+                if (isfinite(hi)) v = dmin2(v, hi);
+            } else {
+                if (isfinite(lo) && isfinite(hi)) push = 0.1 * (hi - lo);
+                else push = 0.1 * dmax2(1.0, fabs(isfinite(lo) ? lo : (isfinite(hi) ? hi : 0.0)));
+                if (isfinite(lo)) v = dmax2(v, lo + push);
+                if (isfinite(hi)) v = dmin2(v, hi - push);
+            }
             w->u[k][i] = v;
         }
     for (int i = 0; i < n; i++) w->z[0][i] = q->z0[i];
@@ -290,10 +302,19 @@ static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w,
     for (int k = 0; k < N; k++)
         for (int i = 0; i < nv; i++) {
             double v = i < m ? w->u[k][i] : w->z[k + 1][i - m];
-            w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], S_MIN) : 1.0;
-            w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, S_MIN) : 1.0;
-            w->l_lo[k][i] = w->fl[k][i] ? MU0 / w->s_lo[k][i] : 0.0;
-            w->l_hi[k][i] = w->fh[k][i] ? MU0 / w->s_hi[k][i] : 0.0;
+            if (warm) {
+                int ks = k + 1 < N ? k + 1 : k;
+                double llo = w->l_lo[ks][i], lhi = w->l_hi[ks][i];
+                w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], WS_SMIN) : 1.0;
+                w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, WS_SMIN) : 1.0;
+                w->l_lo[k][i] = w->fl[k][i] ? dmax2(llo, WS_MU / w->s_lo[k][i]) : 0.0;
+                w->l_hi[k][i] = w->fh[k][i] ? dmax2(lhi, WS_MU / w->s_hi[k][i]) : 0.0;
+            } else {
+                w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], S_MIN) : 1.0;
+                w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, S_MIN) : 1.0;
+                w->l_lo[k][i] = w->fl[k][i] ? MU0 / w->s_lo[k][i] : 0.0;
+                w->l_hi[k][i] = w->fh[k][i] ? MU0 / w->s_hi[k][i] : 0.0;
+            }
         }
     double gscale = 1.0; int stall = 0;
     for (int it = 0;; it++) {
@@ -428,7 +449,7 @@ int orc_ocp_solve(const orc_problem *p, int Bsz, const double *xhat, const doubl
                 err = -3;
                 continue;
             }
-            int stt = rpdip_one(&st, &q, p->max_iter, w, &it, r3);
+            int stt = rpdip_one(&st, &q, p->max_iter, w, &it, r3, 0);
             status[b] = stt; if (iters) iters[b] = it;
             if (res) { res[3 * b] = r3[0]; res[3 * b + 1] = r3[1]; res[3 * b + 2] = r3[2]; }
             if (stt != ST_INFEASIBLE) {
@@ -708,7 +729,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                     double *u /*[B][nu]*/, double *xs /*[B][nx]*/, double *us /*[B][nu]*/,
                     const double *ysp, const double *usp, const double *xsp, const double *pxp, const double *pyp,
                     double *U_log, double *XHAT_log, double *XS_log, double *US_log, double *YS_log, double *XP_log, double *DHAT_log,
-                    int32_t *st_dyn_log, int32_t *st_ss_log, int32_t *it_dyn_log, int32_t *it_ss_log, int nthreads)
+                    int32_t *st_dyn_log, int32_t *st_ss_log, int32_t *it_dyn_log, int32_t *it_ss_log, int nthreads, int warm_start)
 {
     stage_t st; target_t tg;
     const int n = p->nx, m = p->nu, q = p->ny, nd = p->nd, nxp = p->nxp, ne = n + nd;
@@ -729,6 +750,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
 #pragma omp for schedule(dynamic, 4)
         for (int b = 0; b < Bsz; b++) {
             double *xb = x + b * nxp, *xh = xhat + b * n, *dh = dhat + b * nd, *ub = u + b * m, *xsb = xs + b * n, *usb = us + b * m;
+            double pred[MAXN] = {0}, d_prev[MAXD] = {0}, xs_prev[MAXN] = {0}, us_prev[MAXM] = {0}; int ws_valid = 0;
             for (int k = 0; k < nsteps; k++) {
                 size_t lb = (size_t)k * Bsz + b;
                 if (XP_log) memcpy(XP_log + lb * nxp, xb, sizeof(double) * nxp);
@@ -765,12 +787,20 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                 }
                 /* OCP (:733-805) */
                 inst_t qi; int it_dyn = 0; double r3[3];
+                /* warm start when the previous OCP of this instance was solved and the problem data barely moved */
+                double delta = 0.0;
+                for (int i = 0; i < n; i++) delta = dmax2(delta, dmax2(fabs(xh[i] - pred[i]), fabs(xsb[i] - xs_prev[i])));
+                for (int i = 0; i < nd; i++) delta = dmax2(delta, fabs(dh[i] - d_prev[i]));
+                for (int i = 0; i < m; i++) delta = dmax2(delta, fabs(usb[i] - us_prev[i]));
+                const int warm = warm_start && ws_valid && delta <= WS_DELTA;
                 if (build_inst(p, &st, xh, xsb, usb, dh, ub, &qi) != 0) {
 #pragma omp atomic write
                     err = -3;
                     break;
                 }
-                int sd = rpdip_one(&st, &qi, p->max_iter, w, &it_dyn, r3);
+                int sd = rpdip_one(&st, &qi, p->max_iter, w, &it_dyn, r3, warm);
+                ws_valid = (sd == ST_SOLVED);
+                memcpy(d_prev, dh, sizeof(double) * nd); memcpy(xs_prev, xsb, sizeof(double) * n); memcpy(us_prev, usb, sizeof(double) * m);
                 if (sd != ST_INFEASIBLE) {
                     for (int i = 0; i < m; i++) ub[i] = w->u[0][i];              /* :798 */
                     for (int i = 0; i < n; i++) xh[i] = w->z[1][i];              /* :799 */
@@ -785,6 +815,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                     }
                     memcpy(xh, xn, sizeof(double) * n);
                 }
+                memcpy(pred, xh, sizeof(double) * n);
                 if (U_log) memcpy(U_log + lb * m, ub, sizeof(double) * m);
                 if (st_dyn_log) st_dyn_log[lb] = sd;
                 if (st_ss_log) st_ss_log[lb] = sss;

@@ -106,7 +106,7 @@ class OracleC:
             raise RuntimeError(f"orc_kf_update failed: {rc}")
         return xi, P
 
-    def closed_loop(self, nsteps, x0_p, x0_m, sched=None, nthreads=0, logs=True, u0=None, dhat0=None, P0=None):
+    def closed_loop(self, nsteps, x0_p, x0_m, sched=None, nthreads=0, logs=True, u0=None, dhat0=None, P0=None, warm_start=True):
         p = self.p
         x = _c(np.atleast_2d(x0_p)).copy(); xhat = _c(np.atleast_2d(x0_m)).copy(); B = x.shape[0]
         sched = p.schedules(nsteps) if sched is None else sched
@@ -128,7 +128,7 @@ class OracleC:
                                       _ptr(xs), _ptr(us), _ptr(sc["ysp"]), _ptr(sc["usp"]), _ptr(sc["xsp"]),
                                       _ptr(sc["pxp"]), _ptr(sc["pyp"]), f("U"), f("X_HAT"), f("XS"), f("US"), f("YS"),
                                       f("Xp"), f("D_HAT"), g("STATUS_DYN"), g("STATUS_SS"), g("ITERS_DYN"), g("ITERS_SS"),
-                                      int(nthreads))
+                                      int(nthreads), int(bool(warm_start)))
         if rc != 0:
             raise RuntimeError(f"orc_closed_loop failed: {rc}")
         L.update(final=dict(x=x, xhat=xhat, dhat=dhat, P=Pk, u=u, xs=xs, us=us))

@@ -35,6 +35,9 @@ TOL_MU = 1e-12     # ... or s*l <= TOL_MU (degenerate bounds, s* = l* = 0, conve
 MU_FLOOR = 1e-13   # the centring target sigma*mu is never below this ...
 S_FLOOR = 1e-11    # ... nor below l*S_FLOOR: no slack is driven under S_FLOOR (keeps l/s bounded)
 BOUND_RELAX = 1e-8 # relaxation of the stage-0 output rows (constraints on a given quantity)
+WS_DELTA = 1e-2    # closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
+WS_SMIN = 1e-6     # closed-loop warm start: minimum slack
+WS_MU = 1e-8       # closed-loop warm start: minimum complementarity product
 POLISH_AT = (1, 5, 9, 13)  # interior-point iteration counts after which an active-set polish is attempted
 POLISH_W = 1e8     # augmented-Lagrangian weight on the active bounds of the polish
 POLISH_TOL = 1e-9  # polish accepted if bound violation, negative multipliers and the last correction are below this
@@ -120,7 +123,7 @@ def instance_data(p, sd, xhat, xs, us, dhat, u_prev):
                 us=us.copy())
 
 
-def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False):
+def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False, warm=None):
     """Batched Mehrotra predictor-corrector with Riccati KKT solves.  Returns dict of [B,..] arrays."""
     A, Bm, Q, M, R, Pf = sd["A"], sd["B"], sd["Q"], sd["M"], sd["R"], sd["Pf"]
     n, m, N = sd["n"], sd["m"], sd["N"]
@@ -153,6 +156,16 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False)
     v = np.concatenate([u, z[:, 1:]], axis=2)
     s_lo = np.where(fl, np.maximum(v - lo_f, S_MIN), 1.0); s_hi = np.where(fh, np.maximum(hi_f - v, S_MIN), 1.0)
     l_lo = np.where(fl, MU0 / s_lo, 0.0); l_hi = np.where(fh, MU0 / s_hi, 0.0)
+    if warm is not None:     # primal-dual warm start from the previous closed-loop step
+        use = warm["use"]
+        uw = np.minimum(np.maximum(warm["u"], np.where(np.isfinite(ulo), ulo, -np.inf)), np.where(np.isfinite(uhi), uhi, np.inf))
+        zw = simulate(uw)
+        vw = np.concatenate([uw, zw[:, 1:]], axis=2)
+        sw_lo = np.where(fl, np.maximum(vw - lo_f, WS_SMIN), 1.0); sw_hi = np.where(fh, np.maximum(hi_f - vw, WS_SMIN), 1.0)
+        lw_lo = np.where(fl, np.maximum(warm["l_lo"], WS_MU / sw_lo), 0.0); lw_hi = np.where(fh, np.maximum(warm["l_hi"], WS_MU / sw_hi), 0.0)
+        m3 = use[:, None, None]
+        u = np.where(m3, uw, u); z = np.where(m3, zw, z)
+        s_lo = np.where(m3, sw_lo, s_lo); s_hi = np.where(m3, sw_hi, s_hi); l_lo = np.where(m3, lw_lo, l_lo); l_hi = np.where(m3, lw_hi, l_hi)
 
     status = np.full(Bsz, -1, dtype=np.int32)
     iters = np.zeros(Bsz, dtype=np.int32)
@@ -468,7 +481,7 @@ def kalman_batch(p, xi, Pm, y, yhat):
     return xi_c, Aa @ P_corr @ Aa.T + p.Q_kf
 
 
-def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100):
+def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_start=True):
     """The loop of MPC_code.py:485-827 for B instances that share the problem and the schedules."""
     sd, td = stage_data(p), target_data(p)
     x0_p = np.atleast_2d(np.asarray(x0_p, float)); x0_m = np.atleast_2d(np.asarray(x0_m, float))
@@ -502,12 +515,22 @@ def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100):
         e = np.broadcast_to(p.fy_const, (Bsz, p.ny)) + (dhat @ p.Cd.T if p.nd else 0.0)
         log["YS"].append(xs_k @ p.C.T + e)
         inst = instance_data(p, sd, xhat, xs_k, us_k, dhat, u)
-        o = rpdip_solve(sd, inst, max_iter=max_iter)
+        warm = None
+        if warm_start and k > 0:
+            sh = lambda a: np.concatenate([a[:, 1:], a[:, -1:]], axis=1)
+            delta = np.maximum(np.maximum(np.abs(xhat - prev_pred).max(axis=1), np.abs(dhat - prev_d).max(axis=1)),
+                               np.maximum(np.abs(xs_k - prev_xs).max(axis=1), np.abs(us_k - prev_us).max(axis=1)))
+            log.setdefault("WS_DELTA", []).append(delta.copy())
+            warm = dict(u=sh(prev["u"]), l_lo=sh(prev["l_lo"]), l_hi=sh(prev["l_hi"]),
+                        use=(prev["status"] == STATUS_SOLVED) & (delta <= WS_DELTA))
+        o = rpdip_solve(sd, inst, max_iter=max_iter, warm=warm)
+        prev = o; prev_d = dhat.copy(); prev_xs = xs_k.copy(); prev_us = us_k.copy()
         oko = (o["status"] != STATUS_INFEASIBLE)[:, None]
         cx = np.broadcast_to(p.fx_const, (Bsz, n)) + (dhat @ p.Bd.T if p.nd else 0.0)
         xhat_hold = xhat @ p.A.T + u @ p.B.T + cx
         u = np.where(oko, o["u0"], u)
         xhat = np.where(oko, o["z1"][:, :n], xhat_hold)
+        prev_pred = xhat.copy()
         log["U"].append(u.copy()); log["STATUS_SS"].append(t["status"].copy()); log["STATUS_DYN"].append(o["status"].copy())
         log["ITERS_DYN"].append(o["iters"].copy()); log["ITERS_SS"].append(t["iters"].copy())
         x = x @ p.Ap.T + u @ p.Bp.T + sched["pxp"][k]

@@ -127,7 +127,8 @@ def test_stepwise_calls_equal_fused_kernel(cstr, solver_factory):
     b = run_closed_loop(cstr, x0, x0, 12, solver=s, fused=False)
     assert np.array_equal(a["STATUS_DYN"], b["STATUS_DYN"])
     for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT"):
-        assert np.abs(a[k] - b[k]).max() < 1e-7, k       # two instantiations of the same device code (FMA contraction differs)
+        assert np.abs(a[k] - b[k]).max() < 5e-6, k
+    assert b["ITERS_DYN"][6:].mean() > 1.5 * a["ITERS_DYN"][6:].mean()      # the warm start is doing its job
 
 
 def test_shipped_scenarios_follow_the_golden_closed_loop(cstr, wb, solver_factory):
