@@ -27,8 +27,8 @@ constexpr double kTolStatAcc = 1e-6;  // accepted after kStallMax stalled iterat
 constexpr int kStallMax = 2;
 constexpr double kTolFeas = 1e-9;     // bound residual
 constexpr double kTolC = 1e-9;        // complementarity: min(s,l) <= kTolC ...
-constexpr double kTolMu = 1e-12;      // ... or s*l <= kTolMu
-constexpr double kMuFloor = 1e-13;    // centring target never below this
+constexpr double kTolMu = 1e-14;      // ... or s*l <= kTolMu
+constexpr double kMuFloor = 1e-15;    // centring target never below this
 constexpr double kSFloor = 1e-11;     // ... nor below l*kSFloor
 constexpr double kBoundRelax = 1e-8;  // relaxation of the stage-0 output rows
 constexpr double kInfeasZ = 1e10;     // dual blow-up => infeasible

@@ -47,8 +47,8 @@
 #define STALL_MAX 2
 #define TOL_FEAS 1e-9
 #define TOL_C 1e-9
-#define TOL_MU 1e-12
-#define MU_FLOOR 1e-13
+#define TOL_MU 1e-14
+#define MU_FLOOR 1e-15
 #define S_FLOOR 1e-11
 #define BOUND_RELAX 1e-8
 #define INFEAS_Z 1e10

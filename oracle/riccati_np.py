@@ -31,8 +31,8 @@ TOL_STAT_ACC = 1e-6  # accepted after STALL_MAX stalled iterations (rounding flo
 STALL_MAX = 2
 TOL_FEAS = 1e-9    # bound residual |v + s - hi|_inf
 TOL_C = 1e-9       # complementarity, per bound: min(s, l) <= TOL_C ...
-TOL_MU = 1e-12     # ... or s*l <= TOL_MU (degenerate bounds, s* = l* = 0, converge only like sqrt(mu))
-MU_FLOOR = 1e-13   # the centring target sigma*mu is never below this ...
+TOL_MU = 1e-14     # ... or s*l <= TOL_MU (degenerate bounds, s* = l* = 0, converge only like sqrt(mu))
+MU_FLOOR = 1e-15   # the centring target sigma*mu is never below this ...
 S_FLOOR = 1e-11    # ... nor below l*S_FLOOR: no slack is driven under S_FLOOR (keeps l/s bounded)
 BOUND_RELAX = 1e-8 # relaxation of the stage-0 output rows (constraints on a given quantity)
 WS_DELTA = 1e-2    # closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this

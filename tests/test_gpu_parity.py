@@ -56,7 +56,7 @@ def test_ocp_hits_certified_exact_optimum(name, cstr, wb, solver_factory):
     ok = (st == 0) & exact
     err = np.abs(r["u0"] - flat(g["U"]))[ok].max(axis=1)
     # same limits as tests/test_oracle.py::test_riccati_restatement_reproduces_golden_ocps
-    lim = dict(cstr_shipped=(5e-5, 5e-6, 1e-7), wb_shipped=(1e-7, 1e-8, 1e-9), cstr_box=(1e-7, 1e-8, 1e-9))[name]
+    lim = dict(cstr_shipped=(1e-6, 5e-7, 1e-8), wb_shipped=(1e-7, 1e-8, 1e-9), cstr_box=(1e-7, 1e-8, 1e-9))[name]
     assert err.max() < lim[0] and np.quantile(err, 0.9) < lim[1] and np.median(err) < lim[2], (err.max(), np.quantile(err, 0.9), np.median(err))
 
 
@@ -139,8 +139,8 @@ def test_shipped_scenarios_follow_the_golden_closed_loop(cstr, wb, solver_factor
         same = ((r["STATUS_DYN"] == 2) == (g["STATUS_DYN"] == 2)).all(axis=1)
         upto = int(np.argmin(same)) if not same.all() else 100
         assert upto >= 20
-        assert np.abs(r["U"][:upto] - g["U"][:upto]).max() < 2e-5
-        assert np.abs(r["X_HAT"][:upto] - g["X_HAT"][:upto]).max() < 2e-5
+        assert np.abs(r["U"][:upto] - g["U"][:upto]).max() < 5e-6
+        assert np.abs(r["X_HAT"][:upto] - g["X_HAT"][:upto]).max() < 5e-6
     # the shipped CSTR run starts infeasible: u is held at u0 = 0 for steps 0-2
     r = run_closed_loop(cstr, nsteps=4, solver=solver_factory(cstr))
     assert (r["STATUS_DYN"][:3, 0] == 2).all() and r["STATUS_DYN"][3, 0] == 0 and np.all(r["U"][:3] == 0.0)

@@ -95,7 +95,7 @@ def test_riccati_restatement_reproduces_golden_ocps(name, cstr, wb):
     assert ok.sum() > 0.8 * (st == 0).sum()
     # tolerance: an interior-point answer is within ~s of the optimum for active bounds but only
     # ~sqrt(s*lambda) for degenerate ones, which dominate the shipped CSTR run once the target sits on a bound
-    lim = dict(cstr_shipped=(5e-5, 5e-6, 1e-7), wb_shipped=(1e-7, 1e-8, 1e-9), cstr_box=(1e-7, 1e-8, 1e-9))[name]
+    lim = dict(cstr_shipped=(1e-6, 5e-7, 1e-8), wb_shipped=(1e-7, 1e-8, 1e-9), cstr_box=(1e-7, 1e-8, 1e-9))[name]
     assert err.max() < lim[0] and np.quantile(err, 0.9) < lim[1] and np.median(err) < lim[2], (err.max(), np.quantile(err, 0.9), np.median(err))
     assert (r["status"][ok] == 0).all()
 

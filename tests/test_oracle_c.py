@@ -25,7 +25,7 @@ def test_ocp_matches_numpy_statement(which, cstr, wb, oracle_c):
     n = rn.rpdip_solve(sd, rn.instance_data(p, sd, xh, xs, us, d, up))
     assert np.array_equal(c["status"], n["status"])
     ok = c["status"] != 2
-    assert (c["iters"] == n["iters"])[ok].mean() > 0.95
+    assert (c["iters"] == n["iters"])[ok].mean() > 0.9       # the count flips by one when a test value sits on a threshold
     assert np.abs(c["u0"] - n["u0"])[ok].max() < 1e-8          # identical but for summation order: a rare +-1 iteration
     assert np.abs(c["x1"] - n["z1"][:, :p.nx])[ok].max() < 1e-8
     # w is in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) and obeys the model
@@ -70,7 +70,7 @@ def test_closed_loop_reproduces_golden_trajectories(name, cstr, wb, oracle_c):
     first_flip = np.argmin(same.all(axis=1)) if not same.all() else nst
     upto = max(first_flip, 1)
     for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT"):
-        assert np.abs(L[k][:upto] - g[k][:upto]).max() < 2e-5, k
+        assert np.abs(L[k][:upto] - g[k][:upto]).max() < 5e-6, k
     assert upto >= min(nst, 20)
 
 
