@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
     double u0[NU], z1[NS], res[3];
     int it;
-    const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, u0, z1, res, it);
+    const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it);
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
         MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
         const bool warm = ws_valid && delta <= kWsDelta;
-        const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, u0, z1, res, it_dyn);
+        const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, delta, u0, z1, res, it_dyn);
         ws_valid = st_dyn == kSolved;
         if (st_dyn != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = u0[i];          // :798

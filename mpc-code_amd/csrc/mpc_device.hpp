@@ -33,8 +33,9 @@ constexpr double kSFloor = 1e-11;     // ... nor below l*kSFloor
 constexpr double kBoundRelax = 1e-8;  // relaxation of the stage-0 output rows
 constexpr double kInfeasZ = 1e10;     // dual blow-up => infeasible
 constexpr double kWsDelta = 1e-2;     // closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
-constexpr double kWsSMin = 1e-6;      // ... minimum slack
-constexpr double kWsMu = 1e-8;        // ... minimum complementarity product
+constexpr double kWsKappa = 1e-2;     // ... minimum slack = clip(kWsKappa * movement, kWsSMinLo, kWsSMinHi)
+constexpr double kWsSMinLo = 1e-9, kWsSMinHi = 1e-6;
+constexpr double kWsMuFactor = 1e4;   // ... minimum complementarity product = kWsMuFactor * (minimum slack)^2
 
 constexpr int kMaxN = 8, kMaxM = 4, kMaxY = 8, kMaxD = 8, kMaxV = kMaxN + kMaxM, kMaxC = kMaxN + kMaxM + kMaxY,
               kMaxE = kMaxN + kMaxD;
@@ -244,7 +245,7 @@ __device__ __forceinline__ void load_stage_const(const DevProblem &P, StageConst
 // those bounds may be absent (+-inf).  The host picks the cheapest variant the problem allows.
 template <int NS, int NU, bool HASM, int NC, bool MASKED>
 __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, const OcpInst<NS, NU> &q, const Ws &ws,
-                          int max_iter, bool warm, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
+                          int max_iter, bool warm, double ws_delta, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
 {
     using L = BlkLayout<NS, NU, NC>;
     constexpr int NV = NS + NU;
@@ -276,9 +277,11 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
     // ---- initial point ---------------------------------------------------------------------------------
     // cold: u = us pushed inside its box, slacks >= kSMin, multipliers kMu0/s.
     // warm (per lane; closed loop only): the final iterate of the previous step, which is
-    // still in this instance's workspace, shifted by one stage: u clipped to its box, slacks >= kWsSMin,
-    // multipliers max(previous, kWsMu/s).  z is simulated from the new initial state in both cases.
+    // still in this instance's workspace, shifted by one stage: u clipped to its box, slacks >= a floor,
+    // multipliers max(previous, floor/s); the floors scale with how far the problem data moved since the last step.
+    // z is simulated from the new initial state in both cases.
     {
+        const double ws_smin = dmin(dmax(kWsKappa * ws_delta, kWsSMinLo), kWsSMinHi), ws_mu = kWsMuFactor * ws_smin * ws_smin;
         double ucold[NU], z[NS], zero_u[NU], zero_z[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             const double lo = P.ulo[i], hi = P.uhi[i];
@@ -317,12 +320,12 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NC; i++) {
                 MPC_BOUNDS(k, i, lo, hi, fl, fh)
                 const double v = i < NU ? uk[i < NU ? i : 0] : z[i >= NU ? i - NU : 0];
-                const double smin = warm ? kWsSMin : kSMin;
+                const double smin = warm ? ws_smin : kSMin;
                 v2d sv, lv, iv, pz;
                 sv.x = fl ? dmax(v - lo, smin) : 1.0; sv.y = fh ? dmax(hi - v, smin) : 1.0;
                 iv.x = frcp(sv.x); iv.y = frcp(sv.y);
-                const double llo = warm ? dmax(lprev[i].x, kWsMu * iv.x) : kMu0 * iv.x;
-                const double lhi = warm ? dmax(lprev[i].y, kWsMu * iv.y) : kMu0 * iv.y;
+                const double llo = warm ? dmax(lprev[i].x, ws_mu * iv.x) : kMu0 * iv.x;
+                const double lhi = warm ? dmax(lprev[i].y, ws_mu * iv.y) : kMu0 * iv.y;
                 lv.x = fl ? llo : 0.0; lv.y = fh ? lhi : 0.0;
                 pz.x = 0.0; pz.y = 0.0;
                 b[(L::S + i) * 64] = sv; b[(L::L + i) * 64] = lv; b[(L::IS + i) * 64] = iv; b[(L::P + i) * 64] = pz;

@@ -53,8 +53,10 @@
 #define BOUND_RELAX 1e-8
 #define INFEAS_Z 1e10
 #define WS_DELTA 1e-2 /* warm start: used when (xhat-prediction, dhat, xs, us) moved less than this since the last step */
-#define WS_SMIN 1e-6  /* warm start: minimum slack */
-#define WS_MU 1e-8    /* warm start: minimum complementarity product */
+#define WS_KAPPA 1e-2 /* warm start: minimum slack = clip(WS_KAPPA * movement, WS_SMIN_LO, WS_SMIN_HI) ... */
+#define WS_SMIN_LO 1e-9
+#define WS_SMIN_HI 1e-6
+#define WS_MU_FACTOR 1e4 /* ... minimum complementarity product = WS_MU_FACTOR * (minimum slack)^2 */
 
 enum { ST_SOLVED = 0, ST_MAXITER = 1, ST_INFEASIBLE = 2 };
 
@@ -258,7 +260,7 @@ static double max_step(const stage_t *s, const work_t *w)
 /* one OCP; returns status; res[3] = {stationarity, bound residual, mean complementarity} */
 /* warm != 0: w->u, w->l_lo, w->l_hi still hold the final iterate of the previous closed-loop step of this instance;
  * start from it shifted by one stage instead of the cold start. */
-static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w, int *iters_out, double *res, int warm)
+static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w, int *iters_out, double *res, int warm, double delta)
 {
     const int n = s->n, m = s->m, N = s->N, nv = n + m;
     double ncon = 0.0;
@@ -275,7 +277,8 @@ static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w,
             ncon += w->fl[k][i] + w->fh[k][i];
         }
     /* initial point: u = us pushed into the interior of its box (cold), or the previous solution shifted by one
-     * stage and clipped to the box (warm); z simulated */
+     * stage and clipped to the box (warm); z simulated.  The warm floors scale with how far the data moved. */
+    const double ws_smin = dmin2(dmax2(WS_KAPPA * delta, WS_SMIN_LO), WS_SMIN_HI), ws_mu = WS_MU_FACTOR * ws_smin * ws_smin;
     for (int k = 0; k < N; k++)
         for (int i = 0; i < m; i++) {
             double lo = s->ulo[i], hi = s->uhi[i], push, v = q->us[i];
@@ -305,10 +308,10 @@ static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w,
             if (warm) {
                 int ks = k + 1 < N ? k + 1 : k;
                 double llo = w->l_lo[ks][i], lhi = w->l_hi[ks][i];
-                w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], WS_SMIN) : 1.0;
-                w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, WS_SMIN) : 1.0;
-                w->l_lo[k][i] = w->fl[k][i] ? dmax2(llo, WS_MU / w->s_lo[k][i]) : 0.0;
-                w->l_hi[k][i] = w->fh[k][i] ? dmax2(lhi, WS_MU / w->s_hi[k][i]) : 0.0;
+                w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], ws_smin) : 1.0;
+                w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, ws_smin) : 1.0;
+                w->l_lo[k][i] = w->fl[k][i] ? dmax2(llo, ws_mu / w->s_lo[k][i]) : 0.0;
+                w->l_hi[k][i] = w->fh[k][i] ? dmax2(lhi, ws_mu / w->s_hi[k][i]) : 0.0;
             } else {
                 w->s_lo[k][i] = w->fl[k][i] ? dmax2(v - w->lo[k][i], S_MIN) : 1.0;
                 w->s_hi[k][i] = w->fh[k][i] ? dmax2(w->hi[k][i] - v, S_MIN) : 1.0;
@@ -449,7 +452,7 @@ int orc_ocp_solve(const orc_problem *p, int Bsz, const double *xhat, const doubl
                 err = -3;
                 continue;
             }
-            int stt = rpdip_one(&st, &q, p->max_iter, w, &it, r3, 0);
+            int stt = rpdip_one(&st, &q, p->max_iter, w, &it, r3, 0, 0.0);
             status[b] = stt; if (iters) iters[b] = it;
             if (res) { res[3 * b] = r3[0]; res[3 * b + 1] = r3[1]; res[3 * b + 2] = r3[2]; }
             if (stt != ST_INFEASIBLE) {
@@ -798,7 +801,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                     err = -3;
                     break;
                 }
-                int sd = rpdip_one(&st, &qi, p->max_iter, w, &it_dyn, r3, warm);
+                int sd = rpdip_one(&st, &qi, p->max_iter, w, &it_dyn, r3, warm, delta);
                 ws_valid = (sd == ST_SOLVED);
                 memcpy(d_prev, dh, sizeof(double) * nd); memcpy(xs_prev, xsb, sizeof(double) * n); memcpy(us_prev, usb, sizeof(double) * m);
                 if (sd != ST_INFEASIBLE) {

@@ -36,8 +36,10 @@ MU_FLOOR = 1e-15   # the centring target sigma*mu is never below this ...
 S_FLOOR = 1e-11    # ... nor below l*S_FLOOR: no slack is driven under S_FLOOR (keeps l/s bounded)
 BOUND_RELAX = 1e-8 # relaxation of the stage-0 output rows (constraints on a given quantity)
 WS_DELTA = 1e-2    # closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
-WS_SMIN = 1e-6     # closed-loop warm start: minimum slack
-WS_MU = 1e-8       # closed-loop warm start: minimum complementarity product
+WS_KAPPA = 1e-2    # closed-loop warm start: minimum slack = clip(WS_KAPPA * movement, WS_SMIN_LO, WS_SMIN_HI) ...
+WS_SMIN_LO = 1e-9
+WS_SMIN_HI = 1e-6
+WS_MU_FACTOR = 1e4 # ... and minimum complementarity product = WS_MU_FACTOR * (minimum slack)^2   (1e-14 .. 1e-8)
 POLISH_AT = (1, 5, 9, 13)  # interior-point iteration counts after which an active-set polish is attempted
 POLISH_W = 1e8     # augmented-Lagrangian weight on the active bounds of the polish
 POLISH_TOL = 1e-9  # polish accepted if bound violation, negative multipliers and the last correction are below this
@@ -161,8 +163,11 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False,
         uw = np.minimum(np.maximum(warm["u"], np.where(np.isfinite(ulo), ulo, -np.inf)), np.where(np.isfinite(uhi), uhi, np.inf))
         zw = simulate(uw)
         vw = np.concatenate([uw, zw[:, 1:]], axis=2)
-        sw_lo = np.where(fl, np.maximum(vw - lo_f, WS_SMIN), 1.0); sw_hi = np.where(fh, np.maximum(hi_f - vw, WS_SMIN), 1.0)
-        lw_lo = np.where(fl, np.maximum(warm["l_lo"], WS_MU / sw_lo), 0.0); lw_hi = np.where(fh, np.maximum(warm["l_hi"], WS_MU / sw_hi), 0.0)
+        # floors scale with how far the problem data moved: an unchanged problem resumes from its solution
+        smin_w = np.clip(WS_KAPPA * warm["delta"], WS_SMIN_LO, WS_SMIN_HI)[:, None, None]
+        mu_w = WS_MU_FACTOR * smin_w * smin_w
+        sw_lo = np.where(fl, np.maximum(vw - lo_f, smin_w), 1.0); sw_hi = np.where(fh, np.maximum(hi_f - vw, smin_w), 1.0)
+        lw_lo = np.where(fl, np.maximum(warm["l_lo"], mu_w / sw_lo), 0.0); lw_hi = np.where(fh, np.maximum(warm["l_hi"], mu_w / sw_hi), 0.0)
         m3 = use[:, None, None]
         u = np.where(m3, uw, u); z = np.where(m3, zw, z)
         s_lo = np.where(m3, sw_lo, s_lo); s_hi = np.where(m3, sw_hi, s_hi); l_lo = np.where(m3, lw_lo, l_lo); l_hi = np.where(m3, lw_hi, l_hi)
@@ -481,7 +486,7 @@ def kalman_batch(p, xi, Pm, y, yhat):
     return xi_c, Aa @ P_corr @ Aa.T + p.Q_kf
 
 
-def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_start=True):
+def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_start=True, noise=None):
     """The loop of MPC_code.py:485-827 for B instances that share the problem and the schedules."""
     sd, td = stage_data(p), target_data(p)
     x0_p = np.atleast_2d(np.asarray(x0_p, float)); x0_m = np.atleast_2d(np.asarray(x0_m, float))
@@ -521,7 +526,7 @@ def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_star
             delta = np.maximum(np.maximum(np.abs(xhat - prev_pred).max(axis=1), np.abs(dhat - prev_d).max(axis=1)),
                                np.maximum(np.abs(xs_k - prev_xs).max(axis=1), np.abs(us_k - prev_us).max(axis=1)))
             log.setdefault("WS_DELTA", []).append(delta.copy())
-            warm = dict(u=sh(prev["u"]), l_lo=sh(prev["l_lo"]), l_hi=sh(prev["l_hi"]),
+            warm = dict(u=sh(prev["u"]), l_lo=sh(prev["l_lo"]), l_hi=sh(prev["l_hi"]), delta=delta,
                         use=(prev["status"] == STATUS_SOLVED) & (delta <= WS_DELTA))
         o = rpdip_solve(sd, inst, max_iter=max_iter, warm=warm)
         prev = o; prev_d = dhat.copy(); prev_xs = xs_k.copy(); prev_us = us_k.copy()
@@ -534,4 +539,6 @@ def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_star
         log["U"].append(u.copy()); log["STATUS_SS"].append(t["status"].copy()); log["STATUS_DYN"].append(o["status"].copy())
         log["ITERS_DYN"].append(o["iters"].copy()); log["ITERS_SS"].append(t["iters"].copy())
         x = x @ p.Ap.T + u @ p.Bp.T + sched["pxp"][k]
+        if noise is not None:        # robustness studies only: seeded process noise [nsteps,B,nxp]
+            x = x + noise[k]
     return {k: np.array(v) for k, v in log.items()}
