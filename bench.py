@@ -90,20 +90,24 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="instances per GPU (default: BASELINE configs[1])")
     ap.add_argument("--steps-per-launch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     K, W, B = args.steps, args.warmup, args.batch
+    use_dist = world > 1 or args.force_dist
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import mpc_code_amd as m
@@ -123,21 +127,21 @@ def main():
     solver.loop_set_schedule(sched)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     # gather buffers for U: [K][nu][Bpad] per rank
     _, bpad = solver.dev_ptr("U")
     send = torch.empty((K, prob.nu, bpad), dtype=torch.float64, device="cuda")
-    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.float64, device="cuda") if world > 1 else None
+    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.float64, device="cuda") if use_dist else None
 
     # warm-up (untimed), then restore the initial state
     solver.loop_set_state(x0, x0)
     if W > 0:
         solver.loop_run(0, W)
         solver.loop_sync()
-    if world > 1:
+    if use_dist:
         dist.all_gather_into_tensor(recv, send)
     solver.loop_set_state(x0, x0)
 
@@ -146,12 +150,12 @@ def main():
     solver.loop_run(0, K)
     solver.pack_log("U", 0, K, send.data_ptr())
     solver.loop_sync()
-    if world > 1:
+    if use_dist:
         dist.all_gather_into_tensor(recv, send)
     barrier()
     dt = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -188,8 +192,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, x0, K)
         print(json.dumps(out), flush=True)
+    if use_dist and rank == 0:      # the gathered block of this rank must be what the kernel logged
+        mine = recv[rank].cpu().numpy()[:, :, :B]
+        assert np.array_equal(np.moveaxis(mine, 2, 1), solver.loop_get_log("U")[:K]), "all-gather of U corrupted the data"
     solver.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
