@@ -642,7 +642,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             }
         }
         // ======================= sweep F2 (forward): corrector direction ============================
-        double m_cc = 1.0;
+        double m_cc = kTau;      // alpha = min(1, kTau / max_i(-d_i/x_i)): the full step when the boundary is further than 1/kTau away
         {
             struct F2Blk { v2d s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f2 = [&](int k, F2Blk &d) {
@@ -684,7 +684,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 ld_field<NU>(nb, L::U, c3.u); ld_field<NS>(nb, L::Z, c3.z);
             }
         }
-        alpha = kTau * frcp(m_cc);
+        alpha = m_cc <= kTau ? 1.0 : kTau * frcp(m_cc);
     }
 #undef MPC_BOUNDS
     return status;
@@ -779,7 +779,7 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
                 MPC_UNROLL for (int c = 0; c < NR; c++) rhs[c] += h * P.W[r][c];
             }
             MPC_UNROLL for (int i = 0; i < NR; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NR; j++) a += Ht[i][j] * rhs[j]; dy[i] = -a; }
-            double amax = 1.0, s1 = 0.0;
+            double amax = pass == 0 ? 1.0 : 1.0e300, s1 = 0.0;
             MPC_UNROLL for (int r = 0; r < NC; r++) {
                 double dv = 0.0; MPC_UNROLL for (int c = 0; c < NR; c++) dv += P.W[r][c] * dy[c];
                 ds_hi[r] = fh[r] ? -r_hi[r] - dv : 0.0; ds_lo[r] = fl[r] ? r_lo[r] + dv : 0.0;

@@ -244,9 +244,9 @@ static void newton_solve(const stage_t *s, work_t *w)
     }
 }
 
-static double max_step(const stage_t *s, const work_t *w)
+static double max_step(const stage_t *s, const work_t *w, double cap)
 {
-    int nv = s->n + s->m; double a = 1.0;
+    int nv = s->n + s->m; double a = cap;
     for (int k = 0; k < s->N; k++)
         for (int i = 0; i < nv; i++) {
             if (w->ds_lo[k][i] < 0) a = dmin2(a, -w->s_lo[k][i] / w->ds_lo[k][i]);
@@ -407,7 +407,7 @@ static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w,
             w->rc_hi[k][i] = w->fh[k][i] ? w->s_hi[k][i] * w->l_hi[k][i] : 0.0;
         }
         newton_solve(s, w);
-        double a_aff = max_step(s, w), mu_aff = 0.0;
+        double a_aff = max_step(s, w, 1.0), mu_aff = 0.0;
         for (int k = 0; k < N; k++) for (int i = 0; i < nv; i++)
             mu_aff += (w->s_lo[k][i] + a_aff * w->ds_lo[k][i]) * (w->l_lo[k][i] + a_aff * w->dl_lo[k][i])
                     + (w->s_hi[k][i] + a_aff * w->ds_hi[k][i]) * (w->l_hi[k][i] + a_aff * w->dl_hi[k][i]);
@@ -420,7 +420,8 @@ static int rpdip_one(const stage_t *s, const inst_t *q, int max_iter, work_t *w,
             w->rc_hi[k][i] = w->fh[k][i] ? w->s_hi[k][i] * w->l_hi[k][i] - dmax2(sm, w->l_hi[k][i] * S_FLOOR) + w->ds_hi[k][i] * w->dl_hi[k][i] : 0.0;
         }
         newton_solve(s, w);
-        double a = dmin2(1.0, TAU * max_step(s, w));
+        /* full step whenever the boundary is further than 1/TAU away: a Newton step solves an unconstrained QP exactly */
+        double a = dmin2(1.0, TAU * max_step(s, w, INFINITY));
         for (int k = 0; k < N; k++) {
             for (int i = 0; i < m; i++) w->u[k][i] += a * w->d_u[k][i];
             for (int i = 0; i < n; i++) w->z[k + 1][i] += a * w->d_z[k + 1][i];
@@ -621,7 +622,7 @@ static int target_one(const orc_problem *p, const target_t *t, const double *usp
                 rhs[c] = a;
             }
             for (int i = 0; i < nr; i++) { double a = 0.0; for (int j = 0; j < nr; j++) a += Hti[i][j] * rhs[j]; dy[i] = -a; }
-            double amax = 1.0;
+            double amax = pass == 0 ? 1.0 : INFINITY;
             for (int r = 0; r < nc; r++) {
                 double dv = 0.0; for (int c = 0; c < nr; c++) dv += t->W[r][c] * dy[c];
                 ds_hi[r] = fh[r] ? -r_hi[r] - dv : 0.0; ds_lo[r] = fl[r] ? r_lo[r] + dv : 0.0;

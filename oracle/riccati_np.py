@@ -266,8 +266,8 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False,
             dl_lo = np.where(fl, (-rc_lo - l_lo * ds_lo) / s_lo, 0.0)
             return d_u, d_z, ds_lo, ds_hi, dl_lo, dl_hi
 
-        def maxstep(xs_, dxs_):
-            out = np.ones(Bsz)
+        def maxstep(xs_, dxs_, cap=1.0):
+            out = np.full(Bsz, cap)
             for x_, d_ in zip(xs_, dxs_):
                 with np.errstate(divide="ignore", invalid="ignore"):
                     r = np.where(d_ < 0, -x_ / d_, np.inf)
@@ -283,7 +283,8 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False,
         d_u, d_z, ds_lo, ds_hi, dl_lo, dl_hi = solve(
             np.where(fl, s_lo * l_lo - np.maximum(sm, l_lo * S_FLOOR) + ds_lo * dl_lo, 0.0),
             np.where(fh, s_hi * l_hi - np.maximum(sm, l_hi * S_FLOOR) + ds_hi * dl_hi, 0.0))
-        a = np.minimum(1.0, TAU * maxstep((s_lo, s_hi, l_lo, l_hi), (ds_lo, ds_hi, dl_lo, dl_hi)))
+        # full step whenever the boundary is further than 1/TAU away (a Newton step solves an unconstrained QP exactly)
+        a = np.minimum(1.0, TAU * maxstep((s_lo, s_hi, l_lo, l_hi), (ds_lo, ds_hi, dl_lo, dl_hi), cap=np.inf))
         a = np.where(active, a, 0.0)[:, None, None]
         u = u + a * d_u; z = z + a * d_z
         s_lo = s_lo + a * ds_lo; s_hi = s_hi + a * ds_hi; l_lo = l_lo + a * dl_lo; l_hi = l_hi + a * dl_hi
@@ -447,8 +448,8 @@ def target_solve(p, td, usp, ysp, xsp, dhat, us_prev, max_iter=100):
             dl_hi = np.where(fh, (-rc_hi - l_hi * ds_hi) / s_hi, 0.0); dl_lo = np.where(fl, (-rc_lo - l_lo * ds_lo) / s_lo, 0.0)
             return dy, ds_lo, ds_hi, dl_lo, dl_hi
 
-        def maxstep(xs_, dxs_):
-            out = np.ones(Bsz)
+        def maxstep(xs_, dxs_, cap=1.0):
+            out = np.full(Bsz, cap)
             for x_, d_ in zip(xs_, dxs_):
                 with np.errstate(divide="ignore", invalid="ignore"):
                     out = np.minimum(out, np.where(d_ < 0, -x_ / d_, np.inf).min(axis=1))
@@ -461,7 +462,7 @@ def target_solve(p, td, usp, ysp, xsp, dhat, us_prev, max_iter=100):
         sm = np.maximum(sigma * mu, MU_FLOOR)[:, None]
         dy, ds_lo, ds_hi, dl_lo, dl_hi = solve(np.where(fl, s_lo * l_lo - np.maximum(sm, l_lo * S_FLOOR) + ds_lo * dl_lo, 0.0),
                                                np.where(fh, s_hi * l_hi - np.maximum(sm, l_hi * S_FLOOR) + ds_hi * dl_hi, 0.0))
-        a = np.minimum(1.0, TAU * maxstep((s_lo, s_hi, l_lo, l_hi), (ds_lo, ds_hi, dl_lo, dl_hi)))
+        a = np.minimum(1.0, TAU * maxstep((s_lo, s_hi, l_lo, l_hi), (ds_lo, ds_hi, dl_lo, dl_hi), cap=np.inf))
         a = np.where(active, a, 0.0)[:, None]
         y = y + a * dy; s_lo = s_lo + a * ds_lo; s_hi = s_hi + a * ds_hi; l_lo = l_lo + a * dl_lo; l_hi = l_hi + a * dl_hi
     left = status < 0
