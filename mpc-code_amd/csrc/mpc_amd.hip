@@ -948,6 +948,15 @@ extern "C" int mpc_pack_u(mpc_handle *h, void *dst_dev)
     return 0;
 }
 
+#ifdef MPC_STAMPS   /* diagnostic build only, see tools/stamps.py */
+extern "C" int mpc_debug_stamps(unsigned long long *out, int n, int reset)
+{
+    if (out) { if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mpc::mpc_stamp_buf), sizeof(unsigned long long) * n) != hipSuccess) return -1; }
+    if (reset) { static unsigned long long z[4096 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(mpc::mpc_stamp_buf), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 extern "C" int mpc_pack_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, void *dst_dev)
 {
     if (!h || h->B == 0 || !name || !dst_dev) return fail(-1, "bad argument");

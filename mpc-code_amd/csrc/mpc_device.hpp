@@ -61,6 +61,17 @@ struct DevProblem {
 };
 
 #define MPC_UNROLL _Pragma("unroll")
+// Diagnostic build only (-DMPC_STAMPS, tools/stamps.py): shader cycles per sweep accumulated into mpc_stamp_buf[wave][8].
+// Never compiled into the product library; the stamp values reach no output of the solver.
+#ifdef MPC_STAMPS
+__device__ unsigned long long mpc_stamp_buf[4096 * 8];
+#define MPC_STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+    if (threadIdx.x == 0) mpc_stamp_buf[blockIdx.x * 8 + (slot)] += t_ - stamp_prev_; stamp_prev_ = t_; } while (0)
+#define MPC_STAMP_INIT unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime();
+#else
+#define MPC_STAMP(slot) do { } while (0)
+#define MPC_STAMP_INIT
+#endif
 
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64, one instruction
 __device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
@@ -254,6 +265,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
     res[0] = res[1] = res[2] = 0.0;
     iters = 0;
     if (!q.ok0) return kInfeasible;
+    MPC_STAMP_INIT
 
     // bounds of block k = (u_k, z_{k+1}).  cur_lo/cur_hi hold the bounds of the block being processed: the
     // sweeps switch them between "mid" (k < N-1) and "end" (k = N-1) once per sweep instead of selecting per block.
@@ -335,6 +347,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         }
     }
 
+    MPC_STAMP(0);      // init sweep
     double alpha = 0.0, sm = 0.0, gscale = 1.0;
     int stall = 0, status = kMaxIter;
     for (int it = 0;; it++) {
@@ -497,6 +510,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             }
             MPC_UNROLL for (int i = 0; i < NU; i++) unext_dev[i] = du[i];
         }
+        MPC_STAMP(1);  // B1
         // ---- convergence / failure tests at the current iterate ------------------------------------
         const double mu = mu_sum * inv_ncon;
         if (it == 0) gscale = dmax(1.0, res_s);
@@ -555,6 +569,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 ld_field<NU>(nb, L::U, c1.u); ld_field<NS>(nb, L::Z, c1.z);
             }
         }
+        MPC_STAMP(2);  // F1
         {
             const double a_aff = frcp(m_aff);
             const double mu_aff = (mu_sum + a_aff * s1 + a_aff * a_aff * s2) * inv_ncon;
@@ -641,6 +656,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 MPC_UNROLL for (int i = 0; i < NU; i++) und[i] = du[i];
             }
         }
+        MPC_STAMP(3);  // B2
         // ======================= sweep F2 (forward): corrector direction ============================
         double m_cc = kTau;      // alpha = min(1, kTau / max_i(-d_i/x_i)): the full step when the boundary is further than 1/kTau away
         {
@@ -685,6 +701,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             }
         }
         alpha = m_cc <= kTau ? 1.0 : kTau * frcp(m_cc);
+        MPC_STAMP(4);  // F2
     }
 #undef MPC_BOUNDS
     return status;

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Diagnostic: shader cycles per sweep of the OCP solver (needs a library built with -DMPC_STAMPS)."""
+import ctypes as ct, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["MPC_AMD_LIB"] = sys.argv[1]
+import mpc_code_amd as m
+from mpc_code_amd import capi
+p = m.load_problem(m.example_path("cstr_lmpc.py"))
+s = capi.Solver(p)
+B, K = 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 20
+x0 = np.random.default_rng(20250614).uniform([-0.5, -8, -5], [0.5, 8, 5], size=(B, 3))
+s.loop_alloc(B, K, capi.LOG_U); s.loop_set_schedule(p.schedules(K)); s.loop_set_state(x0, x0)
+buf = np.zeros(64 * 8, np.uint64)
+s.lib.mpc_debug_stamps(None, 0, 1)
+names = ["init", "B1", "F1", "B2", "F2"]
+for k in range(K):
+    s.loop_run(k, 1); s.loop_sync()
+    s.lib.mpc_debug_stamps(buf.ctypes.data_as(ct.c_void_p), 64 * 8, 1)
+    c = buf.reshape(64, 8)[:, :5].astype(float)
+    it = s.loop_get_log("ITERS_DYN")[k]
+    ms, _ = s.last_kernel_ms()
+    w = np.argmax(c.sum(axis=1))
+    print(f"step {k:2d} iters max {it.max():2d} kernel {ms:.3f} ms | slowest wave kcycles: " + " ".join(f"{n}={c[w, i]/1e3:.0f}" for i, n in enumerate(names)) + f" | total {c[w].sum()/1e3:.0f}")
