@@ -196,3 +196,65 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
     assert "no kernel compiled" in str(e.value)
     with pytest.raises(capi.MpcAmdError):
         s.loop_run(0, 1)                                       # before mpc_loop_alloc
+
+
+def test_launch_granularity_and_convenience_api_do_not_change_results(cstr, solver_factory):
+    """steps_per_launch (one launch per step vs. all steps in one launch) and mpc_closed_loop (host buffers only)
+    advance the same closed loop; ragged batch (not a multiple of the wave size)."""
+    import ctypes as ct
+    from mpc_code_amd import capi
+    s = solver_factory(cstr)
+    B, K = 131, 9
+    x0 = bench_x0(B, 11)
+    sched = cstr.schedules(K)
+    runs = []
+    for spl in (1, 4, 9):
+        s.set_option("steps_per_launch", spl)
+        s.loop_alloc(B, K, capi.LOG_ALL); s.loop_set_state(x0, x0); s.loop_set_schedule(sched)
+        s.loop_run(0, K); s.loop_sync()
+        runs.append((s.loop_get_log("U"), s.loop_get_log("STATUS_DYN"), s.loop_get_state()))
+    s.set_option("steps_per_launch", 1)
+    for U, st, fin in runs[1:]:
+        assert np.array_equal(U, runs[0][0]) and np.array_equal(st, runs[0][1])
+        for k in ("x_p", "xhat", "dhat", "P", "u", "xs", "us"):
+            assert np.array_equal(fin[k], runs[0][2][k]), k
+    # two halves of the schedule, resumed from resident state, equal one run
+    s.loop_alloc(B, K, capi.LOG_ALL); s.loop_set_state(x0, x0); s.loop_set_schedule(sched)
+    s.loop_run(0, 4); s.loop_run(4, K - 4); s.loop_sync()
+    assert np.array_equal(s.loop_get_log("U"), runs[0][0])
+    # mpc_closed_loop: everything through host buffers
+    dp = lambda a: a.ctypes.data_as(ct.POINTER(ct.c_double))
+    ne = cstr.nx + cstr.nd
+    xp, xh = x0.copy(), x0.copy(); dh = np.zeros((B, cstr.nd)); Pk = np.broadcast_to(cstr.P0, (B, ne, ne)).copy()
+    u = np.zeros((B, cstr.nu)); xs = x0.copy(); us = u.copy(); Ulog = np.zeros((K, B, cstr.nu))
+    rc = s.lib.mpc_closed_loop(s.h, B, K, dp(xp), dp(xh), dp(dh), dp(Pk), dp(u), dp(xs), dp(us), dp(sched["ysp"]), dp(sched["usp"]),
+                               dp(sched["xsp"]), dp(sched["pxp"]), dp(sched["pyp"]), dp(Ulog))
+    assert rc == 0, s.lib.mpc_last_error()
+    assert np.array_equal(Ulog, runs[0][0]) and np.array_equal(u, runs[0][2]["u"]) and np.array_equal(xp, runs[0][2]["x_p"])
+
+
+def test_short_horizon_and_double_integrator(pkg, oracle_c, solver_factory):
+    """Smallest compiled dimension set (nx=2, nu=1) with N=2..5: edge of the sweeps' first/last-block handling."""
+    import copy
+    from mpc_code_amd.problem import LinearMPCProblem
+    import scipy.linalg as scla
+    A = np.array([[1.0, 0.1], [0.0, 1.0]]); Bm = np.array([[0.005], [0.1]]); C = np.array([[1.0, 0.0]])
+    Q = np.diag([1.0, 0.1]); R = np.array([[0.01]])
+    for N, du in ((2, False), (3, True), (5, False)):
+        P = scla.solve_discrete_are(A, Bm, Q, R)
+        inf = np.inf
+        p = LinearMPCProblem(nx=2, nu=1, ny=1, nd=1, nxp=2, N=N, h=0.1, Nsim=10, A=A, B=Bm, C=C, Bd=np.array([[0.0], [0.1]]), Cd=np.zeros((1, 1)),
+                             fx_const=np.zeros(2), fy_const=np.zeros(1), Ap=A, Bp=Bm, Cp=C, Q=Q, R=R, DUForm=du, P=P,
+                             Qss=np.eye(1), Rss=np.zeros((1, 1)), DUssForm=False, umin=np.array([-1.0]), umax=np.array([1.0]),
+                             xmin=np.array([-inf, -0.5]), xmax=np.array([2.0, inf]), ymin=np.array([-inf]), ymax=np.array([inf]), y_bounded=False,
+                             umin_ss=np.array([-1.0]), umax_ss=np.array([1.0]), xmin_ss=np.array([-inf, -0.5]), xmax_ss=np.array([2.0, inf]),
+                             ymin_ss=np.array([-inf]), ymax_ss=np.array([inf]), estimator="kalss", K=np.array([[0.5], [0.1], [0.2]]),
+                             x0_p=np.zeros(2), x0_m=np.zeros(2), u0=np.zeros(1), dhat0=np.zeros(1))
+        rng = np.random.default_rng(N)
+        B = 70
+        xh = rng.uniform(-1, 1, (B, 2)); xs = np.tile([0.5, 0.0], (B, 1)); us = np.zeros((B, 1)); d = rng.uniform(-0.1, 0.1, (B, 1)); up = rng.uniform(-1, 1, (B, 1))
+        g = solver_factory(p).ocp_solve(xh, xs, us, d, up, want_w=True)
+        c = oracle_c.OracleC(p).ocp_solve(xh, xs, us, d, up, want_w=True)
+        assert np.array_equal(g["status"], c["status"])
+        ok = c["status"] != 2
+        assert ok.sum() > 10 and np.abs(g["u0"] - c["u0"])[ok].max() < TOL_PORT and np.nanmax(np.abs(g["w"] - c["w"])[ok]) < 1e-6
