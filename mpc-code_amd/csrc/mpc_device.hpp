@@ -32,7 +32,7 @@ constexpr double kMuFloor = 1e-15;    // centring target never below this
 constexpr double kSFloor = 1e-11;     // ... nor below l*kSFloor
 constexpr double kBoundRelax = 1e-8;  // relaxation of the stage-0 output rows
 constexpr double kInfeasZ = 1e10;     // dual blow-up => infeasible
-constexpr double kWsDelta = 1e-2;     // closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
+constexpr double kWsDelta = 0.3;     // closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
 constexpr double kWsKappa = 1e-2;     // ... minimum slack = clip(kWsKappa * movement, kWsSMinLo, kWsSMinHi)
 constexpr double kWsSMinLo = 1e-9, kWsSMinHi = 1e-6;
 constexpr double kWsMuFactor = 1e4;   // ... minimum complementarity product = kWsMuFactor * (minimum slack)^2

@@ -52,7 +52,7 @@
 #define S_FLOOR 1e-11
 #define BOUND_RELAX 1e-8
 #define INFEAS_Z 1e10
-#define WS_DELTA 1e-2 /* warm start: used when (xhat-prediction, dhat, xs, us) moved less than this since the last step */
+#define WS_DELTA 0.3 /* warm start: used when (xhat-prediction, dhat, xs, us) moved less than this since the last step */
 #define WS_KAPPA 1e-2 /* warm start: minimum slack = clip(WS_KAPPA * movement, WS_SMIN_LO, WS_SMIN_HI) ... */
 #define WS_SMIN_LO 1e-9
 #define WS_SMIN_HI 1e-6

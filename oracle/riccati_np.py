@@ -35,7 +35,7 @@ TOL_MU = 1e-14     # ... or s*l <= TOL_MU (degenerate bounds, s* = l* = 0, conve
 MU_FLOOR = 1e-15   # the centring target sigma*mu is never below this ...
 S_FLOOR = 1e-11    # ... nor below l*S_FLOOR: no slack is driven under S_FLOOR (keeps l/s bounded)
 BOUND_RELAX = 1e-8 # relaxation of the stage-0 output rows (constraints on a given quantity)
-WS_DELTA = 1e-2    # closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
+WS_DELTA = 0.3     # closed-loop warm start: used when (xhat - prediction, dhat, xs, us) moved less than this
 WS_KAPPA = 1e-2    # closed-loop warm start: minimum slack = clip(WS_KAPPA * movement, WS_SMIN_LO, WS_SMIN_HI) ...
 WS_SMIN_LO = 1e-9
 WS_SMIN_HI = 1e-6
