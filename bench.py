@@ -113,7 +113,10 @@ def main():
     import mpc_code_amd as m
     from mpc_code_amd import capi
     prob = m.load_problem(m.example_path("cstr_lmpc.py"))
-    capi.build_library()
+    if rank == 0:
+        capi.build_library()          # no-op when the in-tree .so is current; one rank only (no concurrent hipcc)
+    if use_dist:
+        dist.barrier()
     solver = capi.Solver(prob, device=local_rank)
     solver.set_option("steps_per_launch", args.steps_per_launch)
 
