@@ -69,21 +69,6 @@ def stage_data(p):
                 zlo_m=zlo_m, zhi_m=zhi_m, zlo_e=zlo_e, zhi_e=zhi_e, n=A.shape[0], m=m, N=p.N)
 
 
-def merge_output_bounds(p, sd, dhat):
-    """Fold the g1 rows (Control_Calc.py:130,150-151) into state boxes where C has one entry per row.
-
-    y_i = c x_j + (Cd d + const)_i in [ymin_i, ymax_i], k = 1..N-1  ->  per-instance box on x_j.
-    Returns (zlo_mid[B,n], zhi_mid[B,n], stage0_ok[B]).  Raises if a row of C is not a scaled unit
-    vector (general output rows are a later scope row).
-    """
-    Bsz = dhat.shape[0]
-    n = sd["n"]
-    zlo = np.broadcast_to(sd["zlo_m"], (Bsz, n)).copy()
-    zhi = np.broadcast_to(sd["zhi_m"], (Bsz, n)).copy()
-    ok = np.ones(Bsz, dtype=bool)
-    return zlo, zhi, ok, _ymap(p)
-
-
 def _ymap(p):
     idx = np.full(p.ny, -1, dtype=int); scale = np.zeros(p.ny)
     for i in range(p.ny):
@@ -227,9 +212,7 @@ def rpdip_solve(sd, inst, max_iter=100, verbose=False, trace=None, polish=False,
             break
         # ---- factorisation (depends on sig only) -------------------------------------------
         Pn = np.broadcast_to(Pf, (Bsz, n, n)) + _diag(sig[:, N - 1, m:])
-        Pst = np.empty((Bsz, N, n, n))               # P_{k+1} kept for the rhs sweeps
         for k in range(N - 1, -1, -1):
-            Pst[:, k] = Pn
             PB = Pn @ Bm                              # [B,n,m]
             Lam = R + _diag(sig[:, k, :m]) + Bm.T @ PB
             Psi = M.T + np.swapaxes(PB, 1, 2) @ A     # [B,m,n]
