@@ -6,6 +6,7 @@
 // fails loudly when the device path is unavailable.
 #include "../../include/mpc_amd.h"
 #include "mpc_device.hpp"
+#include "mpc_tp.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -272,6 +273,144 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     a.ws_valid[b] = ws_valid ? 1 : 0;
 }
 
+// The closed loop with the horizon-parallel OCP solver (mpc_tp.hpp): a workgroup of NI waves owns NI instances.
+// Wave 0, lane i < NI does for instance i what one lane of loop_kernel does (estimator, target, hold rules, plant);
+// all waves solve the OCPs together.  Between the two halves of a step the loop state lives in HBM.
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NC, bool MASKED, int NW, int IPW>
+__global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__restrict__ Pp, LoopArgs a)
+{
+    constexpr int NS = NX + (DU ? NU : 0), NE = NX + ND;
+    using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
+    constexpr int NI = Cfg::NI;
+    extern __shared__ double tp_smem[];
+    const TpShared<NS, NU, NC, NW, IPW> sh(tp_smem);
+    const DevProblem &P = *Pp;
+    const size_t Bs = a.Bs;
+    const int lane = threadIdx.x;
+    const bool wl = threadIdx.y == 0 && lane < NI;
+    const int b = blockIdx.x * NI + lane;
+    const bool valid = wl && b < a.B;
+    double *wsg = a.ws + (size_t)blockIdx.x * NI * Cfg::ROWS_ST * 64;      // state rows of this workgroup's instances
+    MPC_STAMP_INIT
+    for (int k = 0; k < a.nsteps; k++) {
+        if (valid) {
+            double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+            MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
+            double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) dh_prev[i] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) us_prev[i] = us[i];
+            if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
+            if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
+            // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
+            if (P.estimator != MPC_EST_NONE) {
+                double xi[NE], innov[NY];
+                MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
+                MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
+                MPC_UNROLL for (int i = 0; i < NY; i++) {
+                    double yh = P.fyc[i], yy = a.pyp[k * NY + i];
+                    MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+                    MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
+                    innov[i] = yy - yh;
+                }
+                if (P.estimator == MPC_EST_KALMAN) {
+                    double Pk[NE][NE];
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
+                    kalman_lane<NE, NY>(P, xi, Pk, innov);
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+                } else {
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+                }
+                MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
+                MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
+            }
+            if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) a.DHAT[((size_t)k * ND + i) * Bs + b] = dh[i]; }
+            // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
+            double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
+            MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
+            MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
+            int it_ss;
+            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss);
+            if (st_ss != kInfeasible) {
+                MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
+                MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
+            }
+            if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XS[((size_t)k * NX + i) * Bs + b] = xs[i]; }
+            if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) a.US[((size_t)k * NU + i) * Bs + b] = us[i]; }
+            if (a.YS) {   // ys = Fy_model(xs, us, dhat), MPC_code.py:730
+                MPC_UNROLL for (int i = 0; i < NY; i++) {
+                    double v = P.fyc[i];
+                    MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Cm[i][j] * xs[j];
+                    MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Cd[i][j] * dh[j];
+                    a.YS[((size_t)k * NY + i) * Bs + b] = v;
+                }
+            }
+            if (a.st_dyn) { a.st_ss[(size_t)k * Bs + b] = st_ss; a.it_ss[(size_t)k * Bs + b] = it_ss; }
+            // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS; loop state -> HBM ------------
+            OcpInst<NS, NU> q;
+            build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
+            double delta = 0.0;
+            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - xh_pred[i]), fabs(xs[i] - xs_prev[i])));
+            MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
+            MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
+            const bool warm = a.ws_valid[b] != 0 && delta <= kWsDelta;
+            double *qd = sh.q + lane * Cfg::QN;
+            MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = q.z0[i]; qd[NS + i] = q.zr[i]; qd[2 * NS + i] = q.c[i]; qd[3 * NS + i] = q.zlo_m[i]; qd[4 * NS + i] = q.zhi_m[i]; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = q.ur[i]; qd[5 * NS + NU + i] = q.us[i]; }
+            qd[5 * NS + 2 * NU] = delta;
+            sh.iflag[lane] = kTpValid | (q.ok0 ? kTpOk0 : 0) | (warm ? kTpWarm : 0);
+            MPC_UNROLL for (int i = 0; i < NX; i++) { a.xhat[i * Bs + b] = xh[i]; a.xs[i * Bs + b] = xs[i]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) a.us[i * Bs + b] = us[i];
+        } else if (wl) sh.iflag[lane] = 0;
+        int st_dyn, it_dyn;
+        double res[3];
+        MPC_TSTAMP(0);
+        tp_solve<NS, NU, DU, NC, MASKED, NW, IPW>(P, sh, wsg, P.max_iter, st_dyn, it_dyn, res);
+        __syncthreads();
+        if (valid) {
+            // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
+            double x[NXP], xh[NX], u[NU];
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = a.u[i * Bs + b];
+            if (st_dyn != kInfeasible) {
+                const double *fin_rows = wsg + (size_t)lane * Cfg::ROWS_ST * 64;     // final iterate, block 0
+                MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = fin_rows[(Cfg::ST_U + i) * 64];          // :798
+                MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = fin_rows[(Cfg::ST_Z + i) * 64];         // :799
+            } else {                                                           // :804-805 hold u, propagate the model
+                double xo[NX], dh[ND > 0 ? ND : 1];
+                MPC_UNROLL for (int i = 0; i < NX; i++) xo[i] = a.xhat[i * Bs + b];
+                MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+                MPC_UNROLL for (int i = 0; i < NX; i++) {
+                    double v = P.fxc[i];
+                    MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Am[i][j] * xo[j];
+                    MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bm[i][j] * u[j];
+                    MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Bd[i][j] * dh[j];
+                    xh[i] = v;
+                }
+            }
+            if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) a.U[((size_t)k * NU + i) * Bs + b] = u[i]; }
+            if (a.st_dyn) { a.st_dyn[(size_t)k * Bs + b] = st_dyn; a.it_dyn[(size_t)k * Bs + b] = it_dyn; }
+            double xn[NXP];
+            MPC_UNROLL for (int i = 0; i < NXP; i++) {
+                double v = a.pxp[k * NXP + i];
+                MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
+                xn[i] = v;
+            }
+            MPC_UNROLL for (int i = 0; i < NXP; i++) a.x[i * Bs + b] = xn[i];
+            MPC_UNROLL for (int i = 0; i < NX; i++) a.xhat[i * Bs + b] = xh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) a.u[i * Bs + b] = u[i];
+            a.ws_valid[b] = st_dyn == kSolved ? 1 : 0;
+        }
+        __syncthreads();
+        MPC_TSTAMP(7);
+    }
+}
+
 // dense [B][nu] copy of u for the all-gather of u* 
 __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__ dst, int B, size_t Bs, int nu)
 {
@@ -288,7 +427,9 @@ struct Launchers {
     void (*target)(const DevProblem *, TargetArgs, hipStream_t);
     void (*kf)(const DevProblem *, KfArgs, hipStream_t);
     void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
-    int ws_rows, nc;
+    int (*loop_tp)(const DevProblem *, LoopArgs, hipStream_t);     // horizon-parallel variant (N <= 64), nullptr if it does not fit
+    int ws_rows, nc, tp_ni;
+    size_t tp_ws_per_inst, tp_ws_per_group, tp_lds;
 };
 
 // bound modes: which variant of the OCP kernels a problem may use (cheapest first)
@@ -303,6 +444,29 @@ static Launchers make_launchers_mode()
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.ws_rows = 2 * BlkLayout<NX + (DU ? NU : 0), NU, NC>::SLOTS;   // doubles per instance per block
+    {
+        // eight waves (256 VGPRs each); two instances per wave when their transposing buffer still fits the 160 KB of LDS
+        constexpr int NW = 8, NSZ = NX + (DU ? NU : 0);
+        constexpr int IPW = TpCfg<NSZ, NU, NC, NW, 2>::lds_bytes() <= 160 * 1024 ? 2 : 1;
+        using Cfg = TpCfg<NSZ, NU, NC, NW, IPW>;
+        constexpr size_t lds = Cfg::lds_bytes();
+        l.tp_ni = Cfg::NI; l.tp_lds = lds; l.tp_ws_per_inst = sizeof(double) * 64 * Cfg::ROWS_ST; l.tp_ws_per_group = 0;
+        l.loop_tp = nullptr;
+        if (lds <= 160 * 1024) {
+            l.loop_tp = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
+                auto kern = loop_kernel_tp<NX, NU, NY, ND, NXP, DU, NC, MASKED, NW, IPW>;
+                static bool attr_set[64] = {};      // per device: more than 64 KB of dynamic LDS has to be asked for
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+                if (!attr_set[dev]) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+                    attr_set[dev] = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((a.B + Cfg::NI - 1) / Cfg::NI), dim3(64, NW), lds, s, p, a);
+                return 0;
+            };
+        }
+    }
     l.nc = NC;
     return l;
 }
@@ -339,6 +503,8 @@ struct mpc_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false; int n_launches = 0;
     int steps_per_launch = 1;
+    int loop_kernel_opt = 0;    // option "loop_kernel": 0 = choose by batch size, 1 = instance per lane, 2 = horizon-parallel
+    int ws_mode = -1;           // which loop kernel's layout the workspace holds (-1 = none: next OCPs start cold)
     // per-call scratch (solve API)
     DevBuf scratch, ws;
     // loop state
@@ -347,6 +513,7 @@ struct mpc_handle {
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
+static constexpr int kTpMaxBatch = 16384;     // auto choice of the loop kernel, see loop_mode()
 static size_t pad64(size_t b) { return (b + 63) / 64 * 64; }
 
 // host [B][d] -> SoA staging [d][Bs]
@@ -577,6 +744,13 @@ extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
 {
     if (!h || !name) return fail(-1, "null argument");
     if (!std::strcmp(name, "steps_per_launch")) { h->steps_per_launch = value >= 1 ? (int)value : 1; return 0; }
+    if (!std::strcmp(name, "loop_kernel")) {
+        const int v = (int)value;
+        if (v < 0 || v > 2) return fail(-1, "loop_kernel must be 0 (auto), 1 (instance per lane) or 2 (horizon-parallel)");
+        if (v == 2 && (!h->L.loop_tp || h->hp.N > 64)) return fail(-8, "the horizon-parallel kernel needs N <= 64 and a problem that fits the LDS");
+        h->loop_kernel_opt = v;
+        return 0;
+    }
     return fail(-1, "unknown option '%s'", name);
 }
 
@@ -598,7 +772,10 @@ extern "C" float mpc_last_kernel_ms(mpc_handle *h, int32_t *n_launches)
 // ---------------------------------------------------------------------------------------------------
 static int ensure_ws(mpc_handle *h, size_t Bs)
 {
-    return h->ws.ensure((size_t)h->L.ws_rows * (h->hp.N + 2) * Bs * sizeof(double));   // +2 guard blocks per wave
+    const size_t lane_bytes = (size_t)h->L.ws_rows * (h->hp.N + 2) * Bs * sizeof(double);   // +2 guard blocks per wave
+    const size_t groups = (Bs + h->L.tp_ni - 1) / h->L.tp_ni;
+    const size_t tp_bytes = groups * h->L.tp_ni * h->L.tp_ws_per_inst + groups * h->L.tp_ws_per_group;
+    return h->ws.ensure(std::max(lane_bytes, tp_bytes));
 }
 
 extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
@@ -618,6 +795,7 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     const size_t bytes = (n_in + n_out) * sizeof(double) + 2 * Bs * sizeof(int32_t);
     if (h->scratch.ensure(bytes)) return -10;
     if (ensure_ws(h, Bs)) return -10;
+    h->ws_mode = -1;            // this solve overwrites the workspace a resident loop may have been warm-starting from
     std::vector<double> stage(n_in + n_out);
     double *sp = stage.data();
     to_soa(xhat, B, nx, Bs, sp); to_soa(xs, B, nx, Bs, sp + (size_t)nx * Bs); to_soa(us, B, nu, Bs, sp + (size_t)2 * nx * Bs);
@@ -852,6 +1030,15 @@ extern "C" int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double
     return 0;
 }
 
+// Which closed-loop kernel: 1 = one instance per lane (loop_kernel; fills the chip from about 65536 instances),
+// 2 = horizon-parallel (loop_kernel_tp; one wave per instance, for batches that leave the chip idle otherwise).
+static int loop_mode(const mpc_handle *h)
+{
+    if (h->loop_kernel_opt != 0) return h->loop_kernel_opt;
+    if (!h->L.loop_tp || h->hp.N > 64) return 1;
+    return h->B <= kTpMaxBatch ? 2 : 1;
+}
+
 extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
 {
     if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
@@ -860,6 +1047,11 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
     const DevProblem &P = h->hp;
     const size_t Bs = h->Bs, ms = h->max_steps;
     const double *sch = (const double *)h->sch.p;
+    const int mode = loop_mode(h);
+    if (mode != h->ws_mode) {      // the workspace holds another layout (or a per-call solve used it): next OCPs start cold
+        HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, Bs * 4, h->stream));
+        h->ws_mode = mode;
+    }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     int launches = 0;
     for (int k = k0; k < k0 + nsteps; k += h->steps_per_launch) {
@@ -881,7 +1073,8 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         } else a.st_dyn = a.st_ss = a.it_dyn = a.it_ss = nullptr;
         a.ws_valid = (int32_t *)h->st_flag.p;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
-        h->L.loop(h->dp, a, h->stream);
+        if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
+        else h->L.loop(h->dp, a, h->stream);
         launches++;
     }
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,504 @@
+// Horizon-parallel variant of the OCP solver for small and medium batches.
+//
+// rpdip_lane (mpc_device.hpp) maps one instance to one lane and walks the horizon sequentially four times per
+// interior-point iteration, streaming every block through HBM.  At batch 4096 that occupies 64 of the 1024 SIMDs.
+// Here a workgroup of NI waves owns NI instances:
+//   * element-wise work (slacks, multipliers, residuals, step lengths) runs with wave = instance and lane = block k of
+//     the horizon (N <= 64): the whole iterate of an instance lives in the registers of one wave, sums and maxima over
+//     the horizon are cross-lane reductions, nothing goes to HBM during a solve;
+//   * the recursions that are sequential in k (Riccati factorisation, adjoint, right-hand sides, Newton direction)
+//     run on wave 0 with lane = instance, exactly as rpdip_lane does them; the two mappings exchange their data
+//     through a transposing buffer in LDS ([row][instance][k], padded so that both views are conflict-free).
+// Between phases the iterate of an instance (slacks, multipliers, inputs, states: ROWS_ST rows of 64 doubles) rests in
+// HBM/L2, one coalesced row per quantity; a wave loads it, works, stores what changed.  That keeps the register budget
+// of a wave independent of how many instances it serves (IPW) and leaves wave 0 all its registers for the recursions.
+// The same rows are the warm start of the next MPC step.
+// The arithmetic per block is that of rpdip_lane; horizon-wide sums are taken in another order.
+#pragma once
+#include "mpc_device.hpp"
+
+#ifdef MPC_STAMPS
+#define MPC_TSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+    if (threadIdx.x == 0 && threadIdx.y == 0) mpc_stamp_buf[(blockIdx.x & 4095) * 8 + (slot)] += t_ - stamp_prev_; stamp_prev_ = t_; } while (0)
+#else
+#define MPC_TSTAMP(slot) do { } while (0)
+#endif
+
+namespace mpc {
+
+template <int NS, int NU, int NC, int NW, int IPW>
+struct TpCfg {
+    static constexpr int NI = NW * IPW;                              // instances per workgroup: NW waves, IPW instances each
+    static constexpr int NV = NS + NU, NKF = NU * NS, NLI = NU * (NU + 1) / 2;
+    // rows of the transposing buffer, per (instance, block):
+    //   RA: sigma | h  (element-wise -> Riccati), overwritten by K | Lambda^-1 (kept for the corrector)
+    //   RG: gu | gz   (-> Riccati), then du | dz (direction ->), then hu | hz (-> corrector rhs), then du | dz
+    //   RK: kff
+    static constexpr int RA = 0, RA_SZ = (2 * NC > NKF + NLI ? 2 * NC : NKF + NLI);
+    static constexpr int RG = RA_SZ, RK = RG + NV, ROWS = RK + NU;
+    static constexpr int LD = 65;                                    // 64 blocks + 1: lane = instance reads hit distinct banks
+    static constexpr int T_DOUBLES = ROWS * NI * LD;
+    static constexpr int QN = 5 * NS + 2 * NU + 1;                   // z0 zr c zlo zhi | ur us | ws_delta
+    // state rows of an instance in HBM, [row][64 blocks]: s_lo s_hi l_lo l_hi dv (NC each) | u | z
+    static constexpr int ST_SL = 0, ST_SH = NC, ST_LL = 2 * NC, ST_LH = 3 * NC, ST_DV = 4 * NC, ST_U = 5 * NC, ST_Z = 5 * NC + NU, ROWS_ST = 5 * NC + NV;
+    static constexpr size_t lds_bytes() { return sizeof(double) * (T_DOUBLES + NI * QN + NI * 4) + sizeof(int) * (3 * NI + 4); }
+};
+
+__device__ __forceinline__ double wave_sum(double v) { MPC_UNROLL for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64); return v; }
+__device__ __forceinline__ double wave_max(double v) { MPC_UNROLL for (int m = 32; m >= 1; m >>= 1) v = dmax(v, __shfl_xor(v, m, 64)); return v; }
+__device__ __forceinline__ double uni(double v)       // a wave-uniform value into scalar registers
+{
+    union { double d; int i[2]; } x; x.d = v;
+    x.i[0] = __builtin_amdgcn_readfirstlane(x.i[0]); x.i[1] = __builtin_amdgcn_readfirstlane(x.i[1]);
+    return x.d;
+}
+
+// Pointers into the dynamic LDS of the workgroup
+template <int NS, int NU, int NC, int NW, int IPW>
+struct TpShared {
+    using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
+    static constexpr int NI = Cfg::NI;
+    double *T, *q, *red; int *flag, *iflag, *misc;
+    __device__ explicit TpShared(double *base)
+    {
+        T = base; q = T + Cfg::T_DOUBLES; red = q + NI * Cfg::QN;
+        flag = (int *)(red + NI * 4); iflag = flag + NI; misc = iflag + 2 * NI;
+    }
+    __device__ __forceinline__ double &t(int row, int inst, int k) const { return T[(row * NI + inst) * Cfg::LD + k]; }
+};
+
+enum : int { kTpOk0 = 1, kTpWarm = 2, kTpValid = 4 };
+
+// Called by all NW*64 threads (lane = threadIdx.x, wave = threadIdx.y).  Instance data come from sh.q / sh.iflag
+// (written by wave 0, lanes < NI, before the call; a barrier is taken here).  On return wave 0, lane i < NI holds
+// status / iters / res of instance i; the final iterate is in the state rows (u0 = row ST_U.. at k = 0, z1 = ST_Z.. at k = 0).
+// wsg: state rows of this workgroup's instances [NI][ROWS_ST][64]; they hold the previous solve's iterate on entry.
+template <int NS, int NU, bool HASM, int NC, bool MASKED, int NW, int IPW>
+__device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW> &sh, double *__restrict__ wsg,
+                         int max_iter, int &status_o, int &iters_o, double (&res_o)[3])
+{
+    using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
+    constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK, NI = Cfg::NI;
+    const int lane = threadIdx.x, w = threadIdx.y, N = P.N;
+    const bool worker = w == 0;
+    const bool wl = worker && lane < NI;          // worker lane with an instance
+    MPC_STAMP_INIT
+    __syncthreads();                              // sh.q / sh.iflag are ready
+
+    // ---- element-wise role: instances w*IPW + j, block k = lane -----------------------------------------------------
+    const int k = lane;
+    const bool blk_on = k < N, last = k == N - 1;
+    struct Inst {          // what stays in registers between phases
+        double lo[NC], hi[NC];
+        double qz0[NS], qzr[NS], qur[NU];        // wave-uniform
+        double mu, mu_sum, sm, inv_ncon;         // wave-uniform
+        bool fl[NC], fh[NC], on, warm;
+    };
+    struct Iter { double sl[NC], sh[NC], ll[NC], lh[NC], u[NU], z[NS]; };      // the iterate of one block
+    Inst I[IPW];
+    auto row = [&](int wi, int r) -> double * { return wsg + ((size_t)wi * Cfg::ROWS_ST + r) * 64 + k; };
+    auto load_iter = [&](int wi, Iter &X) {
+        MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = *row(wi, Cfg::ST_SL + i); X.sh[i] = *row(wi, Cfg::ST_SH + i); X.ll[i] = *row(wi, Cfg::ST_LL + i); X.lh[i] = *row(wi, Cfg::ST_LH + i); }
+        MPC_UNROLL for (int i = 0; i < NU; i++) X.u[i] = *row(wi, Cfg::ST_U + i);
+        MPC_UNROLL for (int i = 0; i < NS; i++) X.z[i] = *row(wi, Cfg::ST_Z + i);
+    };
+    auto store_iter = [&](int wi, const Iter &X) {
+        MPC_UNROLL for (int i = 0; i < NC; i++) { *row(wi, Cfg::ST_SL + i) = X.sl[i]; *row(wi, Cfg::ST_SH + i) = X.sh[i]; *row(wi, Cfg::ST_LL + i) = X.ll[i]; *row(wi, Cfg::ST_LH + i) = X.lh[i]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) *row(wi, Cfg::ST_U + i) = X.u[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) *row(wi, Cfg::ST_Z + i) = X.z[i];
+    };
+    // stage cost of this lane's block in registers: Q (or the terminal weight for the last block), R, M
+    double Qk[NS][NS], Rk[NU][NU], Mk[NS][NU];
+    MPC_UNROLL for (int i = 0; i < NS; i++) {
+        MPC_UNROLL for (int j = 0; j <= i; j++) { const double t = vreg(last ? P.Pf[i][j] : P.Q[i][j]); Qk[i][j] = t; Qk[j][i] = t; }
+        MPC_UNROLL for (int j = 0; j < NU; j++) Mk[i][j] = HASM ? vreg(P.M[i][j]) : 0.0;
+    }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { const double t = vreg(P.R[i][j]); Rk[i][j] = t; Rk[j][i] = t; } }
+    // cost gradient of the current point for this block: gu (NU), gz (NS), with the bound multipliers
+    auto gradient = [&](const Inst &S, const Iter &X, double (&gu)[NU], double (&gz)[NS]) {
+        double dz1[NS], du[NU];
+        MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = X.z[i] - S.qzr[i];
+        MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = X.u[i] - S.qur[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            double a = (NU + i < NC) ? X.lh[NU + i < NC ? NU + i : 0] - X.ll[NU + i < NC ? NU + i : 0] : 0.0;
+            MPC_UNROLL for (int j = 0; j < NS; j++) a += Qk[i][j] * dz1[j];
+            gz[i] = a;
+        }
+        MPC_UNROLL for (int i = 0; i < NU; i++) {
+            double a = X.lh[i] - X.ll[i];
+            MPC_UNROLL for (int j = 0; j < NU; j++) a += Rk[i][j] * du[j];
+            gu[i] = a;
+        }
+        if (HASM) {     // cross terms of the Delta-u form: M (u_{k+1} - ur) into gz (k < N-1), M'(z_k - zr) into gu
+            double un[NU], zp[NS];
+            MPC_UNROLL for (int i = 0; i < NU; i++) un[i] = __shfl_down(du[i], 1, 64);
+            MPC_UNROLL for (int i = 0; i < NS; i++) { const double t = __shfl_up(dz1[i], 1, 64); zp[i] = k > 0 ? t : S.qz0[i] - S.qzr[i]; }
+            if (!last) { MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) gz[i] += Mk[i][j] * un[j]; } }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) gu[i] += Mk[j][i] * zp[j]; }
+        }
+    };
+    // residuals, barrier weights, gradients of the iterate X -> LDS, horizon-wide statistics -> sh.red
+    auto phase_a = [&](Inst &S, const Iter &X, int wi) {
+        double mu_p = 0.0, resp_p = 0.0, cres_p = 0.0, lmax_p = 0.0;
+        MPC_UNROLL for (int i = 0; i < NC; i++) {
+            const double v = i < NU ? X.u[i < NU ? i : 0] : X.z[i >= NU ? i - NU : 0];
+            const double rh = S.fh[i] ? v + X.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - X.sl[i] - S.lo[i] : 0.0;
+            const double isl = frcp(X.sl[i]), ish = frcp(X.sh[i]);
+            mu_p += X.sl[i] * X.ll[i] + X.sh[i] * X.lh[i];
+            sh.t(RA + i, wi, k) = X.ll[i] * isl + X.lh[i] * ish;
+            sh.t(RA + NC + i, wi, k) = X.lh[i] * (rh * ish - 1.0) + X.ll[i] * (rl * isl + 1.0);
+            resp_p = dmax(resp_p, dmax(fabs(rl), fabs(rh)));
+            cres_p = dmax(cres_p, dmax(comp_measure(X.sl[i], X.ll[i]), comp_measure(X.sh[i], X.lh[i])));
+            lmax_p = dmax(lmax_p, dmax(X.ll[i], X.lh[i]));
+        }
+        double gu[NU], gz[NS];
+        gradient(S, X, gu, gz);
+        MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, k) = gu[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, wi, k) = gz[i];
+        S.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
+        const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
+        S.mu = S.mu_sum * S.inv_ncon;
+        if (lane == 0) { sh.red[wi * 4 + 0] = S.mu; sh.red[wi * 4 + 1] = res_p; sh.red[wi * 4 + 2] = cres; sh.red[wi * 4 + 3] = lmax; }
+    };
+
+    // ---- instance constants; initial inputs (cold: us pushed inside the box; warm: previous inputs shifted one stage) -> LDS
+    double ll0[IPW][NC], lh0[IPW][NC], u0v[IPW][NU];
+    MPC_UNROLL for (int j = 0; j < IPW; j++) {
+        Inst &S = I[j];
+        const int wi = w * IPW + j;
+        const double *qd = sh.q + wi * Cfg::QN;
+        const int myflag = sh.iflag[wi];
+        S.on = (myflag & kTpValid) && (myflag & kTpOk0);
+        S.warm = (myflag & kTpWarm) != 0;
+        S.mu = 0.0; S.mu_sum = 0.0; S.sm = 0.0;
+        MPC_UNROLL for (int i = 0; i < NS; i++) { S.qz0[i] = uni(qd[i]); S.qzr[i] = uni(qd[NS + i]); }
+        MPC_UNROLL for (int i = 0; i < NU; i++) S.qur[i] = uni(qd[5 * NS + i]);
+        double ncon = 0.0;
+        MPC_UNROLL for (int i = 0; i < NC; i++) {
+            const double zlm = i >= NU ? uni(qd[3 * NS + (i >= NU ? i - NU : 0)]) : 0.0, zhm = i >= NU ? uni(qd[4 * NS + (i >= NU ? i - NU : 0)]) : 0.0;
+            const double lm = i < NU ? P.ulo[i < NU ? i : 0] : zlm, hm = i < NU ? P.uhi[i < NU ? i : 0] : zhm;
+            const double le = i < NU ? P.ulo[i < NU ? i : 0] : P.zlo_e[i >= NU ? i - NU : 0], he = i < NU ? P.uhi[i < NU ? i : 0] : P.zhi_e[i >= NU ? i - NU : 0];
+            const bool flm = MASKED ? fin(lm) : true, fhm = MASKED ? fin(hm) : true, fle = MASKED ? fin(le) : true, fhe = MASKED ? fin(he) : true;
+            S.fl[i] = last ? fle : flm; S.fh[i] = last ? fhe : fhm;
+            S.lo[i] = last ? (fle ? le : 0.0) : (flm ? lm : 0.0); S.hi[i] = last ? (fhe ? he : 0.0) : (fhm ? hm : 0.0);
+            ncon += (double)(N - 1) * ((flm ? 1 : 0) + (fhm ? 1 : 0)) + (fle ? 1 : 0) + (fhe ? 1 : 0);
+        }
+        S.inv_ncon = 1.0 / dmax(ncon, 1.0);
+        const int ksrc = k + 1 < N ? k + 1 : (k < N ? N - 1 : k);     // shift by one stage, the last block repeats
+        const int sft = ksrc - k;
+        MPC_UNROLL for (int i = 0; i < NU; i++) {
+            const double ulo = P.ulo[i], uhi = P.uhi[i];
+            const bool f_lo = fin(ulo), f_hi = fin(uhi);
+            double v;
+            if (S.warm) {
+                v = row(wi, Cfg::ST_U + i)[sft];
+                if (f_lo) v = dmax(v, ulo);
+                if (f_hi) v = dmin(v, uhi);
+            } else {
+                const double us = uni(qd[5 * NS + NU + i]);
+                double push;
+                if (f_lo && f_hi) push = 0.1 * (uhi - ulo);
+                else push = 0.1 * dmax(1.0, fabs(f_lo ? ulo : (f_hi ? uhi : 0.0)));
+                v = us;
+                if (f_lo) v = dmax(v, ulo + push);
+                if (f_hi) v = dmin(v, uhi - push);
+            }
+            u0v[j][i] = v;
+            sh.t(RG + i, wi, k) = v;
+        }
+        MPC_UNROLL for (int i = 0; i < NC; i++) {
+            ll0[j][i] = S.warm ? row(wi, Cfg::ST_LL + i)[sft] : 0.0;
+            lh0[j][i] = S.warm ? row(wi, Cfg::ST_LH + i)[sft] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (wl && (sh.iflag[lane] & kTpValid) && (sh.iflag[lane] & kTpOk0)) {       // states by forward simulation (lane = instance)
+        double zz[NS], c[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = sh.q[lane * Cfg::QN + i]; c[i] = sh.q[lane * Cfg::QN + 2 * NS + i]; }
+        for (int kk = 0; kk < N; kk++) {
+            double uk[NU], zn[NS];
+            MPC_UNROLL for (int i = 0; i < NU; i++) uk[i] = sh.t(RG + i, lane, kk);
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                double a = c[i];
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[i][j] * zz[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) a += P.B[i][j] * uk[j];
+                zn[i] = a;
+            }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = zn[i]; sh.t(RG + NU + i, lane, kk) = zn[i]; }
+        }
+    }
+    __syncthreads();
+    // slacks and multipliers of the initial point, then the first element-wise phase
+    MPC_UNROLL for (int j = 0; j < IPW; j++) {
+        Inst &S = I[j];
+        const int wi = w * IPW + j;
+        if (S.on) {
+            Iter Xj;
+            MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] = u0v[j][i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = sh.t(RG + NU + i, wi, k);
+            const double ws_delta = uni(sh.q[wi * Cfg::QN + 5 * NS + 2 * NU]);
+            const double ws_smin = dmin(dmax(kWsKappa * ws_delta, kWsSMinLo), kWsSMinHi), ws_mu = kWsMuFactor * ws_smin * ws_smin;
+            const double smin = S.warm ? ws_smin : kSMin;
+            MPC_UNROLL for (int i = 0; i < NC; i++) {
+                const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
+                Xj.sl[i] = S.fl[i] ? dmax(v - S.lo[i], smin) : 1.0; Xj.sh[i] = S.fh[i] ? dmax(S.hi[i] - v, smin) : 1.0;
+                const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
+                const double llo = S.warm ? dmax(ll0[j][i], ws_mu * isl) : kMu0 * isl, lhi = S.warm ? dmax(lh0[j][i], ws_mu * ish) : kMu0 * ish;
+                Xj.ll[i] = S.fl[i] ? llo : 0.0; Xj.lh[i] = S.fh[i] ? lhi : 0.0;
+            }
+            store_iter(wi, Xj);
+            phase_a(S, Xj, wi);
+        }
+    }
+
+    // forward recursion of the Newton direction (lane = instance): K, kff -> du | dz
+    auto direction = [&](const StageConst<NS, NU> &C) {
+        double dz[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
+        for (int kk = 0; kk < N; kk++) {
+            double Kf[NKF], kff[NU], ddu[NU], dzn[NS];
+            MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = sh.t(RA + i, lane, kk);
+            MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = sh.t(RK + i, lane, kk);
+            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Kf[i * NS + j] * dz[j]; ddu[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, lane, kk) = ddu[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, lane, kk) = dz[i];
+        }
+    };
+
+    // worker-lane state of the iteration (lane = instance)
+    int status = kMaxIter, iters = 0, stall = 0;
+    double gscale = 1.0, res[3] = {0.0, 0.0, 0.0};
+    bool wk_on = wl && (sh.iflag[lane < NI ? lane : 0] & kTpValid) && (sh.iflag[lane < NI ? lane : 0] & kTpOk0);
+    if (wl && (sh.iflag[lane] & kTpValid) && !(sh.iflag[lane] & kTpOk0)) status = kInfeasible;
+
+    MPC_TSTAMP(1);
+    for (int it = 0;; it++) {
+        __syncthreads();
+        MPC_TSTAMP(2);
+        // ================= wave 0, lane = instance: Riccati factorisation, adjoint, predictor rhs, direction =============
+        if (worker) {
+            int verdict = 0;
+            StageConst<NS, NU> C;
+            load_stage_const<NS, NU, HASM>(P, C);
+            if (wk_on) {
+                double pi[NS], Pm[NS][NS], pcar[NS], res_s = 0.0;
+                bool pd_ok = true;
+                MPC_UNROLL for (int i = 0; i < NS; i++) {
+                    pi[i] = 0.0; pcar[i] = 0.0;
+                    MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = C.Pf[i][j];
+                }
+                double sg[NC], hh[NC], gun[NU], gzn[NS];
+                MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lane, N - 1); hh[i] = sh.t(RA + NC + i, lane, N - 1); }
+                MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lane, N - 1);
+                MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lane, N - 1);
+                for (int kk = N - 1; kk >= 0; kk--) {
+                    double sig[NV], haff[NV], g1[NS], g2[NU];
+                    MPC_UNROLL for (int i = 0; i < NV; i++) { sig[i] = i < NC ? sg[i < NC ? i : 0] : 0.0; haff[i] = i < NC ? hh[i < NC ? i : 0] : 0.0; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) g1[i] = gzn[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) g2[i] = gun[i];
+                    const int kn = kk > 0 ? kk - 1 : 0;      // next block's data now, they arrive while this block computes
+                    MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lane, kn); hh[i] = sh.t(RA + NC + i, lane, kn); }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lane, kn);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lane, kn);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) Pm[i][i] += sig[NU + i];
+                    double PB[NS][NU], PA[NS][NS], Lam[NU][NU], Psi[NU][NS];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) {
+                        MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * C.B[l][j]; PB[i][j] = a; }
+                        MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * C.A[l][j]; PA[i][j] = a; }
+                    }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) {
+                        MPC_UNROLL for (int j = 0; j <= i; j++) { double a = C.R[i][j] + (i == j ? sig[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += C.B[l][i] * PB[l][j]; Lam[i][j] = a; Lam[j][i] = a; }
+                        MPC_UNROLL for (int j = 0; j < NS; j++) { double a = HASM ? C.M[j][i] : 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += C.B[l][i] * PA[l][j]; Psi[i][j] = a; }
+                    }
+                    pd_ok = sym_inverse<NU>(Lam) && pd_ok;
+                    double Kk[NU][NS];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a += Lam[i][l] * Psi[l][j]; Kk[i][j] = -a; } }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) sh.t(RA + i * NS + j, lane, kk) = Kk[i][j]; }
+                    {
+                        int c = 0;
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { sh.t(RA + NKF + c, lane, kk) = Lam[i][j]; c++; } }
+                    }
+                    if (kk > 0) {       // closed-loop (Joseph) form with T = P Acl = PA + PB K
+                        double Acl[NS][NS], T[NS][NS], RK_[NU][NS];
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = C.A[i][j], t = PA[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) { a += C.B[i][l] * Kk[l][j]; t += PB[i][l] * Kk[l][j]; } Acl[i][j] = a; T[i][j] = t; } }
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = sig[i] * Kk[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += C.R[i][l] * Kk[l][j]; RK_[i][j] = a; } }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) {
+                            MPC_UNROLL for (int j = 0; j <= i; j++) {
+                                double a = C.Q[i][j];
+                                MPC_UNROLL for (int l = 0; l < NS; l++) a += Acl[l][i] * T[l][j];
+                                MPC_UNROLL for (int l = 0; l < NU; l++) a += Kk[l][i] * RK_[l][j];
+                                if (HASM) { MPC_UNROLL for (int l = 0; l < NU; l++) a += C.M[i][l] * Kk[l][j] + Kk[l][i] * C.M[j][l]; }
+                                Pm[i][j] = a; Pm[j][i] = a;
+                            }
+                        }
+                    }
+                    {       // adjoint and stationarity residual
+                        double pn[NS];
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = g1[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pi[j]; pn[i] = a; }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = pn[i];
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = g2[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pi[j]; res_s = dmax(res_s, fabs(a)); }
+                    }
+                    double pv[NS], qu[NU], psi[NU], kff[NU];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = g1[i] + haff[NU + i] + pcar[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) qu[i] = g2[i] + haff[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Lam[i][j] * psi[j]; kff[i] = -a; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lane, kk) = kff[i];
+                    if (kk > 0) {
+                        double pn[NS];
+                        MPC_UNROLL for (int i = 0; i < NS; i++) {
+                            double a = 0.0;
+                            MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
+                            MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j][i] * psi[j];
+                            pn[i] = a;
+                        }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) pcar[i] = pn[i];
+                    }
+                }
+                const double mu_i = sh.red[lane * 4 + 0], res_p = sh.red[lane * 4 + 1], cres = sh.red[lane * 4 + 2], lmax = sh.red[lane * 4 + 3];
+                if (it == 0) gscale = dmax(1.0, res_s);
+                res[0] = res_s; res[1] = res_p; res[2] = mu_i;
+                iters = it;
+                const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
+                stall = ok_cp ? stall + 1 : 0;
+                if (ok_cp && (res_s <= kTolStat * gscale || (stall > kStallMax && res_s <= kTolStatAcc * gscale))) verdict = 1 + kSolved;
+                else if (lmax > kInfeasZ * gscale || !(fabs(mu_i) < 1.0e300) || !pd_ok) verdict = 1 + kInfeasible;
+                else if (it == max_iter) verdict = 1 + kMaxIter;
+                if (verdict != 0) { status = verdict - 1; wk_on = false; }
+                else direction(C);
+            }
+            if (wl) sh.flag[lane] = verdict;
+            const unsigned long long any = __ballot(wk_on);
+            if (lane == 0) sh.misc[0] = any != 0ull ? 1 : 0;
+        }
+        __syncthreads();
+        MPC_TSTAMP(3);
+        MPC_UNROLL for (int j = 0; j < IPW; j++) { if (I[j].on && sh.flag[w * IPW + j] != 0) I[j].on = false; }      // finished: the state rows hold the result
+        if (sh.misc[0] == 0) break;      // uniform over the workgroup
+        // ================= element-wise: predictor step length, centring, corrector rhs -> LDS ===========================
+        {
+            MPC_UNROLL for (int j = 0; j < IPW; j++) {
+                Inst &S = I[j];
+                const int wi = w * IPW + j;
+                if (S.on) {
+                    Iter Xj;
+                    load_iter(wi, Xj);
+                    double maff_p = 1.0, s1_p = 0.0, s2_p = 0.0, dv[NC], pl[NC], ph[NC];
+                    MPC_UNROLL for (int i = 0; i < NC; i++) { dv[i] = sh.t(RG + i, wi, k); *row(wi, Cfg::ST_DV + i) = dv[i]; }      // du | dz of the predictor
+                    MPC_UNROLL for (int i = 0; i < NC; i++) {
+                        const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
+                        const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
+                        const double rh = S.fh[i] ? v + Xj.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - Xj.sl[i] - S.lo[i] : 0.0;
+                        const double dsh = S.fh[i] ? -rh - dv[i] : 0.0, dsl = S.fl[i] ? rl + dv[i] : 0.0;
+                        const double qh = dsh * ish, ql = dsl * isl;
+                        const double dlh = S.fh[i] ? -Xj.lh[i] - Xj.lh[i] * qh : 0.0, dll = S.fl[i] ? -Xj.ll[i] - Xj.ll[i] * ql : 0.0;
+                        maff_p = dmax(maff_p, dmax(-ql, -qh));
+                        if (S.fl[i]) maff_p = dmax(maff_p, 1.0 + ql);
+                        if (S.fh[i]) maff_p = dmax(maff_p, 1.0 + qh);
+                        s1_p += Xj.sl[i] * dll + Xj.ll[i] * dsl + Xj.sh[i] * dlh + Xj.lh[i] * dsh;
+                        s2_p += dsl * dll + dsh * dlh;
+                        pl[i] = dsl * dll; ph[i] = dsh * dlh;
+                    }
+                    const double m_aff = wave_max(blk_on ? maff_p : 1.0), s1 = wave_sum(blk_on ? s1_p : 0.0), s2 = wave_sum(blk_on ? s2_p : 0.0);
+                    const double a_aff = frcp(m_aff);
+                    const double mu_aff = (S.mu_sum + a_aff * s1 + a_aff * a_aff * s2) * S.inv_ncon;
+                    const double rat = S.mu > 0.0 ? mu_aff * frcp(S.mu) : 0.0;
+                    S.sm = dmax(rat * rat * rat * S.mu, kMuFloor);
+                    double gu[NU], gz[NS], hc[NV];
+                    gradient(S, Xj, gu, gz);
+                    MPC_UNROLL for (int i = NC; i < NV; i++) hc[i] = 0.0;
+                    MPC_UNROLL for (int i = 0; i < NC; i++) {
+                        const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
+                        const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
+                        const double rh = S.fh[i] ? v + Xj.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - Xj.sl[i] - S.lo[i] : 0.0;
+                        const double rch = S.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(S.sm, Xj.lh[i] * kSFloor) + ph[i] : 0.0;
+                        const double rcl = S.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + pl[i] : 0.0;
+                        hc[i] = (-rch + Xj.lh[i] * rh) * ish + (rcl + Xj.ll[i] * rl) * isl;
+                    }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, k) = gu[i] + hc[i];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, wi, k) = gz[i] + hc[NU + i];
+                }
+            }
+        }
+        __syncthreads();
+        MPC_TSTAMP(4);
+        // ================= wave 0, lane = instance: corrector rhs recursion and direction ===============================
+        if (worker) {
+            StageConst<NS, NU> C;
+            load_stage_const<NS, NU, HASM>(P, C);
+            if (wk_on) {
+                double pc[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
+                for (int kk = N - 1; kk >= 0; kk--) {
+                    double pv[NS], hu[NU], Li[NU][NU], Kf[NKF], psi[NU], kff[NU];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = sh.t(RG + i, lane, kk);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = sh.t(RG + NU + i, lane, kk) + pc[i];
+                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = sh.t(RA + i, lane, kk);
+                    {
+                        int c = 0;
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { const double t = sh.t(RA + NKF + c, lane, kk); Li[i][j] = t; Li[j][i] = t; c++; } }
+                    }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = hu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lane, kk) = kff[i];
+                    double pn[NS];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) {
+                        double a = 0.0;
+                        MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
+                        MPC_UNROLL for (int j = 0; j < NU; j++) a += Kf[j * NS + i] * psi[j];
+                        pn[i] = a;
+                    }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = pn[i];
+                }
+                direction(C);
+            }
+        }
+        __syncthreads();
+        MPC_TSTAMP(5);
+        // ================= element-wise: corrector step length, step; then the next iterate's residuals / gradients =====
+        {
+            MPC_UNROLL for (int j = 0; j < IPW; j++) {
+                Inst &S = I[j];
+                const int wi = w * IPW + j;
+                if (S.on) {
+                    Iter Xj;
+                    double dvaj[NC], dvzj[NV];
+                    load_iter(wi, Xj);
+                    MPC_UNROLL for (int i = 0; i < NC; i++) dvaj[i] = *row(wi, Cfg::ST_DV + i);
+                    MPC_UNROLL for (int i = 0; i < NV; i++) dvzj[i] = sh.t(RG + i, wi, k);
+                    double mcc_p = kTau;
+                    double dsl[NC], dsh[NC], dll[NC], dlh[NC];
+                    MPC_UNROLL for (int i = 0; i < NC; i++) {
+                        const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
+                        const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
+                        const double rh = S.fh[i] ? v + Xj.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - Xj.sl[i] - S.lo[i] : 0.0;
+                        // second-order products of the predictor direction (recomputed, not stored)
+                        const double ash = S.fh[i] ? -rh - dvaj[i] : 0.0, asl = S.fl[i] ? rl + dvaj[i] : 0.0;
+                        const double alh = S.fh[i] ? -Xj.lh[i] - Xj.lh[i] * (ash * ish) : 0.0, all_ = S.fl[i] ? -Xj.ll[i] - Xj.ll[i] * (asl * isl) : 0.0;
+                        const double rch = S.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(S.sm, Xj.lh[i] * kSFloor) + ash * alh : 0.0;
+                        const double rcl = S.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + asl * all_ : 0.0;
+                        dsh[i] = S.fh[i] ? -rh - dvzj[i] : 0.0; dsl[i] = S.fl[i] ? rl + dvzj[i] : 0.0;
+                        dlh[i] = S.fh[i] ? (-rch - Xj.lh[i] * dsh[i]) * ish : 0.0; dll[i] = S.fl[i] ? (-rcl - Xj.ll[i] * dsl[i]) * isl : 0.0;
+                        mcc_p = dmax(mcc_p, dmax(-dsl[i] * isl, -dsh[i] * ish));
+                        if (S.fl[i]) mcc_p = dmax(mcc_p, -dll[i] * frcp_approx(Xj.ll[i]));
+                        if (S.fh[i]) mcc_p = dmax(mcc_p, -dlh[i] * frcp_approx(Xj.lh[i]));
+                    }
+                    const double m_cc = wave_max(blk_on ? mcc_p : kTau);
+                    const double alpha = m_cc <= kTau ? 1.0 : kTau * frcp(m_cc);
+                    MPC_UNROLL for (int i = 0; i < NC; i++) { Xj.sl[i] += alpha * dsl[i]; Xj.sh[i] += alpha * dsh[i]; Xj.ll[i] += alpha * dll[i]; Xj.lh[i] += alpha * dlh[i]; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] += alpha * dvzj[i];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] += alpha * dvzj[NU + i];
+                    store_iter(wi, Xj);
+                    phase_a(S, Xj, wi);
+                }
+            }
+        }
+        MPC_TSTAMP(6);
+    }
+    status_o = status; iters_o = iters;
+    res_o[0] = res[0]; res_o[1] = res[1]; res_o[2] = res[2];
+}
+
+}  // namespace mpc

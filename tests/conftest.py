@@ -55,8 +55,9 @@ def solver_factory(pkg):
     from mpc_code_amd import capi
     made = []
 
-    def make(problem):
+    def make(problem, loop_kernel=0):
         s = capi.Solver(problem, device=0)
+        s.set_option("loop_kernel", loop_kernel)      # 0 auto, 1 instance per lane, 2 horizon-parallel
         made.append(s)
         return s
 

@@ -101,12 +101,16 @@ def test_target_and_estimator_match_c_restatement(which, cstr, wb, oracle_c, sol
         assert np.abs(b - b2.reshape(B, ne, ne)).max() < 1e-12
 
 
+LOOP_KERNELS = [pytest.param(1, id="lane"), pytest.param(2, id="horizon")]      # the two closed-loop kernels (mpc_set_option "loop_kernel")
+
+
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
 @pytest.mark.parametrize("which,B,nst", [("cstr", 257, 30), ("wb", 64, 40)])
-def test_fused_closed_loop_matches_c_restatement(which, B, nst, cstr, wb, oracle_c, solver_factory):
+def test_fused_closed_loop_matches_c_restatement(which, B, nst, lk, cstr, wb, oracle_c, solver_factory):
     from mpc_code_amd.driver import run_closed_loop
     p = cstr if which == "cstr" else wb
     x0 = bench_x0(B, 9) if p is cstr else 0.05 * np.random.default_rng(9).standard_normal((B, p.nx))
-    g = run_closed_loop(p, x0, x0, nst, solver=solver_factory(p), fused=True)
+    g = run_closed_loop(p, x0, x0, nst, solver=solver_factory(p, lk), fused=True)
     c = oracle_c.OracleC(p).closed_loop(nst, x0, x0)
     same = g["STATUS_DYN"] == c["STATUS_DYN"]
     assert same.mean() > 0.999
@@ -117,11 +121,12 @@ def test_fused_closed_loop_matches_c_restatement(which, B, nst, cstr, wb, oracle
     assert np.array_equal(g["STATUS_SS"][:, good], c["STATUS_SS"][:, good])
 
 
-def test_stepwise_calls_equal_fused_kernel(cstr, solver_factory):
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
+def test_stepwise_calls_equal_fused_kernel(lk, cstr, solver_factory):
     """Calling the three solvers per step through the C-ABI (the literal drop-in for MPC_code.py:704,776 and
     Estimator.py) gives the same closed loop as the fused kernel."""
     from mpc_code_amd.driver import run_closed_loop
-    s = solver_factory(cstr)
+    s = solver_factory(cstr, lk)
     x0 = bench_x0(96, 4)
     a = run_closed_loop(cstr, x0, x0, 12, solver=s, fused=True)
     b = run_closed_loop(cstr, x0, x0, 12, solver=s, fused=False)
@@ -131,18 +136,19 @@ def test_stepwise_calls_equal_fused_kernel(cstr, solver_factory):
     assert b["ITERS_DYN"][6:].mean() > 1.5 * a["ITERS_DYN"][6:].mean()      # the warm start is doing its job
 
 
-def test_shipped_scenarios_follow_the_golden_closed_loop(cstr, wb, solver_factory):
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
+def test_shipped_scenarios_follow_the_golden_closed_loop(lk, cstr, wb, solver_factory):
     from mpc_code_amd.driver import run_closed_loop
     for p, name in ((cstr, "cstr_shipped"), (wb, "wb_shipped")):
         g = np.load(os.path.join(GOLD, name + ".npz"))
-        r = run_closed_loop(p, nsteps=100, solver=solver_factory(p))
+        r = run_closed_loop(p, nsteps=100, solver=solver_factory(p, lk))
         same = ((r["STATUS_DYN"] == 2) == (g["STATUS_DYN"] == 2)).all(axis=1)
         upto = int(np.argmin(same)) if not same.all() else 100
         assert upto >= 20
         assert np.abs(r["U"][:upto] - g["U"][:upto]).max() < 5e-6
         assert np.abs(r["X_HAT"][:upto] - g["X_HAT"][:upto]).max() < 5e-6
     # the shipped CSTR run starts infeasible: u is held at u0 = 0 for steps 0-2
-    r = run_closed_loop(cstr, nsteps=4, solver=solver_factory(cstr))
+    r = run_closed_loop(cstr, nsteps=4, solver=solver_factory(cstr, lk))
     assert (r["STATUS_DYN"][:3, 0] == 2).all() and r["STATUS_DYN"][3, 0] == 0 and np.all(r["U"][:3] == 0.0)
 
 
@@ -198,12 +204,13 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
         s.loop_run(0, 1)                                       # before mpc_loop_alloc
 
 
-def test_launch_granularity_and_convenience_api_do_not_change_results(cstr, solver_factory):
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
+def test_launch_granularity_and_convenience_api_do_not_change_results(lk, cstr, solver_factory):
     """steps_per_launch (one launch per step vs. all steps in one launch) and mpc_closed_loop (host buffers only)
     advance the same closed loop; ragged batch (not a multiple of the wave size)."""
     import ctypes as ct
     from mpc_code_amd import capi
-    s = solver_factory(cstr)
+    s = solver_factory(cstr, lk)
     B, K = 131, 9
     x0 = bench_x0(B, 11)
     sched = cstr.schedules(K)
@@ -258,16 +265,25 @@ def test_short_horizon_and_double_integrator(pkg, oracle_c, solver_factory):
         assert np.array_equal(g["status"], c["status"])
         ok = c["status"] != 2
         assert ok.sum() > 10 and np.abs(g["u0"] - c["u0"])[ok].max() < TOL_PORT and np.nanmax(np.abs(g["w"] - c["w"])[ok]) < 1e-6
+        # the closed loop on the same tiny horizon, both kernels (masked bounds, fixed-gain estimator, ragged batch)
+        from mpc_code_amd.driver import run_closed_loop
+        x0 = rng.uniform(-0.4, 0.4, (37, 2))
+        cl = oracle_c.OracleC(p).closed_loop(8, x0, x0)
+        for lk in (1, 2):
+            gl = run_closed_loop(p, x0, x0, 8, solver=solver_factory(p, lk))
+            assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), (N, lk)
+            assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, (N, lk)
 
 
-def test_full_size_closed_loop(cstr, oracle_c, solver_factory):
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
+def test_full_size_closed_loop(lk, cstr, oracle_c, solver_factory):
     """The benchmark workload itself (4096 instances, first 30 steps incl. the set-point change): every status word and
     a sample of trajectories against the C restatement; invariants on all of them."""
     from mpc_code_amd.driver import run_closed_loop
     p = cstr
     B, K = 4096, 30
     x0 = bench_x0(B)
-    g = run_closed_loop(p, x0, x0, K, solver=solver_factory(p))
+    g = run_closed_loop(p, x0, x0, K, solver=solver_factory(p, lk))
     pick = np.arange(0, B, 61)
     c = oracle_c.OracleC(p).closed_loop(K, x0[pick], x0[pick])
     same = g["STATUS_DYN"][:, pick] == c["STATUS_DYN"]

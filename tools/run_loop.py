@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--example", default="cstr_lmpc.py")
 ap.add_argument("--steps-per-launch", type=int, default=1)
+ap.add_argument("--loop-kernel", type=int, default=0, help="0 auto, 1 instance per lane, 2 horizon-parallel")
 a = ap.parse_args()
 p = m.load_problem(m.example_path(a.example))
 rng = np.random.default_rng(20250614)
@@ -29,6 +30,7 @@ else:
     x0 = 0.05 * rng.standard_normal((a.batch, p.nx))
 s = capi.Solver(p)
 s.set_option("steps_per_launch", a.steps_per_launch)
+s.set_option("loop_kernel", a.loop_kernel)
 s.loop_alloc(a.batch, a.steps, capi.LOG_U)
 s.loop_set_schedule(p.schedules(a.steps))
 s.loop_set_state(x0, x0)
@@ -38,6 +40,6 @@ s.loop_sync()
 dt = time.perf_counter() - t0
 ms, n = s.last_kernel_ms()
 it = s.loop_get_log("ITERS_DYN"); st = s.loop_get_log("STATUS_DYN")
-print(f"B={a.batch} steps={a.steps}: wall {dt*1e3:.2f} ms, kernels {ms:.2f} ms / {n} launches = {ms/n:.3f} ms per launch, "
+print(f"kernel={a.loop_kernel} B={a.batch} steps={a.steps}: wall {dt*1e3:.2f} ms, kernels {ms:.2f} ms / {n} launches = {ms/n:.3f} ms per launch, "
       f"{a.batch*a.steps/dt:.0f} steps/s, iters mean {it[st!=2].mean():.2f} max {it.max()}, infeasible {np.mean(st==2):.3f}")
 s.close()

@@ -14,11 +14,13 @@ x0 = np.random.default_rng(20250614).uniform([-0.5, -8, -5], [0.5, 8, 5], size=(
 s.loop_alloc(B, K, capi.LOG_U); s.loop_set_schedule(p.schedules(K)); s.loop_set_state(x0, x0)
 buf = np.zeros(64 * 8, np.uint64)
 s.lib.mpc_debug_stamps(None, 0, 1)
-names = ["init", "B1", "F1", "B2", "F2"]
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+s.set_option("loop_kernel", MODE)
+names = ["init", "B1", "F1", "B2", "F2"] if MODE == 1 else ["est+target", "init", "A", "B+C", "D+E", "F+G", "H", "post"]
 for k in range(K):
     s.loop_run(k, 1); s.loop_sync()
     s.lib.mpc_debug_stamps(buf.ctypes.data_as(ct.c_void_p), 64 * 8, 1)
-    c = buf.reshape(64, 8)[:, :5].astype(float)
+    c = buf.reshape(64, 8)[:, :len(names)].astype(float)
     it = s.loop_get_log("ITERS_DYN")[k]
     ms, _ = s.last_kernel_ms()
     w = np.argmax(c.sum(axis=1))
