@@ -32,6 +32,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+KERNEL_NAMES = {1: "loop_kernel (one instance per lane)", 2: "loop_kernel_tp (horizon-parallel)"}
 B_PER_GPU = 4096
 SEED = 20250614
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -88,7 +89,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="instances per GPU (default: BASELINE configs[1])")
-    ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="closed-loop steps per kernel launch (0: library default)")
+    ap.add_argument("--loop-kernel", type=int, default=0, help="0: library default (by batch size), 1: instance per lane, 2: horizon-parallel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
@@ -118,7 +120,9 @@ def main():
     if use_dist:
         dist.barrier()
     solver = capi.Solver(prob, device=local_rank)
-    solver.set_option("steps_per_launch", args.steps_per_launch)
+    if args.steps_per_launch > 0:
+        solver.set_option("steps_per_launch", args.steps_per_launch)
+    solver.set_option("loop_kernel", args.loop_kernel)
 
     # synthetic initial states: the same generator for the whole job, each rank takes its block
     rng = np.random.default_rng(SEED)
@@ -163,6 +167,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kernel_ms, n_launch = solver.last_kernel_ms()
+    loop_kernel = int(solver.get_option("loop_kernel"))
 
     if rank == 0:
         st = solver.loop_get_log("STATUS_DYN")[:K]
@@ -179,13 +184,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Ex_LMPC_CSTR (nx=3,nu=2,ny=3,nd=3), N=50, batch=%d per GPU, x0~U([-0.5,0.5]x[-8,8]x[-5,5]) seed %d, "
                                    "closed loop from t=0: Kalman filter + target QP + OCP (Riccati-PDIP) + plant per step" % (B, SEED),
-                       "batch_per_gpu": B, "horizon": prob.N, "steps_per_launch": args.steps_per_launch,
+                       "batch_per_gpu": B, "horizon": prob.N, "steps_per_launch": K / max(n_launch, 1), "loop_kernel": KERNEL_NAMES[loop_kernel],
                        "parallelism": "instances sharded over %d GPU(s), all-gather of U at the end" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (measured_traffic() if (B == B_PER_GPU and K == 100) else None),
                          "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_loop.py --batch 4096 --steps 100; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB)",
-                         "kernel": "loop_kernel<3,2,3,3,3,false,5,false>", "launches": n_launch,
+                         "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
                          "note": "latency / fp64-issue bound at this batch (64 waves on 1024 SIMDs), not HBM bound (SURVEY.md 8d); the measured traffic is the solver workspace streaming through L2 / Infinity Cache"},
             "solver": {"mean_iters": float(it[st != 2].mean()) if (st != 2).any() else None, "max_iters": int(it.max()),

@@ -149,8 +149,13 @@ int mpc_pack_u(mpc_handle *h, void *dst_dev /* [B][nu] float64 */);
  * (asynchronous on the handle's stream) - the send buffer of the end-of-run all-gather of U */
 int mpc_pack_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, void *dst_dev);
 
-/* Tunables (0 / negative = keep default): instances per workgroup and steps fused into one launch. */
+/* Tunables of the resident closed loop (mpc_loop_run); they never change results beyond rounding.
+ *   "steps_per_launch"  closed-loop steps per kernel launch (default 16; a launch starts with cold caches)
+ *   "loop_kernel"       0 = choose by batch size (default), 1 = one instance per lane, 2 = horizon-parallel
+ *                       (one wave per instance and block-parallel element-wise work; needs N <= 64)            */
 int mpc_set_option(mpc_handle *h, const char *name, double value);
+/* Current value; for "loop_kernel" the kernel mpc_loop_run will use for the allocated batch (1 or 2). */
+int mpc_get_option(mpc_handle *h, const char *name, double *value);
 
 /* Library self-description: "gfx950;dims=3/2/3/3/3/0,4/2/2/2/4/1;..." */
 const char *mpc_build_info(void);

@@ -82,6 +82,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     lib.mpc_destroy.argtypes = [ct.c_void_p]
     lib.mpc_lin_create.argtypes = [ct.POINTER(_Desc), ct.POINTER(ct.c_void_p)]
     lib.mpc_set_option.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_double]
+    lib.mpc_get_option.argtypes = [ct.c_void_p, ct.c_char_p, ct.POINTER(ct.c_double)]
     lib.mpc_pack_u.argtypes = [ct.c_void_p, ct.c_void_p]
     lib.mpc_pack_log.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.c_int32, ct.c_void_p]
     lib.mpc_loop_alloc.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_int32]
@@ -103,7 +104,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
 EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update",
            "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_run",
            "mpc_loop_sync", "mpc_loop_get_log", "mpc_closed_loop", "mpc_last_kernel_ms", "mpc_stream", "mpc_dev_ptr",
-           "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_build_info")
+           "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_get_option", "mpc_build_info")
 
 
 def _c(a, shape=None):
@@ -173,6 +174,11 @@ class Solver:
 
     def set_option(self, name: str, value: float):
         self._chk(self.lib.mpc_set_option(self.h, name.encode(), float(value)), "mpc_set_option")
+
+    def get_option(self, name: str) -> float:
+        v = ct.c_double(0.0)
+        self._chk(self.lib.mpc_get_option(self.h, name.encode(), ct.byref(v)), "mpc_get_option")
+        return float(v.value)
 
     def last_kernel_ms(self):
         n = ct.c_int32(0)

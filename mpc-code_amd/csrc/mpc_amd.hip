@@ -153,6 +153,8 @@ struct LoopArgs {
     double *U, *XHAT, *XS, *US, *YS, *XP, *DHAT;     // logs [step][dim][Bs] offset to k0, or nullptr
     int32_t *st_dyn, *st_ss, *it_dyn, *it_ss;        // logs [step][Bs] offset to k0, or nullptr
     int32_t *ws_valid;                               // [Bs] 1 if the workspace holds a solved OCP of the previous step
+    int32_t *kf_valid;                               // [Bs] 1 if Kg / Pn hold the filter gain of this step and the prior after it
+    double *Kg, *Pn;                                 // [ne*ny][Bs], [ne*ne][Bs] (horizon-parallel kernel: computed one step ahead)
     double *ws;
     int B, nsteps; size_t Bs;
 };
@@ -293,13 +295,13 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
     double *wsg = a.ws + (size_t)blockIdx.x * NI * Cfg::ROWS_ST * 64;      // state rows of this workgroup's instances
     MPC_STAMP_INIT
     for (int k = 0; k < a.nsteps; k++) {
+        double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
+        double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU];
         if (valid) {
-            double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
             MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
             MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
             MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
-            double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU];
             MPC_UNROLL for (int i = 0; i < NX; i++) { xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
             MPC_UNROLL for (int i = 0; i < ND; i++) dh_prev[i] = dh[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) us_prev[i] = us[i];
@@ -317,10 +319,16 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                     innov[i] = yy - yh;
                 }
                 if (P.estimator == MPC_EST_KALMAN) {
-                    double Pk[NE][NE];
-                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
-                    kalman_lane<NE, NY>(P, xi, Pk, innov);
-                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+                    double K[NE][NY];
+                    if (a.kf_valid[b] != 0) {      // the gain was computed one step ahead (look-ahead below, which also moves Pn into Pk)
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) K[i][j] = a.Kg[(i * NY + j) * Bs + b]; }
+                    } else {
+                        double Pk[NE][NE];
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
+                        kalman_cov<NE, NY>(P, Pk, K);
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+                    }
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += K[i][l] * innov[l]; xi[i] += s; }      // Estimator.py:303-306
                 } else {
                     MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
                 }
@@ -328,6 +336,27 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                 MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
             }
             if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) a.DHAT[((size_t)k * ND + i) * Bs + b] = dh[i]; }
+            MPC_TSTAMP(7);
+        }
+        // While wave 0 solves the target problems, wave 1 (lane = instance) advances the covariance side of the Kalman
+        // filter by one step: the gain of the next step and the prior after it depend on the model only, not on the data
+        // (Estimator.py:297-309).
+        __syncthreads();
+        if (threadIdx.y == 1 && P.estimator == MPC_EST_KALMAN && lane < NI && blockIdx.x * NI + lane < a.B) {
+            const int bi = blockIdx.x * NI + lane;
+            double Pk[NE][NE], K[NE][NY];
+            if (a.kf_valid[bi] != 0) {       // the prior of the next step is Pn (wave 0 used Kg for this step): it becomes Pk
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pn[(i * NE + j) * Bs + bi]; }
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + bi] = Pk[i][j]; }
+            } else {                         // wave 0 ran the whole filter for this step and left the next prior in Pk
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + bi]; }
+            }
+            kalman_cov<NE, NY>(P, Pk, K);
+            MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) a.Kg[(i * NY + j) * Bs + bi] = K[i][j]; }
+            MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pn[(i * NE + j) * Bs + bi] = Pk[i][j]; }
+            a.kf_valid[bi] = 1;
+        }
+        if (valid) {
             // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
             double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
             MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
@@ -367,10 +396,8 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             MPC_UNROLL for (int i = 0; i < NU; i++) a.us[i * Bs + b] = us[i];
         } else if (wl) sh.iflag[lane] = 0;
         int st_dyn, it_dyn;
-        double res[3];
         MPC_TSTAMP(0);
-        tp_solve<NS, NU, DU, NC, MASKED, NW, IPW>(P, sh, wsg, P.max_iter, st_dyn, it_dyn, res);
-        __syncthreads();
+        tp_solve<NS, NU, DU, NC, MASKED, NW, IPW>(P, sh, wsg, P.max_iter, st_dyn, it_dyn);
         if (valid) {
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
             double x[NXP], xh[NX], u[NU];
@@ -407,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             a.ws_valid[b] = st_dyn == kSolved ? 1 : 0;
         }
         __syncthreads();
-        MPC_TSTAMP(7);
+        MPC_STAMP_RESET
     }
 }
 
@@ -502,14 +529,14 @@ struct mpc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false; int n_launches = 0;
-    int steps_per_launch = 1;
+    int steps_per_launch = 16;  // closed-loop steps per kernel launch (a launch starts with cold scalar / instruction caches)
     int loop_kernel_opt = 0;    // option "loop_kernel": 0 = choose by batch size, 1 = instance per lane, 2 = horizon-parallel
     int ws_mode = -1;           // which loop kernel's layout the workspace holds (-1 = none: next OCPs start cold)
     // per-call scratch (solve API)
     DevBuf scratch, ws;
     // loop state
     int B = 0; size_t Bs = 0; int max_steps = 0, log_level = 0, sched_steps = 0, last_k0 = 0, last_n = 0;
-    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, sch, logs, logi;
+    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
@@ -641,6 +668,13 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
             if (cnt != 1) return fail(-3, "output bound row %d of C has %d non-zero entries: general output rows are not implemented", i, cnt);
         }
     }
+    for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) P.Apow[0][i][j] = P.A[i][j];
+    for (int e = 1; e < 6; e++)
+        for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) {
+            double acc = 0.0;
+            for (int l = 0; l < kMaxN; l++) acc += P.Apow[e - 1][i][l] * P.Apow[e - 1][l][j];
+            P.Apow[e][i][j] = acc;
+        }
     P.has_dsat = (d->dmin && d->dmax) ? 1 : 0;
     for (int i = 0; i < nd; i++) { P.dmin[i] = d->dmin ? d->dmin[i] : -INFINITY; P.dmax[i] = d->dmax ? d->dmax[i] : INFINITY; }
     const int ne = n0 + nd;
@@ -719,7 +753,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->sch, &h->logs, &h->logi}) b->release();
+    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -751,6 +785,16 @@ extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
         h->loop_kernel_opt = v;
         return 0;
     }
+    return fail(-1, "unknown option '%s'", name);
+}
+
+static int loop_mode(const mpc_handle *h);
+
+extern "C" int mpc_get_option(mpc_handle *h, const char *name, double *value)
+{
+    if (!h || !name || !value) return fail(-1, "null argument");
+    if (!std::strcmp(name, "steps_per_launch")) { *value = h->steps_per_launch; return 0; }
+    if (!std::strcmp(name, "loop_kernel")) { *value = loop_mode(h); return 0; }
     return fail(-1, "unknown option '%s'", name);
 }
 
@@ -933,9 +977,10 @@ extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32
     const int ne = P.nx + P.nd;
     if (h->st_x.ensure((size_t)P.nxp * Bs * 8) || h->st_xhat.ensure((size_t)P.nx * Bs * 8) || h->st_dhat.ensure((size_t)(P.nd ? P.nd : 1) * Bs * 8) ||
         h->st_P.ensure((size_t)ne * ne * Bs * 8) || h->st_u.ensure((size_t)P.nu * Bs * 8) || h->st_xs.ensure((size_t)P.nx * Bs * 8) ||
-        h->st_us.ensure((size_t)P.nu * Bs * 8) || h->st_flag.ensure(Bs * 4))
+        h->st_us.ensure((size_t)P.nu * Bs * 8) || h->st_flag.ensure(2 * Bs * 4) ||
+        h->st_Kg.ensure((size_t)ne * P.ny * Bs * 8) || h->st_Pn.ensure((size_t)ne * ne * Bs * 8))
         return -10;
-    HIP_TRY(hipMemset(h->st_flag.p, 0, Bs * 4));
+    HIP_TRY(hipMemset(h->st_flag.p, 0, 2 * Bs * 4));      // [0,Bs): OCP warm start valid, [Bs,2Bs): filter look-ahead valid
     if (ensure_ws(h, Bs)) return -10;
     const int sdim = P.ny + P.nu + P.nxp + P.ny;   // ysp usp pxp pyp
     if (h->sch.ensure((size_t)max_steps * sdim * 8)) return -10;
@@ -990,7 +1035,7 @@ extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double
     rc |= up_state(h, h->st_P, Pk, ne * ne); rc |= up_state(h, h->st_u, u, P.nu); rc |= up_state(h, h->st_xs, xs, P.nx);
     rc |= up_state(h, h->st_us, us, P.nu);
     // a new state invalidates the warm start: the next OCP of every instance starts cold
-    HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, h->Bs * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 2 * h->Bs * 4, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return rc ? -10 : 0;
 }
@@ -1049,7 +1094,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
     const double *sch = (const double *)h->sch.p;
     const int mode = loop_mode(h);
     if (mode != h->ws_mode) {      // the workspace holds another layout (or a per-call solve used it): next OCPs start cold
-        HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, Bs * 4, h->stream));
+        HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 2 * Bs * 4, h->stream));
         h->ws_mode = mode;
     }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -1071,7 +1116,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
             int32_t *li = (int32_t *)h->logi.p;
             a.st_dyn = li + (size_t)k * Bs; a.st_ss = li + ms * Bs + (size_t)k * Bs; a.it_dyn = li + 2 * ms * Bs + (size_t)k * Bs; a.it_ss = li + 3 * ms * Bs + (size_t)k * Bs;
         } else a.st_dyn = a.st_ss = a.it_dyn = a.it_ss = nullptr;
-        a.ws_valid = (int32_t *)h->st_flag.p;
+        a.ws_valid = (int32_t *)h->st_flag.p; a.kf_valid = a.ws_valid + Bs; a.Kg = (double *)h->st_Kg.p; a.Pn = (double *)h->st_Pn.p;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
         if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);

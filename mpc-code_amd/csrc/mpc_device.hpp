@@ -58,6 +58,8 @@ struct DevProblem {
     double Qss[kMaxY][kMaxY], Rss[kMaxM][kMaxM];
     // estimator
     double Aa[kMaxE][kMaxE], Ca[kMaxY][kMaxE], Qkf[kMaxE][kMaxE], Rkf[kMaxY][kMaxY], Kfix[kMaxE][kMaxY];
+    // A^(2^j), j = 0..5, of the stage form: the adjoint recursion as a parallel scan over the horizon (mpc_tp.hpp)
+    double Apow[6][kMaxN][kMaxN];
 };
 
 #define MPC_UNROLL _Pragma("unroll")
@@ -68,9 +70,11 @@ __device__ unsigned long long mpc_stamp_buf[4096 * 8];
 #define MPC_STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
     if (threadIdx.x == 0) mpc_stamp_buf[blockIdx.x * 8 + (slot)] += t_ - stamp_prev_; stamp_prev_ = t_; } while (0)
 #define MPC_STAMP_INIT unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime();
+#define MPC_STAMP_RESET stamp_prev_ = __builtin_amdgcn_s_memtime();
 #else
 #define MPC_STAMP(slot) do { } while (0)
 #define MPC_STAMP_INIT
+#define MPC_STAMP_RESET
 #endif
 
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64, one instruction
@@ -749,17 +753,19 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
     MPC_UNROLL for (int r = 0; r < NC; r++) {
         double v = w0[r]; MPC_UNROLL for (int c = 0; c < NR; c++) v += P.W[r][c] * y[c];
         s_lo[r] = fl[r] ? dmax(v - lo[r], kSMin) : 1.0; s_hi[r] = fh[r] ? dmax(hi[r] - v, kSMin) : 1.0;
-        l_lo[r] = fl[r] ? kMu0 / s_lo[r] : 0.0; l_hi[r] = fh[r] ? kMu0 / s_hi[r] : 0.0;
+        l_lo[r] = fl[r] ? kMu0 * frcp(s_lo[r]) : 0.0; l_hi[r] = fh[r] ? kMu0 * frcp(s_hi[r]) : 0.0;
     }
     double gscale = 1.0; int stall = 0, status = kMaxIter;
     MPC_UNROLL for (int c = 0; c < NR; c++) gscale = dmax(gscale, fabs(gr[c]));
     for (int it = 0;; it++) {
-        double mu = 0.0, res_p = 0.0, res_s = 0.0, cres = 0.0, lmax = 0.0, grad[NR], sig[NC], r_lo[NC], r_hi[NC];
+        // reciprocals of the slacks once per iteration (v_rcp_f64 + Newton, mpc::frcp) instead of IEEE divisions
+        double mu = 0.0, res_p = 0.0, res_s = 0.0, cres = 0.0, lmax = 0.0, grad[NR], sig[NC], r_lo[NC], r_hi[NC], is_lo[NC], is_hi[NC];
         MPC_UNROLL for (int r = 0; r < NC; r++) {
             double v = w0[r]; MPC_UNROLL for (int c = 0; c < NR; c++) v += P.W[r][c] * y[c];
             r_lo[r] = fl[r] ? v - s_lo[r] - lo[r] : 0.0; r_hi[r] = fh[r] ? v + s_hi[r] - hi[r] : 0.0;
             mu += s_lo[r] * l_lo[r] + s_hi[r] * l_hi[r];
-            sig[r] = l_lo[r] / s_lo[r] + l_hi[r] / s_hi[r];
+            is_lo[r] = frcp(s_lo[r]); is_hi[r] = frcp(s_hi[r]);
+            sig[r] = l_lo[r] * is_lo[r] + l_hi[r] * is_hi[r];
             res_p = dmax(res_p, dmax(fabs(r_lo[r]), fabs(r_hi[r])));
             cres = dmax(cres, dmax(comp_measure(s_lo[r], l_lo[r]), comp_measure(s_hi[r], l_hi[r])));
             lmax = dmax(lmax, dmax(l_lo[r], l_hi[r]));
@@ -792,26 +798,27 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
             }
             MPC_UNROLL for (int c = 0; c < NR; c++) rhs[c] = grad[c];
             MPC_UNROLL for (int r = 0; r < NC; r++) {
-                const double h = (-rc_hi[r] + l_hi[r] * r_hi[r]) / s_hi[r] + (rc_lo[r] + l_lo[r] * r_lo[r]) / s_lo[r];
+                const double h = (-rc_hi[r] + l_hi[r] * r_hi[r]) * is_hi[r] + (rc_lo[r] + l_lo[r] * r_lo[r]) * is_lo[r];
                 MPC_UNROLL for (int c = 0; c < NR; c++) rhs[c] += h * P.W[r][c];
             }
             MPC_UNROLL for (int i = 0; i < NR; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NR; j++) a += Ht[i][j] * rhs[j]; dy[i] = -a; }
-            double amax = pass == 0 ? 1.0 : 1.0e300, s1 = 0.0;
+            // step to the boundary = 1 / m with m = max_i (-d_i / x_i); predictor capped at 1 (m >= 1), corrector at 1 / tau
+            double m = pass == 0 ? 1.0 : kTau, s1 = 0.0;
             MPC_UNROLL for (int r = 0; r < NC; r++) {
                 double dv = 0.0; MPC_UNROLL for (int c = 0; c < NR; c++) dv += P.W[r][c] * dy[c];
                 ds_hi[r] = fh[r] ? -r_hi[r] - dv : 0.0; ds_lo[r] = fl[r] ? r_lo[r] + dv : 0.0;
-                dl_hi[r] = fh[r] ? (-rc_hi[r] - l_hi[r] * ds_hi[r]) / s_hi[r] : 0.0;
-                dl_lo[r] = fl[r] ? (-rc_lo[r] - l_lo[r] * ds_lo[r]) / s_lo[r] : 0.0;
-                if (ds_lo[r] < 0) amax = dmin(amax, -s_lo[r] / ds_lo[r]);
-                if (ds_hi[r] < 0) amax = dmin(amax, -s_hi[r] / ds_hi[r]);
-                if (dl_lo[r] < 0) amax = dmin(amax, -l_lo[r] / dl_lo[r]);
-                if (dl_hi[r] < 0) amax = dmin(amax, -l_hi[r] / dl_hi[r]);
+                dl_hi[r] = fh[r] ? (-rc_hi[r] - l_hi[r] * ds_hi[r]) * is_hi[r] : 0.0;
+                dl_lo[r] = fl[r] ? (-rc_lo[r] - l_lo[r] * ds_lo[r]) * is_lo[r] : 0.0;
+                m = dmax(m, dmax(-ds_lo[r] * is_lo[r], -ds_hi[r] * is_hi[r]));
+                if (fl[r]) m = dmax(m, -dl_lo[r] * frcp_approx(l_lo[r]));
+                if (fh[r]) m = dmax(m, -dl_hi[r] * frcp_approx(l_hi[r]));
             }
             if (pass == 0) {
+                const double amax = frcp(m);
                 MPC_UNROLL for (int r = 0; r < NC; r++) s1 += (s_lo[r] + amax * ds_lo[r]) * (l_lo[r] + amax * dl_lo[r]) + (s_hi[r] + amax * ds_hi[r]) * (l_hi[r] + amax * dl_hi[r]);
-                const double mu_aff = s1 * inv_ncon, rat = mu > 0.0 ? mu_aff / mu : 0.0;
+                const double mu_aff = s1 * inv_ncon, rat = mu > 0.0 ? mu_aff * frcp(mu) : 0.0;
                 sm = dmax(rat * rat * rat * mu, kMuFloor);
-            } else alpha = dmin(1.0, kTau * amax);
+            } else alpha = m <= kTau ? 1.0 : kTau * frcp(m);
         }
         MPC_UNROLL for (int c = 0; c < NR; c++) y[c] += alpha * dy[c];
         MPC_UNROLL for (int r = 0; r < NC; r++) { s_lo[r] += alpha * ds_lo[r]; s_hi[r] += alpha * ds_hi[r]; l_lo[r] += alpha * dl_lo[r]; l_hi[r] += alpha * dl_hi[r]; }
@@ -827,10 +834,11 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
 // --------------------------------------------------------------------------------------------------------
 // estimator: xi = [xhat; dhat], Pk row-major [NE][NE]; innov = y - yhat
 // --------------------------------------------------------------------------------------------------------
+// gain K for the prior covariance Pk, and the next prior (the part of the filter that does not see the data)
 template <int NE, int NY>
-__device__ void kalman_lane(const DevProblem &P, double (&xi)[NE], double (&Pk)[NE][NE], const double (&innov)[NY])
+__device__ void kalman_cov(const DevProblem &P, double (&Pk)[NE][NE], double (&K)[NE][NY])
 {
-    double PCt[NE][NY], S[NY][NY], K[NE][NY];
+    double PCt[NE][NY], S[NY][NY];
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += Pk[i][l] * P.Ca[j][l]; PCt[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = P.Rkf[i][j]; MPC_UNROLL for (int l = 0; l < NE; l++) a += P.Ca[i][l] * PCt[l][j]; S[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (S[i][j] + S[j][i]); S[i][j] = a; S[j][i] = a; } }
@@ -839,9 +847,16 @@ __device__ void kalman_lane(const DevProblem &P, double (&xi)[NE], double (&Pk)[
     double CP[NY][NE], Pc[NE][NE], T[NE][NE];
     MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += P.Ca[i][l] * Pk[l][j]; CP[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = Pk[i][j]; MPC_UNROLL for (int l = 0; l < NY; l++) a -= K[i][l] * CP[l][j]; Pc[i][j] = a; } }   // :300
-    MPC_UNROLL for (int i = 0; i < NE; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) a += K[i][l] * innov[l]; xi[i] += a; }                                              // :303-306
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += P.Aa[i][l] * Pc[l][j]; T[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = P.Qkf[i][j]; MPC_UNROLL for (int l = 0; l < NE; l++) a += T[i][l] * P.Aa[j][l]; Pk[i][j] = a; } }  // :309
+}
+
+template <int NE, int NY>
+__device__ void kalman_lane(const DevProblem &P, double (&xi)[NE], double (&Pk)[NE][NE], const double (&innov)[NY])
+{
+    double K[NE][NY];
+    kalman_cov<NE, NY>(P, Pk, K);
+    MPC_UNROLL for (int i = 0; i < NE; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) a += K[i][l] * innov[l]; xi[i] += a; }                                              // :303-306
 }
 
 }  // namespace mpc

@@ -44,8 +44,43 @@ struct TpCfg {
     static constexpr size_t lds_bytes() { return sizeof(double) * (T_DOUBLES + NI * QN + NI * 4) + sizeof(int) * (3 * NI + 4); }
 };
 
-__device__ __forceinline__ double wave_sum(double v) { MPC_UNROLL for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64); return v; }
-__device__ __forceinline__ double wave_max(double v) { MPC_UNROLL for (int m = 32; m >= 1; m >>= 1) v = dmax(v, __shfl_xor(v, m, 64)); return v; }
+// Horizon-wide sums and maxima = reductions over the 64 lanes of a wave, on the DPP network (no LDS round trips):
+// butterflies inside each row of 16 lanes (quad swaps, half-row mirror, row mirror), then row_bcast:15 / row_bcast:31
+// fold the four rows into lane 63, which is read back into scalar registers (the result is wave-uniform).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double old, double v)
+{
+    union { double d; int i[2]; } a, o, r; a.d = v; o.d = old;
+    r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], a.i[0], CTRL, ROW_MASK, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], a.i[1], CTRL, ROW_MASK, 0xF, false);
+    return r.d;
+}
+__device__ __forceinline__ double lane63(double v)
+{
+    union { double d; int i[2]; } x; x.d = v;
+    x.i[0] = __builtin_amdgcn_readlane(x.i[0], 63); x.i[1] = __builtin_amdgcn_readlane(x.i[1], 63);
+    return x.d;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_move<0xB1, 0xF>(0.0, v);        // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(0.0, v);        // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xF>(0.0, v);       // row_half_mirror
+    v += dpp_move<0x140, 0xF>(0.0, v);       // row_mirror
+    v += dpp_move<0x142, 0xA>(0.0, v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xC>(0.0, v);       // row_bcast:31 into rows 2 and 3
+    return lane63(v);
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = dmax(v, dpp_move<0xB1, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x4E, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x141, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x140, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x142, 0xA>(v, v));
+    v = dmax(v, dpp_move<0x143, 0xC>(v, v));
+    return lane63(v);
+}
 __device__ __forceinline__ double uni(double v)       // a wave-uniform value into scalar registers
 {
     union { double d; int i[2]; } x; x.d = v;
@@ -58,11 +93,11 @@ template <int NS, int NU, int NC, int NW, int IPW>
 struct TpShared {
     using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
     static constexpr int NI = Cfg::NI;
-    double *T, *q, *red; int *flag, *iflag, *misc;
+    double *T, *q, *red; int *flag, *iflag, *iters, *misc;
     __device__ explicit TpShared(double *base)
     {
         T = base; q = T + Cfg::T_DOUBLES; red = q + NI * Cfg::QN;
-        flag = (int *)(red + NI * 4); iflag = flag + NI; misc = iflag + 2 * NI;
+        flag = (int *)(red + NI * 4); iflag = flag + NI; iters = iflag + NI; misc = iters + NI;
     }
     __device__ __forceinline__ double &t(int row, int inst, int k) const { return T[(row * NI + inst) * Cfg::LD + k]; }
 };
@@ -75,7 +110,7 @@ enum : int { kTpOk0 = 1, kTpWarm = 2, kTpValid = 4 };
 // wsg: state rows of this workgroup's instances [NI][ROWS_ST][64]; they hold the previous solve's iterate on entry.
 template <int NS, int NU, bool HASM, int NC, bool MASKED, int NW, int IPW>
 __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW> &sh, double *__restrict__ wsg,
-                         int max_iter, int &status_o, int &iters_o, double (&res_o)[3])
+                         int max_iter, int &status_o, int &iters_o)
 {
     using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
     constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK, NI = Cfg::NI;
@@ -91,7 +126,8 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     struct Inst {          // what stays in registers between phases
         double lo[NC], hi[NC];
         double qz0[NS], qzr[NS], qur[NU];        // wave-uniform
-        double mu, mu_sum, sm, inv_ncon;         // wave-uniform
+        double mu, mu_sum, sm, inv_ncon, gscale; // wave-uniform
+        int stall;
         bool fl[NC], fh[NC], on, warm;
     };
     struct Iter { double sl[NC], sh[NC], ll[NC], lh[NC], u[NU], z[NS]; };      // the iterate of one block
@@ -137,8 +173,10 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) gu[i] += Mk[j][i] * zp[j]; }
         }
     };
-    // residuals, barrier weights, gradients of the iterate X -> LDS, horizon-wide statistics -> sh.red
-    auto phase_a = [&](Inst &S, const Iter &X, int wi) {
+    // Residuals, barrier weights, gradients of the iterate X -> LDS; then the convergence test of this iterate: the
+    // stationarity residual needs the costates pi_k = gz_k + A' pi_{k+1}, a linear recursion with a constant matrix,
+    // taken here as a parallel scan over the lanes (log2(64) steps with A^(2^j)) instead of a sequential sweep.
+    auto phase_a = [&](Inst &S, const Iter &X, int wi, int it) {
         double mu_p = 0.0, resp_p = 0.0, cres_p = 0.0, lmax_p = 0.0;
         MPC_UNROLL for (int i = 0; i < NC; i++) {
             const double v = i < NU ? X.u[i < NU ? i : 0] : X.z[i >= NU ? i - NU : 0];
@@ -151,14 +189,33 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             cres_p = dmax(cres_p, dmax(comp_measure(X.sl[i], X.ll[i]), comp_measure(X.sh[i], X.lh[i])));
             lmax_p = dmax(lmax_p, dmax(X.ll[i], X.lh[i]));
         }
-        double gu[NU], gz[NS];
+        double gu[NU], gz[NS], pi[NS];
         gradient(S, X, gu, gz);
         MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, k) = gu[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, wi, k) = gz[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { sh.t(RG + NU + i, wi, k) = gz[i]; pi[i] = blk_on ? gz[i] : 0.0; }
+        MPC_UNROLL for (int e = 0; e < 6; e++) {
+            const int d = 1 << e;
+            if (d < N) {
+                double t[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = __shfl_down(pi[i], d, 64); t[i] = (k + d < N) ? v : 0.0; }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Apow[e][j][i] * t[j]; pi[i] = a; }
+            }
+        }
+        double rs_p = 0.0;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.B[j][i] * pi[j]; rs_p = dmax(rs_p, fabs(a)); }
         S.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
         const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
+        const double res_s = wave_max(blk_on ? rs_p : 0.0);
         S.mu = S.mu_sum * S.inv_ncon;
-        if (lane == 0) { sh.red[wi * 4 + 0] = S.mu; sh.red[wi * 4 + 1] = res_p; sh.red[wi * 4 + 2] = cres; sh.red[wi * 4 + 3] = lmax; }
+        if (it == 0) S.gscale = dmax(1.0, res_s);
+        const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
+        S.stall = ok_cp ? S.stall + 1 : 0;
+        int verdict = 0;
+        if (ok_cp && (res_s <= kTolStat * S.gscale || (S.stall > kStallMax && res_s <= kTolStatAcc * S.gscale))) verdict = 1 + kSolved;
+        else if (lmax > kInfeasZ * S.gscale || !(fabs(S.mu) < 1.0e300)) verdict = 1 + kInfeasible;
+        else if (it == max_iter) verdict = 1 + kMaxIter;
+        if (verdict != 0) S.on = false;
+        if (lane == 0) { sh.flag[wi] = verdict; if (verdict != 0) sh.iters[wi] = it; }
     };
 
     // ---- instance constants; initial inputs (cold: us pushed inside the box; warm: previous inputs shifted one stage) -> LDS
@@ -170,7 +227,8 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         const int myflag = sh.iflag[wi];
         S.on = (myflag & kTpValid) && (myflag & kTpOk0);
         S.warm = (myflag & kTpWarm) != 0;
-        S.mu = 0.0; S.mu_sum = 0.0; S.sm = 0.0;
+        S.mu = 0.0; S.mu_sum = 0.0; S.sm = 0.0; S.gscale = 1.0; S.stall = 0;
+        if (!S.on && lane == 0) { sh.flag[wi] = 1 + ((myflag & kTpValid) && !(myflag & kTpOk0) ? kInfeasible : kMaxIter); sh.iters[wi] = 0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) { S.qz0[i] = uni(qd[i]); S.qzr[i] = uni(qd[NS + i]); }
         MPC_UNROLL for (int i = 0; i < NU; i++) S.qur[i] = uni(qd[5 * NS + i]);
         double ncon = 0.0;
@@ -247,7 +305,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 Xj.ll[i] = S.fl[i] ? llo : 0.0; Xj.lh[i] = S.fh[i] ? lhi : 0.0;
             }
             store_iter(wi, Xj);
-            phase_a(S, Xj, wi);
+            phase_a(S, Xj, wi, 0);
         }
     }
 
@@ -267,26 +325,25 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         }
     };
 
-    // worker-lane state of the iteration (lane = instance)
-    int status = kMaxIter, iters = 0, stall = 0;
-    double gscale = 1.0, res[3] = {0.0, 0.0, 0.0};
-    bool wk_on = wl && (sh.iflag[lane < NI ? lane : 0] & kTpValid) && (sh.iflag[lane < NI ? lane : 0] & kTpOk0);
-    if (wl && (sh.iflag[lane] & kTpValid) && !(sh.iflag[lane] & kTpOk0)) status = kInfeasible;
+    const bool wk_valid = wl && (sh.iflag[lane < NI ? lane : 0] & kTpValid) && (sh.iflag[lane < NI ? lane : 0] & kTpOk0);
+    bool pd_all = true;         // worker lane: every Lambda of this instance was positive definite so far
 
     MPC_TSTAMP(1);
     for (int it = 0;; it++) {
-        __syncthreads();
+        bool mine = false;
+        MPC_UNROLL for (int j = 0; j < IPW; j++) mine = mine || I[j].on;
+        if (!__syncthreads_or(mine ? 1 : 0)) break;      // every instance of the workgroup has its verdict
         MPC_TSTAMP(2);
-        // ================= wave 0, lane = instance: Riccati factorisation, adjoint, predictor rhs, direction =============
+        // ================= wave 0, lane = instance: Riccati factorisation, predictor rhs, direction ======================
+        const bool wk_on = wk_valid && sh.flag[lane < NI ? lane : 0] == 0;
         if (worker) {
-            int verdict = 0;
             StageConst<NS, NU> C;
             load_stage_const<NS, NU, HASM>(P, C);
             if (wk_on) {
-                double pi[NS], Pm[NS][NS], pcar[NS], res_s = 0.0;
+                double Pm[NS][NS], pcar[NS];
                 bool pd_ok = true;
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    pi[i] = 0.0; pcar[i] = 0.0;
+                    pcar[i] = 0.0;
                     MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = C.Pf[i][j];
                 }
                 double sg[NC], hh[NC], gun[NU], gzn[NS];
@@ -334,12 +391,6 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                             }
                         }
                     }
-                    {       // adjoint and stationarity residual
-                        double pn[NS];
-                        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = g1[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pi[j]; pn[i] = a; }
-                        MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = pn[i];
-                        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = g2[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pi[j]; res_s = dmax(res_s, fabs(a)); }
-                    }
                     double pv[NS], qu[NU], psi[NU], kff[NU];
                     MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = g1[i] + haff[NU + i] + pcar[i];
                     MPC_UNROLL for (int i = 0; i < NU; i++) qu[i] = g2[i] + haff[i];
@@ -357,26 +408,20 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                         MPC_UNROLL for (int i = 0; i < NS; i++) pcar[i] = pn[i];
                     }
                 }
-                const double mu_i = sh.red[lane * 4 + 0], res_p = sh.red[lane * 4 + 1], cres = sh.red[lane * 4 + 2], lmax = sh.red[lane * 4 + 3];
-                if (it == 0) gscale = dmax(1.0, res_s);
-                res[0] = res_s; res[1] = res_p; res[2] = mu_i;
-                iters = it;
-                const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
-                stall = ok_cp ? stall + 1 : 0;
-                if (ok_cp && (res_s <= kTolStat * gscale || (stall > kStallMax && res_s <= kTolStatAcc * gscale))) verdict = 1 + kSolved;
-                else if (lmax > kInfeasZ * gscale || !(fabs(mu_i) < 1.0e300) || !pd_ok) verdict = 1 + kInfeasible;
-                else if (it == max_iter) verdict = 1 + kMaxIter;
-                if (verdict != 0) { status = verdict - 1; wk_on = false; }
-                else direction(C);
+                pd_all = pd_all && pd_ok;
+                direction(C);
             }
-            if (wl) sh.flag[lane] = verdict;
-            const unsigned long long any = __ballot(wk_on);
-            if (lane == 0) sh.misc[0] = any != 0ull ? 1 : 0;
+            if (wl && wk_on && !pd_all) sh.flag[lane] = -1;      // a Lambda lost definiteness: the instance stops as infeasible
         }
         __syncthreads();
         MPC_TSTAMP(3);
-        MPC_UNROLL for (int j = 0; j < IPW; j++) { if (I[j].on && sh.flag[w * IPW + j] != 0) I[j].on = false; }      // finished: the state rows hold the result
-        if (sh.misc[0] == 0) break;      // uniform over the workgroup
+        MPC_UNROLL for (int j = 0; j < IPW; j++) {
+            const int wi = w * IPW + j;
+            if (I[j].on && sh.flag[wi] < 0) {       // the factorisation failed
+                I[j].on = false;
+                if (lane == 0) { sh.flag[wi] = 1 + kInfeasible; sh.iters[wi] = it; }
+            }
+        }
         // ================= element-wise: predictor step length, centring, corrector rhs -> LDS ===========================
         {
             MPC_UNROLL for (int j = 0; j < IPW; j++) {
@@ -491,14 +536,16 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] += alpha * dvzj[i];
                     MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] += alpha * dvzj[NU + i];
                     store_iter(wi, Xj);
-                    phase_a(S, Xj, wi);
+                    phase_a(S, Xj, wi, it + 1);
                 }
             }
         }
         MPC_TSTAMP(6);
     }
-    status_o = status; iters_o = iters;
-    res_o[0] = res[0]; res_o[1] = res[1]; res_o[2] = res[2];
+    // wave 0, lane i: the verdict of instance i
+    __syncthreads();
+    status_o = wl ? sh.flag[lane] - 1 : kMaxIter;
+    iters_o = wl ? sh.iters[lane] : 0;
 }
 
 }  // namespace mpc

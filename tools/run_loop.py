@@ -19,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--example", default="cstr_lmpc.py")
-ap.add_argument("--steps-per-launch", type=int, default=1)
+ap.add_argument("--steps-per-launch", type=int, default=0)
 ap.add_argument("--loop-kernel", type=int, default=0, help="0 auto, 1 instance per lane, 2 horizon-parallel")
 a = ap.parse_args()
 p = m.load_problem(m.example_path(a.example))
@@ -29,7 +29,8 @@ if p.nx == 3:
 else:
     x0 = 0.05 * rng.standard_normal((a.batch, p.nx))
 s = capi.Solver(p)
-s.set_option("steps_per_launch", a.steps_per_launch)
+if a.steps_per_launch > 0:
+    s.set_option("steps_per_launch", a.steps_per_launch)
 s.set_option("loop_kernel", a.loop_kernel)
 s.loop_alloc(a.batch, a.steps, capi.LOG_U)
 s.loop_set_schedule(p.schedules(a.steps))
