@@ -155,6 +155,7 @@ struct LoopArgs {
     int32_t *ws_valid;                               // [Bs] 1 if the workspace holds a solved OCP of the previous step
     int32_t *kf_valid;                               // [Bs] 1 if Kg / Pn hold the filter gain of this step and the prior after it
     double *Kg, *Pn;                                 // [ne*ny][Bs], [ne*ne][Bs] (horizon-parallel kernel: computed one step ahead)
+    double *tw; int32_t *tw_valid;                   // warm start of the target solve: [2*nu + 3*(nx+nu+ny)][Bs], [Bs]
     double *ws;
     int B, nsteps; size_t Bs;
 };
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
         MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
         int it_ss;
-        const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss);
+        const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, a.tw + b, Bs, a.tw_valid + b);
         if (st_ss != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
             MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
             int it_ss;
-            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss);
+            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, a.tw + b, Bs, a.tw_valid + b);
             if (st_ss != kInfeasible) {
                 MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
                 MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
@@ -536,7 +537,7 @@ struct mpc_handle {
     DevBuf scratch, ws;
     // loop state
     int B = 0; size_t Bs = 0; int max_steps = 0, log_level = 0, sched_steps = 0, last_k0 = 0, last_n = 0;
-    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, sch, logs, logi;
+    DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
@@ -753,7 +754,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->sch, &h->logs, &h->logi}) b->release();
+    for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -977,10 +978,11 @@ extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32
     const int ne = P.nx + P.nd;
     if (h->st_x.ensure((size_t)P.nxp * Bs * 8) || h->st_xhat.ensure((size_t)P.nx * Bs * 8) || h->st_dhat.ensure((size_t)(P.nd ? P.nd : 1) * Bs * 8) ||
         h->st_P.ensure((size_t)ne * ne * Bs * 8) || h->st_u.ensure((size_t)P.nu * Bs * 8) || h->st_xs.ensure((size_t)P.nx * Bs * 8) ||
-        h->st_us.ensure((size_t)P.nu * Bs * 8) || h->st_flag.ensure(2 * Bs * 4) ||
-        h->st_Kg.ensure((size_t)ne * P.ny * Bs * 8) || h->st_Pn.ensure((size_t)ne * ne * Bs * 8))
+        h->st_us.ensure((size_t)P.nu * Bs * 8) || h->st_flag.ensure(3 * Bs * 4) ||
+        h->st_Kg.ensure((size_t)ne * P.ny * Bs * 8) || h->st_Pn.ensure((size_t)ne * ne * Bs * 8) ||
+        h->st_tw.ensure((size_t)(2 * P.nu + 3 * (P.nx + P.nu + P.ny)) * Bs * 8))
         return -10;
-    HIP_TRY(hipMemset(h->st_flag.p, 0, 2 * Bs * 4));      // [0,Bs): OCP warm start valid, [Bs,2Bs): filter look-ahead valid
+    HIP_TRY(hipMemset(h->st_flag.p, 0, 3 * Bs * 4));      // [0,Bs): OCP warm start valid, [Bs,2Bs): filter look-ahead valid, [2Bs,3Bs): target warm start valid
     if (ensure_ws(h, Bs)) return -10;
     const int sdim = P.ny + P.nu + P.nxp + P.ny;   // ysp usp pxp pyp
     if (h->sch.ensure((size_t)max_steps * sdim * 8)) return -10;
@@ -1035,7 +1037,7 @@ extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double
     rc |= up_state(h, h->st_P, Pk, ne * ne); rc |= up_state(h, h->st_u, u, P.nu); rc |= up_state(h, h->st_xs, xs, P.nx);
     rc |= up_state(h, h->st_us, us, P.nu);
     // a new state invalidates the warm start: the next OCP of every instance starts cold
-    HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 2 * h->Bs * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * h->Bs * 4, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return rc ? -10 : 0;
 }
@@ -1094,7 +1096,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
     const double *sch = (const double *)h->sch.p;
     const int mode = loop_mode(h);
     if (mode != h->ws_mode) {      // the workspace holds another layout (or a per-call solve used it): next OCPs start cold
-        HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 2 * Bs * 4, h->stream));
+        HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * Bs * 4, h->stream));
         h->ws_mode = mode;
     }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -1117,6 +1119,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
             a.st_dyn = li + (size_t)k * Bs; a.st_ss = li + ms * Bs + (size_t)k * Bs; a.it_dyn = li + 2 * ms * Bs + (size_t)k * Bs; a.it_ss = li + 3 * ms * Bs + (size_t)k * Bs;
         } else a.st_dyn = a.st_ss = a.it_dyn = a.it_ss = nullptr;
         a.ws_valid = (int32_t *)h->st_flag.p; a.kf_valid = a.ws_valid + Bs; a.Kg = (double *)h->st_Kg.p; a.Pn = (double *)h->st_Pn.p;
+        a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
         if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);

@@ -714,9 +714,12 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
 // --------------------------------------------------------------------------------------------------------
 // target problem, reduced to the null space of [A-I, B]; registers only
 // --------------------------------------------------------------------------------------------------------
+// tw / twv: warm-start data of the closed loop for this instance, element f at tw[f * tws]: y[NR] l_lo[NC] l_hi[NC] gr[NR] w0[NC]
+// of the last successful solve, and its validity flag; nullptr = cold (the per-call entry point).  DESIGN.md section 4.8.
 template <int NX, int NU, int NY, int ND>
 __device__ int target_lane(const DevProblem &P, const double *usp, const double *ysp, const double *dhat,
-                           const double (&us_prev)[NU], double (&xs)[NX], double (&us)[NU], double (&ys)[NY], int &iters)
+                           const double (&us_prev)[NU], double (&xs)[NX], double (&us)[NU], double (&ys)[NY], int &iters,
+                           double *tw = nullptr, size_t tws = 0, int32_t *twv = nullptr)
 {
     constexpr int NV = NX + NU, NC = NV + NY, NR = NU;
     double cx[NX], e[NY], vp[NV], yp[NY], gr[NR], w0[NC], y[NR];
@@ -754,6 +757,20 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
         double v = w0[r]; MPC_UNROLL for (int c = 0; c < NR; c++) v += P.W[r][c] * y[c];
         s_lo[r] = fl[r] ? dmax(v - lo[r], kSMin) : 1.0; s_hi[r] = fh[r] ? dmax(hi[r] - v, kSMin) : 1.0;
         l_lo[r] = fl[r] ? kMu0 * frcp(s_lo[r]) : 0.0; l_hi[r] = fh[r] ? kMu0 * frcp(s_hi[r]) : 0.0;
+    }
+    if (tw != nullptr && *twv != 0) {
+        double delta = 0.0;
+        MPC_UNROLL for (int c = 0; c < NR; c++) delta = dmax(delta, fabs(gr[c] - tw[(NR + 2 * NC + c) * tws]));
+        MPC_UNROLL for (int r = 0; r < NC; r++) delta = dmax(delta, fabs(w0[r] - tw[(2 * NR + 2 * NC + r) * tws]));
+        if (delta <= kWsDelta) {
+            const double smin = dmin(dmax(kWsKappa * delta, kWsSMinLo), kWsSMinHi), wmu = kWsMuFactor * smin * smin;
+            MPC_UNROLL for (int c = 0; c < NR; c++) y[c] = tw[c * tws];
+            MPC_UNROLL for (int r = 0; r < NC; r++) {
+                double v = w0[r]; MPC_UNROLL for (int c = 0; c < NR; c++) v += P.W[r][c] * y[c];
+                s_lo[r] = fl[r] ? dmax(v - lo[r], smin) : 1.0; s_hi[r] = fh[r] ? dmax(hi[r] - v, smin) : 1.0;
+                l_lo[r] = fl[r] ? dmax(tw[(NR + r) * tws], wmu * frcp(s_lo[r])) : 0.0; l_hi[r] = fh[r] ? dmax(tw[(NR + NC + r) * tws], wmu * frcp(s_hi[r])) : 0.0;
+            }
+        }
     }
     double gscale = 1.0; int stall = 0, status = kMaxIter;
     MPC_UNROLL for (int c = 0; c < NR; c++) gscale = dmax(gscale, fabs(gr[c]));
@@ -828,6 +845,11 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
         if (r < NX) xs[r < NX ? r : 0] = a; else us[r >= NX ? r - NX : 0] = a;
     }
     MPC_UNROLL for (int i = 0; i < NY; i++) { double a = e[i]; MPC_UNROLL for (int j = 0; j < NX; j++) a += P.Cm[i][j] * xs[j]; ys[i] = a; }
+    if (tw != nullptr) {
+        *twv = status == kSolved ? 1 : 0;
+        MPC_UNROLL for (int c = 0; c < NR; c++) { tw[c * tws] = y[c]; tw[(NR + 2 * NC + c) * tws] = gr[c]; }
+        MPC_UNROLL for (int r = 0; r < NC; r++) { tw[(NR + r) * tws] = l_lo[r]; tw[(NR + NC + r) * tws] = l_hi[r]; tw[(2 * NR + 2 * NC + r) * tws] = w0[r]; }
+    }
     return status;
 }
 

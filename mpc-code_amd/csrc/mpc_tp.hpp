@@ -123,20 +123,32 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     // ---- element-wise role: instances w*IPW + j, block k = lane -----------------------------------------------------
     const int k = lane;
     const bool blk_on = k < N, last = k == N - 1;
-    struct Inst {          // what stays in registers between phases
-        double lo[NC], hi[NC];
-        double qz0[NS], qzr[NS], qur[NU];        // wave-uniform
-        double mu, mu_sum, sm, inv_ncon, gscale; // wave-uniform
+    struct Inst {          // what stays in registers between phases: wave-uniform data only
+        double qz0[NS], qzr[NS], qur[NU];
+        double mu, mu_sum, sm, inv_ncon, gscale;
         int stall;
-        bool fl[NC], fh[NC], on, warm;
+        bool on, warm;
     };
-    struct Iter { double sl[NC], sh[NC], ll[NC], lh[NC], u[NU], z[NS]; };      // the iterate of one block
+    struct Iter { double sl[NC], sh[NC], ll[NC], lh[NC], u[NU], z[NS], lo[NC], hi[NC]; bool fl[NC], fh[NC]; };      // one block: iterate, bounds
+    // bounds of this lane's block (the last block has the terminal ones), rebuilt per phase from the instance data in LDS
+    auto bounds = [&](int wi, Iter &X) {
+        const double *qd = sh.q + wi * Cfg::QN;
+        MPC_UNROLL for (int i = 0; i < NC; i++) {
+            const double zlm = i >= NU ? qd[3 * NS + (i >= NU ? i - NU : 0)] : 0.0, zhm = i >= NU ? qd[4 * NS + (i >= NU ? i - NU : 0)] : 0.0;
+            const double lm = i < NU ? P.ulo[i < NU ? i : 0] : zlm, hm = i < NU ? P.uhi[i < NU ? i : 0] : zhm;
+            const double le = i < NU ? P.ulo[i < NU ? i : 0] : P.zlo_e[i >= NU ? i - NU : 0], he = i < NU ? P.uhi[i < NU ? i : 0] : P.zhi_e[i >= NU ? i - NU : 0];
+            const double lo = last ? le : lm, hi = last ? he : hm;
+            X.fl[i] = MASKED ? fin(lo) : true; X.fh[i] = MASKED ? fin(hi) : true;
+            X.lo[i] = X.fl[i] ? lo : 0.0; X.hi[i] = X.fh[i] ? hi : 0.0;
+        }
+    };
     Inst I[IPW];
     auto row = [&](int wi, int r) -> double * { return wsg + ((size_t)wi * Cfg::ROWS_ST + r) * 64 + k; };
     auto load_iter = [&](int wi, Iter &X) {
         MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = *row(wi, Cfg::ST_SL + i); X.sh[i] = *row(wi, Cfg::ST_SH + i); X.ll[i] = *row(wi, Cfg::ST_LL + i); X.lh[i] = *row(wi, Cfg::ST_LH + i); }
         MPC_UNROLL for (int i = 0; i < NU; i++) X.u[i] = *row(wi, Cfg::ST_U + i);
         MPC_UNROLL for (int i = 0; i < NS; i++) X.z[i] = *row(wi, Cfg::ST_Z + i);
+        bounds(wi, X);
     };
     auto store_iter = [&](int wi, const Iter &X) {
         MPC_UNROLL for (int i = 0; i < NC; i++) { *row(wi, Cfg::ST_SL + i) = X.sl[i]; *row(wi, Cfg::ST_SH + i) = X.sh[i]; *row(wi, Cfg::ST_LL + i) = X.ll[i]; *row(wi, Cfg::ST_LH + i) = X.lh[i]; }
@@ -180,7 +192,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         double mu_p = 0.0, resp_p = 0.0, cres_p = 0.0, lmax_p = 0.0;
         MPC_UNROLL for (int i = 0; i < NC; i++) {
             const double v = i < NU ? X.u[i < NU ? i : 0] : X.z[i >= NU ? i - NU : 0];
-            const double rh = S.fh[i] ? v + X.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - X.sl[i] - S.lo[i] : 0.0;
+            const double rh = X.fh[i] ? v + X.sh[i] - X.hi[i] : 0.0, rl = X.fl[i] ? v - X.sl[i] - X.lo[i] : 0.0;
             const double isl = frcp(X.sl[i]), ish = frcp(X.sh[i]);
             mu_p += X.sl[i] * X.ll[i] + X.sh[i] * X.lh[i];
             sh.t(RA + i, wi, k) = X.ll[i] * isl + X.lh[i] * ish;
@@ -237,8 +249,6 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             const double lm = i < NU ? P.ulo[i < NU ? i : 0] : zlm, hm = i < NU ? P.uhi[i < NU ? i : 0] : zhm;
             const double le = i < NU ? P.ulo[i < NU ? i : 0] : P.zlo_e[i >= NU ? i - NU : 0], he = i < NU ? P.uhi[i < NU ? i : 0] : P.zhi_e[i >= NU ? i - NU : 0];
             const bool flm = MASKED ? fin(lm) : true, fhm = MASKED ? fin(hm) : true, fle = MASKED ? fin(le) : true, fhe = MASKED ? fin(he) : true;
-            S.fl[i] = last ? fle : flm; S.fh[i] = last ? fhe : fhm;
-            S.lo[i] = last ? (fle ? le : 0.0) : (flm ? lm : 0.0); S.hi[i] = last ? (fhe ? he : 0.0) : (fhm ? hm : 0.0);
             ncon += (double)(N - 1) * ((flm ? 1 : 0) + (fhm ? 1 : 0)) + (fle ? 1 : 0) + (fhe ? 1 : 0);
         }
         S.inv_ncon = 1.0 / dmax(ncon, 1.0);
@@ -294,15 +304,16 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             Iter Xj;
             MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] = u0v[j][i];
             MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = sh.t(RG + NU + i, wi, k);
+            bounds(wi, Xj);
             const double ws_delta = uni(sh.q[wi * Cfg::QN + 5 * NS + 2 * NU]);
             const double ws_smin = dmin(dmax(kWsKappa * ws_delta, kWsSMinLo), kWsSMinHi), ws_mu = kWsMuFactor * ws_smin * ws_smin;
             const double smin = S.warm ? ws_smin : kSMin;
             MPC_UNROLL for (int i = 0; i < NC; i++) {
                 const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
-                Xj.sl[i] = S.fl[i] ? dmax(v - S.lo[i], smin) : 1.0; Xj.sh[i] = S.fh[i] ? dmax(S.hi[i] - v, smin) : 1.0;
+                Xj.sl[i] = Xj.fl[i] ? dmax(v - Xj.lo[i], smin) : 1.0; Xj.sh[i] = Xj.fh[i] ? dmax(Xj.hi[i] - v, smin) : 1.0;
                 const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
                 const double llo = S.warm ? dmax(ll0[j][i], ws_mu * isl) : kMu0 * isl, lhi = S.warm ? dmax(lh0[j][i], ws_mu * ish) : kMu0 * ish;
-                Xj.ll[i] = S.fl[i] ? llo : 0.0; Xj.lh[i] = S.fh[i] ? lhi : 0.0;
+                Xj.ll[i] = Xj.fl[i] ? llo : 0.0; Xj.lh[i] = Xj.fh[i] ? lhi : 0.0;
             }
             store_iter(wi, Xj);
             phase_a(S, Xj, wi, 0);
@@ -435,13 +446,13 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     MPC_UNROLL for (int i = 0; i < NC; i++) {
                         const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
                         const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
-                        const double rh = S.fh[i] ? v + Xj.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - Xj.sl[i] - S.lo[i] : 0.0;
-                        const double dsh = S.fh[i] ? -rh - dv[i] : 0.0, dsl = S.fl[i] ? rl + dv[i] : 0.0;
+                        const double rh = Xj.fh[i] ? v + Xj.sh[i] - Xj.hi[i] : 0.0, rl = Xj.fl[i] ? v - Xj.sl[i] - Xj.lo[i] : 0.0;
+                        const double dsh = Xj.fh[i] ? -rh - dv[i] : 0.0, dsl = Xj.fl[i] ? rl + dv[i] : 0.0;
                         const double qh = dsh * ish, ql = dsl * isl;
-                        const double dlh = S.fh[i] ? -Xj.lh[i] - Xj.lh[i] * qh : 0.0, dll = S.fl[i] ? -Xj.ll[i] - Xj.ll[i] * ql : 0.0;
+                        const double dlh = Xj.fh[i] ? -Xj.lh[i] - Xj.lh[i] * qh : 0.0, dll = Xj.fl[i] ? -Xj.ll[i] - Xj.ll[i] * ql : 0.0;
                         maff_p = dmax(maff_p, dmax(-ql, -qh));
-                        if (S.fl[i]) maff_p = dmax(maff_p, 1.0 + ql);
-                        if (S.fh[i]) maff_p = dmax(maff_p, 1.0 + qh);
+                        if (Xj.fl[i]) maff_p = dmax(maff_p, 1.0 + ql);
+                        if (Xj.fh[i]) maff_p = dmax(maff_p, 1.0 + qh);
                         s1_p += Xj.sl[i] * dll + Xj.ll[i] * dsl + Xj.sh[i] * dlh + Xj.lh[i] * dsh;
                         s2_p += dsl * dll + dsh * dlh;
                         pl[i] = dsl * dll; ph[i] = dsh * dlh;
@@ -457,9 +468,9 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     MPC_UNROLL for (int i = 0; i < NC; i++) {
                         const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
                         const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
-                        const double rh = S.fh[i] ? v + Xj.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - Xj.sl[i] - S.lo[i] : 0.0;
-                        const double rch = S.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(S.sm, Xj.lh[i] * kSFloor) + ph[i] : 0.0;
-                        const double rcl = S.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + pl[i] : 0.0;
+                        const double rh = Xj.fh[i] ? v + Xj.sh[i] - Xj.hi[i] : 0.0, rl = Xj.fl[i] ? v - Xj.sl[i] - Xj.lo[i] : 0.0;
+                        const double rch = Xj.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(S.sm, Xj.lh[i] * kSFloor) + ph[i] : 0.0;
+                        const double rcl = Xj.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + pl[i] : 0.0;
                         hc[i] = (-rch + Xj.lh[i] * rh) * ish + (rcl + Xj.ll[i] * rl) * isl;
                     }
                     MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, k) = gu[i] + hc[i];
@@ -518,17 +529,17 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     MPC_UNROLL for (int i = 0; i < NC; i++) {
                         const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
                         const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
-                        const double rh = S.fh[i] ? v + Xj.sh[i] - S.hi[i] : 0.0, rl = S.fl[i] ? v - Xj.sl[i] - S.lo[i] : 0.0;
+                        const double rh = Xj.fh[i] ? v + Xj.sh[i] - Xj.hi[i] : 0.0, rl = Xj.fl[i] ? v - Xj.sl[i] - Xj.lo[i] : 0.0;
                         // second-order products of the predictor direction (recomputed, not stored)
-                        const double ash = S.fh[i] ? -rh - dvaj[i] : 0.0, asl = S.fl[i] ? rl + dvaj[i] : 0.0;
-                        const double alh = S.fh[i] ? -Xj.lh[i] - Xj.lh[i] * (ash * ish) : 0.0, all_ = S.fl[i] ? -Xj.ll[i] - Xj.ll[i] * (asl * isl) : 0.0;
-                        const double rch = S.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(S.sm, Xj.lh[i] * kSFloor) + ash * alh : 0.0;
-                        const double rcl = S.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + asl * all_ : 0.0;
-                        dsh[i] = S.fh[i] ? -rh - dvzj[i] : 0.0; dsl[i] = S.fl[i] ? rl + dvzj[i] : 0.0;
-                        dlh[i] = S.fh[i] ? (-rch - Xj.lh[i] * dsh[i]) * ish : 0.0; dll[i] = S.fl[i] ? (-rcl - Xj.ll[i] * dsl[i]) * isl : 0.0;
+                        const double ash = Xj.fh[i] ? -rh - dvaj[i] : 0.0, asl = Xj.fl[i] ? rl + dvaj[i] : 0.0;
+                        const double alh = Xj.fh[i] ? -Xj.lh[i] - Xj.lh[i] * (ash * ish) : 0.0, all_ = Xj.fl[i] ? -Xj.ll[i] - Xj.ll[i] * (asl * isl) : 0.0;
+                        const double rch = Xj.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(S.sm, Xj.lh[i] * kSFloor) + ash * alh : 0.0;
+                        const double rcl = Xj.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + asl * all_ : 0.0;
+                        dsh[i] = Xj.fh[i] ? -rh - dvzj[i] : 0.0; dsl[i] = Xj.fl[i] ? rl + dvzj[i] : 0.0;
+                        dlh[i] = Xj.fh[i] ? (-rch - Xj.lh[i] * dsh[i]) * ish : 0.0; dll[i] = Xj.fl[i] ? (-rcl - Xj.ll[i] * dsl[i]) * isl : 0.0;
                         mcc_p = dmax(mcc_p, dmax(-dsl[i] * isl, -dsh[i] * ish));
-                        if (S.fl[i]) mcc_p = dmax(mcc_p, -dll[i] * frcp_approx(Xj.ll[i]));
-                        if (S.fh[i]) mcc_p = dmax(mcc_p, -dlh[i] * frcp_approx(Xj.lh[i]));
+                        if (Xj.fl[i]) mcc_p = dmax(mcc_p, -dll[i] * frcp_approx(Xj.ll[i]));
+                        if (Xj.fh[i]) mcc_p = dmax(mcc_p, -dlh[i] * frcp_approx(Xj.lh[i]));
                     }
                     const double m_cc = wave_max(blk_on ? mcc_p : kTau);
                     const double alpha = m_cc <= kTau ? 1.0 : kTau * frcp(m_cc);

@@ -542,8 +542,10 @@ static int build_target(const orc_problem *p, target_t *t)
     return 0;
 }
 
+/* tw / twv: warm-start data of the closed loop (riccati_np.target_solve `warm`): y[nr] l_lo[nc] l_hi[nc] gr[nr] w0[nc]
+ * of the last successful solve and its validity; NULL = cold (the per-call entry point). */
 static int target_one(const orc_problem *p, const target_t *t, const double *usp, const double *ysp, const double *dhat,
-                      const double *us_prev, double *xs, double *us, double *ys, int *iters_out)
+                      const double *us_prev, double *xs, double *us, double *ys, int *iters_out, double *tw, int *twv)
 {
     const int n = t->n, m = t->m, q = t->q, nr = t->nr, nc = t->nc, nv = n + m, nd = p->nd;
     double cx[MAXN], e[MAXY], vp[MAXV], yp[MAXY], gr[MAXM], w0[MAXC], y[MAXM];
@@ -573,6 +575,21 @@ static int target_one(const orc_problem *p, const target_t *t, const double *usp
         double v = w0[r]; for (int c = 0; c < nr; c++) v += t->W[r][c] * y[c];
         s_lo[r] = fl[r] ? dmax2(v - lo[r], S_MIN) : 1.0; s_hi[r] = fh[r] ? dmax2(hi[r] - v, S_MIN) : 1.0;
         l_lo[r] = fl[r] ? MU0 / s_lo[r] : 0.0; l_hi[r] = fh[r] ? MU0 / s_hi[r] : 0.0;
+    }
+    if (tw && twv && *twv) {
+        const double *ty = tw, *tll = tw + nr, *tlh = tw + nr + nc, *tgr = tw + nr + 2 * nc, *tw0 = tw + 2 * nr + 2 * nc;
+        double delta = 0.0;
+        for (int c = 0; c < nr; c++) delta = dmax2(delta, fabs(gr[c] - tgr[c]));
+        for (int r = 0; r < nc; r++) delta = dmax2(delta, fabs(w0[r] - tw0[r]));
+        if (delta <= WS_DELTA) {
+            const double smin = dmin2(dmax2(WS_KAPPA * delta, WS_SMIN_LO), WS_SMIN_HI), wmu = WS_MU_FACTOR * smin * smin;
+            for (int c = 0; c < nr; c++) y[c] = ty[c];
+            for (int r = 0; r < nc; r++) {
+                double v = w0[r]; for (int c = 0; c < nr; c++) v += t->W[r][c] * y[c];
+                s_lo[r] = fl[r] ? dmax2(v - lo[r], smin) : 1.0; s_hi[r] = fh[r] ? dmax2(hi[r] - v, smin) : 1.0;
+                l_lo[r] = fl[r] ? dmax2(tll[r], wmu / s_lo[r]) : 0.0; l_hi[r] = fh[r] ? dmax2(tlh[r], wmu / s_hi[r]) : 0.0;
+            }
+        }
     }
     double gscale = 1.0; int stall = 0, status = -1;
     for (int c = 0; c < nr; c++) gscale = dmax2(gscale, fabs(gr[c]));
@@ -646,6 +663,11 @@ static int target_one(const orc_problem *p, const target_t *t, const double *usp
     }
     for (int r = 0; r < nv; r++) { double a = vp[r]; for (int c = 0; c < nr; c++) a += t->Z[r][c] * y[c]; if (r < n) xs[r] = a; else us[r - n] = a; }
     for (int i = 0; i < q; i++) { double a = e[i]; for (int j = 0; j < n; j++) a += p->C[i * n + j] * xs[j]; ys[i] = a; }
+    if (tw && twv) {
+        *twv = status == ST_SOLVED;
+        for (int c = 0; c < nr; c++) { tw[c] = y[c]; tw[nr + 2 * nc + c] = gr[c]; }
+        for (int r = 0; r < nc; r++) { tw[nr + r] = l_lo[r]; tw[nr + nc + r] = l_hi[r]; tw[2 * nr + 2 * nc + r] = w0[r]; }
+    }
     return status;
 }
 
@@ -660,7 +682,7 @@ int orc_target_solve(const orc_problem *p, int Bsz, const double *usp, const dou
     for (int b = 0; b < Bsz; b++) {
         int it = 0;
         int st = target_one(p, &t, usp + b * p->nu, ysp + b * p->ny, dhat + b * p->nd, us_prev + b * p->nu,
-                            xs + b * p->nx, us + b * p->nu, ys + b * p->ny, &it);
+                            xs + b * p->nx, us + b * p->nu, ys + b * p->ny, &it, NULL, NULL);
         status[b] = st; if (iters) iters[b] = it;
     }
     return 0;
@@ -755,6 +777,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
         for (int b = 0; b < Bsz; b++) {
             double *xb = x + b * nxp, *xh = xhat + b * n, *dh = dhat + b * nd, *ub = u + b * m, *xsb = xs + b * n, *usb = us + b * m;
             double pred[MAXN] = {0}, d_prev[MAXD] = {0}, xs_prev[MAXN] = {0}, us_prev[MAXM] = {0}; int ws_valid = 0;
+            double tws[2 * MAXM + 3 * MAXC] = {0}; int tw_valid = 0;      /* warm start of the target solve */
             for (int k = 0; k < nsteps; k++) {
                 size_t lb = (size_t)k * Bsz + b;
                 if (XP_log) memcpy(XP_log + lb * nxp, xb, sizeof(double) * nxp);
@@ -778,7 +801,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                 if (DHAT_log) memcpy(DHAT_log + lb * nd, dh, sizeof(double) * nd);
                 /* target (:693-718): keep the previous one when infeasible */
                 double xs_n[MAXN], us_n[MAXM], ys_n[MAXY]; int it_ss = 0;
-                int sss = target_one(p, &tg, usp + k * m, ysp + k * q, dh, usb, xs_n, us_n, ys_n, &it_ss);
+                int sss = target_one(p, &tg, usp + k * m, ysp + k * q, dh, usb, xs_n, us_n, ys_n, &it_ss, warm_start ? tws : NULL, &tw_valid);
                 (void)xsp;
                 if (sss != ST_INFEASIBLE) { memcpy(xsb, xs_n, sizeof(double) * n); memcpy(usb, us_n, sizeof(double) * m); }
                 if (XS_log) memcpy(XS_log + lb * n, xsb, sizeof(double) * n);

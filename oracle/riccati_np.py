@@ -378,8 +378,11 @@ def target_data(p):
     return dict(Ep=Ep, Z=Z, Zx=Zx, Zu=Zu, CZx=CZx, Hr=0.5 * (Hr + Hr.T), W=W, lo=lo, hi=hi, nr=Z.shape[1])
 
 
-def target_solve(p, td, usp, ysp, xsp, dhat, us_prev, max_iter=100):
-    """Batched Mehrotra predictor-corrector on the reduced target QP.  Returns xs, us, ys, status, iters."""
+def target_solve(p, td, usp, ysp, xsp, dhat, us_prev, max_iter=100, warm=None):
+    """Batched Mehrotra predictor-corrector on the reduced target QP.  Returns xs, us, ys, status, iters, and `warm`:
+    the data a later call may start from (closed loop only: y, multipliers and the QP vectors gr, w0 they belong to).
+    A call given `warm` starts an instance from it when that solve succeeded and (gr, w0) moved by at most WS_DELTA,
+    with the same slack / multiplier floors as the OCP warm start."""
     usp, ysp, dhat, us_prev = (np.atleast_2d(np.asarray(a, float)) for a in (usp, ysp, dhat, us_prev))
     Bsz, n, m, q, nr = dhat.shape[0], p.nx, p.nu, p.ny, td["nr"]
     usp = np.broadcast_to(usp, (Bsz, m)); ysp = np.broadcast_to(ysp, (Bsz, q))
@@ -398,6 +401,16 @@ def target_solve(p, td, usp, ysp, xsp, dhat, us_prev, max_iter=100):
     v = w0 + y @ W.T
     s_lo = np.where(fl, np.maximum(v - lo_f, S_MIN), 1.0); s_hi = np.where(fh, np.maximum(hi_f - v, S_MIN), 1.0)
     l_lo = np.where(fl, MU0 / s_lo, 0.0); l_hi = np.where(fh, MU0 / s_hi, 0.0)
+    if warm is not None:
+        delta = np.maximum(np.abs(gr - warm["gr"]).max(axis=1), np.abs(w0 - warm["w0"]).max(axis=1))
+        use = warm["valid"] & (delta <= WS_DELTA)
+        smin = np.clip(WS_KAPPA * delta, WS_SMIN_LO, WS_SMIN_HI)[:, None]; wmu = WS_MU_FACTOR * smin * smin
+        yw = warm["y"]; vw = w0 + yw @ W.T
+        sw_lo = np.where(fl, np.maximum(vw - lo_f, smin), 1.0); sw_hi = np.where(fh, np.maximum(hi_f - vw, smin), 1.0)
+        lw_lo = np.where(fl, np.maximum(warm["l_lo"], wmu / sw_lo), 0.0); lw_hi = np.where(fh, np.maximum(warm["l_hi"], wmu / sw_hi), 0.0)
+        u_ = use[:, None]
+        y = np.where(u_, yw, y); s_lo = np.where(u_, sw_lo, s_lo); s_hi = np.where(u_, sw_hi, s_hi)
+        l_lo = np.where(u_, lw_lo, l_lo); l_hi = np.where(u_, lw_hi, l_hi)
     status = np.full(Bsz, -1, dtype=np.int32); iters = np.zeros(Bsz, dtype=np.int32); active = np.ones(Bsz, dtype=bool)
     gscale = None
     stall = np.zeros(Bsz, dtype=np.int64)
@@ -452,7 +465,8 @@ def target_solve(p, td, usp, ysp, xsp, dhat, us_prev, max_iter=100):
     status[left] = STATUS_MAXITER; iters[left] = max_iter
     vv = vp + y @ td["Z"].T
     xs, us = vv[:, :n], vv[:, n:]
-    return dict(xs=xs, us=us, ys=xs @ p.C.T + e, status=status, iters=iters)
+    return dict(xs=xs, us=us, ys=xs @ p.C.T + e, status=status, iters=iters,
+                warm=dict(y=y, l_lo=l_lo, l_hi=l_hi, gr=gr, w0=w0, valid=status == STATUS_SOLVED))
 
 
 # ==========================================================================================
@@ -497,7 +511,9 @@ def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_star
         if p.dmin is not None:
             dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)
         log["D_HAT"].append(dhat.copy())
-        t = target_solve(p, td, sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_k, max_iter=max_iter)
+        t = target_solve(p, td, sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_k, max_iter=max_iter,
+                         warm=tw if (warm_start and k > 0) else None)
+        tw = t["warm"]
         okt = (t["status"] != STATUS_INFEASIBLE)[:, None]
         xs_k = np.where(okt, t["xs"], xs_k); us_k = np.where(okt, t["us"], us_k)
         log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy())
