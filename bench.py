@@ -41,14 +41,16 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spe
 def alg_bytes_per_step(p) -> int:
     """Algorithmic HBM bytes per closed-loop step per instance.
 
-    State in/out as SURVEY 8d (920 B for the CSTR) plus the warm start this solver carries between steps, in and
-    out: per stage the inputs and the bound multipliers (the reference carries the primal w, MPC_code.py:764)."""
+    State in/out as SURVEY 8d (920 B for the CSTR) plus the warm starts this solver carries between steps, in and
+    out: for the OCP the inputs and the bound multipliers per stage (the reference carries the primal w,
+    MPC_code.py:764), for the target problem its reduced optimum, multipliers and the QP vectors they belong to."""
     ne = p.nx + p.nd
     n_in = p.nxp + p.nx + p.nd + (ne * ne if p.estimator == "kal" else 0) + p.nu + (p.ny + p.nu + p.nx) + (p.nx + p.nu)
     n_out = p.nxp + p.nx + p.nd + (ne * ne if p.estimator == "kal" else 0) + p.nu + p.nx + p.nu + p.ny
     nbounded = p.nu + (p.nx if (np.isfinite(p.xmin).any() or np.isfinite(p.xmax).any() or p.y_bounded) else 0)
-    warm = 2 * p.N * (p.nu + 2 * nbounded)
-    return 8 * (n_in + n_out + warm)
+    warm_ocp = 2 * p.N * (p.nu + 2 * nbounded)
+    warm_target = 2 * (2 * p.nu + 3 * (p.nx + p.nu + p.ny))
+    return 8 * (n_in + n_out + warm_ocp + warm_target)
 
 
 def measured_traffic():
@@ -189,10 +191,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (measured_traffic() if (B == B_PER_GPU and K == 100) else None),
-                         "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_loop.py --batch 4096 --steps 100; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB)",
+                         "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_loop.py --batch 4096 --steps 100; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, per launch)",
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
-                         "note": "latency / fp64-issue bound at this batch (64 waves on 1024 SIMDs), not HBM bound (SURVEY.md 8d); the measured traffic is the solver workspace streaming through L2 / Infinity Cache"},
+                         "note": "bound by the latency of the sequential recursions (Riccati sweep on one wave per 16 instances) and fp64 issue, not by HBM (SURVEY.md 8d)"},
             "solver": {"mean_iters": float(it[st != 2].mean()) if (st != 2).any() else None, "max_iters": int(it.max()),
                        "frac_solved": float((st == 0).mean()), "frac_maxiter": float((st == 1).mean()),
                        "frac_infeasible_hold": float((st == 2).mean())},

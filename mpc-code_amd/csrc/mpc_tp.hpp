@@ -322,12 +322,17 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
 
     // forward recursion of the Newton direction (lane = instance): K, kff -> du | dz
     auto direction = [&](const StageConst<NS, NU> &C) {
-        double dz[NS];
+        double dz[NS], Kn[NKF], kn[NU];
         MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
+        MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, 0);
+        MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lane, 0);
         for (int kk = 0; kk < N; kk++) {
             double Kf[NKF], kff[NU], ddu[NU], dzn[NS];
-            MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = sh.t(RA + i, lane, kk);
-            MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = sh.t(RK + i, lane, kk);
+            MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = Kn[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = kn[i];
+            const int kx = kk + 1 < N ? kk + 1 : kk;      // the next block's gains now, they arrive while this block computes
+            MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, kx);
+            MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lane, kx);
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Kf[i * NS + j] * dz[j]; ddu[i] = a; }
             MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
@@ -361,7 +366,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lane, N - 1); hh[i] = sh.t(RA + NC + i, lane, N - 1); }
                 MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lane, N - 1);
                 MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lane, N - 1);
-                for (int kk = N - 1; kk >= 0; kk--) {
+                _Pragma("unroll 2") for (int kk = N - 1; kk >= 0; kk--) {
                     double sig[NV], haff[NV], g1[NS], g2[NU];
                     MPC_UNROLL for (int i = 0; i < NV; i++) { sig[i] = i < NC ? sg[i < NC ? i : 0] : 0.0; haff[i] = i < NC ? hh[i < NC ? i : 0] : 0.0; }
                     MPC_UNROLL for (int i = 0; i < NS; i++) g1[i] = gzn[i];
@@ -485,17 +490,24 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             StageConst<NS, NU> C;
             load_stage_const<NS, NU, HASM>(P, C);
             if (wk_on) {
-                double pc[NS];
+                double pc[NS], hn[NV], Kn[NKF], ln[NLI];
                 MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
+                MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lane, N - 1);
+                MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, N - 1);
+                MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lane, N - 1);
                 for (int kk = N - 1; kk >= 0; kk--) {
                     double pv[NS], hu[NU], Li[NU][NU], Kf[NKF], psi[NU], kff[NU];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = sh.t(RG + i, lane, kk);
-                    MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = sh.t(RG + NU + i, lane, kk) + pc[i];
-                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = sh.t(RA + i, lane, kk);
+                    MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = hn[i];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = hn[NU + i] + pc[i];
+                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = Kn[i];
                     {
                         int c = 0;
-                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { const double t = sh.t(RA + NKF + c, lane, kk); Li[i][j] = t; Li[j][i] = t; c++; } }
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { Li[i][j] = ln[c]; Li[j][i] = ln[c]; c++; } }
                     }
+                    const int kx = kk > 0 ? kk - 1 : 0;      // the next block's data now, they arrive while this block computes
+                    MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lane, kx);
+                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, kx);
+                    MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lane, kx);
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = hu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
                     MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lane, kk) = kff[i];
