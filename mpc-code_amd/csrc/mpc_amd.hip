@@ -541,7 +541,7 @@ struct mpc_handle {
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
-static constexpr int kTpMaxBatch = 16384;     // auto choice of the loop kernel, see loop_mode()
+static constexpr int kTpMaxBatch = 8192;      // auto choice of the loop kernel, see loop_mode(): measured crossover between 8192 and 16384
 static size_t pad64(size_t b) { return (b + 63) / 64 * 64; }
 
 // host [B][d] -> SoA staging [d][Bs]
