@@ -202,6 +202,33 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
     assert "no kernel compiled" in str(e.value)
     with pytest.raises(capi.MpcAmdError):
         s.loop_run(0, 1)                                       # before mpc_loop_alloc
+    with pytest.raises(capi.MpcAmdError):
+        s.set_option("loop_kernel", 3)
+    with pytest.raises(capi.MpcAmdError):
+        s.set_option("no_such_option", 1)
+
+
+def test_loop_kernel_choice(cstr, solver_factory):
+    """mpc_loop_run picks the horizon-parallel kernel for small batches and the lane kernel for large ones or long horizons;
+    steps_per_launch defaults to 16."""
+    import copy
+    from mpc_code_amd import capi
+    s = solver_factory(cstr)
+    assert s.get_option("steps_per_launch") == 16
+    s.loop_alloc(100, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 2
+    s.loop_alloc(20000, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 1
+    s.set_option("loop_kernel", 2); assert s.get_option("loop_kernel") == 2
+    s.set_option("loop_kernel", 0)
+    q = copy.copy(cstr); q.N = 70                               # N > 64 does not fit a wave: lane kernel, and 2 is refused
+    t = capi.Solver(q)
+    try:
+        t.loop_alloc(100, 2, capi.LOG_NONE); assert t.get_option("loop_kernel") == 1
+        with pytest.raises(capi.MpcAmdError):
+            t.set_option("loop_kernel", 2)
+        x0 = bench_x0(100, 3)
+        t.loop_set_schedule(q.schedules(2)); t.loop_set_state(x0, x0); t.loop_run(0, 2); t.loop_sync()
+    finally:
+        t.close()
 
 
 @pytest.mark.parametrize("lk", LOOP_KERNELS)

@@ -81,3 +81,21 @@ def test_closed_loop_matches_numpy_batch(cstr, oracle_c):
     assert np.array_equal(c["STATUS_DYN"], n["STATUS_DYN"]) and np.array_equal(c["STATUS_SS"], n["STATUS_SS"])
     for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT", "YS"):
         assert np.abs(c[k] - n[k]).max() < 1e-6, k
+
+
+@pytest.mark.parametrize("which", ["cstr", "wb"])
+def test_warm_starts_do_not_move_the_answer(which, cstr, wb, oracle_c):
+    """The closed-loop warm starts (OCP and target problem) change iteration counts, not the trajectory: the warm and the
+    cold loop both converge to the same optima within the solver tolerances; numpy and C agree on the iteration counts."""
+    p = cstr if which == "cstr" else wb
+    x0 = bench_x0(24, 5) if p is cstr else 0.05 * np.random.default_rng(5).standard_normal((24, p.nx))
+    oc = oracle_c.OracleC(p)
+    warm, cold = oc.closed_loop(40, x0, x0, warm_start=True), oc.closed_loop(40, x0, x0, warm_start=False)
+    assert np.array_equal(warm["STATUS_SS"], cold["STATUS_SS"]) and (warm["STATUS_DYN"] == cold["STATUS_DYN"]).mean() > 0.995
+    good = (warm["STATUS_DYN"] == cold["STATUS_DYN"]).all(axis=0)
+    for k in ("U", "XS", "US", "X_HAT"):
+        assert np.abs(warm[k] - cold[k])[:, good].max() < 2e-6, k
+    assert warm["ITERS_SS"][10:].mean() < 0.7 * cold["ITERS_SS"][10:].mean()          # the target warm start pays
+    assert warm["ITERS_DYN"][10:].mean() < 0.7 * cold["ITERS_DYN"][10:].mean()        # so does the OCP's
+    n = rn.closed_loop_batch(p, 40, x0, x0)
+    assert np.array_equal(n["ITERS_SS"], warm["ITERS_SS"])
