@@ -766,7 +766,7 @@ extern "C" const char *mpc_build_info(void)
 {
     static std::string s;
     if (s.empty()) {
-        s = "gfx950;mapping=instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
+        s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=8192),instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
