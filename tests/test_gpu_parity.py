@@ -327,3 +327,27 @@ def test_full_size_closed_loop(lk, cstr, oracle_c, solver_factory):
     assert (g["STATUS_DYN"] != 1).all() and (g["STATUS_SS"] == 0).all()
     # the warm start pays: after the transients the slowest instance needs at most 2 iterations
     assert g["ITERS_DYN"][8:15].max() <= 2
+
+
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
+def test_edge_batches_horizon_64_and_iteration_limit(lk, cstr, oracle_c, solver_factory):
+    """Batch sizes around the workgroup granularity (1, 15, 17 instances), the longest horizon one wave holds (N = 64), and a
+    run that hits the iteration limit (status 1 is accepted like any other, MPC_code.py:786): same closed loop as the C restatement."""
+    import copy
+    from mpc_code_amd.driver import run_closed_loop
+    for B in (1, 15, 17):
+        x0 = bench_x0(B, 40 + B)
+        g = run_closed_loop(cstr, x0, x0, 6, solver=solver_factory(cstr, lk))
+        c = oracle_c.OracleC(cstr).closed_loop(6, x0, x0)
+        assert np.array_equal(g["STATUS_DYN"], c["STATUS_DYN"]) and np.abs(g["U"] - c["U"]).max() < TOL_PORT, B
+    q = copy.copy(cstr); q.N = 64
+    x0 = bench_x0(40, 77)
+    g = run_closed_loop(q, x0, x0, 5, solver=solver_factory(q, lk))
+    c = oracle_c.OracleC(q).closed_loop(5, x0, x0)
+    same = g["STATUS_DYN"] == c["STATUS_DYN"]
+    assert same.mean() > 0.99 and np.abs(g["U"] - c["U"])[:, same.all(axis=0)].max() < TOL_PORT
+    r = copy.copy(cstr); r.max_iter = 4
+    g = run_closed_loop(r, x0, x0, 3, solver=solver_factory(r, lk))
+    c = oracle_c.OracleC(r).closed_loop(3, x0, x0)
+    assert (c["STATUS_DYN"] == 1).any() and np.array_equal(g["STATUS_DYN"], c["STATUS_DYN"])
+    assert np.abs(g["U"] - c["U"]).max() < 1e-6 and g["ITERS_DYN"].max() <= 4
