@@ -47,6 +47,7 @@ extern "C" const char *mpc_last_error(void) { return g_err; }
 #define MPC_DIM_LIST(X) \
     X(3, 2, 3, 3, 3, 0) /* Ex_LMPC_CSTR */ \
     X(4, 2, 2, 2, 4, 1) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */ \
+    X(3, 2, 2, 2, 3, 1) /* Ex_LMPC_nlplant (linear controller, Delta-u cost, non-linear plant on the host) */ \
     X(2, 1, 1, 1, 2, 0) /* double integrator (tests: LQR known answer) */ \
     X(2, 1, 1, 1, 2, 1)
 #endif

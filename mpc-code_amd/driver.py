@@ -36,6 +36,8 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
     s = capi.Solver(p, device=device) if own else solver
     try:
         sched = p.schedules(nsteps)
+        if fused and not p.plant_is_linear:
+            raise ValueError("a non-linear plant (User_fxp_Cont) is simulated on the host: call run_closed_loop(..., fused=False)")
         if fused:
             s.loop_alloc(B, nsteps, capi.LOG_ALL)
             s.loop_set_state(x0_p, x0_m)
@@ -84,5 +86,5 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched):
         log["U"].append(u.copy())
         log["STATUS_DYN"].append(o["status"]); log["STATUS_SS"].append(t["status"])
         log["ITERS_DYN"].append(o["iters"]); log["ITERS_SS"].append(t["iters"])
-        x = x @ p.Ap.T + u @ p.Bp.T + sched["pxp"][k]                                        # :816
+        x = p.plant_step(x, u, k * p.h, sched["pxp"][k])                                     # :813-816
     return {k: np.array(v) for k, v in log.items()}

@@ -15,11 +15,11 @@ while the file executes we install tiny stand-in modules in ``sys.modules``:
 * ``casadi``      - ``SX.sym(name, n[, m])`` objects that know their shape
   (``.size1()`` is all the driver reads: reference ``MPC_code.py:31-35``) plus the
   handful of element-wise names the example bodies mention (``exp``, ``sqrt``,
-  ``vertcat`` ...) so that ``def`` blocks compile; nothing symbolic is evaluated
-  for the linear examples.
+  ``vertcat`` ...), bound to NumPy: nothing symbolic is evaluated, but a user
+  *plant* function (``User_fxp_Cont``) can be called on arrays ``x[nx, B]``
+  (:meth:`LinearMPCProblem.plant_step`).
 * ``casadi.tools``, ``Utilities`` - empty.
-* ``past.utils``  - ``old_div`` (true division, the files use ``from __future__
-  import division``).
+* ``past.utils``  - ``old_div`` (floor division of two integers, true division otherwise).
 
 The stand-ins are removed again afterwards; a real CasADi, if one is installed,
 is never touched.
@@ -88,18 +88,42 @@ class SymVec:
         return f"SymVec({self.name!r}, {self._n}, {self._m})"
 
 
+def _vertcat(*parts):
+    """Numeric ``vertcat``: stacks scalars / arrays along axis 0 (the state index), broadcasting over trailing batch
+    axes, so that a user plant function written for CasADi evaluates on ``x[nx, B]`` arrays; shape objects pass through."""
+    if any(isinstance(a, SymVec) for a in parts):
+        return list(parts)
+    rows = [np.asarray(a, dtype=np.float64) for a in parts]
+    tail = np.broadcast_shapes(*[r.shape[1:] if r.ndim >= 2 else r.shape for r in rows])
+    out = []
+    for r in rows:
+        if r.ndim >= 2:                       # an [n, B] block: its rows are appended one by one
+            out.extend(np.broadcast_to(r, (r.shape[0],) + tail))
+        else:                                 # a scalar, or one component over the batch [B]
+            out.append(np.broadcast_to(r, tail))
+    return np.stack(out, axis=0)
+
+
+def _old_div(a, b):
+    """``past.utils.old_div``: floor division when both operands are integers, true division otherwise."""
+    import numbers
+    if isinstance(a, numbers.Integral) and isinstance(b, numbers.Integral):
+        return a // b
+    return a / b
+
+
 def _make_standins() -> Dict[str, types.ModuleType]:
     cas = types.ModuleType("casadi")
     cas.SX = SymVec
     cas.MX = SymVec
     cas.DM = np.asarray
-    cas.vertcat = lambda *a: list(a)
+    cas.vertcat = _vertcat
     cas.horzcat = lambda *a: list(a)
     cas.mtimes = lambda *a: NotImplemented
     cas.pi = math.pi
     cas.inf = math.inf
-    for fn in ("exp", "log", "sqrt", "sin", "cos", "tan", "fabs", "tanh"):
-        setattr(cas, fn, getattr(math, fn))
+    for fn in ("exp", "log", "sqrt", "sin", "cos", "tan", "fabs", "tanh"):      # NumPy's: scalars and arrays alike
+        setattr(cas, fn, getattr(np, fn))
     cas.__all__ = [k for k in vars(cas) if not k.startswith("_")]
     tools = types.ModuleType("casadi.tools")
     tools.__all__ = []
@@ -108,7 +132,7 @@ def _make_standins() -> Dict[str, types.ModuleType]:
     util.__all__ = []
     past = types.ModuleType("past")
     putils = types.ModuleType("past.utils")
-    putils.old_div = lambda a, b: a / b
+    putils.old_div = _old_div
     past.utils = putils
     mods = {"casadi": cas, "casadi.tools": tools, "Utilities": util, "past": past, "past.utils": putils}
     try:  # the examples import pylab but never use it at module level

@@ -114,6 +114,10 @@ class LinearMPCProblem:
     def_pyp: Optional[Callable] = None
     name: str = ""
     extras: Dict[str, Any] = field(default_factory=dict)
+    # non-linear continuous-time plant (Utilities.py:58-82): User_fxp_Cont(x, t, u, pxp, pxmp) integrated by classical RK4
+    # with Mx sub-steps per sampling interval; the controller path (estimator, target, OCP) stays linear.
+    plant_fx_cont: Optional[Callable] = None
+    plant_Mx: int = 10
 
     # ------------------------------------------------------------------ schedules
     def schedules(self, nsteps: int, k0: int = 0) -> Dict[str, np.ndarray]:
@@ -133,6 +137,35 @@ class LinearMPCProblem:
             if self.def_pyp is not None:
                 pyp[i] = np.ravel(self.def_pyp(t)[0])
         return dict(ysp=ysp, usp=usp, xsp=xsp, pxp=pxp, pyp=pyp)
+
+    # ------------------------------------------------------------------ plant
+    @property
+    def plant_is_linear(self) -> bool:
+        return self.plant_fx_cont is None
+
+    def plant_step(self, xp: np.ndarray, u: np.ndarray, t: float, pxp: np.ndarray) -> np.ndarray:
+        """x_p(t+h) for a batch ``xp[B, nxp]``, ``u[B, nu]`` (MPC_code.py:813-816).
+
+        Linear plant: ``Ap x + Bp u + pxp`` (Utilities.py:45-49).  Non-linear continuous plant (Utilities.py:58-82): the user
+        function on the augmented state ``[x; t]`` (``dt/dt = 1``), integrated over ``h`` by ``casadi.tools.simpleRK(f, Mx)`` -
+        ``Mx`` classical Runge-Kutta-4 steps of ``h / Mx`` with the inputs held - then ``+ pxp`` (LinPar)."""
+        if self.plant_fx_cont is None:
+            return xp @ self.Ap.T + u @ self.Bp.T + pxp
+        x = np.ascontiguousarray(np.asarray(xp, dtype=np.float64).T)           # [nxp, B]: x[0] is a component over the batch
+        uu = np.ascontiguousarray(np.asarray(u, dtype=np.float64).T)
+        pp = np.broadcast_to(np.asarray(pxp, dtype=np.float64).reshape(self.nxp, -1), x.shape)
+        zero = np.zeros_like(pp)
+        f = lambda xx, tt: np.asarray(self.plant_fx_cont(xx, tt, uu, pp, zero), dtype=np.float64)
+        dt = self.h / self.plant_Mx
+        tt = float(t)
+        for _ in range(self.plant_Mx):
+            k1 = f(x, tt)
+            k2 = f(x + 0.5 * dt * k1, tt + 0.5 * dt)
+            k3 = f(x + 0.5 * dt * k2, tt + 0.5 * dt)
+            k4 = f(x + dt * k3, tt + dt)
+            x = x + (dt / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+            tt += dt
+        return np.ascontiguousarray(x.T) + np.asarray(pxp, dtype=np.float64)
 
     # ------------------------------------------------------------------ derived
     @property
@@ -156,7 +189,7 @@ def _has(ns, name):
 
 def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProblem:
     """Classify an Ex-file namespace and emit the numeric descriptor (or raise)."""
-    for bad in ("User_fxm_Cont", "User_fxm_Dis", "User_fym", "User_fxp_Cont", "User_fxp_Dis", "User_fyp",
+    for bad in ("User_fxm_Cont", "User_fxm_Dis", "User_fym", "User_fxp_Dis", "User_fyp",
                 "User_fobj_Cont", "User_fobj_Dis", "User_fobj_Coll", "User_fssobj", "User_vfin",
                 "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y",
                 "def_px", "def_py", "def_pxmp", "def_pymp", "R_wn", "G_wn"):
@@ -168,7 +201,8 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
             raise UnsupportedProblem(f"flag {flag}=True is outside the batched linear hot path")
     if not ns.get("LinPar", True):
         raise UnsupportedProblem("LinPar=False")
-    for req in ("A", "B", "C", "Ap", "Bp", "Cp", "Q", "Qss", "N", "h", "Nsim", "x", "u", "y", "d", "xp"):
+    nl_plant = _has(ns, "User_fxp_Cont") and ns["User_fxp_Cont"] is not None      # plant only: the controller stays linear
+    for req in ("A", "B", "C", "Cp", "Q", "Qss", "N", "h", "Nsim", "x", "u", "y", "d", "xp") + (() if nl_plant else ("Ap", "Bp")):
         if not _has(ns, req):
             raise UnsupportedProblem(f"'{req}' missing: not a matrix-defined linear example")
 
@@ -200,8 +234,11 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
     else:
         fy_const = np.zeros(ny)
 
-    Ap = _mat(ns["Ap"], nxp, nxp, "Ap")
-    Bp = _mat(ns["Bp"], nxp, nu, "Bp")
+    if nl_plant:         # MPC_code.py:176-199: a user plant takes the place of Ap, Bp (zeros here: only plant_step uses them)
+        Ap, Bp = np.zeros((nxp, nxp)), np.zeros((nxp, nu))
+    else:
+        Ap = _mat(ns["Ap"], nxp, nxp, "Ap")
+        Bp = _mat(ns["Bp"], nxp, nu, "Bp")
     Cp = _mat(ns["Cp"], ny, nxp, "Cp")
 
     Q = _mat(ns["Q"], nx, nx, "Q")
@@ -277,5 +314,6 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         max_iter=int(ns.get("Sol_itmax", 100)),
         defSP=ns.get("defSP"), def_pxp=ns.get("def_pxp"), def_pyp=ns.get("def_pyp"),
         name=name or str(ns.get("__name__", "")),
+        plant_fx_cont=ns["User_fxp_Cont"] if nl_plant else None, plant_Mx=int(ns.get("Mx", 10)),
     )
     return prob

@@ -63,8 +63,11 @@ def model_fy(p, x, d, py=None):
     return out if py is None else out + py
 
 
-def plant_fx(p, xp, u, pxp):
-    """Fx_p: Ap x + Bp u + pxp + pxmp (pxmp = 0 without def_px)   (Utilities.py:45-49)."""
+def plant_fx(p, xp, u, pxp, t=0.0):
+    """Fx_p: Ap x + Bp u + pxp + pxmp (pxmp = 0 without def_px)   (Utilities.py:45-49); a non-linear continuous plant
+    (Utilities.py:58-82) is integrated by the problem object's RK4 (host code, outside the hot path)."""
+    if getattr(p, "plant_fx_cont", None) is not None:
+        return p.plant_step(np.asarray(xp)[None], np.asarray(u)[None], t, pxp)[0]
     return p.Ap @ xp + p.Bp @ u + pxp
 
 
@@ -411,7 +414,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, u0=None, dhat0=None, P0=None, s
         log["U"].append(u.copy()); log["STATUS_DYN"].append(o["status"])
         log["KKT_DYN"].append(kkt_max(o["res"]) if o["res"] else np.nan)
         log["ITERS_DYN"].append(o["iters"]); log["EXACT_DYN"].append(bool(o.get("exact", False)))
-        x = plant_fx(p, x, u, sched["pxp"][k])                   # MPC_code.py:816
+        x = plant_fx(p, x, u, sched["pxp"][k], k * p.h)                 # MPC_code.py:816
     return {k: np.array(v) for k, v in log.items()}
 
 

@@ -538,7 +538,7 @@ def closed_loop_batch(p, nsteps, x0_p, x0_m, sched=None, max_iter=100, warm_star
         prev_pred = xhat.copy()
         log["U"].append(u.copy()); log["STATUS_SS"].append(t["status"].copy()); log["STATUS_DYN"].append(o["status"].copy())
         log["ITERS_DYN"].append(o["iters"].copy()); log["ITERS_SS"].append(t["iters"].copy())
-        x = x @ p.Ap.T + u @ p.Bp.T + sched["pxp"][k]
+        x = p.plant_step(x, u, k * p.h, sched["pxp"][k]) if hasattr(p, "plant_step") else x @ p.Ap.T + u @ p.Bp.T + sched["pxp"][k]
         if noise is not None:        # robustness studies only: seeded process noise [nsteps,B,nxp]
             x = x + noise[k]
     return {k: np.array(v) for k, v in log.items()}

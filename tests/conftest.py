@@ -43,6 +43,11 @@ def wb(pkg):
 
 
 @pytest.fixture(scope="session")
+def nlplant(pkg):
+    return pkg.load_problem(pkg.example_path("cstr_nlplant_lmpc.py"))
+
+
+@pytest.fixture(scope="session")
 def oracle_c():
     import oracle_c as oc
     oc.build()

@@ -99,3 +99,23 @@ def test_warm_starts_do_not_move_the_answer(which, cstr, wb, oracle_c):
     assert warm["ITERS_DYN"][10:].mean() < 0.7 * cold["ITERS_DYN"][10:].mean()        # so does the OCP's
     n = rn.closed_loop_batch(p, 40, x0, x0)
     assert np.array_equal(n["ITERS_SS"], warm["ITERS_SS"])
+
+
+def test_nonlinear_plant_example_controller_path(nlplant, oracle_c):
+    """Ex_LMPC_nlplant: linear controller (Delta-u cost, state bounds, operating-point offsets) around an open-loop unstable
+    CSTR (|eig A| = 1.75 per step): C and NumPy statements agree on OCPs of that problem, and on the first closed-loop steps
+    with the non-linear plant integrated on the host (later the loop limit-cycles between input bounds and amplifies
+    rounding differences by about 3x per step, so a long comparison is meaningless)."""
+    p = nlplant
+    rng = np.random.default_rng(5)
+    B = 40
+    xh = p.x0_m + rng.normal(size=(B, 3)) * [2e-3, 0.3, 2e-3]; xs = p.x0_m + rng.normal(size=(B, 3)) * [1e-3, 0.1, 1e-3]
+    us = np.tile(p.u0, (B, 1)); d = rng.normal(size=(B, 2)) * 0.01; up = p.u0 + rng.normal(size=(B, 2)) * [0.5, 0.005]
+    c = oracle_c.OracleC(p).ocp_solve(xh, xs, us, d, up)
+    sd = rn.stage_data(p); n = rn.rpdip_solve(sd, rn.instance_data(p, sd, xh, xs, us, d, up))
+    assert np.array_equal(c["status"], n["status"]) and (c["status"] == 0).all()
+    assert np.abs(c["u0"] - n["u0"]).max() < 1e-6                     # |u| = 300: 3e-9 relative
+    x0 = p.x0_p + rng.normal(size=(6, 3)) * [2e-4, 0.02, 2e-4]
+    a = rn.closed_loop_batch(p, 8, x0, x0)
+    assert (a["STATUS_DYN"] == 0).all() and np.isfinite(a["Xp"]).all()
+    assert np.abs(a["Xp"][1] - p.plant_step(x0, a["U"][0], 0.0, np.zeros(3))).max() == 0.0      # the loop uses the RK4 plant
