@@ -2,16 +2,17 @@
 //
 // rpdip_lane (mpc_device.hpp) maps one instance to one lane and walks the horizon sequentially four times per
 // interior-point iteration, streaming every block through HBM.  At batch 4096 that occupies 64 of the 1024 SIMDs.
-// Here a workgroup of NI waves owns NI instances:
-//   * element-wise work (slacks, multipliers, residuals, step lengths) runs with wave = instance and lane = block k of
-//     the horizon (N <= 64): the whole iterate of an instance lives in the registers of one wave, sums and maxima over
-//     the horizon are cross-lane reductions, nothing goes to HBM during a solve;
-//   * the recursions that are sequential in k (Riccati factorisation, adjoint, right-hand sides, Newton direction)
-//     run on wave 0 with lane = instance, exactly as rpdip_lane does them; the two mappings exchange their data
-//     through a transposing buffer in LDS ([row][instance][k], padded so that both views are conflict-free).
+// Here a workgroup of NW waves owns NI = NW * IPW instances:
+//   * element-wise work (slacks, multipliers, residuals, step lengths, the convergence test) runs with wave = instance
+//     (IPW instances per wave, one after the other) and lane = block k of the horizon (N <= 64): sums and maxima over the
+//     horizon are DPP reductions over the wave, the costate recursion of the test is a scan over the lanes;
+//   * the recursions that are sequential in k (Riccati factorisation, right-hand sides, Newton direction) run on wave 0
+//     with lane = instance, as rpdip_lane does them; the two mappings exchange their data through a transposing buffer
+//     in LDS ([row][instance][k], padded so that both views are conflict-free).
 // Between phases the iterate of an instance (slacks, multipliers, inputs, states: ROWS_ST rows of 64 doubles) rests in
 // HBM/L2, one coalesced row per quantity; a wave loads it, works, stores what changed.  That keeps the register budget
-// of a wave independent of how many instances it serves (IPW) and leaves wave 0 all its registers for the recursions.
+// of a wave independent of how many instances it serves (IPW) and leaves wave 0 all its registers for the recursions
+// (keeping the iterates in registers instead was measured: hipcc spills them next to the recursion code).
 // The same rows are the warm start of the next MPC step.
 // The arithmetic per block is that of rpdip_lane; horizon-wide sums are taken in another order.
 #pragma once
