@@ -375,3 +375,20 @@ def test_nonlinear_plant_example_through_the_three_calls(nlplant, oracle_c, solv
     nl = rn.closed_loop_batch(p, 8, x0, x0, warm_start=False)
     assert np.array_equal(gl["STATUS_DYN"], nl["STATUS_DYN"]) and (gl["STATUS_DYN"] == 0).all()
     assert np.abs(gl["U"] - nl["U"]).max() < 1e-5 and np.abs(gl["Xp"] - nl["Xp"]).max() < 1e-5
+
+
+def test_both_kernels_leave_the_same_resident_state(cstr, solver_factory):
+    """mpc_loop_get_state means the same after either kernel: in particular P is the prior covariance of the next step,
+    although the horizon-parallel kernel computes the filter's covariance half one step ahead."""
+    from mpc_code_amd import capi
+    B, K = 50, 7
+    x0 = bench_x0(B, 123)
+    fin = []
+    for lk in (1, 2):
+        s = solver_factory(cstr, lk)
+        s.loop_alloc(B, K, capi.LOG_U); s.loop_set_schedule(cstr.schedules(K)); s.loop_set_state(x0, x0)
+        s.loop_run(0, 3); s.loop_run(3, K - 3); s.loop_sync()
+        fin.append(s.loop_get_state())
+    for k in ("x_p", "xhat", "dhat", "u", "xs", "us"):
+        assert np.abs(fin[0][k] - fin[1][k]).max() < 1e-6, k
+    assert np.array_equal(fin[0]["P"], fin[1]["P"])                     # same operations on the same numbers
