@@ -297,18 +297,22 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
     double *wsg = a.ws + (size_t)blockIdx.x * NI * Cfg::ROWS_ST * 64;      // state rows of this workgroup's instances
     MPC_STAMP_INIT
     for (int k = 0; k < a.nsteps; k++) {
+        // the instance index is made opaque once per step: the address arithmetic of the ~40 per-instance arrays below is loop
+        // invariant, and hoisted out of this loop it occupies registers (then scratch) for the whole kernel
+        unsigned bq = (unsigned)b;      // 32-bit index next to a uniform column pointer: global_load with scalar base + vector offset
+        asm volatile("" : "+v"(bq));
         double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
         double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU];
         if (valid) {
-            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
-            MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
-            MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
-            MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = (a.x + (size_t)(i) * Bs)[bq];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = (a.xhat + (size_t)(i) * Bs)[bq]; xs[i] = (a.xs + (size_t)(i) * Bs)[bq]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = (a.dhat + (size_t)(i) * Bs)[bq];
+            MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = (a.u + (size_t)(i) * Bs)[bq]; us[i] = (a.us + (size_t)(i) * Bs)[bq]; }
             MPC_UNROLL for (int i = 0; i < NX; i++) { xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
             MPC_UNROLL for (int i = 0; i < ND; i++) dh_prev[i] = dh[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) us_prev[i] = us[i];
-            if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
-            if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
+            if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) (a.XP + (size_t)((size_t)k * NXP + i) * Bs)[bq] = x[i]; }
+            if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XHAT + (size_t)((size_t)k * NX + i) * Bs)[bq] = xh[i]; }
             // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
             if (P.estimator != MPC_EST_NONE) {
                 double xi[NE], innov[NY];
@@ -322,13 +326,13 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                 }
                 if (P.estimator == MPC_EST_KALMAN) {
                     double K[NE][NY];
-                    if (a.kf_valid[b] != 0) {      // the gain was computed one step ahead (look-ahead below, which also moves Pn into Pk)
-                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) K[i][j] = a.Kg[(i * NY + j) * Bs + b]; }
+                    if (a.kf_valid[bq] != 0) {      // the gain was computed one step ahead (look-ahead below, which also moves Pn into Pk)
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) K[i][j] = (a.Kg + (size_t)(i * NY + j) * Bs)[bq]; }
                     } else {
                         double Pk[NE][NE];
-                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = (a.Pk + (size_t)(i * NE + j) * Bs)[bq]; }
                         kalman_cov<NE, NY>(P, Pk, K);
-                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) (a.Pk + (size_t)(i * NE + j) * Bs)[bq] = Pk[i][j]; }
                     }
                     MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += K[i][l] * innov[l]; xi[i] += s; }      // Estimator.py:303-306
                 } else {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                 MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
                 MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
             }
-            if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) a.DHAT[((size_t)k * ND + i) * Bs + b] = dh[i]; }
+            if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) (a.DHAT + (size_t)((size_t)k * ND + i) * Bs)[bq] = dh[i]; }
             MPC_TSTAMP(7);
         }
         // While wave 0 solves the target problems, wave 1 (lane = instance) advances the covariance side of the Kalman
@@ -345,17 +349,18 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
         // (Estimator.py:297-309).
         __syncthreads();
         if (threadIdx.y == 1 && P.estimator == MPC_EST_KALMAN && lane < NI && blockIdx.x * NI + lane < a.B) {
-            const int bi = blockIdx.x * NI + lane;
+            unsigned bi = blockIdx.x * NI + lane;
+            asm volatile("" : "+v"(bi));      // opaque per step, like bq above
             double Pk[NE][NE], K[NE][NY];
             if (a.kf_valid[bi] != 0) {       // the prior of the next step is Pn (wave 0 used Kg for this step): it becomes Pk
-                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pn[(i * NE + j) * Bs + bi]; }
-                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + bi] = Pk[i][j]; }
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = (a.Pn + (size_t)(i * NE + j) * Bs)[bi]; }
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) (a.Pk + (size_t)(i * NE + j) * Bs)[bi] = Pk[i][j]; }
             } else {                         // wave 0 ran the whole filter for this step and left the next prior in Pk
-                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + bi]; }
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = (a.Pk + (size_t)(i * NE + j) * Bs)[bi]; }
             }
             kalman_cov<NE, NY>(P, Pk, K);
-            MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) a.Kg[(i * NY + j) * Bs + bi] = K[i][j]; }
-            MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pn[(i * NE + j) * Bs + bi] = Pk[i][j]; }
+            MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) (a.Kg + (size_t)(i * NY + j) * Bs)[bi] = K[i][j]; }
+            MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) (a.Pn + (size_t)(i * NE + j) * Bs)[bi] = Pk[i][j]; }
             a.kf_valid[bi] = 1;
         }
         if (valid) {
@@ -364,22 +369,22 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
             MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
             int it_ss;
-            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, a.tw + b, Bs, a.tw_valid + b);
+            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, a.tw + bq, Bs, a.tw_valid + bq);
             if (st_ss != kInfeasible) {
                 MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
                 MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
             }
-            if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XS[((size_t)k * NX + i) * Bs + b] = xs[i]; }
-            if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) a.US[((size_t)k * NU + i) * Bs + b] = us[i]; }
+            if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XS + (size_t)((size_t)k * NX + i) * Bs)[bq] = xs[i]; }
+            if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.US + (size_t)((size_t)k * NU + i) * Bs)[bq] = us[i]; }
             if (a.YS) {   // ys = Fy_model(xs, us, dhat), MPC_code.py:730
                 MPC_UNROLL for (int i = 0; i < NY; i++) {
                     double v = P.fyc[i];
                     MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Cm[i][j] * xs[j];
                     MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Cd[i][j] * dh[j];
-                    a.YS[((size_t)k * NY + i) * Bs + b] = v;
+                    (a.YS + (size_t)((size_t)k * NY + i) * Bs)[bq] = v;
                 }
             }
-            if (a.st_dyn) { a.st_ss[(size_t)k * Bs + b] = st_ss; a.it_ss[(size_t)k * Bs + b] = it_ss; }
+            if (a.st_dyn) { (a.st_ss + (size_t)k * Bs)[bq] = st_ss; (a.it_ss + (size_t)k * Bs)[bq] = it_ss; }
             // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS; loop state -> HBM ------------
             OcpInst<NS, NU> q;
             build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
@@ -387,15 +392,15 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - xh_pred[i]), fabs(xs[i] - xs_prev[i])));
             MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
             MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
-            const bool warm = a.ws_valid[b] != 0 && delta <= kWsDelta;
+            const bool warm = a.ws_valid[bq] != 0 && delta <= kWsDelta;
             double *qd = sh.q + lane * Cfg::QN;
             MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = q.z0[i]; qd[NS + i] = q.zr[i]; qd[2 * NS + i] = q.c[i]; qd[3 * NS + i] = q.zlo_m[i]; qd[4 * NS + i] = q.zhi_m[i]; }
             MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = q.ur[i]; qd[5 * NS + NU + i] = q.us[i]; }
             qd[5 * NS + 2 * NU] = delta;
             sh.iflag[lane] = kTpValid | (q.ok0 ? kTpOk0 : 0) | (warm ? kTpWarm : 0);
-            MPC_UNROLL for (int i = 0; i < NX; i++) { a.xhat[i * Bs + b] = xh[i]; a.xs[i * Bs + b] = xs[i]; }
-            MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
-            MPC_UNROLL for (int i = 0; i < NU; i++) a.us[i * Bs + b] = us[i];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { (a.xhat + (size_t)(i) * Bs)[bq] = xh[i]; (a.xs + (size_t)(i) * Bs)[bq] = xs[i]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) (a.dhat + (size_t)(i) * Bs)[bq] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) (a.us + (size_t)(i) * Bs)[bq] = us[i];
         } else if (wl) sh.iflag[lane] = 0;
         int st_dyn, it_dyn;
         MPC_TSTAMP(0);
@@ -403,16 +408,16 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
         if (valid) {
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
             double x[NXP], xh[NX], u[NU];
-            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
-            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = a.u[i * Bs + b];
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = (a.x + (size_t)(i) * Bs)[bq];
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (a.u + (size_t)(i) * Bs)[bq];
             if (st_dyn != kInfeasible) {
                 const double *fin_rows = wsg + (size_t)lane * Cfg::ROWS_ST * 64;     // final iterate, block 0
                 MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = fin_rows[(Cfg::ST_U + i) * 64];          // :798
                 MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = fin_rows[(Cfg::ST_Z + i) * 64];         // :799
             } else {                                                           // :804-805 hold u, propagate the model
                 double xo[NX], dh[ND > 0 ? ND : 1];
-                MPC_UNROLL for (int i = 0; i < NX; i++) xo[i] = a.xhat[i * Bs + b];
-                MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+                MPC_UNROLL for (int i = 0; i < NX; i++) xo[i] = (a.xhat + (size_t)(i) * Bs)[bq];
+                MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = (a.dhat + (size_t)(i) * Bs)[bq];
                 MPC_UNROLL for (int i = 0; i < NX; i++) {
                     double v = P.fxc[i];
                     MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Am[i][j] * xo[j];
@@ -421,8 +426,8 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                     xh[i] = v;
                 }
             }
-            if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) a.U[((size_t)k * NU + i) * Bs + b] = u[i]; }
-            if (a.st_dyn) { a.st_dyn[(size_t)k * Bs + b] = st_dyn; a.it_dyn[(size_t)k * Bs + b] = it_dyn; }
+            if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.U + (size_t)((size_t)k * NU + i) * Bs)[bq] = u[i]; }
+            if (a.st_dyn) { (a.st_dyn + (size_t)k * Bs)[bq] = st_dyn; (a.it_dyn + (size_t)k * Bs)[bq] = it_dyn; }
             double xn[NXP];
             MPC_UNROLL for (int i = 0; i < NXP; i++) {
                 double v = a.pxp[k * NXP + i];
@@ -430,10 +435,10 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                 MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
                 xn[i] = v;
             }
-            MPC_UNROLL for (int i = 0; i < NXP; i++) a.x[i * Bs + b] = xn[i];
-            MPC_UNROLL for (int i = 0; i < NX; i++) a.xhat[i * Bs + b] = xh[i];
-            MPC_UNROLL for (int i = 0; i < NU; i++) a.u[i * Bs + b] = u[i];
-            a.ws_valid[b] = st_dyn == kSolved ? 1 : 0;
+            MPC_UNROLL for (int i = 0; i < NXP; i++) (a.x + (size_t)(i) * Bs)[bq] = xn[i];
+            MPC_UNROLL for (int i = 0; i < NX; i++) (a.xhat + (size_t)(i) * Bs)[bq] = xh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) (a.u + (size_t)(i) * Bs)[bq] = u[i];
+            a.ws_valid[bq] = st_dyn == kSolved ? 1 : 0;
         }
         __syncthreads();
         MPC_STAMP_RESET

@@ -144,17 +144,21 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         }
     };
     Inst I[IPW];
-    auto row = [&](int wi, int r) -> double * { return wsg + ((size_t)wi * Cfg::ROWS_ST + r) * 64 + k; };
+    // A row access is (wave-uniform row pointer)[lane]: global_load / store with a scalar base and one shared 32-bit vector offset.
+    // Written as one 64-bit per-lane address the compiler hoists all ~150 of them into the kernel prologue and spills them.
+    unsigned ku = (unsigned)k;      // made opaque at every phase boundary (fresh()), so that the addresses are built where they are used
+    auto fresh = [&]() { asm volatile("" : "+v"(ku)); };
+    auto rowp = [&](int wi, int r) -> double * { return wsg + ((size_t)wi * Cfg::ROWS_ST + r) * 64; };
     auto load_iter = [&](int wi, Iter &X) {
-        MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = *row(wi, Cfg::ST_SL + i); X.sh[i] = *row(wi, Cfg::ST_SH + i); X.ll[i] = *row(wi, Cfg::ST_LL + i); X.lh[i] = *row(wi, Cfg::ST_LH + i); }
-        MPC_UNROLL for (int i = 0; i < NU; i++) X.u[i] = *row(wi, Cfg::ST_U + i);
-        MPC_UNROLL for (int i = 0; i < NS; i++) X.z[i] = *row(wi, Cfg::ST_Z + i);
+        MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = rowp(wi, Cfg::ST_SL + i)[ku]; X.sh[i] = rowp(wi, Cfg::ST_SH + i)[ku]; X.ll[i] = rowp(wi, Cfg::ST_LL + i)[ku]; X.lh[i] = rowp(wi, Cfg::ST_LH + i)[ku]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) X.u[i] = rowp(wi, Cfg::ST_U + i)[ku];
+        MPC_UNROLL for (int i = 0; i < NS; i++) X.z[i] = rowp(wi, Cfg::ST_Z + i)[ku];
         bounds(wi, X);
     };
     auto store_iter = [&](int wi, const Iter &X) {
-        MPC_UNROLL for (int i = 0; i < NC; i++) { *row(wi, Cfg::ST_SL + i) = X.sl[i]; *row(wi, Cfg::ST_SH + i) = X.sh[i]; *row(wi, Cfg::ST_LL + i) = X.ll[i]; *row(wi, Cfg::ST_LH + i) = X.lh[i]; }
-        MPC_UNROLL for (int i = 0; i < NU; i++) *row(wi, Cfg::ST_U + i) = X.u[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) *row(wi, Cfg::ST_Z + i) = X.z[i];
+        MPC_UNROLL for (int i = 0; i < NC; i++) { rowp(wi, Cfg::ST_SL + i)[ku] = X.sl[i]; rowp(wi, Cfg::ST_SH + i)[ku] = X.sh[i]; rowp(wi, Cfg::ST_LL + i)[ku] = X.ll[i]; rowp(wi, Cfg::ST_LH + i)[ku] = X.lh[i]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) rowp(wi, Cfg::ST_U + i)[ku] = X.u[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) rowp(wi, Cfg::ST_Z + i)[ku] = X.z[i];
     };
     // stage cost of this lane's block in registers: Q (or the terminal weight for the last block), R, M
     double Qk[NS][NS], Rk[NU][NU], Mk[NS][NU];
@@ -260,7 +264,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             const bool f_lo = fin(ulo), f_hi = fin(uhi);
             double v;
             if (S.warm) {
-                v = row(wi, Cfg::ST_U + i)[sft];
+                v = rowp(wi, Cfg::ST_U + i)[ku + sft];
                 if (f_lo) v = dmax(v, ulo);
                 if (f_hi) v = dmin(v, uhi);
             } else {
@@ -276,8 +280,8 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             sh.t(RG + i, wi, k) = v;
         }
         MPC_UNROLL for (int i = 0; i < NC; i++) {
-            ll0[j][i] = S.warm ? row(wi, Cfg::ST_LL + i)[sft] : 0.0;
-            lh0[j][i] = S.warm ? row(wi, Cfg::ST_LH + i)[sft] : 0.0;
+            ll0[j][i] = S.warm ? rowp(wi, Cfg::ST_LL + i)[ku + sft] : 0.0;
+            lh0[j][i] = S.warm ? rowp(wi, Cfg::ST_LH + i)[ku + sft] : 0.0;
         }
     }
     __syncthreads();
@@ -345,12 +349,12 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     const bool wk_valid = wl && (sh.iflag[lane < NI ? lane : 0] & kTpValid) && (sh.iflag[lane < NI ? lane : 0] & kTpOk0);
     bool pd_all = true;         // worker lane: every Lambda of this instance was positive definite so far
 
-    MPC_TSTAMP(1);
+    MPC_TSTAMP(1); fresh();
     for (int it = 0;; it++) {
         bool mine = false;
         MPC_UNROLL for (int j = 0; j < IPW; j++) mine = mine || I[j].on;
         if (!__syncthreads_or(mine ? 1 : 0)) break;      // every instance of the workgroup has its verdict
-        MPC_TSTAMP(2);
+        MPC_TSTAMP(2); fresh();
         // ================= wave 0, lane = instance: Riccati factorisation, predictor rhs, direction ======================
         const bool wk_on = wk_valid && sh.flag[lane < NI ? lane : 0] == 0;
         if (worker) {
@@ -431,7 +435,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             if (wl && wk_on && !pd_all) sh.flag[lane] = -1;      // a Lambda lost definiteness: the instance stops as infeasible
         }
         __syncthreads();
-        MPC_TSTAMP(3);
+        MPC_TSTAMP(3); fresh();
         MPC_UNROLL for (int j = 0; j < IPW; j++) {
             const int wi = w * IPW + j;
             if (I[j].on && sh.flag[wi] < 0) {       // the factorisation failed
@@ -448,7 +452,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     Iter Xj;
                     load_iter(wi, Xj);
                     double maff_p = 1.0, s1_p = 0.0, s2_p = 0.0, dv[NC], pl[NC], ph[NC];
-                    MPC_UNROLL for (int i = 0; i < NC; i++) { dv[i] = sh.t(RG + i, wi, k); *row(wi, Cfg::ST_DV + i) = dv[i]; }      // du | dz of the predictor
+                    MPC_UNROLL for (int i = 0; i < NC; i++) { dv[i] = sh.t(RG + i, wi, k); rowp(wi, Cfg::ST_DV + i)[ku] = dv[i]; }      // du | dz of the predictor
                     MPC_UNROLL for (int i = 0; i < NC; i++) {
                         const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
                         const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
@@ -485,7 +489,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             }
         }
         __syncthreads();
-        MPC_TSTAMP(4);
+        MPC_TSTAMP(4); fresh();
         // ================= wave 0, lane = instance: corrector rhs recursion and direction ===============================
         if (worker) {
             StageConst<NS, NU> C;
@@ -525,7 +529,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             }
         }
         __syncthreads();
-        MPC_TSTAMP(5);
+        MPC_TSTAMP(5); fresh();
         // ================= element-wise: corrector step length, step; then the next iterate's residuals / gradients =====
         {
             MPC_UNROLL for (int j = 0; j < IPW; j++) {
@@ -535,7 +539,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     Iter Xj;
                     double dvaj[NC], dvzj[NV];
                     load_iter(wi, Xj);
-                    MPC_UNROLL for (int i = 0; i < NC; i++) dvaj[i] = *row(wi, Cfg::ST_DV + i);
+                    MPC_UNROLL for (int i = 0; i < NC; i++) dvaj[i] = rowp(wi, Cfg::ST_DV + i)[ku];
                     MPC_UNROLL for (int i = 0; i < NV; i++) dvzj[i] = sh.t(RG + i, wi, k);
                     double mcc_p = kTau;
                     double dsl[NC], dsh[NC], dll[NC], dlh[NC];
@@ -564,7 +568,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 }
             }
         }
-        MPC_TSTAMP(6);
+        MPC_TSTAMP(6); fresh();
     }
     // wave 0, lane i: the verdict of instance i
     __syncthreads();
