@@ -200,16 +200,16 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             const double rh = X.fh[i] ? v + X.sh[i] - X.hi[i] : 0.0, rl = X.fl[i] ? v - X.sl[i] - X.lo[i] : 0.0;
             const double isl = frcp(X.sl[i]), ish = frcp(X.sh[i]);
             mu_p += X.sl[i] * X.ll[i] + X.sh[i] * X.lh[i];
-            sh.t(RA + i, wi, k) = X.ll[i] * isl + X.lh[i] * ish;
-            sh.t(RA + NC + i, wi, k) = X.lh[i] * (rh * ish - 1.0) + X.ll[i] * (rl * isl + 1.0);
+            sh.t(RA + i, wi, ku) = X.ll[i] * isl + X.lh[i] * ish;
+            sh.t(RA + NC + i, wi, ku) = X.lh[i] * (rh * ish - 1.0) + X.ll[i] * (rl * isl + 1.0);
             resp_p = dmax(resp_p, dmax(fabs(rl), fabs(rh)));
             cres_p = dmax(cres_p, dmax(comp_measure(X.sl[i], X.ll[i]), comp_measure(X.sh[i], X.lh[i])));
             lmax_p = dmax(lmax_p, dmax(X.ll[i], X.lh[i]));
         }
         double gu[NU], gz[NS], pi[NS];
         gradient(S, X, gu, gz);
-        MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, k) = gu[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { sh.t(RG + NU + i, wi, k) = gz[i]; pi[i] = blk_on ? gz[i] : 0.0; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, ku) = gu[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { sh.t(RG + NU + i, wi, ku) = gz[i]; pi[i] = blk_on ? gz[i] : 0.0; }
         MPC_UNROLL for (int e = 0; e < 6; e++) {
             const int d = 1 << e;
             if (d < N) {
@@ -277,7 +277,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 if (f_hi) v = dmin(v, uhi - push);
             }
             u0v[j][i] = v;
-            sh.t(RG + i, wi, k) = v;
+            sh.t(RG + i, wi, ku) = v;
         }
         MPC_UNROLL for (int i = 0; i < NC; i++) {
             ll0[j][i] = S.warm ? rowp(wi, Cfg::ST_LL + i)[ku + sft] : 0.0;
@@ -308,7 +308,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         if (S.on) {
             Iter Xj;
             MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] = u0v[j][i];
-            MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = sh.t(RG + NU + i, wi, k);
+            MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = sh.t(RG + NU + i, wi, ku);
             bounds(wi, Xj);
             const double ws_delta = uni(sh.q[wi * Cfg::QN + 5 * NS + 2 * NU]);
             const double ws_smin = dmin(dmax(kWsKappa * ws_delta, kWsSMinLo), kWsSMinHi), ws_mu = kWsMuFactor * ws_smin * ws_smin;
@@ -452,7 +452,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     Iter Xj;
                     load_iter(wi, Xj);
                     double maff_p = 1.0, s1_p = 0.0, s2_p = 0.0, dv[NC], pl[NC], ph[NC];
-                    MPC_UNROLL for (int i = 0; i < NC; i++) { dv[i] = sh.t(RG + i, wi, k); rowp(wi, Cfg::ST_DV + i)[ku] = dv[i]; }      // du | dz of the predictor
+                    MPC_UNROLL for (int i = 0; i < NC; i++) { dv[i] = sh.t(RG + i, wi, ku); rowp(wi, Cfg::ST_DV + i)[ku] = dv[i]; }      // du | dz of the predictor
                     MPC_UNROLL for (int i = 0; i < NC; i++) {
                         const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
                         const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
@@ -483,8 +483,8 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                         const double rcl = Xj.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(S.sm, Xj.ll[i] * kSFloor) + pl[i] : 0.0;
                         hc[i] = (-rch + Xj.lh[i] * rh) * ish + (rcl + Xj.ll[i] * rl) * isl;
                     }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, k) = gu[i] + hc[i];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, wi, k) = gz[i] + hc[NU + i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, ku) = gu[i] + hc[i];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, wi, ku) = gz[i] + hc[NU + i];
                 }
             }
         }
@@ -540,7 +540,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     double dvaj[NC], dvzj[NV];
                     load_iter(wi, Xj);
                     MPC_UNROLL for (int i = 0; i < NC; i++) dvaj[i] = rowp(wi, Cfg::ST_DV + i)[ku];
-                    MPC_UNROLL for (int i = 0; i < NV; i++) dvzj[i] = sh.t(RG + i, wi, k);
+                    MPC_UNROLL for (int i = 0; i < NV; i++) dvzj[i] = sh.t(RG + i, wi, ku);
                     double mcc_p = kTau;
                     double dsl[NC], dsh[NC], dll[NC], dlh[NC];
                     MPC_UNROLL for (int i = 0; i < NC; i++) {
