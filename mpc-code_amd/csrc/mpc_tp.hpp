@@ -147,7 +147,8 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     // A row access is (wave-uniform row pointer)[lane]: global_load / store with a scalar base and one shared 32-bit vector offset.
     // Written as one 64-bit per-lane address the compiler hoists all ~150 of them into the kernel prologue and spills them.
     unsigned ku = (unsigned)k;      // made opaque at every phase boundary (fresh()), so that the addresses are built where they are used
-    auto fresh = [&]() { asm volatile("" : "+v"(ku)); };
+    unsigned lq = (unsigned)lane;   // the same for wave 0's lane = instance view
+    auto fresh = [&]() { asm volatile("" : "+v"(ku), "+v"(lq)); };
     auto rowp = [&](int wi, int r) -> double * { return wsg + ((size_t)wi * Cfg::ROWS_ST + r) * 64; };
     auto load_iter = [&](int wi, Iter &X) {
         MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = rowp(wi, Cfg::ST_SL + i)[ku]; X.sh[i] = rowp(wi, Cfg::ST_SH + i)[ku]; X.ll[i] = rowp(wi, Cfg::ST_LL + i)[ku]; X.lh[i] = rowp(wi, Cfg::ST_LH + i)[ku]; }
@@ -290,14 +291,14 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = sh.q[lane * Cfg::QN + i]; c[i] = sh.q[lane * Cfg::QN + 2 * NS + i]; }
         for (int kk = 0; kk < N; kk++) {
             double uk[NU], zn[NS];
-            MPC_UNROLL for (int i = 0; i < NU; i++) uk[i] = sh.t(RG + i, lane, kk);
+            MPC_UNROLL for (int i = 0; i < NU; i++) uk[i] = sh.t(RG + i, lq, kk);
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = c[i];
                 MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[i][j] * zz[j];
                 MPC_UNROLL for (int j = 0; j < NU; j++) a += P.B[i][j] * uk[j];
                 zn[i] = a;
             }
-            MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = zn[i]; sh.t(RG + NU + i, lane, kk) = zn[i]; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = zn[i]; sh.t(RG + NU + i, lq, kk) = zn[i]; }
         }
     }
     __syncthreads();
@@ -329,20 +330,20 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     auto direction = [&](const StageConst<NS, NU> &C) {
         double dz[NS], Kn[NKF], kn[NU];
         MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
-        MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, 0);
-        MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lane, 0);
+        MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, 0);
+        MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lq, 0);
         for (int kk = 0; kk < N; kk++) {
             double Kf[NKF], kff[NU], ddu[NU], dzn[NS];
             MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = Kn[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = kn[i];
             const int kx = kk + 1 < N ? kk + 1 : kk;      // the next block's gains now, they arrive while this block computes
-            MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, kx);
-            MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lane, kx);
+            MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, kx);
+            MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lq, kx);
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Kf[i * NS + j] * dz[j]; ddu[i] = a; }
             MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
-            MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, lane, kk) = ddu[i];
-            MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, lane, kk) = dz[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, lq, kk) = ddu[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, lq, kk) = dz[i];
         }
     };
 
@@ -368,18 +369,18 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = C.Pf[i][j];
                 }
                 double sg[NC], hh[NC], gun[NU], gzn[NS];
-                MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lane, N - 1); hh[i] = sh.t(RA + NC + i, lane, N - 1); }
-                MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lane, N - 1);
-                MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lane, N - 1);
+                MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lq, N - 1); hh[i] = sh.t(RA + NC + i, lq, N - 1); }
+                MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lq, N - 1);
+                MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lq, N - 1);
                 _Pragma("unroll 2") for (int kk = N - 1; kk >= 0; kk--) {
                     double sig[NV], haff[NV], g1[NS], g2[NU];
                     MPC_UNROLL for (int i = 0; i < NV; i++) { sig[i] = i < NC ? sg[i < NC ? i : 0] : 0.0; haff[i] = i < NC ? hh[i < NC ? i : 0] : 0.0; }
                     MPC_UNROLL for (int i = 0; i < NS; i++) g1[i] = gzn[i];
                     MPC_UNROLL for (int i = 0; i < NU; i++) g2[i] = gun[i];
                     const int kn = kk > 0 ? kk - 1 : 0;      // next block's data now, they arrive while this block computes
-                    MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lane, kn); hh[i] = sh.t(RA + NC + i, lane, kn); }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lane, kn);
-                    MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lane, kn);
+                    MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lq, kn); hh[i] = sh.t(RA + NC + i, lq, kn); }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lq, kn);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lq, kn);
                     MPC_UNROLL for (int i = 0; i < NS; i++) Pm[i][i] += sig[NU + i];
                     double PB[NS][NU], PA[NS][NS], Lam[NU][NU], Psi[NU][NS];
                     MPC_UNROLL for (int i = 0; i < NS; i++) {
@@ -393,10 +394,10 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     pd_ok = sym_inverse<NU>(Lam) && pd_ok;
                     double Kk[NU][NS];
                     MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a += Lam[i][l] * Psi[l][j]; Kk[i][j] = -a; } }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) sh.t(RA + i * NS + j, lane, kk) = Kk[i][j]; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) sh.t(RA + i * NS + j, lq, kk) = Kk[i][j]; }
                     {
                         int c = 0;
-                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { sh.t(RA + NKF + c, lane, kk) = Lam[i][j]; c++; } }
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { sh.t(RA + NKF + c, lq, kk) = Lam[i][j]; c++; } }
                     }
                     if (kk > 0) {       // closed-loop (Joseph) form with T = P Acl = PA + PB K
                         double Acl[NS][NS], T[NS][NS], RK_[NU][NS];
@@ -417,7 +418,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                     MPC_UNROLL for (int i = 0; i < NU; i++) qu[i] = g2[i] + haff[i];
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Lam[i][j] * psi[j]; kff[i] = -a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lane, kk) = kff[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lq, kk) = kff[i];
                     if (kk > 0) {
                         double pn[NS];
                         MPC_UNROLL for (int i = 0; i < NS; i++) {
@@ -497,9 +498,9 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             if (wk_on) {
                 double pc[NS], hn[NV], Kn[NKF], ln[NLI];
                 MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
-                MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lane, N - 1);
-                MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, N - 1);
-                MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lane, N - 1);
+                MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, N - 1);
+                MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, N - 1);
+                MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, N - 1);
                 for (int kk = N - 1; kk >= 0; kk--) {
                     double pv[NS], hu[NU], Li[NU][NU], Kf[NKF], psi[NU], kff[NU];
                     MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = hn[i];
@@ -510,12 +511,12 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                         MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { Li[i][j] = ln[c]; Li[j][i] = ln[c]; c++; } }
                     }
                     const int kx = kk > 0 ? kk - 1 : 0;      // the next block's data now, they arrive while this block computes
-                    MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lane, kx);
-                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lane, kx);
-                    MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lane, kx);
+                    MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, kx);
+                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, kx);
+                    MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, kx);
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = hu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lane, kk) = kff[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lq, kk) = kff[i];
                     double pn[NS];
                     MPC_UNROLL for (int i = 0; i < NS; i++) {
                         double a = 0.0;
