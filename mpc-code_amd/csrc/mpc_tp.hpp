@@ -278,30 +278,12 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 if (f_hi) v = dmin(v, uhi - push);
             }
             u0v[j][i] = v;
-            sh.t(RG + i, wi, ku) = v;
         }
         MPC_UNROLL for (int i = 0; i < NC; i++) {
             ll0[j][i] = S.warm ? rowp(wi, Cfg::ST_LL + i)[ku + sft] : 0.0;
             lh0[j][i] = S.warm ? rowp(wi, Cfg::ST_LH + i)[ku + sft] : 0.0;
         }
     }
-    __syncthreads();
-    if (wl && (sh.iflag[lane] & kTpValid) && (sh.iflag[lane] & kTpOk0)) {       // states by forward simulation (lane = instance)
-        double zz[NS], c[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = sh.q[lane * Cfg::QN + i]; c[i] = sh.q[lane * Cfg::QN + 2 * NS + i]; }
-        for (int kk = 0; kk < N; kk++) {
-            double uk[NU], zn[NS];
-            MPC_UNROLL for (int i = 0; i < NU; i++) uk[i] = sh.t(RG + i, lq, kk);
-            MPC_UNROLL for (int i = 0; i < NS; i++) {
-                double a = c[i];
-                MPC_UNROLL for (int j = 0; j < NS; j++) a += P.A[i][j] * zz[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) a += P.B[i][j] * uk[j];
-                zn[i] = a;
-            }
-            MPC_UNROLL for (int i = 0; i < NS; i++) { zz[i] = zn[i]; sh.t(RG + NU + i, lq, kk) = zn[i]; }
-        }
-    }
-    __syncthreads();
     // slacks and multipliers of the initial point, then the first element-wise phase
     MPC_UNROLL for (int j = 0; j < IPW; j++) {
         Inst &S = I[j];
@@ -309,7 +291,27 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         if (S.on) {
             Iter Xj;
             MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] = u0v[j][i];
-            MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = sh.t(RG + NU + i, wi, ku);
+            // states of the initial point by forward simulation z_{k+1} = A z_k + B u_k + c: again a linear recursion with a
+            // constant matrix, taken as a scan over the lanes with A^(2^e) (lane k ends up with z_{k+1})
+            {
+                const double *qd = sh.q + wi * Cfg::QN;
+                double xk[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) {
+                    double a = qd[2 * NS + i];
+                    MPC_UNROLL for (int l = 0; l < NU; l++) a += P.B[i][l] * Xj.u[l];
+                    if (k == 0) { MPC_UNROLL for (int l = 0; l < NS; l++) a += P.A[i][l] * qd[l]; }
+                    xk[i] = blk_on ? a : 0.0;
+                }
+                MPC_UNROLL for (int e = 0; e < 6; e++) {
+                    const int d = 1 << e;
+                    if (d < N) {
+                        double t[NS];
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = __shfl_up(xk[i], d, 64); t[i] = k >= d ? v : 0.0; }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = xk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += P.Apow[e][i][l] * t[l]; xk[i] = a; }
+                    }
+                }
+                MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = xk[i];
+            }
             bounds(wi, Xj);
             const double ws_delta = uni(sh.q[wi * Cfg::QN + 5 * NS + 2 * NU]);
             const double ws_smin = dmin(dmax(kWsKappa * ws_delta, kWsSMinLo), kWsSMinHi), ws_mu = kWsMuFactor * ws_smin * ws_smin;
