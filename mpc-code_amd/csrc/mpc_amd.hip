@@ -547,7 +547,7 @@ struct mpc_handle {
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
-static constexpr int kTpMaxBatch = 8192;      // auto choice of the loop kernel, see loop_mode(): measured crossover between 8192 and 16384
+static constexpr int kTpMaxBatch = 16384;     // auto choice of the loop kernel, see loop_mode(): measured crossover between 16384 and 32768
 static size_t pad64(size_t b) { return (b + 63) / 64 * 64; }
 
 // host [B][d] -> SoA staging [d][Bs]
@@ -772,7 +772,7 @@ extern "C" const char *mpc_build_info(void)
 {
     static std::string s;
     if (s.empty()) {
-        s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=8192),instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
+        s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
