@@ -295,6 +295,15 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
     const int b = blockIdx.x * NI + lane;
     const bool valid = wl && b < a.B;
     double *wsg = a.ws + (size_t)blockIdx.x * NI * Cfg::ROWS_ST * 64;      // state rows of this workgroup's instances
+    // the warm start of the target problem lives in LDS for the steps of this launch: a dependent round trip to HBM costs
+    // about 12 k cycles while the other workgroups stream their iterates, and the target solve would make three per step
+    constexpr int NTW = 2 * NU + 3 * (NX + NU + NY);
+    static_assert(NTW <= Cfg::KEEP_MAX, "target warm start does not fit its LDS slot");
+    double *twk = sh.keep + lane * Cfg::KEEP_MAX;
+    if (valid) {
+        sh.keepflag[lane] = a.tw_valid[b];
+        MPC_UNROLL for (int f = 0; f < NTW; f++) twk[f] = (a.tw + (size_t)f * Bs)[(unsigned)b];
+    }
     MPC_STAMP_INIT
     for (int k = 0; k < a.nsteps; k++) {
         // the instance index is made opaque once per step: the address arithmetic of the ~40 per-instance arrays below is loop
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
             MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
             int it_ss;
-            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, a.tw + bq, Bs, a.tw_valid + bq);
+            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, twk, 1, sh.keepflag + lane);
             if (st_ss != kInfeasible) {
                 MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
                 MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
@@ -442,6 +451,10 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
         }
         __syncthreads();
         MPC_STAMP_RESET
+    }
+    if (valid) {
+        a.tw_valid[b] = sh.keepflag[lane];
+        MPC_UNROLL for (int f = 0; f < NTW; f++) (a.tw + (size_t)f * Bs)[(unsigned)b] = twk[f];
     }
 }
 

@@ -42,7 +42,10 @@ struct TpCfg {
     static constexpr int QN = 5 * NS + 2 * NU + 1;                   // z0 zr c zlo zhi | ur us | ws_delta
     // state rows of an instance in HBM, [row][64 blocks]: s_lo s_hi l_lo l_hi dv (NC each) | u | z
     static constexpr int ST_SL = 0, ST_SH = NC, ST_LL = 2 * NC, ST_LH = 3 * NC, ST_DV = 4 * NC, ST_U = 5 * NC, ST_Z = 5 * NC + NU, ROWS_ST = 5 * NC + NV;
-    static constexpr size_t lds_bytes() { return sizeof(double) * (T_DOUBLES + NI * QN + NI * 4) + sizeof(int) * (3 * NI + 4); }
+    // per-instance data the closed loop keeps in LDS across the steps of one launch (HBM copy at launch start / end):
+    // the warm start of the target problem (its size depends on ny, which this struct does not know: room for ny <= 8) + flag
+    static constexpr int KEEP_MAX = 2 * NU + 3 * (NS + NU + 8);
+    static constexpr size_t lds_bytes() { return sizeof(double) * (T_DOUBLES + NI * QN + NI * 4 + NI * KEEP_MAX) + sizeof(int) * (4 * NI + 4); }
 };
 
 // Horizon-wide sums and maxima = reductions over the 64 lanes of a wave, on the DPP network (no LDS round trips):
@@ -94,11 +97,11 @@ template <int NS, int NU, int NC, int NW, int IPW>
 struct TpShared {
     using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
     static constexpr int NI = Cfg::NI;
-    double *T, *q, *red; int *flag, *iflag, *iters, *misc;
+    double *T, *q, *red, *keep; int *flag, *iflag, *iters, *keepflag, *misc;
     __device__ explicit TpShared(double *base)
     {
-        T = base; q = T + Cfg::T_DOUBLES; red = q + NI * Cfg::QN;
-        flag = (int *)(red + NI * 4); iflag = flag + NI; iters = iflag + NI; misc = iters + NI;
+        T = base; q = T + Cfg::T_DOUBLES; red = q + NI * Cfg::QN; keep = red + NI * 4;
+        flag = (int *)(keep + NI * Cfg::KEEP_MAX); iflag = flag + NI; iters = iflag + NI; keepflag = iters + NI; misc = keepflag + NI;
     }
     __device__ __forceinline__ double &t(int row, int inst, int k) const { return T[(row * NI + inst) * Cfg::LD + k]; }
 };
