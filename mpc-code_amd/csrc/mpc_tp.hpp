@@ -110,7 +110,7 @@ enum : int { kTpOk0 = 1, kTpWarm = 2, kTpValid = 4 };
 
 // Called by all NW*64 threads (lane = threadIdx.x, wave = threadIdx.y).  Instance data come from sh.q / sh.iflag
 // (written by wave 0, lanes < NI, before the call; a barrier is taken here).  On return wave 0, lane i < NI holds
-// status / iters / res of instance i; the final iterate is in the state rows (u0 = row ST_U.. at k = 0, z1 = ST_Z.. at k = 0).
+// status / iters of instance i; the final iterate is in the state rows (u0 = row ST_U.. at k = 0, z1 = ST_Z.. at k = 0).
 // wsg: state rows of this workgroup's instances [NI][ROWS_ST][64]; they hold the previous solve's iterate on entry.
 template <int NS, int NU, bool HASM, int NC, bool MASKED, int NW, int IPW>
 __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW> &sh, double *__restrict__ wsg,
@@ -239,7 +239,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         if (lane == 0) { sh.flag[wi] = verdict; if (verdict != 0) sh.iters[wi] = it; }
     };
 
-    // ---- instance constants; initial inputs (cold: us pushed inside the box; warm: previous inputs shifted one stage) -> LDS
+    // ---- instance constants; initial inputs (cold: us pushed inside the box; warm: previous inputs shifted one stage)
     double ll0[IPW][NC], lh0[IPW][NC], u0v[IPW][NU];
     MPC_UNROLL for (int j = 0; j < IPW; j++) {
         Inst &S = I[j];
