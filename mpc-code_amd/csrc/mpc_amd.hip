@@ -41,15 +41,18 @@ static int fail(int code, const char *fmt, ...)
 extern "C" const char *mpc_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------------
-// compiled dimension sets: NX, NU, NY, ND, NXP, DU
+// compiled dimension sets: NX, NU, NY, ND, NXP, DU, NG  (NG = bounded output rows that are not a multiple of one state;
+// each is carried as one more stage state, see build_problem)
 // ---------------------------------------------------------------------------------------------------
 #ifndef MPC_DIM_LIST
 #define MPC_DIM_LIST(X) \
-    X(3, 2, 3, 3, 3, 0) /* Ex_LMPC_CSTR */ \
-    X(4, 2, 2, 2, 4, 1) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */ \
-    X(3, 2, 2, 2, 3, 1) /* Ex_LMPC_nlplant (linear controller, Delta-u cost, non-linear plant on the host) */ \
-    X(2, 1, 1, 1, 2, 0) /* double integrator (tests: LQR known answer) */ \
-    X(2, 1, 1, 1, 2, 1)
+    X(3, 2, 3, 3, 3, 0, 0) /* Ex_LMPC_CSTR */ \
+    X(4, 2, 2, 2, 4, 1, 0) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */ \
+    X(3, 2, 2, 2, 3, 1, 0) /* Ex_LMPC_nlplant (linear controller, Delta-u cost, non-linear plant on the host) */ \
+    X(4, 2, 2, 2, 3, 1, 1) /* Ex_LMPCxp_nlplant (model state 4, plant state 3, one general output row: stage state 7) */ \
+    X(2, 1, 1, 1, 2, 0, 0) /* double integrator (tests: LQR known answer) */ \
+    X(2, 1, 1, 1, 2, 1, 0) \
+    X(2, 1, 1, 1, 2, 0, 1) /* double integrator with a bound on x0 + x1 (tests: general output row) */
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -63,10 +66,10 @@ struct OcpArgs {
     int B; size_t Bs;
 };
 
-template <int NX, int NU, int NY, int ND, bool DU, int NC, bool MASKED>
+template <int NX, int NU, int NY, int ND, bool DU, int NG, int NC, bool MASKED>
 __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ Pp, OcpArgs a)
 {
-    constexpr int NS = NX + (DU ? NU : 0);
+    constexpr int NS = NX + (DU ? NU : 0) + NG;
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
     const DevProblem &P = *Pp;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     MPC_UNROLL for (int i = 0; i < NU; i++) { us[i] = a.us[i * a.Bs + b]; up[i] = a.u_prev[i * a.Bs + b]; }
     MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
     OcpInst<NS, NU> q;
-    build_inst<NX, NU, NY, ND, DU>(P, xhat, xs, us, dh, up, q);
+    build_inst<NX, NU, NY, ND, DU, NG>(P, xhat, xs, us, dh, up, q);
     StageConst<NS, NU> C;
     load_stage_const<NS, NU, DU>(P, C);
     constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
@@ -161,10 +164,10 @@ struct LoopArgs {
     int B, nsteps; size_t Bs;
 };
 
-template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NC, bool MASKED>
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
 __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__ Pp, LoopArgs a)
 {
-    constexpr int NS = NX + (DU ? NU : 0), NE = NX + ND;
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NE = NX + ND;
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
     const DevProblem &P = *Pp;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         }
         // ---- OCP (MPC_code.py:733-805) -------------------------------------------------------------
         OcpInst<NS, NU> q;
-        build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
+        build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, q);
         double u0[NU], z1[NS], res[3];
         int it_dyn;
         double delta = 0.0;
@@ -280,10 +283,10 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
 // The closed loop with the horizon-parallel OCP solver (mpc_tp.hpp): a workgroup of NI waves owns NI instances.
 // Wave 0, lane i < NI does for instance i what one lane of loop_kernel does (estimator, target, hold rules, plant);
 // all waves solve the OCPs together.  Between the two halves of a step the loop state lives in HBM.
-template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NC, bool MASKED, int NW, int IPW>
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED, int NW, int IPW>
 __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__restrict__ Pp, LoopArgs a)
 {
-    constexpr int NS = NX + (DU ? NU : 0), NE = NX + ND;
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NE = NX + ND;
     using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
     constexpr int NI = Cfg::NI;
     extern __shared__ double tp_smem[];
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             if (a.st_dyn) { (a.st_ss + (size_t)k * Bs)[bq] = st_ss; (a.it_ss + (size_t)k * Bs)[bq] = it_ss; }
             // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS; loop state -> HBM ------------
             OcpInst<NS, NU> q;
-            build_inst<NX, NU, NY, ND, DU>(P, xh, xs, us, dh, u, q);
+            build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, q);
             double delta = 0.0;
             MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - xh_pred[i]), fabs(xs[i] - xs_prev[i])));
             MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
@@ -482,18 +485,18 @@ struct Launchers {
 // bound modes: which variant of the OCP kernels a problem may use (cheapest first)
 enum { kBoundsAllFinite = 1, kBoundsInputsOnly = 2, kBoundsGeneric = 0 };
 
-template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NC, bool MASKED>
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
 static Launchers make_launchers_mode()
 {
     Launchers l;
-    l.ocp = [](const DevProblem *p, OcpArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel<NX, NU, NY, ND, DU, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.ocp = [](const DevProblem *p, OcpArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel<NX, NU, NY, ND, DU, NG, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
-    l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
-    l.ws_rows = 2 * BlkLayout<NX + (DU ? NU : 0), NU, NC>::SLOTS;   // doubles per instance per block
+    l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    l.ws_rows = 2 * BlkLayout<NX + (DU ? NU : 0) + NG, NU, NC>::SLOTS;   // doubles per instance per block
     {
         // eight waves (256 VGPRs each); two instances per wave when their transposing buffer still fits the 160 KB of LDS
-        constexpr int NW = 8, NSZ = NX + (DU ? NU : 0);
+        constexpr int NW = 8, NSZ = NX + (DU ? NU : 0) + NG;
         constexpr int IPW = TpCfg<NSZ, NU, NC, NW, 2>::lds_bytes() <= 160 * 1024 ? 2 : 1;
         using Cfg = TpCfg<NSZ, NU, NC, NW, IPW>;
         constexpr size_t lds = Cfg::lds_bytes();
@@ -501,7 +504,7 @@ static Launchers make_launchers_mode()
         l.loop_tp = nullptr;
         if (lds <= 160 * 1024) {
             l.loop_tp = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
-                auto kern = loop_kernel_tp<NX, NU, NY, ND, NXP, DU, NC, MASKED, NW, IPW>;
+                auto kern = loop_kernel_tp<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NW, IPW>;
                 static bool attr_set[64] = {};      // per device: more than 64 KB of dynamic LDS has to be asked for
                 int dev = 0;
                 if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -518,13 +521,13 @@ static Launchers make_launchers_mode()
     return l;
 }
 
-template <int NX, int NU, int NY, int ND, int NXP, bool DU>
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG>
 static Launchers make_launchers(int mode)
 {
-    constexpr int NS = NX + (DU ? NU : 0);
-    if (mode == kBoundsAllFinite) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NS + NU, false>();
-    if (mode == kBoundsInputsOnly) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NU, false>();
-    return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NS + NU, true>();
+    constexpr int NS = NX + (DU ? NU : 0) + NG;
+    if (NG == 0 && mode == kBoundsAllFinite) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NG, NS + NU, false>();
+    if (NG == 0 && mode == kBoundsInputsOnly) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NG, NU, false>();
+    return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NG, NS + NU, true>();      // output-row states are free at the terminal stage: masks
 }
 
 struct DevBuf {
@@ -578,6 +581,19 @@ static void from_soa(const double *src, int B, int d, size_t Bs, double *dst)
         const double *row = src + (size_t)i * Bs;
         for (int b = 0; b < B; b++) dst[(size_t)b * d + i] = row[b];
     }
+}
+
+// bounded output rows that are not a multiple of one state; rows[] (optional) receives their indices
+static int general_output_rows(const mpc_lin_desc *d, int *rows)
+{
+    int ng = 0;
+    if (!d->y_bounded) return 0;
+    for (int i = 0; i < d->ny; i++) {
+        int cnt = 0;
+        for (int j = 0; j < d->nx; j++) if (d->C[i * d->nx + j] != 0.0) cnt++;
+        if (cnt != 1 && (std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]))) { if (rows && ng < kMaxY) rows[ng] = i; ng++; }
+    }
+    return ng;
 }
 
 // Householder QR of [A-I, B]' and the reduced target problem
@@ -681,11 +697,22 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
         for (int j = 0; j < nxp; j++) P.Ap[i][j] = d->Ap[i * nxp + j];
         for (int j = 0; j < m; j++) P.Bp[i][j] = d->Bp[i * m + j];
     }
+    // Bounded output rows (Control_Calc.py:130,150-151,229-230).  A row with a single non-zero entry is a box on that state.
+    // Any other row i gets a stage state of its own, w = C_i x, carried by w+ = C_i (A x + B u + c): the row becomes a box on w
+    // at k = 1..N-1 (the terminal state has no output row); no cost on w.
+    P.ng = general_output_rows(d, P.yg_row);
     if (d->y_bounded) {
+        const int nb = n0 + (d->du_form ? m : 0);
         for (int i = 0; i < q; i++) {
-            int cnt = 0;
-            for (int j = 0; j < n0; j++) if (d->C[i * n0 + j] != 0.0) { P.ymap_idx[i] = j; P.ymap_scale[i] = d->C[i * n0 + j]; cnt++; }
-            if (cnt != 1) return fail(-3, "output bound row %d of C has %d non-zero entries: general output rows are not implemented", i, cnt);
+            P.ymap_idx[i] = -1;       // unbounded rows and rows that are identically zero: nothing to map
+            for (int j = 0; j < n0; j++) if (d->C[i * n0 + j] != 0.0) { P.ymap_idx[i] = j; P.ymap_scale[i] = d->C[i * n0 + j]; }
+        }
+        for (int g = 0; g < P.ng; g++) {
+            const int i = P.yg_row[g], r = nb + g;
+            P.ymap_idx[i] = r; P.ymap_scale[i] = 1.0;
+            for (int j = 0; j < n0; j++) { double acc = 0.0; for (int l = 0; l < n0; l++) acc += d->C[i * n0 + l] * d->A[l * n0 + j]; P.A[r][j] = acc; }
+            for (int j = 0; j < m; j++) { double acc = 0.0; for (int l = 0; l < n0; l++) acc += d->C[i * n0 + l] * d->B[l * m + j]; P.B[r][j] = acc; }
+            P.zlo_m[r] = P.zlo_e[r] = -INFINITY; P.zhi_m[r] = P.zhi_e[r] = INFINITY;
         }
     }
     for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) P.Apow[0][i][j] = P.A[i][j];
@@ -735,7 +762,7 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
 {
     if (!d || !out) return fail(-1, "null argument");
     *out = nullptr;
-    const int ns = d->nx + (d->du_form ? d->nu : 0);
+    const int ns = d->nx + (d->du_form ? d->nu : 0) + general_output_rows(d, nullptr);
     if (d->nx < 1 || d->nu < 1 || ns > kMaxN || d->nu > kMaxM || d->ny > kMaxY || d->nd > kMaxD || d->nxp > kMaxN || d->N < 2 || d->N > 512)
         return fail(-2, "dimensions out of range (stage state <= %d, nu <= %d, ny <= %d, nd <= %d, 2 <= N <= 512)", kMaxN, kMaxM, kMaxY, kMaxD);
     int ndev = 0;
@@ -743,16 +770,17 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
     if (d->device < 0 || d->device >= ndev) return fail(-11, "device %d out of range (have %d)", d->device, ndev);
     mpc_handle *h = new mpc_handle();
     bool found = false;
-#define MPC_TRY_DIM(NX, NU, NY, ND, NXP, DU)                                                                  \
-    if (!found && d->nx == NX && d->nu == NU && d->ny == NY && d->nd == ND && d->nxp == NXP && (d->du_form != 0) == (DU != 0)) { \
-        h->L = make_launchers<NX, NU, NY, ND, NXP, (DU != 0)>(bound_mode(d));                                 \
+    const int ng = general_output_rows(d, nullptr);
+#define MPC_TRY_DIM(NX, NU, NY, ND, NXP, DU, NG)                                                              \
+    if (!found && d->nx == NX && d->nu == NU && d->ny == NY && d->nd == ND && d->nxp == NXP && (d->du_form != 0) == (DU != 0) && ng == NG) { \
+        h->L = make_launchers<NX, NU, NY, ND, NXP, (DU != 0), NG>(bound_mode(d));                             \
         found = true;                                                                                         \
     }
     MPC_DIM_LIST(MPC_TRY_DIM)
 #undef MPC_TRY_DIM
     if (!found) {
         delete h;
-        return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, d->du_form, mpc_build_info());
+        return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d general_output_rows=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, d->du_form, ng, mpc_build_info());
     }
     int rc = build_problem(d, h->hp);
     if (rc != 0) { delete h; return rc; }
@@ -786,7 +814,7 @@ extern "C" const char *mpc_build_info(void)
     static std::string s;
     if (s.empty()) {
         s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
-#define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU ",";
+#define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU, NG) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU "/" #NG ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
         s.pop_back();

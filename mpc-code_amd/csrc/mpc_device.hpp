@@ -52,7 +52,8 @@ struct DevProblem {
     double Am[kMaxN][kMaxN], Bm[kMaxN][kMaxM], Cm[kMaxY][kMaxN], Bd[kMaxN][kMaxD], Cd[kMaxY][kMaxD], fxc[kMaxN], fyc[kMaxY];
     double Ap[kMaxN][kMaxN], Bp[kMaxN][kMaxM], Cp[kMaxY][kMaxN];
     double ymin[kMaxY], ymax[kMaxY], dmin[kMaxD], dmax[kMaxD];
-    int ymap_idx[kMaxY]; double ymap_scale[kMaxY];
+    int ymap_idx[kMaxY]; double ymap_scale[kMaxY];      // bounded output row i = ymap_scale * stage state ymap_idx (< 0: none)
+    int ng, yg_row[kMaxY];                               // output rows carried as stage states of their own (general rows of C)
     // target problem in null-space coordinates
     double Ep[kMaxV][kMaxN], Zn[kMaxV][kMaxM], CZx[kMaxY][kMaxM], Hr[kMaxM][kMaxM], W[kMaxC][kMaxM], tlo[kMaxC], thi[kMaxC];
     double Qss[kMaxY][kMaxY], Rss[kMaxM][kMaxM];
@@ -194,12 +195,12 @@ struct OcpInst {
 };
 
 // xhat, xs [NX]; us, u_prev [NU]; dhat [ND]  ->  stage-form instance
-template <int NX, int NU, int NY, int ND, bool DU>
+template <int NX, int NU, int NY, int ND, bool DU, int NG>
 __device__ __forceinline__ void build_inst(const DevProblem &P, const double (&xhat)[NX], const double (&xs)[NX],
                                            const double (&us)[NU], const double *dhat, const double (&u_prev)[NU],
-                                           OcpInst<NX + (DU ? NU : 0), NU> &q)
+                                           OcpInst<NX + (DU ? NU : 0) + NG, NU> &q)
 {
-    constexpr int NS = NX + (DU ? NU : 0);
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NB = NX + (DU ? NU : 0);
     MPC_UNROLL for (int i = 0; i < NX; i++) {
         double c = P.fxc[i];
         MPC_UNROLL for (int j = 0; j < ND; j++) c += P.Bd[i][j] * dhat[j];
@@ -208,6 +209,12 @@ __device__ __forceinline__ void build_inst(const DevProblem &P, const double (&x
     MPC_UNROLL for (int i = 0; i < NU; i++) { q.us[i] = us[i]; q.ur[i] = DU ? 0.0 : us[i]; }
     if (DU) {
         MPC_UNROLL for (int i = 0; i < NU; i++) { q.z0[NX + i] = u_prev[i]; q.zr[NX + i] = 0.0; q.c[NX + i] = 0.0; }
+    }
+    MPC_UNROLL for (int g = 0; g < NG; g++) {      // output-row states w = C_i x: initial value, reference, affine term
+        const int r = P.yg_row[g];
+        double w0 = 0.0, wr = 0.0, wc = 0.0;
+        MPC_UNROLL for (int j = 0; j < NX; j++) { const double cij = P.Cm[r][j]; w0 += cij * xhat[j]; wr += cij * xs[j]; wc += cij * q.c[j]; }
+        q.z0[NB + g] = w0; q.zr[NB + g] = wr; q.c[NB + g] = wc;
     }
     MPC_UNROLL for (int i = 0; i < NS; i++) { q.zlo_m[i] = P.zlo_m[i]; q.zhi_m[i] = P.zhi_m[i]; }
     q.ok0 = true;
@@ -224,7 +231,7 @@ __device__ __forceinline__ void build_inst(const DevProblem &P, const double (&x
             const double a = (P.ymin[i] - e) / sc, b = (P.ymax[i] - e) / sc;
             const double lo = sc > 0 ? a : b, hi = sc > 0 ? b : a;
             const int idx = P.ymap_idx[i];
-            MPC_UNROLL for (int j = 0; j < NX; j++)
+            MPC_UNROLL for (int j = 0; j < NS; j++)
                 if (j == idx) { q.zlo_m[j] = dmax(q.zlo_m[j], lo); q.zhi_m[j] = dmin(q.zhi_m[j], hi); }
         }
     }

@@ -79,10 +79,26 @@ static double dmin2(double a, double b) { return a < b ? a : b; }
  * stage form (see the docstring of oracle/riccati_np.py)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-    int n, m, N;
+    int n, m, N, ng, yg[MAXN];      /* yg: output rows carried as extra stage states (general rows of C) */
     double A[MAXN][MAXN], B[MAXN][MAXM], Q[MAXN][MAXN], M[MAXN][MAXM], R[MAXM][MAXM], Pf[MAXN][MAXN];
     double ulo[MAXM], uhi[MAXM], zlo_m[MAXN], zhi_m[MAXN], zlo_e[MAXN], zhi_e[MAXN];
 } stage_t;
+
+/* bounded output row that is not a multiple of one state (riccati_np.general_output_rows) */
+static int general_row(const orc_problem *p, int i)
+{
+    int cnt = 0;
+    if (!p->y_bounded) return 0;
+    for (int j = 0; j < p->nx; j++) if (p->C[i * p->nx + j] != 0.0) cnt++;
+    return cnt != 1 && (isfinite(p->ymin[i]) || isfinite(p->ymax[i]));
+}
+
+static int stage_dim(const orc_problem *p)
+{
+    int n = p->nx + (p->du_form ? p->nu : 0);
+    for (int i = 0; i < p->ny; i++) n += general_row(p, i);
+    return n;
+}
 
 static void build_stage(const orc_problem *p, stage_t *s)
 {
@@ -107,6 +123,16 @@ static void build_stage(const orc_problem *p, stage_t *s)
             s->zhi_m[n0 + i] = s->zhi_e[n0 + i] = INFINITY;
         }
     }
+    /* general output rows: w_i = C_i x as an extra state, w+ = C_i (A x + B u + c); box on w for k = 1..N-1 only */
+    for (int i = 0; i < p->ny; i++) {
+        if (!general_row(p, i)) continue;
+        int r = n + s->ng;
+        s->yg[s->ng++] = i;
+        for (int j = 0; j < n0; j++) { double a = 0.0; for (int l = 0; l < n0; l++) a += p->C[i * n0 + l] * p->A[l * n0 + j]; s->A[r][j] = a; }
+        for (int j = 0; j < m; j++) { double a = 0.0; for (int l = 0; l < n0; l++) a += p->C[i * n0 + l] * p->B[l * m + j]; s->B[r][j] = a; }
+        s->zlo_m[r] = s->zlo_e[r] = -INFINITY; s->zhi_m[r] = s->zhi_e[r] = INFINITY;
+    }
+    s->n = n + s->ng;
 }
 
 typedef struct {
@@ -127,6 +153,12 @@ static int build_inst(const orc_problem *p, const stage_t *s, const double *xhat
     }
     for (int i = 0; i < m; i++) { q->us[i] = us[i]; q->ur[i] = p->du_form ? 0.0 : us[i]; }
     if (p->du_form) for (int i = 0; i < m; i++) { q->z0[n0 + i] = u_prev[i]; q->zr[n0 + i] = 0.0; q->c[n0 + i] = 0.0; }
+    for (int g = 0; g < s->ng; g++) {
+        int r = s->n - s->ng + g, i = s->yg[g];
+        double a = 0.0, b = 0.0, cc = 0.0;
+        for (int j = 0; j < n0; j++) { double cij = p->C[i * n0 + j]; a += cij * xhat[j]; b += cij * xs[j]; cc += cij * q->c[j]; }
+        q->z0[r] = a; q->zr[r] = b; q->c[r] = cc;
+    }
     for (int i = 0; i < s->n; i++) { q->zlo_m[i] = s->zlo_m[i]; q->zhi_m[i] = s->zhi_m[i]; }
     q->ok0 = 1;
     if (p->y_bounded) {
@@ -139,10 +171,14 @@ static int build_inst(const orc_problem *p, const stage_t *s, const double *xhat
                 y0 += cij * xhat[j];
                 if (cij != 0.0) { idx = j; sc = cij; cnt++; }
             }
-            if (cnt != 1) return -1;          /* general output rows: not supported */
             /* stage-0 row: pure feasibility test with IPOPT's bound relaxation (Control_Calc.py:128-151) */
             double rl = BOUND_RELAX * dmax2(1.0, fabs(p->ymin[i])), rh = BOUND_RELAX * dmax2(1.0, fabs(p->ymax[i]));
             if (!(y0 >= p->ymin[i] - rl) || !(y0 <= p->ymax[i] + rh)) q->ok0 = 0;
+            if (cnt != 1) {                    /* general row: its own stage state, or unbounded */
+                for (int g = 0; g < s->ng; g++)
+                    if (s->yg[g] == i) { q->zlo_m[s->n - s->ng + g] = p->ymin[i] - e; q->zhi_m[s->n - s->ng + g] = p->ymax[i] - e; }
+                continue;
+            }
             double a = (p->ymin[i] - e) / sc, b = (p->ymax[i] - e) / sc;
             double lo = sc > 0 ? a : b, hi = sc > 0 ? b : a;
             q->zlo_m[idx] = dmax2(q->zlo_m[idx], lo);
@@ -438,7 +474,7 @@ int orc_ocp_solve(const orc_problem *p, int Bsz, const double *xhat, const doubl
                   int32_t *iters, double *res, double *w_out)
 {
     stage_t st;
-    if (p->nx + (p->du_form ? p->nu : 0) > MAXN || p->nu > MAXM || p->N > MAXH || p->ny > MAXY || p->nd > MAXD) return -2;
+    if (stage_dim(p) > MAXN || p->nu > MAXM || p->N > MAXH || p->ny > MAXY || p->nd > MAXD) return -2;
     build_stage(p, &st);
     int err = 0;
 #pragma omp parallel
@@ -760,7 +796,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
     stage_t st; target_t tg;
     const int n = p->nx, m = p->nu, q = p->ny, nd = p->nd, nxp = p->nxp, ne = n + nd;
     double Aa[MAXE][MAXE], Ca[MAXY][MAXE];
-    if (p->nx + (p->du_form ? p->nu : 0) > MAXN || m > MAXM || p->N > MAXH || q > MAXY || nd > MAXD) return -2;
+    if (stage_dim(p) > MAXN || m > MAXM || p->N > MAXH || q > MAXY || nd > MAXD) return -2;
     build_stage(p, &st);
     if (build_target(p, &tg) != 0) return -4;
     est_mats(p, Aa, Ca);

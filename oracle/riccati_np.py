@@ -65,18 +65,41 @@ def stage_data(p):
         inf = np.full(m, np.inf)
         zlo_m, zhi_m = np.concatenate([p.xmin, -inf]), np.concatenate([p.xmax, inf])
         zlo_e, zhi_e = zlo_m.copy(), zhi_m.copy()
+    # Output rows C_i x with several (or no) non-zero entries: one extra stage state w_i = C_i x each, carried by
+    # w+ = C_i (A x + B u + c), so that the row becomes a box on a state (k = 1..N-1; the terminal state has no output row,
+    # Control_Calc.py:150-151,229-230).  No cost on w.
+    yg = general_output_rows(p)
+    if len(yg):
+        na, ng = A.shape[0], len(yg)
+        Cg = p.C[yg]
+        A2 = np.zeros((na + ng, na + ng)); A2[:na, :na] = A; A2[na:, :n] = Cg @ p.A
+        B = np.vstack([B, Cg @ p.B])
+        Q2 = np.zeros((na + ng, na + ng)); Q2[:na, :na] = Q
+        Pf2 = np.zeros((na + ng, na + ng)); Pf2[:na, :na] = Pf
+        M = np.vstack([M, np.zeros((ng, m))])
+        inf = np.full(ng, np.inf)
+        zlo_m, zhi_m = np.concatenate([zlo_m, -inf]), np.concatenate([zhi_m, inf])
+        zlo_e, zhi_e = np.concatenate([zlo_e, -inf]), np.concatenate([zhi_e, inf])
+        A, Q, Pf = A2, Q2, Pf2
     return dict(A=A, B=B, Q=Q, M=M, R=R, Pf=Pf, ulo=p.umin.copy(), uhi=p.umax.copy(),
-                zlo_m=zlo_m, zhi_m=zhi_m, zlo_e=zlo_e, zhi_e=zhi_e, n=A.shape[0], m=m, N=p.N)
+                zlo_m=zlo_m, zhi_m=zhi_m, zlo_e=zlo_e, zhi_e=zhi_e, n=A.shape[0], m=m, N=p.N, yg=yg)
+
+
+def general_output_rows(p):
+    """Indices of the bounded output rows that are not a multiple of one state (those map onto that state's box)."""
+    if not p.y_bounded:
+        return np.zeros(0, dtype=int)
+    return np.array([i for i in range(p.ny) if np.count_nonzero(p.C[i]) != 1
+                     and (np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i]))], dtype=int)
 
 
 def _ymap(p):
     idx = np.full(p.ny, -1, dtype=int); scale = np.zeros(p.ny)
     for i in range(p.ny):
         nz = np.nonzero(p.C[i])[0]
-        if len(nz) != 1:
-            raise NotImplementedError("output bound row with more than one state entry")
-        idx[i], scale[i] = nz[0], p.C[i, nz[0]]
-    return idx, scale
+        if len(nz) == 1:
+            idx[i], scale[i] = nz[0], p.C[i, nz[0]]
+    return idx, scale      # idx < 0: a general row (own stage state) or an unbounded one
 
 
 def instance_data(p, sd, xhat, xs, us, dhat, u_prev):
@@ -89,6 +112,10 @@ def instance_data(p, sd, xhat, xs, us, dhat, u_prev):
     else:
         z0 = np.hstack([xhat, u_prev]); zr = np.hstack([xs, np.zeros((Bsz, m))]); ur = np.zeros((Bsz, m))
         c = np.hstack([c, np.zeros((Bsz, m))])
+    yg = sd.get("yg", ())
+    if len(yg):
+        Cg = p.C[yg]
+        z0 = np.hstack([z0, xhat @ Cg.T]); zr = np.hstack([zr, xs @ Cg.T]); c = np.hstack([c, c[:, :n] @ Cg.T])
     na = sd["n"]
     zlo_m = np.broadcast_to(sd["zlo_m"], (Bsz, na)).copy(); zhi_m = np.broadcast_to(sd["zhi_m"], (Bsz, na)).copy()
     ok0 = np.ones(Bsz, dtype=bool)
@@ -101,10 +128,14 @@ def instance_data(p, sd, xhat, xs, us, dhat, u_prev):
         rl = BOUND_RELAX * np.maximum(1.0, np.abs(p.ymin)); rh = BOUND_RELAX * np.maximum(1.0, np.abs(p.ymax))
         ok0 = np.all((y0 >= p.ymin - rl) & (y0 <= p.ymax + rh), axis=1)
         for i in range(p.ny):
+            if idx[i] < 0:
+                continue
             a, b = (p.ymin[i] - e[:, i]) / scale[i], (p.ymax[i] - e[:, i]) / scale[i]
             lo_i, hi_i = (a, b) if scale[i] > 0 else (b, a)
             zlo_m[:, idx[i]] = np.maximum(zlo_m[:, idx[i]], lo_i)
             zhi_m[:, idx[i]] = np.minimum(zhi_m[:, idx[i]], hi_i)
+        for g, i in enumerate(yg):
+            zlo_m[:, na - len(yg) + g] = p.ymin[i] - e[:, i]; zhi_m[:, na - len(yg) + g] = p.ymax[i] - e[:, i]
     zlo_e = np.broadcast_to(sd["zlo_e"], (Bsz, na)).copy(); zhi_e = np.broadcast_to(sd["zhi_e"], (Bsz, na)).copy()
     return dict(z0=z0, zr=zr, ur=ur, c=c, zlo_m=zlo_m, zhi_m=zhi_m, zlo_e=zlo_e, zhi_e=zhi_e, ok0=ok0,
                 us=us.copy())

@@ -48,6 +48,33 @@ def nlplant(pkg):
 
 
 @pytest.fixture(scope="session")
+def xp_nlplant(pkg):
+    return pkg.load_problem(pkg.example_path("cstr_xp_nlplant_lmpc.py"))
+
+
+def double_integrator_with_output_row(N=20, du=False):
+    """nx=2, nu=1 with the bounded output y = x0 + x1: a general row of C (no single state carries it)."""
+    import scipy.linalg as scla
+    from mpc_code_amd.problem import LinearMPCProblem
+    A = np.array([[1.0, 0.1], [0.0, 1.0]]); Bm = np.array([[0.005], [0.1]]); C = np.array([[1.0, 1.0]])
+    Q = np.diag([1.0, 0.1]); R = np.array([[0.01]])
+    P = scla.solve_discrete_are(A, Bm, Q, R)
+    inf = np.inf
+    return LinearMPCProblem(nx=2, nu=1, ny=1, nd=1, nxp=2, N=N, h=0.1, Nsim=10, A=A, B=Bm, C=C, Bd=np.array([[0.0], [0.1]]), Cd=np.array([[0.3]]),
+                            fx_const=np.zeros(2), fy_const=np.array([0.05]), Ap=A, Bp=Bm, Cp=C, Q=Q, R=R, DUForm=du, P=P,
+                            Qss=np.eye(1), Rss=np.zeros((1, 1)), DUssForm=False, umin=np.array([-1.0]), umax=np.array([1.0]),
+                            xmin=np.array([-inf, -0.8]), xmax=np.array([2.0, inf]), ymin=np.array([-0.4]), ymax=np.array([0.7]), y_bounded=True,
+                            umin_ss=np.array([-1.0]), umax_ss=np.array([1.0]), xmin_ss=np.array([-inf, -0.8]), xmax_ss=np.array([2.0, inf]),
+                            ymin_ss=np.array([-inf]), ymax_ss=np.array([inf]), estimator="kalss", K=np.array([[0.5], [0.1], [0.2]]),
+                            x0_p=np.zeros(2), x0_m=np.zeros(2), u0=np.zeros(1), dhat0=np.zeros(1))
+
+
+@pytest.fixture(scope="session")
+def dint_yrow(pkg):
+    return double_integrator_with_output_row()
+
+
+@pytest.fixture(scope="session")
 def oracle_c():
     import oracle_c as oc
     oc.build()

@@ -7,7 +7,7 @@ import pytest
 from conftest import REF
 
 FIELDS = ["A", "B", "C", "Bd", "Cd", "Ap", "Bp", "Cp", "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax",
-          "ymin", "ymax", "x0_p", "x0_m", "u0"]
+          "ymin", "ymax", "x0_p", "x0_m", "u0", "fx_const", "fy_const", "Q_kf", "R_kf", "P0"]
 
 
 def test_cstr_dimensions_and_flags(cstr):
@@ -38,7 +38,8 @@ def test_schedules_follow_callbacks(cstr):
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("ours,theirs", [("cstr_lmpc.py", "Ex_LMPC_CSTR.py"), ("wood_berry_lmpc.py", "Ex_LMPC_WB.py"),
-                                         ("cstr_nlplant_lmpc.py", "Ex_LMPC_nlplant.py")])
+                                         ("cstr_nlplant_lmpc.py", "Ex_LMPC_nlplant.py"),
+                                         ("cstr_xp_nlplant_lmpc.py", "Ex_LMPCxp_nlplant.py")])
 def test_unmodified_reference_examples_load_to_the_same_problem(pkg, ours, theirs):
     a = pkg.load_problem(pkg.example_path(ours))
     b = pkg.load_problem(os.path.join(REF, theirs))

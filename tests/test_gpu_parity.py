@@ -392,3 +392,49 @@ def test_both_kernels_leave_the_same_resident_state(cstr, solver_factory):
     for k in ("x_p", "xhat", "dhat", "u", "xs", "us"):
         assert np.abs(fin[0][k] - fin[1][k]).max() < 1e-6, k
     assert np.array_equal(fin[0]["P"], fin[1]["P"])                     # same operations on the same numbers
+
+
+def test_general_output_rows(dint_yrow, xp_nlplant, oracle_c, solver_factory):
+    """Bounded output rows that touch several states (Control_Calc.py:130,150-151,229-230): one extra stage state each
+    (mpc_amd.hip:build_problem).  Double integrator with y = x0 + x1 bounded, row active: per solve and in the fused closed
+    loop of both kernels; then Ex_LMPCxp_nlplant (model state 4, plant state 3, ylin, one general row) through the three
+    calls with the non-linear plant on the host."""
+    from mpc_code_amd.driver import run_closed_loop
+    p = dint_yrow
+    rng = np.random.default_rng(8)
+    B = 200
+    xh = np.column_stack([rng.uniform(-0.3, 0.3, B), rng.uniform(-0.5, 0.5, B)]); xs = np.tile([1.0, 0.0], (B, 1)); us = np.zeros((B, 1))
+    d = rng.uniform(-0.1, 0.1, (B, 1)); up = rng.uniform(-0.5, 0.5, (B, 1))
+    s, oc = solver_factory(p), oracle_c.OracleC(p)
+    assert "2/1/1/1/2/0/1" in s.build_info()
+    g, c = s.ocp_solve(xh, xs, us, d, up, want_w=True), oc.ocp_solve(xh, xs, us, d, up, want_w=True)
+    assert np.array_equal(g["status"], c["status"]) and (c["status"] == 2).any()
+    ok = c["status"] == 0
+    assert ok.sum() > 100 and np.abs(g["u0"] - c["u0"])[ok].max() < TOL_PORT and np.abs(g["x1"] - c["x1"])[ok].max() < TOL_PORT
+    w = g["w"][ok]; nxu = 3
+    y = np.stack([w[:, k * nxu:k * nxu + 2] @ p.C[0] for k in range(1, p.N)], axis=1) + p.fy_const[0] + p.Cd[0, 0] * d[ok]
+    assert y.max() <= p.ymax[0] + 1e-7 and y.min() >= p.ymin[0] - 1e-7 and (y.max(axis=1) > p.ymax[0] - 1e-5).sum() > 20      # the row binds
+    x0 = rng.uniform(-0.2, 0.2, (150, 2))
+    cl = oc.closed_loop(25, x0, x0)
+    for lk in (1, 2):
+        gl = run_closed_loop(p, x0, x0, 25, solver=solver_factory(p, lk))
+        assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), lk
+        assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, lk
+    # the reference example
+    q = xp_nlplant
+    B = 96
+    xh = q.x0_m + rng.normal(size=(B, 4)) * [0.02, 1.0, 0.02, 0.3]; dq = rng.normal(size=(B, 2)) * [0.5, 0.01]
+    xs = q.x0_m + rng.normal(size=(B, 4)) * [0.005, 0.3, 0.005, 0.1]; us = q.u0 + rng.normal(size=(B, 2)) * [0.5, 0.005]; uq = np.tile(q.u0, (B, 1))
+    s, oc = solver_factory(q), oracle_c.OracleC(q)
+    g, c = s.ocp_solve(xh, xs, us, dq, uq), oc.ocp_solve(xh, xs, us, dq, uq)
+    assert np.array_equal(g["status"], c["status"])
+    ok = c["status"] == 0
+    assert ok.sum() > B // 2 and np.abs(g["u0"] - c["u0"])[ok].max() < 1e-6 and np.abs(g["x1"] - c["x1"])[ok].max() < 1e-6
+    ysp, usp, xsp = q.defSP(0.0)
+    t, tc = s.target_solve(usp, ysp, xsp, dq, uq), oc.target_solve(usp, ysp, xsp, dq, uq)
+    assert np.array_equal(t["status"], tc["status"]) and np.abs(t["xs"] - tc["xs"]).max() < 1e-8 and np.abs(t["us"] - tc["us"]).max() < 1e-8
+    x0p = q.x0_p + rng.normal(size=(12, 3)) * [2e-4, 0.02, 2e-4]; x0m = np.hstack([x0p, np.zeros((12, 1))])
+    gl = run_closed_loop(q, x0p, x0m, 8, solver=s, fused=False)
+    nl = rn.closed_loop_batch(q, 8, x0p, x0m, warm_start=False)
+    assert np.array_equal(gl["STATUS_DYN"], nl["STATUS_DYN"]) and (gl["STATUS_DYN"] == 0).all()
+    assert np.abs(gl["U"] - nl["U"]).max() < 1e-5 and np.abs(gl["Xp"] - nl["Xp"]).max() < 1e-5

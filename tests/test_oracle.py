@@ -125,3 +125,46 @@ def test_kalman_matches_textbook_form(cstr):
     assert np.allclose(a, xi + K @ (y - yhat)) and np.allclose(b, Aa @ (Pm - K @ Ca @ Pm) @ Aa.T + cstr.Q_kf)
     a2, b2 = rn.kalman_batch(cstr, xi[None], Pm[None], y[None], yhat[None])
     assert np.allclose(a2[0], a) and np.allclose(b2[0], b)
+
+
+def test_general_output_rows_against_the_dense_statement(dint_yrow, xp_nlplant):
+    """Output rows that touch several states (Control_Calc.py:130,150-151,229-230) are carried by the Riccati statement as
+    extra stage states; the dense statement has them as plain inequality rows.  Same optimum, with the row active."""
+    p = dint_yrow
+    sd = rn.stage_data(p)
+    assert sd["n"] == 3 and list(sd["yg"]) == [0]
+    rng = np.random.default_rng(3)
+    B = 24
+    xh = np.column_stack([rng.uniform(-0.3, 0.3, B), rng.uniform(-0.5, 0.5, B)]); xs = np.tile([1.0, 0.0], (B, 1)); us = np.zeros((B, 1))
+    d = rng.uniform(-0.1, 0.1, (B, 1)); up = np.zeros((B, 1))
+    r = rn.rpdip_solve(sd, rn.instance_data(p, sd, xh, xs, us, d, up))
+    n_active = 0
+    for b in range(B):
+        e = o.ocp_solve_exact(p, xh[b], xs[b], us[b], d[b], up[b])
+        assert (e["status"] == 2) == (r["status"][b] == 2)
+        if e["status"] != 0:
+            continue
+        assert np.abs(e["u0"] - r["u0"][b]).max() < 1e-6
+        y = r["z"][b, 1:p.N, :2] @ p.C[0] + p.fy_const[0] + p.Cd[0, 0] * d[b, 0] if "z" in r else None
+        if y is not None:
+            assert y.max() <= p.ymax[0] + 1e-7 and y.min() >= p.ymin[0] - 1e-7
+            assert np.abs(r["z"][b, :, 2] - r["z"][b, :, :2] @ p.C[0]).max() < 1e-9       # the extra state is C_i x along the whole horizon
+            n_active += int(y.max() > p.ymax[0] - 1e-5)
+    assert n_active >= 3                                    # the set-point xs = (1, 0) lies beyond y <= 0.7: the row binds
+    # a stage-0 violation of the row is an infeasible problem (the row constrains a given quantity there)
+    bad = rn.instance_data(p, sd, np.array([[0.5, 0.4]]), xs[:1], us[:1], np.zeros((1, 1)), up[:1])
+    assert not bad["ok0"][0]
+    # the reference example with such a row
+    q = xp_nlplant
+    sq = rn.stage_data(q)
+    assert sq["n"] == 4 + 2 + 1 and list(sq["yg"]) == [0]
+    xh = q.x0_m + rng.normal(size=(6, 4)) * [0.02, 1.0, 0.02, 0.3]; dq = rng.normal(size=(6, 2)) * [0.5, 0.01]
+    ysp, usp, xsp = q.defSP(0.0)
+    t = rn.target_solve(q, rn.target_data(q), np.tile(usp, (6, 1)), np.tile(ysp, (6, 1)), np.tile(xsp, (6, 1)), dq, np.tile(q.u0, (6, 1)))
+    uq = np.tile(q.u0, (6, 1))
+    rq = rn.rpdip_solve(sq, rn.instance_data(q, sq, xh, t["xs"], t["us"], dq, uq))
+    for b in range(6):
+        e = o.ocp_solve_exact(q, xh[b], t["xs"][b], t["us"][b], dq[b], uq[b])
+        if e["status"] == 0 and rq["status"][b] == 0:
+            assert np.abs(e["u0"] - rq["u0"][b]).max() < 1e-6
+    assert (rq["status"] == 0).sum() >= 4

@@ -119,3 +119,33 @@ def test_nonlinear_plant_example_controller_path(nlplant, oracle_c):
     a = rn.closed_loop_batch(p, 8, x0, x0)
     assert (a["STATUS_DYN"] == 0).all() and np.isfinite(a["Xp"]).all()
     assert np.abs(a["Xp"][1] - p.plant_step(x0, a["U"][0], 0.0, np.zeros(3))).max() == 0.0      # the loop uses the RK4 plant
+
+
+def test_general_output_rows_match_numpy(dint_yrow, xp_nlplant, oracle_c):
+    """Output rows carried as extra stage states (oracle/riccati_np.py:stage_data): C restatement against NumPy, per solve and
+    in the closed loop."""
+    p = dint_yrow
+    rng = np.random.default_rng(8)
+    B = 80
+    xh = np.column_stack([rng.uniform(-0.3, 0.3, B), rng.uniform(-0.5, 0.5, B)]); xs = np.tile([1.0, 0.0], (B, 1)); us = np.zeros((B, 1))
+    d = rng.uniform(-0.1, 0.1, (B, 1)); up = rng.uniform(-0.5, 0.5, (B, 1))
+    sd = rn.stage_data(p)
+    n = rn.rpdip_solve(sd, rn.instance_data(p, sd, xh, xs, us, d, up))
+    c = oracle_c.OracleC(p).ocp_solve(xh, xs, us, d, up)
+    assert np.array_equal(c["status"], n["status"]) and (c["status"] == 2).any() and (c["status"] == 0).sum() > 40
+    ok = c["status"] == 0
+    assert np.abs(c["u0"] - n["u0"])[ok].max() < 1e-8 and np.abs(c["x1"] - n["z1"][:, :2])[ok].max() < 1e-8
+    x0 = rng.uniform(-0.2, 0.2, (20, 2))
+    cl = oracle_c.OracleC(p).closed_loop(25, x0, x0)
+    nl = rn.closed_loop_batch(p, 25, x0, x0)
+    assert np.array_equal(cl["STATUS_DYN"], nl["STATUS_DYN"]) and np.abs(cl["U"] - nl["U"]).max() < 1e-7
+    # the reference example with one general row (model state 4, plant state 3): per solve
+    q = xp_nlplant
+    xh = q.x0_m + rng.normal(size=(B, 4)) * [0.02, 1.0, 0.02, 0.3]; dq = rng.normal(size=(B, 2)) * [0.5, 0.01]
+    xs = q.x0_m + rng.normal(size=(B, 4)) * [0.005, 0.3, 0.005, 0.1]; us = q.u0 + rng.normal(size=(B, 2)) * [0.5, 0.005]; uq = np.tile(q.u0, (B, 1))
+    sq = rn.stage_data(q)
+    n = rn.rpdip_solve(sq, rn.instance_data(q, sq, xh, xs, us, dq, uq))
+    c = oracle_c.OracleC(q).ocp_solve(xh, xs, us, dq, uq)
+    assert np.array_equal(c["status"], n["status"])
+    ok = c["status"] == 0
+    assert ok.sum() > B // 2 and np.abs(c["u0"] - n["u0"])[ok].max() < 1e-7 and np.abs(c["x1"] - n["z1"][:, :4])[ok].max() < 1e-7
