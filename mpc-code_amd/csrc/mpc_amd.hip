@@ -294,7 +294,8 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
     const DevProblem &P = *Pp;
     const size_t Bs = a.Bs;
     const int lane = threadIdx.x;
-    const bool wl = threadIdx.y == 0 && lane < NI;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);       // uniform over a wave: scalar branches, no exec masking
+    const bool wl = wave == 0 && lane < NI;
     const int b = blockIdx.x * NI + lane;
     const bool valid = wl && b < a.B;
     double *wsg = a.ws + (size_t)blockIdx.x * NI * Cfg::ROWS_ST * 64;      // state rows of this workgroup's instances
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
         unsigned bq = (unsigned)b;      // 32-bit index next to a uniform column pointer: global_load with scalar base + vector offset
         asm volatile("" : "+v"(bq));
         double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
-        double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU];
+        double xh_pred[NX], dh_prev[ND > 0 ? ND : 1], xs_prev[NX], us_prev[NU], delta_est = 0.0;
         if (valid) {
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = (a.x + (size_t)(i) * Bs)[bq];
             MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = (a.xhat + (size_t)(i) * Bs)[bq]; xs[i] = (a.xs + (size_t)(i) * Bs)[bq]; }
@@ -354,13 +355,16 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
                 MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
             }
             if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) (a.DHAT + (size_t)((size_t)k * ND + i) * Bs)[bq] = dh[i]; }
+            // warm-start test, the part that does not need the target (so that the predictions need not survive the target solve)
+            MPC_UNROLL for (int i = 0; i < NX; i++) delta_est = dmax(delta_est, fabs(xh[i] - xh_pred[i]));
+            MPC_UNROLL for (int i = 0; i < ND; i++) delta_est = dmax(delta_est, fabs(dh[i] - dh_prev[i]));
             MPC_TSTAMP(7);
         }
         // While wave 0 solves the target problems, wave 1 (lane = instance) advances the covariance side of the Kalman
         // filter by one step: the gain of the next step and the prior after it depend on the model only, not on the data
         // (Estimator.py:297-309).
         __syncthreads();
-        if (threadIdx.y == 1 && P.estimator == MPC_EST_KALMAN && lane < NI && blockIdx.x * NI + lane < a.B) {
+        if (wave == 1 && P.estimator == MPC_EST_KALMAN && lane < NI && blockIdx.x * NI + lane < a.B) {
             unsigned bi = blockIdx.x * NI + lane;
             asm volatile("" : "+v"(bi));      // opaque per step, like bq above
             double Pk[NE][NE], K[NE][NY];
@@ -400,9 +404,8 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS; loop state -> HBM ------------
             OcpInst<NS, NU> q;
             build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, q);
-            double delta = 0.0;
-            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - xh_pred[i]), fabs(xs[i] - xs_prev[i])));
-            MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
+            double delta = delta_est;
+            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xs[i] - xs_prev[i]));
             MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
             const bool warm = a.ws_valid[bq] != 0 && delta <= kWsDelta;
             double *qd = sh.q + lane * Cfg::QN;
@@ -813,7 +816,7 @@ extern "C" const char *mpc_build_info(void)
 {
     static std::string s;
     if (s.empty()) {
-        s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du)=";
+        s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU, NG) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU "/" #NG ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM

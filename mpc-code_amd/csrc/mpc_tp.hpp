@@ -24,6 +24,14 @@
 #else
 #define MPC_TSTAMP(slot) do { } while (0)
 #endif
+// -DMPC_STAMPS_FINE (with -DMPC_STAMPS): the iteration phases share slot 3 and slots 4..6 resolve the start-up of a solve
+#ifdef MPC_STAMPS_FINE
+#define MPC_TSTAMP_IT(slot) MPC_TSTAMP(3)
+#define MPC_TSTAMP_FINE(slot) MPC_TSTAMP(slot)
+#else
+#define MPC_TSTAMP_IT(slot) MPC_TSTAMP(slot)
+#define MPC_TSTAMP_FINE(slot) do { } while (0)
+#endif
 
 namespace mpc {
 
@@ -118,7 +126,9 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
 {
     using Cfg = TpCfg<NS, NU, NC, NW, IPW>;
     constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK, NI = Cfg::NI;
-    const int lane = threadIdx.x, w = threadIdx.y, N = P.N;
+    // the wave index is uniform over a wave (the x extent of the workgroup is the wave size): told to the compiler, everything
+    // indexed by it (row pointers, LDS slots of this wave's instances) is scalar arithmetic instead of per-lane address registers
+    const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y), N = P.N;
     const bool worker = w == 0;
     const bool wl = worker && lane < NI;          // worker lane with an instance
     MPC_STAMP_INIT
@@ -152,6 +162,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     unsigned ku = (unsigned)k;      // made opaque at every phase boundary (fresh()), so that the addresses are built where they are used
     unsigned lq = (unsigned)lane;   // the same for wave 0's lane = instance view
     auto fresh = [&]() { asm volatile("" : "+v"(ku), "+v"(lq)); };
+    fresh();                        // also for the start-up below: this function is inlined into the caller's loop over the MPC steps
     auto rowp = [&](int wi, int r) -> double * { return wsg + ((size_t)wi * Cfg::ROWS_ST + r) * 64; };
     auto load_iter = [&](int wi, Iter &X) {
         MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = rowp(wi, Cfg::ST_SL + i)[ku]; X.sh[i] = rowp(wi, Cfg::ST_SH + i)[ku]; X.ll[i] = rowp(wi, Cfg::ST_LL + i)[ku]; X.lh[i] = rowp(wi, Cfg::ST_LH + i)[ku]; }
@@ -210,6 +221,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             cres_p = dmax(cres_p, dmax(comp_measure(X.sl[i], X.ll[i]), comp_measure(X.sh[i], X.lh[i])));
             lmax_p = dmax(lmax_p, dmax(X.ll[i], X.lh[i]));
         }
+        MPC_TSTAMP_FINE(1);
         double gu[NU], gz[NS], pi[NS];
         gradient(S, X, gu, gz);
         MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, ku) = gu[i];
@@ -222,6 +234,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Apow[e][j][i] * t[j]; pi[i] = a; }
             }
         }
+        MPC_TSTAMP_FINE(2);
         double rs_p = 0.0;
         MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.B[j][i] * pi[j]; rs_p = dmax(rs_p, fabs(a)); }
         S.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
@@ -287,6 +300,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             lh0[j][i] = S.warm ? rowp(wi, Cfg::ST_LH + i)[ku + sft] : 0.0;
         }
     }
+    MPC_TSTAMP_FINE(4);
     // slacks and multipliers of the initial point, then the first element-wise phase
     MPC_UNROLL for (int j = 0; j < IPW; j++) {
         Inst &S = I[j];
@@ -326,8 +340,10 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 const double llo = S.warm ? dmax(ll0[j][i], ws_mu * isl) : kMu0 * isl, lhi = S.warm ? dmax(lh0[j][i], ws_mu * ish) : kMu0 * ish;
                 Xj.ll[i] = Xj.fl[i] ? llo : 0.0; Xj.lh[i] = Xj.fh[i] ? lhi : 0.0;
             }
+            MPC_TSTAMP_FINE(5);
             store_iter(wi, Xj);
             phase_a(S, Xj, wi, 0);
+            MPC_TSTAMP_FINE(6);
         }
     }
 
@@ -337,7 +353,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
         MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, 0);
         MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lq, 0);
-        for (int kk = 0; kk < N; kk++) {
+        _Pragma("unroll 2") for (int kk = 0; kk < N; kk++) {      // two blocks per trip: the prefetched gains rotate without register copies
             double Kf[NKF], kff[NU], ddu[NU], dzn[NS];
             MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = Kn[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = kn[i];
@@ -441,7 +457,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             if (wl && wk_on && !pd_all) sh.flag[lane] = -1;      // a Lambda lost definiteness: the instance stops as infeasible
         }
         __syncthreads();
-        MPC_TSTAMP(3); fresh();
+        MPC_TSTAMP_IT(3); fresh();
         MPC_UNROLL for (int j = 0; j < IPW; j++) {
             const int wi = w * IPW + j;
             if (I[j].on && sh.flag[wi] < 0) {       // the factorisation failed
@@ -495,7 +511,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             }
         }
         __syncthreads();
-        MPC_TSTAMP(4); fresh();
+        MPC_TSTAMP_IT(4); fresh();
         // ================= wave 0, lane = instance: corrector rhs recursion and direction ===============================
         if (worker) {
             StageConst<NS, NU> C;
@@ -506,7 +522,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, N - 1);
                 MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, N - 1);
                 MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, N - 1);
-                for (int kk = N - 1; kk >= 0; kk--) {
+                _Pragma("unroll 2") for (int kk = N - 1; kk >= 0; kk--) {
                     double pv[NS], hu[NU], Li[NU][NU], Kf[NKF], psi[NU], kff[NU];
                     MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = hn[i];
                     MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = hn[NU + i] + pc[i];
@@ -535,7 +551,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             }
         }
         __syncthreads();
-        MPC_TSTAMP(5); fresh();
+        MPC_TSTAMP_IT(5); fresh();
         // ================= element-wise: corrector step length, step; then the next iterate's residuals / gradients =====
         {
             MPC_UNROLL for (int j = 0; j < IPW; j++) {
@@ -574,7 +590,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 }
             }
         }
-        MPC_TSTAMP(6); fresh();
+        MPC_TSTAMP_IT(6); fresh();
     }
     // wave 0, lane i: the verdict of instance i
     __syncthreads();
