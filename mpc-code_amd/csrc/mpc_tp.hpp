@@ -6,12 +6,17 @@
 //   * element-wise work (slacks, multipliers, residuals, step lengths, the convergence test) runs with wave = instance
 //     (IPW instances per wave, one after the other) and lane = block k of the horizon (N <= 64): sums and maxima over the
 //     horizon are DPP reductions over the wave, the costate recursion of the test is a scan over the lanes;
-//   * the recursions that are sequential in k (Riccati factorisation, right-hand sides, Newton direction) run on wave 0
-//     with lane = instance, as rpdip_lane does them; the two mappings exchange their data through a transposing buffer
-//     in LDS ([row][instance][k], padded so that both views are conflict-free).
+//   * the recursions that are sequential in k run on dedicated waves while the others wait at the barrier:
+//       - the matrix recursion (Riccati factorisation) on the matrix cores when the stage fits a 4x4 tile (NS <= 4, NU <= 2):
+//         v_mfma_f64_4x4x4f64 multiplies four pairs of 4x4 tiles per wave, so one wave factorises four instances and NI / 4
+//         waves work side by side; otherwise on wave 0 with lane = instance, as rpdip_lane does it;
+//       - the vector recursions (right-hand sides, Newton direction) on the next wave with lane = instance; for the
+//         predictor it follows the factorisation block by block through progress words in LDS;
+//     the mappings exchange their data through a transposing buffer in LDS ([row][instance][k], padded so that the
+//     lane = k and lane = instance views are conflict-free).
 // Between phases the iterate of an instance (slacks, multipliers, inputs, states: ROWS_ST rows of 64 doubles) rests in
 // HBM/L2, one coalesced row per quantity; a wave loads it, works, stores what changed.  That keeps the register budget
-// of a wave independent of how many instances it serves (IPW) and leaves wave 0 all its registers for the recursions
+// of a wave independent of how many instances it serves (IPW) and leaves the recursion waves their registers
 // (keeping the iterates in registers instead was measured: hipcc spills them next to the recursion code).
 // The same rows are the warm start of the next MPC step.
 // The arithmetic per block is that of rpdip_lane; horizon-wide sums are taken in another order.
@@ -24,7 +29,7 @@
 #else
 #define MPC_TSTAMP(slot) do { } while (0)
 #endif
-// -DMPC_STAMPS_FINE (with -DMPC_STAMPS): the iteration phases share slot 3 and slots 4..6 resolve the start-up of a solve
+// -DMPC_STAMPS_FINE (with -DMPC_STAMPS): the iteration phases share slot 3, slot 4 takes wave 0's matrix recursion
 #ifdef MPC_STAMPS_FINE
 #define MPC_TSTAMP_IT(slot) MPC_TSTAMP(3)
 #define MPC_TSTAMP_FINE(slot) MPC_TSTAMP(slot)
@@ -40,10 +45,10 @@ struct TpCfg {
     static constexpr int NI = NW * IPW;                              // instances per workgroup: NW waves, IPW instances each
     static constexpr int NV = NS + NU, NKF = NU * NS, NLI = NU * (NU + 1) / 2;
     // rows of the transposing buffer, per (instance, block):
-    //   RA: sigma | h  (element-wise -> Riccati), overwritten by K | Lambda^-1 (kept for the corrector)
-    //   RG: gu | gz   (-> Riccati), then du | dz (direction ->), then hu | hz (-> corrector rhs), then du | dz
+    //   RA: sigma (element-wise -> Riccati), overwritten by K | Lambda^-1 (kept for the corrector)
+    //   RG: gu + hu | gz + hz (-> predictor rhs), then du | dz (direction ->), then the same for the corrector
     //   RK: kff
-    static constexpr int RA = 0, RA_SZ = (2 * NC > NKF + NLI ? 2 * NC : NKF + NLI);
+    static constexpr int RA = 0, RA_SZ = (NC > NKF + NLI ? NC : NKF + NLI);
     static constexpr int RG = RA_SZ, RK = RG + NV, ROWS = RK + NU;
     static constexpr int LD = 65;                                    // 64 blocks + 1: lane = instance reads hit distinct banks
     static constexpr int T_DOUBLES = ROWS * NI * LD;
@@ -209,23 +214,23 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     // stationarity residual needs the costates pi_k = gz_k + A' pi_{k+1}, a linear recursion with a constant matrix,
     // taken here as a parallel scan over the lanes (log2(64) steps with A^(2^j)) instead of a sequential sweep.
     auto phase_a = [&](Inst &S, const Iter &X, int wi, int it) {
-        double mu_p = 0.0, resp_p = 0.0, cres_p = 0.0, lmax_p = 0.0;
+        double mu_p = 0.0, resp_p = 0.0, cres_p = 0.0, lmax_p = 0.0, hb[NC];
         MPC_UNROLL for (int i = 0; i < NC; i++) {
             const double v = i < NU ? X.u[i < NU ? i : 0] : X.z[i >= NU ? i - NU : 0];
             const double rh = X.fh[i] ? v + X.sh[i] - X.hi[i] : 0.0, rl = X.fl[i] ? v - X.sl[i] - X.lo[i] : 0.0;
             const double isl = frcp(X.sl[i]), ish = frcp(X.sh[i]);
             mu_p += X.sl[i] * X.ll[i] + X.sh[i] * X.lh[i];
             sh.t(RA + i, wi, ku) = X.ll[i] * isl + X.lh[i] * ish;
-            sh.t(RA + NC + i, wi, ku) = X.lh[i] * (rh * ish - 1.0) + X.ll[i] * (rl * isl + 1.0);
+            hb[i] = X.lh[i] * (rh * ish - 1.0) + X.ll[i] * (rl * isl + 1.0);
             resp_p = dmax(resp_p, dmax(fabs(rl), fabs(rh)));
             cres_p = dmax(cres_p, dmax(comp_measure(X.sl[i], X.ll[i]), comp_measure(X.sh[i], X.lh[i])));
             lmax_p = dmax(lmax_p, dmax(X.ll[i], X.lh[i]));
         }
-        MPC_TSTAMP_FINE(1);
         double gu[NU], gz[NS], pi[NS];
         gradient(S, X, gu, gz);
-        MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, ku) = gu[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { sh.t(RG + NU + i, wi, ku) = gz[i]; pi[i] = blk_on ? gz[i] : 0.0; }
+        // right-hand side of the predictor: gradient + barrier term of the bounds on this variable
+        MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, wi, ku) = gu[i] + hb[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { sh.t(RG + NU + i, wi, ku) = gz[i] + (NU + i < NC ? hb[NU + i < NC ? NU + i : 0] : 0.0); pi[i] = blk_on ? gz[i] : 0.0; }
         MPC_UNROLL for (int e = 0; e < 6; e++) {
             const int d = 1 << e;
             if (d < N) {
@@ -234,7 +239,6 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.Apow[e][j][i] * t[j]; pi[i] = a; }
             }
         }
-        MPC_TSTAMP_FINE(2);
         double rs_p = 0.0;
         MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += P.B[j][i] * pi[j]; rs_p = dmax(rs_p, fabs(a)); }
         S.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
@@ -300,7 +304,6 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             lh0[j][i] = S.warm ? rowp(wi, Cfg::ST_LH + i)[ku + sft] : 0.0;
         }
     }
-    MPC_TSTAMP_FINE(4);
     // slacks and multipliers of the initial point, then the first element-wise phase
     MPC_UNROLL for (int j = 0; j < IPW; j++) {
         Inst &S = I[j];
@@ -340,15 +343,79 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 const double llo = S.warm ? dmax(ll0[j][i], ws_mu * isl) : kMu0 * isl, lhi = S.warm ? dmax(lh0[j][i], ws_mu * ish) : kMu0 * ish;
                 Xj.ll[i] = Xj.fl[i] ? llo : 0.0; Xj.lh[i] = Xj.fh[i] ? lhi : 0.0;
             }
-            MPC_TSTAMP_FINE(5);
             store_iter(wi, Xj);
             phase_a(S, Xj, wi, 0);
-            MPC_TSTAMP_FINE(6);
         }
     }
 
-    // forward recursion of the Newton direction (lane = instance): K, kff -> du | dz
-    auto direction = [&](const StageConst<NS, NU> &C) {
+    // ---- the two recursion waves (lane = instance) ----------------------------------------------------------------------
+    // Wave 0 runs the matrix recursion (Riccati: sigma -> K, Lambda^-1), wave 1 everything that is a vector recursion: the
+    // right-hand side (backward; for the predictor it follows wave 0 block by block through a progress word in LDS) and the
+    // Newton direction (forward).
+    // Matrix recursion on the matrix cores when the stage fits a 4x4 tile (v_mfma_f64_4x4x4f64: four independent 4x4x4 products
+    // per wave): then one wave serves four instances, NI / 4 waves factorise at once; otherwise wave 0 with lane = instance.
+    constexpr bool MFMA = NS <= 4 && NU <= 2 && NI % 4 == 0 && NI / 4 < NW;
+    constexpr int NMW = MFMA ? NI / 4 : 1;      // matrix waves: 0 .. NMW-1; the vector wave comes next
+    const int mw = w;                                  // index of this wave among the matrix waves
+    const bool matw = w < NMW, vecw = w == NMW;        // the vector wave comes right after the matrix wave(s)
+    double Av[NS][NS], Bv[NS][NU];      // wave 1: model matrices in registers
+    if (vecw) {
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) Av[i][j] = vreg(P.A[i][j]);
+            MPC_UNROLL for (int j = 0; j < NU; j++) Bv[i][j] = vreg(P.B[i][j]);
+        }
+    }
+    int *const progress = sh.misc;      // per matrix wave: the block its recursion has finished last (N: none yet)
+    if (worker && lane < NMW) progress[lane] = N;
+    // backward recursion of the right-hand side: h (RG rows), K, Lambda^-1 -> kff; `follow`: K and Lambda^-1 of a block exist
+    // only once wave 0 has announced it
+    auto rhs_pass = [&](bool follow) {
+        int done = N;       // every matrix wave is known to have finished this block (and the ones after it)
+        auto wait_for = [&](int blk) {
+            if (follow) {
+                while (done > blk) {      // look again only when the known state does not cover the block
+                    int d = 0;
+                    MPC_UNROLL for (int m = 0; m < NMW; m++) { const int v = __hip_atomic_load(progress + m, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); d = v > d ? v : d; }
+                    done = d;
+                    if (done > blk) __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        };
+        double pc[NS], hn[NV], Kn[NKF], ln[NLI];
+        MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
+        wait_for(N - 1);
+        MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, N - 1);
+        MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, N - 1);
+        MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, N - 1);
+        _Pragma("unroll 2") for (int kk = N - 1; kk >= 0; kk--) {
+            double pv[NS], hu[NU], Li[NU][NU], Kf[NKF], psi[NU], kff[NU];
+            MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = hn[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = hn[NU + i] + pc[i];
+            MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = Kn[i];
+            {
+                int c = 0;
+                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { Li[i][j] = ln[c]; Li[j][i] = ln[c]; c++; } }
+            }
+            const int kx = kk > 0 ? kk - 1 : 0;      // the next block's data now, they arrive while this block computes
+            wait_for(kx);
+            MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, kx);
+            MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, kx);
+            MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, kx);
+            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = hu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Bv[j][i] * pv[j]; psi[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lq, kk) = kff[i];
+            double pn[NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                double a = 0.0;
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += Av[j][i] * pv[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) a += Kf[j * NS + i] * psi[j];
+                pn[i] = a;
+            }
+            MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = pn[i];
+        }
+    };
+    // forward recursion of the Newton direction: K, kff -> du | dz
+    auto direction = [&]() {
         double dz[NS], Kn[NKF], kn[NU];
         MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
         MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, 0);
@@ -361,15 +428,83 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, kx);
             MPC_UNROLL for (int i = 0; i < NU; i++) kn[i] = sh.t(RK + i, lq, kx);
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Kf[i * NS + j] * dz[j]; ddu[i] = a; }
-            MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += Av[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += Bv[i][j] * ddu[j]; dzn[i] = a; }
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RG + i, lq, kk) = ddu[i];
             MPC_UNROLL for (int i = 0; i < NS; i++) sh.t(RG + NU + i, lq, kk) = dz[i];
         }
     };
 
-    const bool wk_valid = wl && (sh.iflag[lane < NI ? lane : 0] & kTpValid) && (sh.iflag[lane < NI ? lane : 0] & kTpOk0);
-    bool pd_all = true;         // worker lane: every Lambda of this instance was positive definite so far
+    // ---- the matrix recursion on the matrix cores (MFMA variant) --------------------------------------------------------------
+    // v_mfma_f64_4x4x4f64 multiplies four independent pairs of 4x4 tiles per wave: lane 16 r + 4 b + c holds element (r, c) of
+    // tile b; with M, S in this layout the instruction gives M'S + C (its first operand is read transposed).  Tile b of wave w
+    // belongs to instance 4 w + b; matrices are zero-padded to 4x4.  Barrier weights, K and Lambda^-1 go through the same LDS
+    // rows as in the lane = instance variant, one masked access per tile.
+    const int tr = lane >> 4, tb = (lane >> 2) & 3, tc = lane & 3, tinst = (MFMA && matw) ? 4 * mw + tb : 0;
+    const int tfl = sh.iflag[tinst];
+    const bool t_valid = MFMA && matw && (tfl & kTpValid) && (tfl & kTpOk0);
+    const bool in_ss = tr < NS && tc < NS, in_su = tr < NS && tc < NU, in_us = tr < NU && tc < NS, in_uu = tr < NU && tc < NU;
+    auto mm = [](double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); };      // a' b + c on tiles
+    bool pd_all = true;         // every Lambda of this lane's instance was positive definite so far
+    // backward: Riccati factorisation, sigma -> K, Lambda^-1 in LDS; each finished block is announced to the vector wave
+    auto tile_factor = [&](bool t_on) {
+        const double Ar = in_ss ? P.A[tr][tc] : 0.0, Br = in_su ? P.B[tr][tc] : 0.0, Btr = in_us ? P.B[tc][tr] : 0.0;
+        const double Rr = in_uu ? P.R[tr][tc] : 0.0, Qr = in_ss ? P.Q[tr][tc] : 0.0, Mtr = (HASM && in_us) ? P.M[tc][tr] : 0.0;
+        // rows 0 / 1 of Lambda = R~ + B'PB broadcast over the tile rows 0..1, straight from PB: (B E_i)' PB + E_i' R~
+        const double BE0 = (tr < NS && tc < 2) ? P.B[tr][0] : 0.0, BE1 = (NU > 1 && tr < NS && tc < 2) ? P.B[tr][NU > 1 ? 1 : 0] : 0.0;
+        const double RE0 = (tr < 2 && tc < NU) ? P.R[0][tc] : 0.0, RE1 = (NU > 1 && tr < 2 && tc < NU) ? P.R[NU > 1 ? 1 : 0][tc] : 0.0;
+        double Pm = in_ss ? P.Pf[tr][tc] : 0.0;
+        // barrier weights: sigma_z[r] on the diagonal of P, sigma_u[r] on the diagonal of R~, sigma_u[c] in column c of the broadcast rows
+        const bool dz_on = tr == tc && tr < NS && NU + tr < NC, du_on = tr == tc && tr < NU, db_on = tr < 2 && tc < NU;
+        unsigned tq = (unsigned)tinst, tl = (unsigned)lane;
+        asm volatile("" : "+v"(tq));
+        const int rz = dz_on ? RA + NU + tr : RA, ru = du_on ? RA + tr : RA, rb = db_on ? RA + tc : RA;      // the other lanes read row RA and drop it
+        double szn = sh.t(rz, tq, N - 1), sun = sh.t(ru, tq, N - 1), sbn = sh.t(rb, tq, N - 1);
+        bool pd_ok = true;
+        for (int kk = N - 1; kk >= 0; kk--) {
+            // the identity tile rebuilt from the lane index on every trip (as a loop invariant it ends up in scratch, and a reload is a
+            // memory round trip on the critical path)
+            asm volatile("" : "+v"(tl));
+            const double Ir = (tl >> 4) == (tl & 3) ? 1.0 : 0.0;
+            const double sz = dz_on ? szn : 0.0, su = du_on ? sun : 0.0, sb = db_on ? sbn : 0.0;
+            const int kn = kk > 0 ? kk - 1 : 0;      // next block's weights now
+            szn = sh.t(rz, tq, kn); sun = sh.t(ru, tq, kn); sbn = sh.t(rb, tq, kn);
+            Pm += sz;
+            const double PA = mm(Pm, Ar, 0.0), PB = mm(Pm, Br, 0.0);      // P A, P B (P symmetric)
+            const double Rs = Rr + su;
+            const double Psi = mm(Br, PA, Mtr);                             // M' + B'PA
+            // Lambda^-1 (NU <= 2): every lane of rows 0..1 gets the four numbers (columns via the quad), then its own element
+            double Li;
+            const double X0 = mm(BE0, PB, RE0 + (tc == 0 ? sb : 0.0));
+            if (NU == 1) {
+                const double a = dpp_move<0x00, 0xF>(X0, X0);
+                pd_ok = pd_ok && (a > 0.0);
+                Li = (tr == 0 && tc == 0) ? frcp(a) : 0.0;
+            } else {
+                const double X1 = mm(BE1, PB, RE1 + (tc == 1 ? sb : 0.0));
+                const double a = dpp_move<0x00, 0xF>(X0, X0), b0 = dpp_move<0x55, 0xF>(X0, X0), c0 = dpp_move<0x00, 0xF>(X1, X1), d = dpp_move<0x55, 0xF>(X1, X1);
+                const double off = 0.5 * (b0 + c0), det = a * d - off * off, rdet = frcp(det);
+                pd_ok = pd_ok && (a > 0.0) && (det > 0.0);
+                Li = (tr < 2 && tc < 2) ? (tr == tc ? (tr == 0 ? d : a) * rdet : -off * rdet) : 0.0;
+            }
+            const double Kk = mm(-Li, Psi, 0.0);      // K = -Lambda^-1 Psi
+            if (t_on && in_us) sh.t(RA + tr * NS + tc, tq, kk) = Kk;
+            if (t_on && in_uu && tc <= tr) sh.t(RA + NKF + tr * (tr + 1) / 2 + tc, tq, kk) = Li;
+            if (lane == 0) __hip_atomic_store(progress + mw, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // block kk is in LDS
+            if (kk > 0) {       // closed-loop (Joseph) form: Q + Acl' P Acl + K' R~ K (+ M K + K' M'), then symmetrised
+                const double Acl = mm(Btr, Kk, Ar), RK_ = mm(Rs, Kk, 0.0);
+                const double T = mm(Pm, Acl, 0.0);
+                double Pn = mm(Kk, RK_, mm(Acl, T, Qr));
+                if (HASM) { const double MK = mm(Mtr, Kk, 0.0); Pn = mm(MK, Ir, Pn + MK); }
+                Pm = 0.5 * (Pn + mm(Pn, Ir, 0.0));
+            }
+        }
+        pd_all = pd_all && pd_ok;
+        if (t_on && !pd_all && tr == 0 && tc == 0) sh.flag[tinst] = -1;      // a Lambda lost definiteness: the instance stops as infeasible
+    };
+
+    const int rfl = sh.iflag[lane < NI ? lane : 0];
+    const bool wk_valid = ((!MFMA && worker) || vecw) && lane < NI && (rfl & kTpValid) && (rfl & kTpOk0);
 
     MPC_TSTAMP(1); fresh();
     for (int it = 0;; it++) {
@@ -377,31 +512,27 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         MPC_UNROLL for (int j = 0; j < IPW; j++) mine = mine || I[j].on;
         if (!__syncthreads_or(mine ? 1 : 0)) break;      // every instance of the workgroup has its verdict
         MPC_TSTAMP(2); fresh();
-        // ================= wave 0, lane = instance: Riccati factorisation, predictor rhs, direction ======================
         const bool wk_on = wk_valid && sh.flag[lane < NI ? lane : 0] == 0;
-        if (worker) {
+        // ================= matrix wave(s): Riccati factorisation; the vector wave behind: predictor rhs, then the direction ===
+        if (MFMA && matw) {
+            const bool t_on = t_valid && sh.flag[tinst] == 0;
+            if (__any(t_on ? 1 : 0)) tile_factor(t_on);
+            else if (lane == 0) __hip_atomic_store(progress + mw, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // nobody waits for this wave
+            MPC_TSTAMP_FINE(4);      // fine stamps: slot 4 = the factorisation alone, slot 3 = the rest of the iteration
+        } else if (!MFMA && worker) {
             StageConst<NS, NU> C;
             load_stage_const<NS, NU, HASM>(P, C);
             if (wk_on) {
-                double Pm[NS][NS], pcar[NS];
+                double Pm[NS][NS];
                 bool pd_ok = true;
-                MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    pcar[i] = 0.0;
-                    MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = C.Pf[i][j];
-                }
-                double sg[NC], hh[NC], gun[NU], gzn[NS];
-                MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lq, N - 1); hh[i] = sh.t(RA + NC + i, lq, N - 1); }
-                MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lq, N - 1);
-                MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lq, N - 1);
+                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Pm[i][j] = C.Pf[i][j]; }
+                double sg[NC];
+                MPC_UNROLL for (int i = 0; i < NC; i++) sg[i] = sh.t(RA + i, lq, N - 1);
                 _Pragma("unroll 2") for (int kk = N - 1; kk >= 0; kk--) {
-                    double sig[NV], haff[NV], g1[NS], g2[NU];
-                    MPC_UNROLL for (int i = 0; i < NV; i++) { sig[i] = i < NC ? sg[i < NC ? i : 0] : 0.0; haff[i] = i < NC ? hh[i < NC ? i : 0] : 0.0; }
-                    MPC_UNROLL for (int i = 0; i < NS; i++) g1[i] = gzn[i];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) g2[i] = gun[i];
+                    double sig[NV];
+                    MPC_UNROLL for (int i = 0; i < NV; i++) sig[i] = i < NC ? sg[i < NC ? i : 0] : 0.0;
                     const int kn = kk > 0 ? kk - 1 : 0;      // next block's data now, they arrive while this block computes
-                    MPC_UNROLL for (int i = 0; i < NC; i++) { sg[i] = sh.t(RA + i, lq, kn); hh[i] = sh.t(RA + NC + i, lq, kn); }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) gun[i] = sh.t(RG + i, lq, kn);
-                    MPC_UNROLL for (int i = 0; i < NS; i++) gzn[i] = sh.t(RG + NU + i, lq, kn);
+                    MPC_UNROLL for (int i = 0; i < NC; i++) sg[i] = sh.t(RA + i, lq, kn);
                     MPC_UNROLL for (int i = 0; i < NS; i++) Pm[i][i] += sig[NU + i];
                     double PB[NS][NU], PA[NS][NS], Lam[NU][NU], Psi[NU][NS];
                     MPC_UNROLL for (int i = 0; i < NS; i++) {
@@ -420,6 +551,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                         int c = 0;
                         MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { sh.t(RA + NKF + c, lq, kk) = Lam[i][j]; c++; } }
                     }
+                    __hip_atomic_store(progress, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // block kk is in LDS
                     if (kk > 0) {       // closed-loop (Joseph) form with T = P Acl = PA + PB K
                         double Acl[NS][NS], T[NS][NS], RK_[NU][NS];
                         MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = C.A[i][j], t = PA[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) { a += C.B[i][l] * Kk[l][j]; t += PB[i][l] * Kk[l][j]; } Acl[i][j] = a; T[i][j] = t; } }
@@ -434,30 +566,17 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                             }
                         }
                     }
-                    double pv[NS], qu[NU], psi[NU], kff[NU];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = g1[i] + haff[NU + i] + pcar[i];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) qu[i] = g2[i] + haff[i];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Lam[i][j] * psi[j]; kff[i] = -a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lq, kk) = kff[i];
-                    if (kk > 0) {
-                        double pn[NS];
-                        MPC_UNROLL for (int i = 0; i < NS; i++) {
-                            double a = 0.0;
-                            MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
-                            MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j][i] * psi[j];
-                            pn[i] = a;
-                        }
-                        MPC_UNROLL for (int i = 0; i < NS; i++) pcar[i] = pn[i];
-                    }
                 }
                 pd_all = pd_all && pd_ok;
-                direction(C);
             }
+            MPC_TSTAMP_FINE(4);      // fine stamps: slot 4 = the matrix recursion alone, slot 3 = the rest of the iteration
             if (wl && wk_on && !pd_all) sh.flag[lane] = -1;      // a Lambda lost definiteness: the instance stops as infeasible
+        } else if (vecw) {
+            if (wk_on) { rhs_pass(true); direction(); }
         }
         __syncthreads();
         MPC_TSTAMP_IT(3); fresh();
+        if (worker && lane < NMW) progress[lane] = N;      // for the next iteration's factorisation
         MPC_UNROLL for (int j = 0; j < IPW; j++) {
             const int wi = w * IPW + j;
             if (I[j].on && sh.flag[wi] < 0) {       // the factorisation failed
@@ -512,44 +631,8 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         }
         __syncthreads();
         MPC_TSTAMP_IT(4); fresh();
-        // ================= wave 0, lane = instance: corrector rhs recursion and direction ===============================
-        if (worker) {
-            StageConst<NS, NU> C;
-            load_stage_const<NS, NU, HASM>(P, C);
-            if (wk_on) {
-                double pc[NS], hn[NV], Kn[NKF], ln[NLI];
-                MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = 0.0;
-                MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, N - 1);
-                MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, N - 1);
-                MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, N - 1);
-                _Pragma("unroll 2") for (int kk = N - 1; kk >= 0; kk--) {
-                    double pv[NS], hu[NU], Li[NU][NU], Kf[NKF], psi[NU], kff[NU];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) hu[i] = hn[i];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = hn[NU + i] + pc[i];
-                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kf[i] = Kn[i];
-                    {
-                        int c = 0;
-                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { Li[i][j] = ln[c]; Li[j][i] = ln[c]; c++; } }
-                    }
-                    const int kx = kk > 0 ? kk - 1 : 0;      // the next block's data now, they arrive while this block computes
-                    MPC_UNROLL for (int i = 0; i < NV; i++) hn[i] = sh.t(RG + i, lq, kx);
-                    MPC_UNROLL for (int i = 0; i < NKF; i++) Kn[i] = sh.t(RA + i, lq, kx);
-                    MPC_UNROLL for (int i = 0; i < NLI; i++) ln[i] = sh.t(RA + NKF + i, lq, kx);
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = hu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
-                    MPC_UNROLL for (int i = 0; i < NU; i++) sh.t(RK + i, lq, kk) = kff[i];
-                    double pn[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) {
-                        double a = 0.0;
-                        MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
-                        MPC_UNROLL for (int j = 0; j < NU; j++) a += Kf[j * NS + i] * psi[j];
-                        pn[i] = a;
-                    }
-                    MPC_UNROLL for (int i = 0; i < NS; i++) pc[i] = pn[i];
-                }
-                direction(C);
-            }
-        }
+        // ================= wave 1, lane = instance: corrector rhs recursion and direction ===============================
+        if (vecw && wk_on) { rhs_pass(false); direction(); }
         __syncthreads();
         MPC_TSTAMP_IT(5); fresh();
         // ================= element-wise: corrector step length, step; then the next iterate's residuals / gradients =====
