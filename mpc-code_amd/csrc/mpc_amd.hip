@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -482,8 +483,11 @@ struct Launchers {
     void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
     int (*loop_tp)(const DevProblem *, LoopArgs, hipStream_t);     // horizon-parallel variant (N <= 64), nullptr if it does not fit
     int ws_rows, nc, tp_ni;
+    int tp_max_batch;           // auto choice of the loop kernel: largest batch the horizon-parallel kernel is preferred for
     size_t tp_ws_per_inst, tp_ws_per_group, tp_lds;
 };
+
+static constexpr int kTpMaxBatch = 16384;     // auto choice of the loop kernel without the matrix-core factorisation, see loop_mode()
 
 // bound modes: which variant of the OCP kernels a problem may use (cheapest first)
 enum { kBoundsAllFinite = 1, kBoundsInputsOnly = 2, kBoundsGeneric = 0 };
@@ -505,6 +509,9 @@ static Launchers make_launchers_mode()
         constexpr size_t lds = Cfg::lds_bytes();
         l.tp_ni = Cfg::NI; l.tp_lds = lds; l.tp_ws_per_inst = sizeof(double) * 64 * Cfg::ROWS_ST; l.tp_ws_per_group = 0;
         l.loop_tp = nullptr;
+        // measured on LMPC-CSTR / Wood-Berry: with the factorisation on the matrix cores (stage fits a 4x4 tile)
+        // the horizon-parallel kernel wins at every batch size; with the lane = instance factorisation it wins up to about 16384
+        l.tp_max_batch = (NSZ <= 4 && NU <= 2) ? INT32_MAX : kTpMaxBatch;
         if (lds <= 160 * 1024) {
             l.loop_tp = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
                 auto kern = loop_kernel_tp<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NW, IPW>;
@@ -566,7 +573,6 @@ struct mpc_handle {
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
 };
 
-static constexpr int kTpMaxBatch = 16384;     // auto choice of the loop kernel, see loop_mode(): measured crossover between 16384 and 32768
 static size_t pad64(size_t b) { return (b + 63) / 64 * 64; }
 
 // host [B][d] -> SoA staging [d][Bs]
@@ -816,7 +822,7 @@ extern "C" const char *mpc_build_info(void)
 {
     static std::string s;
     if (s.empty()) {
-        s = "gfx950;loop_kernels=horizon-parallel(N<=64,batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
+        s = "gfx950;loop_kernels=horizon-parallel(N<=64;mfma-riccati:ns<=4&nu<=2,else-batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU, NG) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU "/" #NG ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
@@ -1133,7 +1139,7 @@ static int loop_mode(const mpc_handle *h)
 {
     if (h->loop_kernel_opt != 0) return h->loop_kernel_opt;
     if (!h->L.loop_tp || h->hp.N > 64) return 1;
-    return h->B <= kTpMaxBatch ? 2 : 1;
+    return h->B <= h->L.tp_max_batch ? 2 : 1;
 }
 
 extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
