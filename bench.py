@@ -194,7 +194,7 @@ def main():
                          "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_loop.py --batch 4096 --steps 100; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, per launch)",
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
-                         "note": "bound by the latency of the sequential recursions (Riccati sweep on one wave per 16 instances) and fp64 issue, not by HBM (SURVEY.md 8d)"},
+                         "note": "bound by single-wave instruction issue in the sequential recursions (Riccati factorisation of four instances per wave on the fp64 matrix cores, vector recursions on one wave per 16 instances), not by HBM (SURVEY.md 8d)"},
             "solver": {"mean_iters": float(it[st != 2].mean()) if (st != 2).any() else None, "max_iters": int(it.max()),
                        "frac_solved": float((st == 0).mean()), "frac_maxiter": float((st == 1).mean()),
                        "frac_infeasible_hold": float((st == 2).mean())},
