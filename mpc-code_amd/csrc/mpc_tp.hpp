@@ -116,7 +116,13 @@ struct TpShared {
         T = base; q = T + Cfg::T_DOUBLES; red = q + NI * Cfg::QN; keep = red + NI * 4;
         flag = (int *)(keep + NI * Cfg::KEEP_MAX); iflag = flag + NI; iters = iflag + NI; keepflag = iters + NI; misc = keepflag + NI;
     }
-    __device__ __forceinline__ double &t(int row, int inst, int k) const { return T[(row * NI + inst) * Cfg::LD + k]; }
+    // rows in groups of eight: inside a group the row offset fits the 16-bit immediate of ds_read / ds_write, so that unrolled code
+    // with constant rows needs one address register per group and (instance, block), not one addition per access
+    __device__ __forceinline__ double &t(int row, int inst, int k) const
+    {
+        double *g = T + (((row >> 3) * 8 * NI + inst) * Cfg::LD + k);
+        return g[(row & 7) * NI * Cfg::LD];
+    }
 };
 
 enum : int { kTpOk0 = 1, kTpWarm = 2, kTpValid = 4 };
