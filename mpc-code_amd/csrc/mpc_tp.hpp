@@ -456,53 +456,64 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     auto tile_factor = [&](bool t_on) {
         const double Ar = in_ss ? P.A[tr][tc] : 0.0, Br = in_su ? P.B[tr][tc] : 0.0, Btr = in_us ? P.B[tc][tr] : 0.0;
         const double Rr = in_uu ? P.R[tr][tc] : 0.0, Qr = in_ss ? P.Q[tr][tc] : 0.0, Mtr = (HASM && in_us) ? P.M[tc][tr] : 0.0;
-        // rows 0 / 1 of Lambda = R~ + B'PB broadcast over the tile rows 0..1, straight from PB: (B E_i)' PB + E_i' R~
-        const double BE0 = (tr < NS && tc < 2) ? P.B[tr][0] : 0.0, BE1 = (NU > 1 && tr < NS && tc < 2) ? P.B[tr][NU > 1 ? 1 : 0] : 0.0;
-        const double RE0 = (tr < 2 && tc < NU) ? P.R[0][tc] : 0.0, RE1 = (NU > 1 && tr < 2 && tc < NU) ? P.R[NU > 1 ? 1 : 0][tc] : 0.0;
+        // rows 0 / 1 of Lambda = R~ + B'PB broadcast over all tile rows, straight from PB: (B E_i)' PB + E_i' R~
+        const double BE0 = tr < NS ? P.B[tr][0] : 0.0, BE1 = (NU > 1 && tr < NS) ? P.B[tr][NU > 1 ? 1 : 0] : 0.0;
+        const double RE0 = tc < NU ? P.R[0][tc] : 0.0, RE1 = (NU > 1 && tc < NU) ? P.R[NU > 1 ? 1 : 0][tc] : 0.0;
         double Pm = in_ss ? P.Pf[tr][tc] : 0.0;
-        // barrier weights: sigma_z[r] on the diagonal of P, sigma_u[r] on the diagonal of R~, sigma_u[c] in column c of the broadcast rows
-        const bool dz_on = tr == tc && tr < NS && NU + tr < NC, du_on = tr == tc && tr < NU, db_on = tr < 2 && tc < NU;
+        // barrier weights: sigma_z[r] on the diagonal of P, sigma_u[r] on the diagonal of R~, sigma_u[c] in column c of the broadcast
+        // rows.  Every lane reads some row of its instance (row RA where it has no use for one) and multiplies by its 0 / 1 weight.
+        const bool dz_on = tr == tc && tr < NS && NU + tr < NC, du_on = tr == tc && tr < NU, db_on = tc < NU;
         unsigned tq = (unsigned)tinst, tl = (unsigned)lane;
         asm volatile("" : "+v"(tq));
-        const int rz = dz_on ? RA + NU + tr : RA, ru = du_on ? RA + tr : RA, rb = db_on ? RA + tc : RA;      // the other lanes read row RA and drop it
+        const int rz = dz_on ? RA + NU + tr : RA, ru = du_on ? RA + tr : RA, rb = db_on ? RA + tc : RA;
         double szn = sh.t(rz, tq, N - 1), sun = sh.t(ru, tq, N - 1), sbn = sh.t(rb, tq, N - 1);
+        // K goes to LDS from the lanes that hold it (rows < NU of the tile), Lambda^-1 from rows 2..3, which compute it as well:
+        // one store per block.  (r', c) = (r - 2, c) of the lower triangle -> row RA + NKF + r'(r' + 1)/2 + c
+        const bool st_k = in_us, st_l = tr >= 2 && tc < NU && tc <= tr - 2 && tr - 2 < NU;
+        const int st_row = st_k ? RA + tr * NS + tc : RA + NKF + (st_l ? (tr - 2) * (tr - 1) / 2 + tc : 0);
+        const bool st_on = t_on && (st_k || st_l);
         bool pd_ok = true;
         for (int kk = N - 1; kk >= 0; kk--) {
             // the identity tile rebuilt from the lane index on every trip (as a loop invariant it ends up in scratch, and a reload is a
             // memory round trip on the critical path)
             asm volatile("" : "+v"(tl));
-            const double Ir = (tl >> 4) == (tl & 3) ? 1.0 : 0.0;
-            const double sz = dz_on ? szn : 0.0, su = du_on ? sun : 0.0, sb = db_on ? sbn : 0.0;
+            const unsigned lr = tl >> 4, lc = tl & 3;
+            const double Ir = lr == lc ? 1.0 : 0.0;
+            // 0 / 1 weights of this lane, rebuilt like the identity
+            const double mz = (lr == lc && lr < (unsigned)(NS < NC - NU ? NS : NC - NU)) ? 1.0 : 0.0, mu_ = (lr == lc && lr < (unsigned)NU) ? 1.0 : 0.0;
+            const double mb0 = lc == 0 ? 1.0 : 0.0, mb1 = (NU > 1 && lc == 1) ? 1.0 : 0.0;
+            const double sz = szn, su = sun, sb = sbn;
             const int kn = kk > 0 ? kk - 1 : 0;      // next block's weights now
             szn = sh.t(rz, tq, kn); sun = sh.t(ru, tq, kn); sbn = sh.t(rb, tq, kn);
-            Pm += sz;
-            const double PA = mm(Pm, Ar, 0.0), PB = mm(Pm, Br, 0.0);      // P A, P B (P symmetric)
-            const double Rs = Rr + su;
+            Pm = __builtin_fma(sz, mz, Pm);
+            // P A, P B, B'P (P symmetric).  The products are ordered for a short dependency chain: a matrix-core product whose operand
+            // is the previous one's result waits ~60 cycles for it, and the chain of a block is what the recursion costs.
+            const double PA = mm(Pm, Ar, 0.0), PB = mm(Pm, Br, 0.0), BtP = mm(Br, Pm, 0.0);
+            const double Rs = __builtin_fma(su, mu_, Rr);
             const double Psi = mm(Br, PA, Mtr);                             // M' + B'PA
-            // Lambda^-1 (NU <= 2): every lane of rows 0..1 gets the four numbers (columns via the quad), then its own element
-            double Li;
-            const double X0 = mm(BE0, PB, RE0 + (tc == 0 ? sb : 0.0));
+            // Lambda^-1 (NU <= 2): every lane gets the numbers it is made of (columns via the quad), then forms the element (r mod 2, c)
+            double Lall;
+            const double X0 = mm(BE0, PB, __builtin_fma(sb, mb0, RE0));
             if (NU == 1) {
                 const double a = dpp_move<0x00, 0xF>(X0, X0);
                 pd_ok = pd_ok && (a > 0.0);
-                Li = (tr == 0 && tc == 0) ? frcp(a) : 0.0;
+                Lall = tc == 0 ? frcp(a) : 0.0;
             } else {
-                const double X1 = mm(BE1, PB, RE1 + (tc == 1 ? sb : 0.0));
-                const double a = dpp_move<0x00, 0xF>(X0, X0), b0 = dpp_move<0x55, 0xF>(X0, X0), c0 = dpp_move<0x00, 0xF>(X1, X1), d = dpp_move<0x55, 0xF>(X1, X1);
-                const double off = 0.5 * (b0 + c0), det = a * d - off * off, rdet = frcp(det);
+                const double X1 = mm(BE1, PB, __builtin_fma(sb, mb1, RE1));
+                const double a = dpp_move<0x00, 0xF>(X0, X0), off = dpp_move<0x55, 0xF>(X0, X0), d = dpp_move<0x55, 0xF>(X1, X1);
+                const double det = a * d - off * off, rdet = frcp(det);
                 pd_ok = pd_ok && (a > 0.0) && (det > 0.0);
-                Li = (tr < 2 && tc < 2) ? (tr == tc ? (tr == 0 ? d : a) * rdet : -off * rdet) : 0.0;
+                Lall = tc < 2 ? ((tr & 1) == tc ? (tc == 0 ? d : a) * rdet : -off * rdet) : 0.0;
             }
+            const double Li = tr < NU ? Lall : 0.0;
             const double Kk = mm(-Li, Psi, 0.0);      // K = -Lambda^-1 Psi
-            if (t_on && in_us) sh.t(RA + tr * NS + tc, tq, kk) = Kk;
-            if (t_on && in_uu && tc <= tr) sh.t(RA + NKF + tr * (tr + 1) / 2 + tc, tq, kk) = Li;
+            if (st_on) sh.t(st_row, tq, kk) = st_k ? Kk : Lall;
             if (lane == 0) __hip_atomic_store(progress + mw, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // block kk is in LDS
-            if (kk > 0) {       // closed-loop (Joseph) form: Q + Acl' P Acl + K' R~ K (+ M K + K' M'), then symmetrised
-                const double Acl = mm(Btr, Kk, Ar), RK_ = mm(Rs, Kk, 0.0);
-                const double T = mm(Pm, Acl, 0.0);
-                double Pn = mm(Kk, RK_, mm(Acl, T, Qr));
+            if (kk > 0) {       // closed-loop (Joseph) form: Q + Acl' P Acl + K' R~ K (+ M K + K' M')
+                const double Acl = mm(Btr, Kk, Ar), RK_ = mm(Rs, Kk, 0.0), T = mm(BtP, Kk, PA);      // A + B K,  R~ K,  P Acl = PA + PB K
+                double Pn = mm(Acl, T, mm(Kk, RK_, Qr));
                 if (HASM) { const double MK = mm(Mtr, Kk, 0.0); Pn = mm(MK, Ir, Pn + MK); }
-                Pm = 0.5 * (Pn + mm(Pn, Ir, 0.0));
+                Pm = Pn;      // symmetric up to rounding; the recursion does not amplify the difference
             }
         }
         pd_all = pd_all && pd_ok;
