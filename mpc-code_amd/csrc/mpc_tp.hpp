@@ -378,6 +378,9 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
     auto rhs_pass = [&](bool follow) {
         int done = N;       // every matrix wave is known to have finished this block (and the ones after it)
         auto wait_for = [&](int blk) {
+#ifdef MPC_NOFOLLOW
+            blk = 0;      // diagnostic build: the vector wave starts only when the whole factorisation is in LDS
+#endif
             if (follow) {
                 while (done > blk) {      // look again only when the known state does not cover the block
                     int d = 0;
