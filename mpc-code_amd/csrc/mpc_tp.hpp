@@ -29,7 +29,8 @@
 #else
 #define MPC_TSTAMP(slot) do { } while (0)
 #endif
-// -DMPC_STAMPS_FINE (with -DMPC_STAMPS): the iteration phases share slot 3, slot 4 takes wave 0's matrix recursion
+// -DMPC_STAMPS_FINE (with -DMPC_STAMPS): the iteration phases share slot 3, slot 4 takes wave 0's matrix recursion and
+// slots 5, 6, 2 three segments of its loop body (sums kept in registers, written once per pass)
 #ifdef MPC_STAMPS_FINE
 #define MPC_TSTAMP_IT(slot) MPC_TSTAMP(3)
 #define MPC_TSTAMP_FINE(slot) MPC_TSTAMP(slot)
@@ -476,6 +477,12 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         const int st_row = st_k ? RA + tr * NS + tc : RA + NKF + (st_l ? (tr - 2) * (tr - 1) / 2 + tc : 0);
         const bool st_on = t_on && (st_k || st_l);
         bool pd_ok = true;
+#ifdef MPC_STAMPS_FINE
+        unsigned long long seg_a = 0, seg_b = 0, seg_c = 0, tprev = __builtin_amdgcn_s_memtime();      // cycle sums kept in registers
+#define MPC_SEG(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tprev; tprev = t_; } while (0)
+#else
+#define MPC_SEG(acc) do { } while (0)
+#endif
         for (int kk = N - 1; kk >= 0; kk--) {
             // the identity tile rebuilt from the lane index on every trip (as a loop invariant it ends up in scratch, and a reload is a
             // memory round trip on the critical path)
@@ -504,6 +511,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             } else {
                 const double X1 = mm(BE1, PB, __builtin_fma(sb, mb1, RE1));
                 const double a = dpp_move<0x00, 0xF>(X0, X0), off = dpp_move<0x55, 0xF>(X0, X0), d = dpp_move<0x55, 0xF>(X1, X1);
+                MPC_SEG(seg_a);      // weights arrived, first two product levels done (a is read by the vector pipe)
                 const double det = a * d - off * off, rdet = frcp(det);
                 pd_ok = pd_ok && (a > 0.0) && (det > 0.0);
                 Lall = tc < 2 ? ((tr & 1) == tc ? (tc == 0 ? d : a) * rdet : -off * rdet) : 0.0;
@@ -511,6 +519,7 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
             const double Li = tr < NU ? Lall : 0.0;
             const double Kk = mm(-Li, Psi, 0.0);      // K = -Lambda^-1 Psi
             if (st_on) sh.t(st_row, tq, kk) = st_k ? Kk : Lall;
+            MPC_SEG(seg_b);          // inverse, K, store (the stamp waits for the store)
             if (lane == 0) __hip_atomic_store(progress + mw, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // block kk is in LDS
             if (kk > 0) {       // closed-loop (Joseph) form: Q + Acl' P Acl + K' R~ K (+ M K + K' M')
                 const double Acl = mm(Btr, Kk, Ar), RK_ = mm(Rs, Kk, 0.0), T = mm(BtP, Kk, PA);      // A + B K,  R~ K,  P Acl = PA + PB K
@@ -518,7 +527,14 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
                 if (HASM) { const double MK = mm(Mtr, Kk, 0.0); Pn = mm(MK, Ir, Pn + MK); }
                 Pm = Pn;      // symmetric up to rounding; the recursion does not amplify the difference
             }
+#ifdef MPC_STAMPS_FINE
+            Pm = vreg(Pm);           // the update has to be complete when the stamp is taken
+#endif
+            MPC_SEG(seg_c);          // flag, Joseph update
         }
+#ifdef MPC_STAMPS_FINE
+        if (threadIdx.x == 0 && threadIdx.y == 0) { mpc_stamp_buf[(blockIdx.x & 4095) * 8 + 5] += seg_a; mpc_stamp_buf[(blockIdx.x & 4095) * 8 + 6] += seg_b; mpc_stamp_buf[(blockIdx.x & 4095) * 8 + 2] += seg_c; }
+#endif
         pd_all = pd_all && pd_ok;
         if (t_on && !pd_all && tr == 0 && tc == 0) sh.flag[tinst] = -1;      // a Lambda lost definiteness: the instance stops as infeasible
     };
