@@ -45,7 +45,9 @@ typedef struct mpc_lin_desc {
     int32_t N;                   /* horizon */
     int32_t du_form;             /* cost on u_k - u_{k-1} with weight R (the Ex-file's S), Control_Calc.py:163-166,180-181 */
     int32_t duss_form;           /* target cost on us - us_prev, Target_Calc.py:121-122 */
-    int32_t y_bounded;           /* the g1 rows exist (yFree False), Control_Calc.py:60-63,150-151 */
+    int32_t y_bounded;           /* the g1 rows exist (yFree False), Control_Calc.py:60-63,150-151.  A bounded row of C with one
+                                    non-zero entry is a box on that state; any other bounded row is carried as one more stage
+                                    state (the compiled kernel set must have that many, see mpc_build_info) */
     int32_t estimator;           /* MPC_EST_* */
     int32_t max_iter;            /* ipopt.max_iter = Sol_itmax, MPC_code.py:262-263 */
     int32_t device;              /* HIP device ordinal */
