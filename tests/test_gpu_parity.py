@@ -442,3 +442,25 @@ def test_general_output_rows(dint_yrow, xp_nlplant, oracle_c, solver_factory):
     nl = rn.closed_loop_batch(q, 8, x0p, x0m, warm_start=False)
     assert np.array_equal(gl["STATUS_DYN"], nl["STATUS_DYN"]) and (gl["STATUS_DYN"] == 0).all()
     assert np.abs(gl["U"] - nl["U"]).max() < 1e-5 and np.abs(gl["Xp"] - nl["Xp"]).max() < 1e-5
+
+
+def test_kernel_variants_of_the_bound_sets(cstr, oracle_c, solver_factory):
+    """The three kernel variants mpc_lin_create chooses from (bounds on everything: no masks; inputs only: no state rows at
+    all; anything else: masks), each through the fused loop of both kernels - the matrix-core factorisation reads its barrier
+    weights per variant (no sigma_z rows when only the inputs are bounded)."""
+    import copy
+    from mpc_code_amd.driver import run_closed_loop
+    inf = np.inf
+    x0 = bench_x0(150, 11) * [1.0, 0.5, 0.5]
+    variants = {"all finite": {}, "inputs only": dict(xmin=np.full(3, -inf), xmax=np.full(3, inf), ymin=np.full(3, -inf), ymax=np.full(3, inf), y_bounded=False),
+                "one-sided": dict(xmin=np.array([-inf, -8.0, -inf]), xmax=np.array([10.0, inf, 10.0]), ymin=np.full(3, -inf), ymax=np.array([inf, 10.0, inf]))}
+    for name, over in variants.items():
+        p = copy.copy(cstr)
+        for k, v in over.items():
+            setattr(p, k, v)
+        cl = oracle_c.OracleC(p).closed_loop(25, x0, x0)
+        assert (cl["STATUS_DYN"] == 0).mean() > 0.9, name
+        for lk in (1, 2):
+            gl = run_closed_loop(p, x0, x0, 25, solver=solver_factory(p, lk))
+            assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), (name, lk)
+            assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, (name, lk)
