@@ -152,7 +152,7 @@ int mpc_pack_u(mpc_handle *h, void *dst_dev /* [B][nu] float64 */);
 int mpc_pack_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, void *dst_dev);
 
 /* Tunables of the resident closed loop (mpc_loop_run); they never change results beyond rounding.
- *   "steps_per_launch"  closed-loop steps per kernel launch (default 16; a launch starts with cold caches)
+ *   "steps_per_launch"  closed-loop steps per kernel launch (default 50; a launch starts with cold caches)
  *   "loop_kernel"       0 = choose by batch size (default), 1 = one instance per lane, 2 = horizon-parallel
  *                       (one wave per instance and block-parallel element-wise work; needs N <= 64)            */
 int mpc_set_option(mpc_handle *h, const char *name, double value);

@@ -562,7 +562,7 @@ struct mpc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false; int n_launches = 0;
-    int steps_per_launch = 16;  // closed-loop steps per kernel launch (a launch starts with cold scalar / instruction caches)
+    int steps_per_launch = 50;  // closed-loop steps per kernel launch (a launch starts with cold scalar / instruction caches)
     int loop_kernel_opt = 0;    // option "loop_kernel": 0 = choose by batch size, 1 = instance per lane, 2 = horizon-parallel
     int ws_mode = -1;           // which loop kernel's layout the workspace holds (-1 = none: next OCPs start cold)
     // per-call scratch (solve API)

@@ -211,11 +211,11 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
 def test_loop_kernel_choice(cstr, wb, solver_factory):
     """mpc_loop_run picks the horizon-parallel kernel whenever its factorisation runs on the matrix cores (stage fits a 4x4
     tile: CSTR), otherwise (Wood-Berry, stage state 6) for small batches only; the lane kernel for long horizons;
-    steps_per_launch defaults to 16."""
+    steps_per_launch defaults to 50."""
     import copy
     from mpc_code_amd import capi
     s = solver_factory(cstr)
-    assert s.get_option("steps_per_launch") == 16
+    assert s.get_option("steps_per_launch") == 50
     s.loop_alloc(100, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 2
     s.loop_alloc(20000, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 2
     sw = solver_factory(wb)
