@@ -21,6 +21,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--example", default="cstr_lmpc.py")
 ap.add_argument("--steps-per-launch", type=int, default=0)
 ap.add_argument("--loop-kernel", type=int, default=0, help="0 auto, 1 instance per lane, 2 horizon-parallel")
+ap.add_argument("--warmup", type=int, default=0, help="untimed steps first (the first launch of a kernel pays for code upload and scratch allocation), then the state is reset")
 a = ap.parse_args()
 p = m.load_problem(m.example_path(a.example))
 rng = np.random.default_rng(20250614)
@@ -35,6 +36,9 @@ s.set_option("loop_kernel", a.loop_kernel)
 s.loop_alloc(a.batch, a.steps, capi.LOG_U)
 s.loop_set_schedule(p.schedules(a.steps))
 s.loop_set_state(x0, x0)
+if a.warmup > 0:
+    s.loop_run(0, min(a.warmup, a.steps)); s.loop_sync()
+    s.loop_set_state(x0, x0)
 t0 = time.perf_counter()
 s.loop_run(0, a.steps)
 s.loop_sync()
