@@ -46,7 +46,7 @@ class _Desc(ct.Structure):
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile ``csrc/mpc_amd.hip`` for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp", "mpc_tp.hpp")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp", "mpc_tp.hpp", "mpc_wave.hpp")] + \
            [os.path.join(os.path.dirname(PKG_DIR), "include", "mpc_amd.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
         return LIB_PATH

@@ -7,6 +7,7 @@
 #include "../../include/mpc_amd.h"
 #include "mpc_device.hpp"
 #include "mpc_tp.hpp"
+#include "mpc_wave.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -465,6 +466,190 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
     }
 }
 
+// The closed loop on autonomous waves (mpc_wave.hpp): one wave = one workgroup = four instances, for all steps of the launch.
+// Lane i < 4 does for instance i what one lane of loop_kernel does (estimator, target, hold rules, plant) on state kept in LDS;
+// all 64 lanes solve the four OCPs.  HBM sees the state at the first and the last step of a launch and the logs in between.
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
+struct WvKernelCfg {
+    static constexpr int NS = NX + (DU ? NU : 0) + NG, NE = NX + ND, NDD = ND > 0 ? ND : 1;
+    using Cfg = WvCfg<NS, NU, NC>;
+    static constexpr int NTW = 2 * NU + 3 * (NX + NU + NY);
+    // per-instance state kept in LDS across the steps of a launch
+    static constexpr int K_X = 0, K_XH = NXP, K_DH = K_XH + NX, K_U = K_DH + NDD, K_XS = K_U + NU, K_US = K_XS + NX, K_P = K_US + NU,
+                         K_TW = K_P + NE * NE, KEEP = K_TW + NTW;
+    static constexpr size_t lds_bytes() { return sizeof(double) * Cfg::lds_doubles(KEEP) + sizeof(int) * 16; }
+};
+
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
+__global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restrict__ Pp, LoopArgs a)
+{
+    using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>;
+    using Cfg = typename KC::Cfg;
+    constexpr int NS = KC::NS, NE = KC::NE, NDD = KC::NDD, NTW = KC::NTW, KEEP = KC::KEEP;
+    extern __shared__ double wv_smem[];
+    double *const T = wv_smem, *const q = T + Cfg::T_DOUBLES, *const outv = q + 4 * Cfg::QN, *const keep = outv + 4 * Cfg::OUT;
+    int *const iflag = (int *)(keep + 4 * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
+    const DevProblem &P = *Pp;
+    const size_t Bs = a.Bs;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * 4 + (lane & 3);
+    const bool valid = lane < 4 && b < a.B;
+    double *const kp = keep + (lane & 3) * KEEP;
+    if (valid) {
+        MPC_UNROLL for (int i = 0; i < NXP; i++) kp[KC::K_X + i] = (a.x + (size_t)i * Bs)[b];
+        MPC_UNROLL for (int i = 0; i < NX; i++) { kp[KC::K_XH + i] = (a.xhat + (size_t)i * Bs)[b]; kp[KC::K_XS + i] = (a.xs + (size_t)i * Bs)[b]; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) kp[KC::K_DH + i] = (a.dhat + (size_t)i * Bs)[b];
+        MPC_UNROLL for (int i = 0; i < NU; i++) { kp[KC::K_U + i] = (a.u + (size_t)i * Bs)[b]; kp[KC::K_US + i] = (a.us + (size_t)i * Bs)[b]; }
+        if (P.estimator == MPC_EST_KALMAN) { for (int i = 0; i < NE * NE; i++) kp[KC::K_P + i] = (a.Pk + (size_t)i * Bs)[b]; }
+        for (int f = 0; f < NTW; f++) kp[KC::K_TW + f] = (a.tw + (size_t)f * Bs)[b];
+        twv[lane] = a.tw_valid[b]; wsv[lane] = a.ws_valid[b];
+    } else if (lane < 4) { twv[lane] = 0; wsv[lane] = 0; }
+    __syncthreads();
+    // resident iterates: the warm start of a previous launch (inputs and bound multipliers), lane = block
+    WvIter<NS, NU, NC> X[4];
+    WvInst S[4];
+    MPC_UNROLL for (int j = 0; j < 4; j++) {
+        const double *rows = a.ws + ((size_t)(blockIdx.x * 4 + j) * Cfg::ROWS_WS) * 64;
+        const bool w = __builtin_amdgcn_readfirstlane(wsv[j]) != 0;
+        MPC_UNROLL for (int i = 0; i < NU; i++) X[j].u[i] = w ? rows[i * 64 + lane] : 0.0;
+        MPC_UNROLL for (int i = 0; i < NC; i++) { X[j].ll[i] = w ? rows[(NU + i) * 64 + lane] : 0.0; X[j].lh[i] = w ? rows[(NU + NC + i) * 64 + lane] : 0.0; X[j].sl[i] = 1.0; X[j].sh[i] = 1.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) X[j].z[i] = 0.0;
+    }
+    for (int k = 0; k < a.nsteps; k++) {
+        unsigned bq = (unsigned)b;      // opaque per step: the address arithmetic of the log arrays stays next to the stores
+        asm volatile("" : "+v"(bq));
+        if (valid) {
+            double x[NXP], xh[NX], dh[NDD], u[NU], xs[NX], us[NU];
+            double xh_pred[NX], dh_prev[NDD], xs_prev[NX], us_prev[NU], delta = 0.0;
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = kp[KC::K_XH + i]; xs[i] = kp[KC::K_XS + i]; xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) { dh[i] = kp[KC::K_DH + i]; dh_prev[i] = dh[i]; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = kp[KC::K_U + i]; us[i] = kp[KC::K_US + i]; us_prev[i] = us[i]; }
+            if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) (a.XP + (size_t)((size_t)k * NXP + i) * Bs)[bq] = x[i]; }
+            if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XHAT + (size_t)((size_t)k * NX + i) * Bs)[bq] = xh[i]; }
+            // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
+            if (P.estimator != MPC_EST_NONE) {
+                double xi[NE], innov[NY];
+                MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
+                MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
+                MPC_UNROLL for (int i = 0; i < NY; i++) {
+                    double yh = P.fyc[i], yy = a.pyp[k * NY + i];
+                    MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+                    MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
+                    innov[i] = yy - yh;
+                }
+                if (P.estimator == MPC_EST_KALMAN) {
+                    double Pk[NE][NE];
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = kp[KC::K_P + i * NE + j]; }
+                    kalman_lane<NE, NY>(P, xi, Pk, innov);
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) kp[KC::K_P + i * NE + j] = Pk[i][j]; }
+                } else {
+                    MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+                }
+                MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
+                MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
+            }
+            if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) (a.DHAT + (size_t)((size_t)k * ND + i) * Bs)[bq] = dh[i]; }
+            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xh[i] - xh_pred[i]));
+            MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
+            // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
+            double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
+            MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
+            MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
+            int it_ss;
+            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, kp + KC::K_TW, 1, twv + lane);
+            if (st_ss != kInfeasible) {
+                MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
+                MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
+            }
+            if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XS + (size_t)((size_t)k * NX + i) * Bs)[bq] = xs[i]; }
+            if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.US + (size_t)((size_t)k * NU + i) * Bs)[bq] = us[i]; }
+            if (a.YS) {   // ys = Fy_model(xs, us, dhat), MPC_code.py:730
+                MPC_UNROLL for (int i = 0; i < NY; i++) {
+                    double v = P.fyc[i];
+                    MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Cm[i][j] * xs[j];
+                    MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Cd[i][j] * dh[j];
+                    (a.YS + (size_t)((size_t)k * NY + i) * Bs)[bq] = v;
+                }
+            }
+            if (a.st_dyn) { (a.st_ss + (size_t)k * Bs)[bq] = st_ss; (a.it_ss + (size_t)k * Bs)[bq] = it_ss; }
+            // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS ------------------------------
+            OcpInst<NS, NU> qi;
+            build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, qi);
+            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xs[i] - xs_prev[i]));
+            MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
+            const bool warm = wsv[lane] != 0 && delta <= kWsDelta;
+            double *qd = q + lane * Cfg::QN;
+            MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = qi.ur[i]; qd[5 * NS + NU + i] = qi.us[i]; }
+            qd[5 * NS + 2 * NU] = delta;
+            iflag[lane] = kWvValid | (qi.ok0 ? kWvOk0 : 0) | (warm ? kWvWarm : 0);
+            MPC_UNROLL for (int i = 0; i < NX; i++) { kp[KC::K_XH + i] = xh[i]; kp[KC::K_XS + i] = xs[i]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) kp[KC::K_DH + i] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) kp[KC::K_US + i] = us[i];
+        } else if (lane < 4) iflag[lane] = 0;
+        __syncthreads();
+        wv_solve<NS, NU, DU, NC, MASKED>(P, T, q, iflag, X, S, P.max_iter);
+        // first input and next state of the final iterates: block 0 = lane 0
+        if (lane == 0) {
+            MPC_UNROLL for (int j = 0; j < 4; j++) {
+                MPC_UNROLL for (int i = 0; i < NU; i++) outv[j * Cfg::OUT + i] = X[j].u[i];
+                MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = X[j].z[i];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
+            const int st_dyn = lane == 0 ? S[0].status : (lane == 1 ? S[1].status : (lane == 2 ? S[2].status : S[3].status));
+            const int it_dyn = lane == 0 ? S[0].iters : (lane == 1 ? S[1].iters : (lane == 2 ? S[2].iters : S[3].iters));
+            double x[NXP], xh[NX], u[NU];
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = kp[KC::K_U + i];
+            if (st_dyn != kInfeasible) {
+                MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = outv[lane * Cfg::OUT + i];               // :798
+                MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = outv[lane * Cfg::OUT + NU + i];         // :799
+            } else {                                                           // :804-805 hold u, propagate the model
+                double xo[NX], dh[NDD];
+                MPC_UNROLL for (int i = 0; i < NX; i++) xo[i] = kp[KC::K_XH + i];
+                MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = kp[KC::K_DH + i];
+                MPC_UNROLL for (int i = 0; i < NX; i++) {
+                    double v = P.fxc[i];
+                    MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Am[i][j] * xo[j];
+                    MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bm[i][j] * u[j];
+                    MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Bd[i][j] * dh[j];
+                    xh[i] = v;
+                }
+            }
+            if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.U + (size_t)((size_t)k * NU + i) * Bs)[bq] = u[i]; }
+            if (a.st_dyn) { (a.st_dyn + (size_t)k * Bs)[bq] = st_dyn; (a.it_dyn + (size_t)k * Bs)[bq] = it_dyn; }
+            MPC_UNROLL for (int i = 0; i < NXP; i++) {
+                double v = a.pxp[k * NXP + i];
+                MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
+                kp[KC::K_X + i] = v;
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) kp[KC::K_XH + i] = xh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) kp[KC::K_U + i] = u[i];
+            wsv[lane] = st_dyn == kSolved ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        MPC_UNROLL for (int i = 0; i < NXP; i++) (a.x + (size_t)i * Bs)[b] = kp[KC::K_X + i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) { (a.xhat + (size_t)i * Bs)[b] = kp[KC::K_XH + i]; (a.xs + (size_t)i * Bs)[b] = kp[KC::K_XS + i]; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) (a.dhat + (size_t)i * Bs)[b] = kp[KC::K_DH + i];
+        MPC_UNROLL for (int i = 0; i < NU; i++) { (a.u + (size_t)i * Bs)[b] = kp[KC::K_U + i]; (a.us + (size_t)i * Bs)[b] = kp[KC::K_US + i]; }
+        if (P.estimator == MPC_EST_KALMAN) { for (int i = 0; i < NE * NE; i++) (a.Pk + (size_t)i * Bs)[b] = kp[KC::K_P + i]; }
+        for (int f = 0; f < NTW; f++) (a.tw + (size_t)f * Bs)[b] = kp[KC::K_TW + f];
+        a.tw_valid[b] = twv[lane]; a.ws_valid[b] = wsv[lane];
+    }
+    MPC_UNROLL for (int j = 0; j < 4; j++) {
+        double *rows = a.ws + ((size_t)(blockIdx.x * 4 + j) * Cfg::ROWS_WS) * 64;
+        MPC_UNROLL for (int i = 0; i < NU; i++) rows[i * 64 + lane] = X[j].u[i];
+        MPC_UNROLL for (int i = 0; i < NC; i++) { rows[(NU + i) * 64 + lane] = X[j].ll[i]; rows[(NU + NC + i) * 64 + lane] = X[j].lh[i]; }
+    }
+}
+
 // dense [B][nu] copy of u for the all-gather of u* 
 __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__ dst, int B, size_t Bs, int nu)
 {
@@ -482,6 +667,8 @@ struct Launchers {
     void (*kf)(const DevProblem *, KfArgs, hipStream_t);
     void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
     int (*loop_tp)(const DevProblem *, LoopArgs, hipStream_t);     // horizon-parallel variant (N <= 64), nullptr if it does not fit
+    int (*loop_wv)(const DevProblem *, LoopArgs, hipStream_t);     // wave-autonomous variant (N <= 64, stage fits a 4x4 tile), nullptr otherwise
+    size_t wv_ws_per_inst, wv_lds;
     int ws_rows, nc, tp_ni;
     int tp_max_batch;           // auto choice of the loop kernel: largest batch the horizon-parallel kernel is preferred for
     size_t tp_ws_per_inst, tp_ws_per_group, tp_lds;
@@ -523,6 +710,26 @@ static Launchers make_launchers_mode()
                     attr_set[dev] = true;
                 }
                 hipLaunchKernelGGL(kern, dim3((a.B + Cfg::NI - 1) / Cfg::NI), dim3(64, NW), lds, s, p, a);
+                return 0;
+            };
+        }
+    }
+    l.loop_wv = nullptr; l.wv_ws_per_inst = 0; l.wv_lds = 0;
+    if constexpr (NX + (DU ? NU : 0) + NG <= 4 && NU <= 2) {
+        using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>;
+        constexpr size_t lds = KC::lds_bytes();
+        l.wv_lds = lds; l.wv_ws_per_inst = sizeof(double) * 64 * KC::Cfg::ROWS_WS;
+        if (lds <= 160 * 1024) {
+            l.loop_wv = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
+                auto kern = loop_kernel_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>;
+                static bool attr_set[64] = {};
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+                if (!attr_set[dev]) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+                    attr_set[dev] = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((a.B + 3) / 4), dim3(64), lds, s, p, a);
                 return 0;
             };
         }
@@ -837,7 +1044,8 @@ extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
     if (!std::strcmp(name, "steps_per_launch")) { h->steps_per_launch = value >= 1 ? (int)value : 1; return 0; }
     if (!std::strcmp(name, "loop_kernel")) {
         const int v = (int)value;
-        if (v < 0 || v > 2) return fail(-1, "loop_kernel must be 0 (auto), 1 (instance per lane) or 2 (horizon-parallel)");
+        if (v < 0 || v > 3) return fail(-1, "loop_kernel must be 0 (auto), 1 (instance per lane), 2 (horizon-parallel) or 3 (wave-autonomous)");
+        if (v == 3 && (!h->L.loop_wv || h->hp.N > 64)) return fail(-8, "the wave-autonomous kernel needs N <= 64 and a stage that fits a 4x4 tile (stage state <= 4, nu <= 2)");
         if (v == 2 && (!h->L.loop_tp || h->hp.N > 64)) return fail(-8, "the horizon-parallel kernel needs N <= 64 and a problem that fits the LDS");
         h->loop_kernel_opt = v;
         return 0;
@@ -876,7 +1084,8 @@ static int ensure_ws(mpc_handle *h, size_t Bs)
     const size_t lane_bytes = (size_t)h->L.ws_rows * (h->hp.N + 2) * Bs * sizeof(double);   // +2 guard blocks per wave
     const size_t groups = (Bs + h->L.tp_ni - 1) / h->L.tp_ni;
     const size_t tp_bytes = groups * h->L.tp_ni * h->L.tp_ws_per_inst + groups * h->L.tp_ws_per_group;
-    return h->ws.ensure(std::max(lane_bytes, tp_bytes));
+    const size_t wv_bytes = ((Bs + 3) / 4 * 4) * h->L.wv_ws_per_inst;
+    return h->ws.ensure(std::max(std::max(lane_bytes, tp_bytes), wv_bytes));
 }
 
 extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
@@ -1138,6 +1347,7 @@ extern "C" int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double
 static int loop_mode(const mpc_handle *h)
 {
     if (h->loop_kernel_opt != 0) return h->loop_kernel_opt;
+    if (h->L.loop_wv && h->hp.N <= 64) return 3;
     if (!h->L.loop_tp || h->hp.N > 64) return 1;
     return h->B <= h->L.tp_max_batch ? 2 : 1;
 }
@@ -1177,7 +1387,8 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         a.ws_valid = (int32_t *)h->st_flag.p; a.kf_valid = a.ws_valid + Bs; a.Kg = (double *)h->st_Kg.p; a.Pn = (double *)h->st_Pn.p;
         a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
-        if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
+        if (mode == 3) { if (h->L.loop_wv(h->dp, a, h->stream)) return fail(-9, "cannot configure the wave-autonomous kernel (LDS %zu bytes)", h->L.wv_lds); }
+        else if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);
         launches++;
     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Closed loop with each loop kernel (1 = instance per lane, 2 = horizon-parallel) against oracle/mpc_oracle.c (development check)."""
+"""Closed loop with each loop kernel (1 = instance per lane, 2 = horizon-parallel, 3 = wave-autonomous) against oracle/mpc_oracle.c (development check)."""
 import os
 import sys
 import time
@@ -17,9 +17,12 @@ for ex, B, K in (("cstr_lmpc.py", 1000, 30), ("wood_berry_lmpc.py", 200, 20)):
     rng = np.random.default_rng(7)
     x0 = rng.uniform([-0.5, -8.0, -5.0], [0.5, 8.0, 5.0], size=(B, 3)) if p.nx == 3 else 0.05 * rng.standard_normal((B, p.nx))
     ref = oracle_c.OracleC(p).closed_loop(K, x0, x0)
-    for mode in (1, 2):
+    for mode in (3, 2, 1):
         s = capi.Solver(p)
-        s.set_option("loop_kernel", mode)
+        try:
+            s.set_option("loop_kernel", mode)
+        except capi.MpcAmdError as e:
+            print(f"{ex} kernel={mode}: not available ({e})"); s.close(); continue
         s.loop_alloc(B, K, capi.LOG_ALL)
         s.loop_set_schedule(p.schedules(K)); s.loop_set_state(x0, x0)
         t0 = time.perf_counter(); s.loop_run(0, K); s.loop_sync(); dt = time.perf_counter() - t0
