@@ -469,32 +469,36 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
 // The closed loop on autonomous waves (mpc_wave.hpp): one wave = one workgroup = four instances, for all steps of the launch.
 // Lane i < 4 does for instance i what one lane of loop_kernel does (estimator, target, hold rules, plant) on state kept in LDS;
 // all 64 lanes solve the four OCPs.  HBM sees the state at the first and the last step of a launch and the logs in between.
-template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED, int NI>
 struct WvKernelCfg {
     static constexpr int NS = NX + (DU ? NU : 0) + NG, NE = NX + ND, NDD = ND > 0 ? ND : 1;
-    using Cfg = WvCfg<NS, NU, NC>;
+    using Cfg = WvCfg<NS, NU, NC, NI>;
     static constexpr int NTW = 2 * NU + 3 * (NX + NU + NY);
     // per-instance state kept in LDS across the steps of a launch
     static constexpr int K_X = 0, K_XH = NXP, K_DH = K_XH + NX, K_U = K_DH + NDD, K_XS = K_U + NU, K_US = K_XS + NX, K_P = K_US + NU,
                          K_TW = K_P + NE * NE, KEEP = K_TW + NTW;
     static constexpr size_t lds_bytes() { return sizeof(double) * Cfg::lds_doubles(KEEP) + sizeof(int) * 16; }
+    static constexpr int ni() { return NI; }
 };
 
-template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
-__global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restrict__ Pp, LoopArgs a)
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED, int NI>
+__global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const DevProblem *__restrict__ Pp, LoopArgs a)
 {
-    using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>;
+    using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
     using Cfg = typename KC::Cfg;
     constexpr int NS = KC::NS, NE = KC::NE, NDD = KC::NDD, NTW = KC::NTW, KEEP = KC::KEEP;
     extern __shared__ double wv_smem[];
-    double *const T = wv_smem, *const q = T + Cfg::T_DOUBLES, *const outv = q + 4 * Cfg::QN, *const keep = outv + 4 * Cfg::OUT;
-    int *const iflag = (int *)(keep + 4 * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
-    const DevProblem &P = *Pp;
+    double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::T_DOUBLES, *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
+    int *const iflag = (int *)(keep + NI * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
+    // the problem constants are read through the constant address space: immutable by definition, so every access is a scalar
+    // load whatever the kernel has stored to global memory in between (as plain global data they turn into vector loads + waits)
+    const ConstProblem &P = *(const ConstProblem *)Pp;
     const size_t Bs = a.Bs;
     const int lane = threadIdx.x;
-    const int b = blockIdx.x * 4 + (lane & 3);
-    const bool valid = lane < 4 && b < a.B;
-    double *const kp = keep + (lane & 3) * KEEP;
+    const int il = lane < NI ? lane : 0;      // lane i < NI is the lane of instance i
+    const int b = blockIdx.x * NI + il;
+    const bool valid = lane < NI && b < a.B;
+    double *const kp = keep + il * KEEP;
     if (valid) {
         MPC_UNROLL for (int i = 0; i < NXP; i++) kp[KC::K_X + i] = (a.x + (size_t)i * Bs)[b];
         MPC_UNROLL for (int i = 0; i < NX; i++) { kp[KC::K_XH + i] = (a.xhat + (size_t)i * Bs)[b]; kp[KC::K_XS + i] = (a.xs + (size_t)i * Bs)[b]; }
@@ -503,18 +507,21 @@ __global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restric
         if (P.estimator == MPC_EST_KALMAN) { for (int i = 0; i < NE * NE; i++) kp[KC::K_P + i] = (a.Pk + (size_t)i * Bs)[b]; }
         for (int f = 0; f < NTW; f++) kp[KC::K_TW + f] = (a.tw + (size_t)f * Bs)[b];
         twv[lane] = a.tw_valid[b]; wsv[lane] = a.ws_valid[b];
-    } else if (lane < 4) { twv[lane] = 0; wsv[lane] = 0; }
+    } else if (lane < NI) { twv[lane] = 0; wsv[lane] = 0; }
+    for (int i = lane; i < NI * Cfg::LD; i += 64) T[Cfg::RZ * NI * Cfg::LD + i] = 0.0;      // the zero row of the tile view
+    if (lane < Cfg::GUARD) wv_smem[lane] = 0.0;
     __syncthreads();
     // resident iterates: the warm start of a previous launch (inputs and bound multipliers), lane = block
-    WvIter<NS, NU, NC> X[4];
-    WvInst S[4];
-    MPC_UNROLL for (int j = 0; j < 4; j++) {
-        const double *rows = a.ws + ((size_t)(blockIdx.x * 4 + j) * Cfg::ROWS_WS) * 64;
+    WvIter<NS, NU, NC> X[NI];
+    WvInst S[NI];
+    MPC_UNROLL for (int j = 0; j < NI; j++) {
+        const double *rows = a.ws + ((size_t)(blockIdx.x * NI + j) * Cfg::ROWS_WS) * 64;
         const bool w = __builtin_amdgcn_readfirstlane(wsv[j]) != 0;
         MPC_UNROLL for (int i = 0; i < NU; i++) X[j].u[i] = w ? rows[i * 64 + lane] : 0.0;
         MPC_UNROLL for (int i = 0; i < NC; i++) { X[j].ll[i] = w ? rows[(NU + i) * 64 + lane] : 0.0; X[j].lh[i] = w ? rows[(NU + NC + i) * 64 + lane] : 0.0; X[j].sl[i] = 1.0; X[j].sh[i] = 1.0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) X[j].z[i] = 0.0;
     }
+    MPC_STAMP_INIT
     for (int k = 0; k < a.nsteps; k++) {
         unsigned bq = (unsigned)b;      // opaque per step: the address arithmetic of the log arrays stays next to the stores
         asm volatile("" : "+v"(bq));
@@ -587,12 +594,14 @@ __global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restric
             MPC_UNROLL for (int i = 0; i < NX; i++) { kp[KC::K_XH + i] = xh[i]; kp[KC::K_XS + i] = xs[i]; }
             MPC_UNROLL for (int i = 0; i < ND; i++) kp[KC::K_DH + i] = dh[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) kp[KC::K_US + i] = us[i];
-        } else if (lane < 4) iflag[lane] = 0;
+        } else if (lane < NI) iflag[lane] = 0;
         __syncthreads();
-        wv_solve<NS, NU, DU, NC, MASKED>(P, T, q, iflag, X, S, P.max_iter);
+        MPC_TSTAMP(0);
+        wv_solve<NS, NU, DU, NC, MASKED, NI>(P, T, q, iflag, X, S, P.max_iter);
+        MPC_STAMP_RESET
         // first input and next state of the final iterates: block 0 = lane 0
         if (lane == 0) {
-            MPC_UNROLL for (int j = 0; j < 4; j++) {
+            MPC_UNROLL for (int j = 0; j < NI; j++) {
                 MPC_UNROLL for (int i = 0; i < NU; i++) outv[j * Cfg::OUT + i] = X[j].u[i];
                 MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = X[j].z[i];
             }
@@ -600,8 +609,8 @@ __global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restric
         __syncthreads();
         if (valid) {
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
-            const int st_dyn = lane == 0 ? S[0].status : (lane == 1 ? S[1].status : (lane == 2 ? S[2].status : S[3].status));
-            const int it_dyn = lane == 0 ? S[0].iters : (lane == 1 ? S[1].iters : (lane == 2 ? S[2].iters : S[3].iters));
+            int st_dyn = S[0].status, it_dyn = S[0].iters;
+            MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st_dyn = S[j].status; it_dyn = S[j].iters; } }
             double x[NXP], xh[NX], u[NU];
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = kp[KC::K_U + i];
@@ -633,6 +642,7 @@ __global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restric
             wsv[lane] = st_dyn == kSolved ? 1 : 0;
         }
         __syncthreads();
+        MPC_TSTAMP(7);
     }
     if (valid) {
         MPC_UNROLL for (int i = 0; i < NXP; i++) (a.x + (size_t)i * Bs)[b] = kp[KC::K_X + i];
@@ -643,8 +653,8 @@ __global__ __launch_bounds__(64) void loop_kernel_wv(const DevProblem *__restric
         for (int f = 0; f < NTW; f++) (a.tw + (size_t)f * Bs)[b] = kp[KC::K_TW + f];
         a.tw_valid[b] = twv[lane]; a.ws_valid[b] = wsv[lane];
     }
-    MPC_UNROLL for (int j = 0; j < 4; j++) {
-        double *rows = a.ws + ((size_t)(blockIdx.x * 4 + j) * Cfg::ROWS_WS) * 64;
+    MPC_UNROLL for (int j = 0; j < NI; j++) {
+        double *rows = a.ws + ((size_t)(blockIdx.x * NI + j) * Cfg::ROWS_WS) * 64;
         MPC_UNROLL for (int i = 0; i < NU; i++) rows[i * 64 + lane] = X[j].u[i];
         MPC_UNROLL for (int i = 0; i < NC; i++) { rows[(NU + i) * 64 + lane] = X[j].ll[i]; rows[(NU + NC + i) * 64 + lane] = X[j].lh[i]; }
     }
@@ -716,12 +726,16 @@ static Launchers make_launchers_mode()
     }
     l.loop_wv = nullptr; l.wv_ws_per_inst = 0; l.wv_lds = 0;
     if constexpr (NX + (DU ? NU : 0) + NG <= 4 && NU <= 2) {
-        using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>;
+#ifndef MPC_WV_NI
+#define MPC_WV_NI 4
+#endif
+        constexpr int NI = MPC_WV_NI;      // instances per wave of the wave-autonomous kernel
+        using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
         constexpr size_t lds = KC::lds_bytes();
         l.wv_lds = lds; l.wv_ws_per_inst = sizeof(double) * 64 * KC::Cfg::ROWS_WS;
         if (lds <= 160 * 1024) {
             l.loop_wv = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
-                auto kern = loop_kernel_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>;
+                auto kern = loop_kernel_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
                 static bool attr_set[64] = {};
                 int dev = 0;
                 if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
@@ -729,7 +743,7 @@ static Launchers make_launchers_mode()
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
                     attr_set[dev] = true;
                 }
-                hipLaunchKernelGGL(kern, dim3((a.B + 3) / 4), dim3(64), lds, s, p, a);
+                hipLaunchKernelGGL(kern, dim3((a.B + NI - 1) / NI), dim3(64), lds, s, p, a);
                 return 0;
             };
         }

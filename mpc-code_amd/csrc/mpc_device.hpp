@@ -43,6 +43,8 @@ constexpr int kMaxN = 8, kMaxM = 4, kMaxY = 8, kMaxD = 8, kMaxV = kMaxN + kMaxM,
 enum : int { kSolved = 0, kMaxIter = 1, kInfeasible = 2 };
 
 // Problem constants as the kernels read them (one copy in HBM, wave-uniform loads).
+// PT in the device templates below: DevProblem, or DevProblem in the constant address space (ConstProblem) - then every access
+// is a scalar load, whatever the kernel has stored to global memory in between
 struct DevProblem {
     int nx, nu, ny, nd, nxp, N, du_form, duss_form, y_bounded, estimator, max_iter, has_dsat;
     // stage form (z = x, or [x; u_prev] when du_form)
@@ -62,6 +64,8 @@ struct DevProblem {
     // A^(2^j), j = 0..5, of the stage form: the adjoint recursion as a parallel scan over the horizon (mpc_tp.hpp)
     double Apow[6][kMaxN][kMaxN];
 };
+
+typedef __attribute__((address_space(4))) DevProblem ConstProblem;
 
 #define MPC_UNROLL _Pragma("unroll")
 // Diagnostic build only (-DMPC_STAMPS, tools/stamps.py): shader cycles per sweep accumulated into mpc_stamp_buf[wave][8].
@@ -195,8 +199,8 @@ struct OcpInst {
 };
 
 // xhat, xs [NX]; us, u_prev [NU]; dhat [ND]  ->  stage-form instance
-template <int NX, int NU, int NY, int ND, bool DU, int NG>
-__device__ __forceinline__ void build_inst(const DevProblem &P, const double (&xhat)[NX], const double (&xs)[NX],
+template <int NX, int NU, int NY, int ND, bool DU, int NG, class PT>
+__device__ __forceinline__ void build_inst(const PT &P, const double (&xhat)[NX], const double (&xs)[NX],
                                            const double (&us)[NU], const double *dhat, const double (&u_prev)[NU],
                                            OcpInst<NX + (DU ? NU : 0) + NG, NU> &q)
 {
@@ -723,8 +727,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
 // --------------------------------------------------------------------------------------------------------
 // tw / twv: warm-start data of the closed loop for this instance, element f at tw[f * tws]: y[NR] l_lo[NC] l_hi[NC] gr[NR] w0[NC]
 // of the last successful solve, and its validity flag; nullptr = cold (the per-call entry point).  DESIGN.md section 4.8.
-template <int NX, int NU, int NY, int ND>
-__device__ int target_lane(const DevProblem &P, const double *usp, const double *ysp, const double *dhat,
+template <int NX, int NU, int NY, int ND, class PT>
+__device__ int target_lane(const PT &P, const double *usp, const double *ysp, const double *dhat,
                            const double (&us_prev)[NU], double (&xs)[NX], double (&us)[NU], double (&ys)[NY], int &iters,
                            double *tw = nullptr, size_t tws = 0, int32_t *twv = nullptr)
 {
@@ -864,8 +868,8 @@ __device__ int target_lane(const DevProblem &P, const double *usp, const double 
 // estimator: xi = [xhat; dhat], Pk row-major [NE][NE]; innov = y - yhat
 // --------------------------------------------------------------------------------------------------------
 // gain K for the prior covariance Pk, and the next prior (the part of the filter that does not see the data)
-template <int NE, int NY>
-__device__ void kalman_cov(const DevProblem &P, double (&Pk)[NE][NE], double (&K)[NE][NY])
+template <int NE, int NY, class PT>
+__device__ void kalman_cov(const PT &P, double (&Pk)[NE][NE], double (&K)[NE][NY])
 {
     double PCt[NE][NY], S[NY][NY];
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += Pk[i][l] * P.Ca[j][l]; PCt[i][j] = a; } }
@@ -880,8 +884,8 @@ __device__ void kalman_cov(const DevProblem &P, double (&Pk)[NE][NE], double (&K
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = P.Qkf[i][j]; MPC_UNROLL for (int l = 0; l < NE; l++) a += T[i][l] * P.Aa[j][l]; Pk[i][j] = a; } }  // :309
 }
 
-template <int NE, int NY>
-__device__ void kalman_lane(const DevProblem &P, double (&xi)[NE], double (&Pk)[NE][NE], const double (&innov)[NY])
+template <int NE, int NY, class PT>
+__device__ void kalman_lane(const PT &P, double (&xi)[NE], double (&Pk)[NE][NE], const double (&innov)[NY])
 {
     double K[NE][NY];
     kalman_cov<NE, NY>(P, Pk, K);

@@ -18,7 +18,8 @@ s.lib.mpc_debug_stamps(None, 0, 1)
 s.set_option("steps_per_launch", 1)
 MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 s.set_option("loop_kernel", MODE)
-names = ["init", "B1", "F1", "B2", "F2"] if MODE == 1 else ["target", "init", "A", "B+C", "D+E", "F+G", "H+A", "est"]
+names = ["init", "B1", "F1", "B2", "F2"] if MODE == 1 else (["target", "init", "A", "B+C", "D+E", "F+G", "H+A", "est"] if MODE == 2 else
+         ["est+target", "init", "factor+rhs", "forward(x2)", "predictor ew", "rhs", "corrector ew + test", "accept+plant"])
 for k in range(K):
     s.loop_run(k, 1); s.loop_sync()
     s.lib.mpc_debug_stamps(buf.ctypes.data_as(ct.c_void_p), 64 * 8, 1)
