@@ -477,7 +477,7 @@ struct WvKernelCfg {
     // per-instance state kept in LDS across the steps of a launch
     static constexpr int K_X = 0, K_XH = NXP, K_DH = K_XH + NX, K_U = K_DH + NDD, K_XS = K_U + NU, K_US = K_XS + NX, K_P = K_US + NU,
                          K_TW = K_P + NE * NE, KEEP = K_TW + NTW;
-    static constexpr size_t lds_bytes() { return sizeof(double) * Cfg::lds_doubles(KEEP) + sizeof(int) * 16; }
+    static constexpr size_t lds_bytes() { return sizeof(double) * (Cfg::lds_doubles(KEEP) + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 16; }
     static constexpr int ni() { return NI; }
 };
 
@@ -490,6 +490,8 @@ __global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const De
     extern __shared__ double wv_smem[];
     double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::T_DOUBLES, *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
     int *const iflag = (int *)(keep + NI * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
+    using RT = Row16Tab<NX, NU, NY, ND>;
+    double *const tab = (double *)(wsv + 8);      // per-row constants of the 16-lanes-per-instance phases
     // the problem constants are read through the constant address space: immutable by definition, so every access is a scalar
     // load whatever the kernel has stored to global memory in between (as plain global data they turn into vector loads + waits)
     const ConstProblem &P = *(const ConstProblem *)Pp;
@@ -510,67 +512,115 @@ __global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const De
     } else if (lane < NI) { twv[lane] = 0; wsv[lane] = 0; }
     for (int i = lane; i < NI * Cfg::LD; i += 64) T[Cfg::RZ * NI * Cfg::LD + i] = 0.0;      // the zero row of the tile view
     if (lane < Cfg::GUARD) wv_smem[lane] = 0.0;
+    if (RT::fits) row16_fill_tables<NX, NU, NY, ND>(P, tab, lane);
     __syncthreads();
     // resident iterates: the warm start of a previous launch (inputs and bound multipliers), lane = block
-    WvIter<NS, NU, NC> X[NI];
+    WvIterA<NS, NU, NC> X[NI];
     WvInst S[NI];
     MPC_UNROLL for (int j = 0; j < NI; j++) {
         const double *rows = a.ws + ((size_t)(blockIdx.x * NI + j) * Cfg::ROWS_WS) * 64;
         const bool w = __builtin_amdgcn_readfirstlane(wsv[j]) != 0;
-        MPC_UNROLL for (int i = 0; i < NU; i++) X[j].u[i] = w ? rows[i * 64 + lane] : 0.0;
-        MPC_UNROLL for (int i = 0; i < NC; i++) { X[j].ll[i] = w ? rows[(NU + i) * 64 + lane] : 0.0; X[j].lh[i] = w ? rows[(NU + NC + i) * 64 + lane] : 0.0; X[j].sl[i] = 1.0; X[j].sh[i] = 1.0; }
-        MPC_UNROLL for (int i = 0; i < NS; i++) X[j].z[i] = 0.0;
+        WvIter<NS, NU, NC> X0;
+        MPC_UNROLL for (int i = 0; i < NU; i++) X0.u[i] = w ? rows[i * 64 + lane] : 0.0;
+        MPC_UNROLL for (int i = 0; i < NC; i++) { X0.ll[i] = w ? rows[(NU + i) * 64 + lane] : 0.0; X0.lh[i] = w ? rows[(NU + NC + i) * 64 + lane] : 0.0; X0.sl[i] = 1.0; X0.sh[i] = 1.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) X0.z[i] = 0.0;
+        X[j].put(X0);
     }
     MPC_STAMP_INIT
     for (int k = 0; k < a.nsteps; k++) {
         unsigned bq = (unsigned)b;      // opaque per step: the address arithmetic of the log arrays stays next to the stores
         asm volatile("" : "+v"(bq));
+        if constexpr (RT::fits) {
+            // ---- estimator and target with 16 lanes per instance (mpc_wave.hpp) --------------------------------------
+            const int b16 = lane >> 4, r16 = lane & 15, b16c = b16 < NI ? b16 : 0;
+            const unsigned bi = (unsigned)(blockIdx.x * NI + b16c);
+            const bool inst16 = b16 < NI && (int)bi < a.B;
+            double *const kq = keep + b16c * KEEP;
+            if (inst16) {
+                if (a.XP && r16 < NXP) (a.XP + (size_t)((size_t)k * NXP + r16) * Bs)[bi] = kq[KC::K_X + r16];
+                if (a.XHAT && r16 < NX) (a.XHAT + (size_t)((size_t)k * NX + r16) * Bs)[bi] = kq[KC::K_XH + r16];
+            }
+            double xi_old = 0.0, xi_new = 0.0;
+            if (P.estimator != MPC_EST_NONE)
+                kalman_row16<NX, NY, ND, NXP, NU>(P, r16, kq, KC::K_X, KC::K_XH, KC::K_P, a.pyp + k * NY, tab, T + b16c * RT::XCH, xi_old, xi_new);
+            if (inst16 && a.DHAT && r16 >= NX && r16 < NE) (a.DHAT + (size_t)((size_t)k * ND + (r16 - NX)) * Bs)[bi] = xi_new;
+            double delta = row16_max(r16 < NE ? fabs(xi_new - xi_old) : 0.0);      // warm-start test: estimate against its prediction
+            __syncthreads();
+            double dh[NDD], usv[NU];
+            MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = kq[KC::K_DH + i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) usv[i] = kq[KC::K_US + i];
+            int it_ss; double vrow;
+            const int st_ss = target_row16<NX, NU, NY, ND>(P, r16, tab, a.usp + k * NU, a.ysp + k * NY, dh, usv, kq + KC::K_TW, twv + b16c, inst16, vrow, it_ss);
+            // accept, or keep the previous target when infeasible (MPC_code.py:714-718); rows 0..NX-1 = xs, NX..NX+NU-1 = us
+            const bool trow = r16 < NX + NU;
+            const double prev = trow ? kq[KC::K_XS + r16] : 0.0;      // K_XS.. and K_US.. are adjacent
+            const double tnew = (st_ss != kInfeasible && trow) ? vrow : prev;
+            delta = dmax(delta, row16_max(fabs(tnew - prev)));
+            if (trow) kq[KC::K_XS + r16] = tnew;
+            if (inst16) {
+                if (a.XS && r16 < NX) (a.XS + (size_t)((size_t)k * NX + r16) * Bs)[bi] = tnew;
+                if (a.US && r16 >= NX && trow) (a.US + (size_t)((size_t)k * NU + (r16 - NX)) * Bs)[bi] = tnew;
+                if (a.st_dyn && r16 == 0) { (a.st_ss + (size_t)k * Bs)[bi] = st_ss; (a.it_ss + (size_t)k * Bs)[bi] = it_ss; }
+            }
+            if (r16 == 0) outv[b16c * Cfg::OUT] = delta;
+            __syncthreads();
+        }
         if (valid) {
-            double x[NXP], xh[NX], dh[NDD], u[NU], xs[NX], us[NU];
-            double xh_pred[NX], dh_prev[NDD], xs_prev[NX], us_prev[NU], delta = 0.0;
-            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
-            MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = kp[KC::K_XH + i]; xs[i] = kp[KC::K_XS + i]; xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
-            MPC_UNROLL for (int i = 0; i < ND; i++) { dh[i] = kp[KC::K_DH + i]; dh_prev[i] = dh[i]; }
-            MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = kp[KC::K_U + i]; us[i] = kp[KC::K_US + i]; us_prev[i] = us[i]; }
-            if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) (a.XP + (size_t)((size_t)k * NXP + i) * Bs)[bq] = x[i]; }
-            if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XHAT + (size_t)((size_t)k * NX + i) * Bs)[bq] = xh[i]; }
-            // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
-            if (P.estimator != MPC_EST_NONE) {
-                double xi[NE], innov[NY];
-                MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
-                MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
-                MPC_UNROLL for (int i = 0; i < NY; i++) {
-                    double yh = P.fyc[i], yy = a.pyp[k * NY + i];
-                    MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
-                    MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
-                    innov[i] = yy - yh;
+            double xh[NX], dh[NDD], u[NU], xs[NX], us[NU], delta = 0.0;
+            MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = kp[KC::K_XH + i]; xs[i] = kp[KC::K_XS + i]; }
+            MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = kp[KC::K_DH + i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = kp[KC::K_U + i]; us[i] = kp[KC::K_US + i]; }
+            if constexpr (RT::fits) delta = outv[lane * Cfg::OUT];
+            else {
+                double x[NXP];
+                double xh_pred[NX], dh_prev[NDD], xs_prev[NX], us_prev[NU];
+                MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
+                MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = kp[KC::K_XH + i]; xs[i] = kp[KC::K_XS + i]; xh_pred[i] = xh[i]; xs_prev[i] = xs[i]; }
+                MPC_UNROLL for (int i = 0; i < ND; i++) { dh[i] = kp[KC::K_DH + i]; dh_prev[i] = dh[i]; }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = kp[KC::K_U + i]; us[i] = kp[KC::K_US + i]; us_prev[i] = us[i]; }
+                if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) (a.XP + (size_t)((size_t)k * NXP + i) * Bs)[bq] = x[i]; }
+                if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XHAT + (size_t)((size_t)k * NX + i) * Bs)[bq] = xh[i]; }
+                // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
+                if (P.estimator != MPC_EST_NONE) {
+                    double xi[NE], innov[NY];
+                    MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
+                    MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
+                    MPC_UNROLL for (int i = 0; i < NY; i++) {
+                        double yh = P.fyc[i], yy = a.pyp[k * NY + i];
+                        MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+                        MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
+                        innov[i] = yy - yh;
+                    }
+                    if (P.estimator == MPC_EST_KALMAN) {
+                        double Pk[NE][NE];
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = kp[KC::K_P + i * NE + j]; }
+                        kalman_lane<NE, NY>(P, xi, Pk, innov);
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) kp[KC::K_P + i * NE + j] = Pk[i][j]; }
+                    } else {
+                        MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+                    }
+                    MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
+                    MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
                 }
-                if (P.estimator == MPC_EST_KALMAN) {
-                    double Pk[NE][NE];
-                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = kp[KC::K_P + i * NE + j]; }
-                    kalman_lane<NE, NY>(P, xi, Pk, innov);
-                    MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) kp[KC::K_P + i * NE + j] = Pk[i][j]; }
-                } else {
-                    MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+                if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) (a.DHAT + (size_t)((size_t)k * ND + i) * Bs)[bq] = dh[i]; }
+                MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xh[i] - xh_pred[i]));
+                MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
+                // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
+                double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
+                MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
+                MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
+                int it_ss;
+                const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, kp + KC::K_TW, 1, twv + lane);
+                if (st_ss != kInfeasible) {
+                    MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
                 }
-                MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
-                MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
+                if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XS + (size_t)((size_t)k * NX + i) * Bs)[bq] = xs[i]; }
+                if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.US + (size_t)((size_t)k * NU + i) * Bs)[bq] = us[i]; }
+                if (a.st_dyn) { (a.st_ss + (size_t)k * Bs)[bq] = st_ss; (a.it_ss + (size_t)k * Bs)[bq] = it_ss; }
+                MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xs[i] - xs_prev[i]));
+                MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
             }
-            if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) (a.DHAT + (size_t)((size_t)k * ND + i) * Bs)[bq] = dh[i]; }
-            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xh[i] - xh_pred[i]));
-            MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
-            // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
-            double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
-            MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
-            MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
-            int it_ss;
-            const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, kp + KC::K_TW, 1, twv + lane);
-            if (st_ss != kInfeasible) {
-                MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
-                MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
-            }
-            if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) (a.XS + (size_t)((size_t)k * NX + i) * Bs)[bq] = xs[i]; }
-            if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.US + (size_t)((size_t)k * NU + i) * Bs)[bq] = us[i]; }
             if (a.YS) {   // ys = Fy_model(xs, us, dhat), MPC_code.py:730
                 MPC_UNROLL for (int i = 0; i < NY; i++) {
                     double v = P.fyc[i];
@@ -579,12 +629,9 @@ __global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const De
                     (a.YS + (size_t)((size_t)k * NY + i) * Bs)[bq] = v;
                 }
             }
-            if (a.st_dyn) { (a.st_ss + (size_t)k * Bs)[bq] = st_ss; (a.it_ss + (size_t)k * Bs)[bq] = it_ss; }
             // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS ------------------------------
             OcpInst<NS, NU> qi;
             build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, qi);
-            MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xs[i] - xs_prev[i]));
-            MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
             const bool warm = wsv[lane] != 0 && delta <= kWsDelta;
             double *qd = q + lane * Cfg::QN;
             MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
@@ -602,8 +649,8 @@ __global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const De
         // first input and next state of the final iterates: block 0 = lane 0
         if (lane == 0) {
             MPC_UNROLL for (int j = 0; j < NI; j++) {
-                MPC_UNROLL for (int i = 0; i < NU; i++) outv[j * Cfg::OUT + i] = X[j].u[i];
-                MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = X[j].z[i];
+                MPC_UNROLL for (int i = 0; i < NU; i++) outv[j * Cfg::OUT + i] = a_get(X[j].u[i]);
+                MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = a_get(X[j].z[i]);
             }
         }
         __syncthreads();
@@ -655,8 +702,8 @@ __global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const De
     }
     MPC_UNROLL for (int j = 0; j < NI; j++) {
         double *rows = a.ws + ((size_t)(blockIdx.x * NI + j) * Cfg::ROWS_WS) * 64;
-        MPC_UNROLL for (int i = 0; i < NU; i++) rows[i * 64 + lane] = X[j].u[i];
-        MPC_UNROLL for (int i = 0; i < NC; i++) { rows[(NU + i) * 64 + lane] = X[j].ll[i]; rows[(NU + NC + i) * 64 + lane] = X[j].lh[i]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) rows[i * 64 + lane] = a_get(X[j].u[i]);
+        MPC_UNROLL for (int i = 0; i < NC; i++) { rows[(NU + i) * 64 + lane] = a_get(X[j].ll[i]); rows[(NU + NC + i) * 64 + lane] = a_get(X[j].lh[i]); }
     }
 }
 

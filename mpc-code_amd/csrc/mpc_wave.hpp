@@ -50,6 +50,41 @@ struct WvCfg {
 template <int NS, int NU, int NC>
 struct WvIter { double sl[NC], sh[NC], ll[NC], lh[NC], u[NU], z[NS]; };      // one block of one instance (lane = block)
 
+// A double parked in two accumulation registers (AGPRs).  The resident iterates of a wave are 240 registers that are touched three
+// times per interior-point iteration; left to the register allocator about a third of them ends up in scratch (a memory round trip
+// per touch).  Parked explicitly they occupy the AGPR file, which nothing else here needs (the matrix-core results stay in VGPRs),
+// and moving one instance's block in or out is 50 + 50 one-cycle-issue moves per phase.
+struct AReg2 { int lo, hi; };
+__device__ __forceinline__ void a_put(AReg2 &r, double v)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(r.lo) : "v"(u.i[0]));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(r.hi) : "v"(u.i[1]));
+}
+__device__ __forceinline__ double a_get(const AReg2 &r)
+{
+    union { double d; int i[2]; } u;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(u.i[0]) : "a"(r.lo));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(u.i[1]) : "a"(r.hi));
+    return u.d;
+}
+template <int NS, int NU, int NC>
+struct WvIterA {
+    AReg2 sl[NC], sh[NC], ll[NC], lh[NC], u[NU], z[NS];
+    __device__ __forceinline__ void get(WvIter<NS, NU, NC> &X) const
+    {
+        MPC_UNROLL for (int i = 0; i < NC; i++) { X.sl[i] = a_get(sl[i]); X.sh[i] = a_get(sh[i]); X.ll[i] = a_get(ll[i]); X.lh[i] = a_get(lh[i]); }
+        MPC_UNROLL for (int i = 0; i < NU; i++) X.u[i] = a_get(u[i]);
+        MPC_UNROLL for (int i = 0; i < NS; i++) X.z[i] = a_get(z[i]);
+    }
+    __device__ __forceinline__ void put(const WvIter<NS, NU, NC> &X)
+    {
+        MPC_UNROLL for (int i = 0; i < NC; i++) { a_put(sl[i], X.sl[i]); a_put(sh[i], X.sh[i]); a_put(ll[i], X.ll[i]); a_put(lh[i], X.lh[i]); }
+        MPC_UNROLL for (int i = 0; i < NU; i++) a_put(u[i], X.u[i]);
+        MPC_UNROLL for (int i = 0; i < NS; i++) a_put(z[i], X.z[i]);
+    }
+};
+
 struct WvInst { double mu, mu_sum, sm, inv_ncon, gscale; int stall, iters, status; bool on, warm; };
 
 enum : int { kWvOk0 = 1, kWvWarm = 2, kWvValid = 4 };
@@ -76,8 +111,8 @@ __device__ __forceinline__ double row16_max(double v)
 // iflag[4] (kWv*) written by the caller; X: the resident iterates - on entry the previous step's final iterate (used when
 // kWvWarm), on return this step's.  S[j].status / iters: verdicts.
 template <int NS, int NU, bool HASM, int NC, bool MASKED, int NI, class PT>
-__device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, const double *__restrict__ q, const int *__restrict__ iflag,
-                                         WvIter<NS, NU, NC> (&X)[NI], WvInst (&S)[NI], int max_iter)
+__device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q, const int *iflag,
+                                         WvIterA<NS, NU, NC> (&X)[NI], WvInst (&S)[NI], int max_iter)
 {
     using Cfg = WvCfg<NS, NU, NC, NI>;
     using Iter = WvIter<NS, NU, NC>;
@@ -176,7 +211,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
     // ---- instance constants and the initial point (cold: us pushed inside the box; warm: previous iterate shifted one stage)
     MPC_UNROLL for (int j = 0; j < NI; j++) {
         WvInst &Sj = S[j];
-        Iter &Xj = X[j];
+        Iter Xj;
         const PT &Pl = P;
         const double *qd = q + j * Cfg::QN;
         const int myflag = __builtin_amdgcn_readfirstlane(iflag[j]);
@@ -194,6 +229,10 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
         }
         Sj.inv_ncon = 1.0 / dmax(ncon, 1.0);
         if (Sj.on) {
+            if (Sj.warm) {      // the previous step's inputs and multipliers
+                MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] = a_get(X[j].u[i]);
+                MPC_UNROLL for (int i = 0; i < NC; i++) { Xj.ll[i] = a_get(X[j].ll[i]); Xj.lh[i] = a_get(X[j].lh[i]); }
+            }
             const bool rep = k >= N - 1;       // shift by one stage, the last block repeats
             double ll0[NC], lh0[NC];
             MPC_UNROLL for (int i = 0; i < NU; i++) {
@@ -253,8 +292,10 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
                 const double llo = Sj.warm ? dmax(ll0[i], ws_mu * isl) : kMu0 * isl, lhi = Sj.warm ? dmax(lh0[i], ws_mu * ish) : kMu0 * ish;
                 Xj.ll[i] = Bd.fl[i] ? llo : 0.0; Xj.lh[i] = Bd.fh[i] ? lhi : 0.0;
             }
+            X[j].put(Xj);
             phase_a(Pl, j, Sj, Xj, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     MPC_TSTAMP(1);
@@ -436,7 +477,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
 
-    double dvp[NI][NC];      // predictor direction of each instance's bounded variables, kept for the corrector's second-order terms
+    AReg2 dvp[NI][NC];       // predictor direction of each instance's bounded variables, kept for the corrector's second-order terms
     for (int it = 0;; it++) {
         bool any_on = false;
         MPC_UNROLL for (int j = 0; j < NI; j++) any_on = any_on || S[j].on;
@@ -459,16 +500,16 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
         MPC_UNROLL for (int j = 0; j < NI; j++) {
             WvInst &Sj = S[j];
             if (Sj.on) {
-                const Iter &Xj = X[j];
+                Iter Xj; X[j].get(Xj);
                 const PT &Pl = P;
                 Bnd Bd; bounds(Pl, j, Bd);
-                double maff_p = 1.0, s1_p = 0.0, s2_p = 0.0, pl[NC], ph[NC];
-                MPC_UNROLL for (int i = 0; i < NC; i++) dvp[j][i] = tk(RG + i, j);      // du | dz of the predictor
+                double maff_p = 1.0, s1_p = 0.0, s2_p = 0.0, pl[NC], ph[NC], dvj[NC];
+                MPC_UNROLL for (int i = 0; i < NC; i++) { dvj[i] = tk(RG + i, j); a_put(dvp[j][i], dvj[i]); }      // du | dz of the predictor
                 MPC_UNROLL for (int i = 0; i < NC; i++) {
                     const double v = i < NU ? Xj.u[i < NU ? i : 0] : Xj.z[i >= NU ? i - NU : 0];
                     const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
                     const double rh = Bd.fh[i] ? v + Xj.sh[i] - Bd.hi[i] : 0.0, rl = Bd.fl[i] ? v - Xj.sl[i] - Bd.lo[i] : 0.0;
-                    const double dsh = Bd.fh[i] ? -rh - dvp[j][i] : 0.0, dsl = Bd.fl[i] ? rl + dvp[j][i] : 0.0;
+                    const double dsh = Bd.fh[i] ? -rh - dvj[i] : 0.0, dsl = Bd.fl[i] ? rl + dvj[i] : 0.0;
                     const double qh = dsh * ish, ql = dsl * isl;
                     const double dlh = Bd.fh[i] ? -Xj.lh[i] - Xj.lh[i] * qh : 0.0, dll = Bd.fl[i] ? -Xj.ll[i] - Xj.ll[i] * ql : 0.0;
                     maff_p = dmax(maff_p, dmax(-ql, -qh));
@@ -497,6 +538,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
                 MPC_UNROLL for (int i = 0; i < NU; i++) tk(RG + i, j) = gu[i] + hc[i];
                 MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + hc[NU + i];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         MPC_TSTAMP(4);
@@ -510,10 +552,11 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
         MPC_UNROLL for (int j = 0; j < NI; j++) {
             WvInst &Sj = S[j];
             if (Sj.on) {
-                Iter &Xj = X[j];
+                Iter Xj; X[j].get(Xj);
                 const PT &Pl = P;
                 Bnd Bd; bounds(Pl, j, Bd);
-                double dvzj[NV];
+                double dvzj[NV], dvj[NC];
+                MPC_UNROLL for (int i = 0; i < NC; i++) dvj[i] = a_get(dvp[j][i]);
                 MPC_UNROLL for (int i = 0; i < NV; i++) dvzj[i] = tk(RG + i, j);
                 double mcc_p = kTau;
                 double dsl[NC], dsh[NC], dll[NC], dlh[NC];
@@ -522,7 +565,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
                     const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
                     const double rh = Bd.fh[i] ? v + Xj.sh[i] - Bd.hi[i] : 0.0, rl = Bd.fl[i] ? v - Xj.sl[i] - Bd.lo[i] : 0.0;
                     // second-order products of the predictor direction (recomputed, not stored)
-                    const double ash = Bd.fh[i] ? -rh - dvp[j][i] : 0.0, asl = Bd.fl[i] ? rl + dvp[j][i] : 0.0;
+                    const double ash = Bd.fh[i] ? -rh - dvj[i] : 0.0, asl = Bd.fl[i] ? rl + dvj[i] : 0.0;
                     const double alh = Bd.fh[i] ? -Xj.lh[i] - Xj.lh[i] * (ash * ish) : 0.0, all_ = Bd.fl[i] ? -Xj.ll[i] - Xj.ll[i] * (asl * isl) : 0.0;
                     const double rch = Bd.fh[i] ? Xj.sh[i] * Xj.lh[i] - dmax(Sj.sm, Xj.lh[i] * kSFloor) + ash * alh : 0.0;
                     const double rcl = Bd.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(Sj.sm, Xj.ll[i] * kSFloor) + asl * all_ : 0.0;
@@ -537,11 +580,245 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *__restrict__ T, co
                 MPC_UNROLL for (int i = 0; i < NC; i++) { Xj.sl[i] += alpha * dsl[i]; Xj.sh[i] += alpha * dsh[i]; Xj.ll[i] += alpha * dll[i]; Xj.lh[i] += alpha * dlh[i]; }
                 MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] += alpha * dvzj[i];
                 MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] += alpha * dvzj[NU + i];
+                X[j].put(Xj);
                 phase_a(Pl, j, Sj, Xj, it + 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         MPC_TSTAMP(6);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Estimator and target problem with 16 lanes per instance (lane = 16 b + r, b = instance of the wave, r = row): the four
+// instances of a wave at once, sums over the rows on the DPP network (row16_sum / row16_max), matrices exchanged through LDS.
+// The lane = instance versions (kalman_lane, target_lane in mpc_device.hpp) keep 60 of 64 lanes idle for ~6000 instructions.
+// Same operations on the same numbers; sums over rows are taken in tree order.
+// ------------------------------------------------------------------------------------------------------------------------
+
+// per-row constants in LDS, filled once per launch (row r < NE: Aa[r][:] Qkf[r][:] Kfix[r][:] dmin dmax; row r < NCT: W[r][:] tlo thi)
+template <int NX, int NU, int NY, int ND>
+struct Row16Tab {
+    static constexpr int NE = NX + ND, NR = NU, NCT = NX + NU + NY;
+    static constexpr int E_A = 0, E_Q = NE, E_K = 2 * NE, E_DMIN = 2 * NE + NY, E_DMAX = E_DMIN + 1, ESZ = E_DMAX + 1;
+    static constexpr int T_W = 0, T_LO = NR, T_HI = NR + 1, TSZ = NR + 2;
+    static constexpr int DOUBLES = NE * ESZ + NCT * TSZ;
+    static constexpr bool fits = NE <= 16 && NCT <= 16;
+    // exchange space per instance (in the transposing buffer, which is idle outside the OCP solve)
+    static constexpr int XCH = NE * NY + NE * NE;
+};
+
+template <int NX, int NU, int NY, int ND, class PT>
+__device__ __forceinline__ void row16_fill_tables(const PT &P, double *tab, int lane)
+{
+    using RT = Row16Tab<NX, NU, NY, ND>;
+    constexpr int NE = RT::NE;
+    if (lane < NE) {
+        double *e = tab + lane * RT::ESZ;
+        for (int j = 0; j < NE; j++) { e[RT::E_A + j] = P.Aa[lane][j]; e[RT::E_Q + j] = P.Qkf[lane][j]; }
+        for (int j = 0; j < NY; j++) e[RT::E_K + j] = P.Kfix[lane][j];
+        e[RT::E_DMIN] = lane >= NX ? P.dmin[lane - NX] : 0.0; e[RT::E_DMAX] = lane >= NX ? P.dmax[lane - NX] : 0.0;
+    }
+    if (lane < RT::NCT) {
+        double *t = tab + NE * RT::ESZ + lane * RT::TSZ;
+        for (int c = 0; c < NU; c++) t[RT::T_W + c] = P.W[lane][c];
+        t[RT::T_LO] = P.tlo[lane]; t[RT::T_HI] = P.thi[lane];
+    }
+}
+
+// Estimator step (MPC_code.py:524-534, 577-668; kalman(): Estimator.py:297-309): xi = [xhat; dhat] at kp[xi_off + r], plant state at
+// kp[x_off..], covariance rows at kp[p_off + r * NE ..].  On return lane r < NE holds xi_old / xi_new of its row (also written back).
+template <int NX, int NY, int ND, int NXP, int NU, class PT>
+__device__ __forceinline__ void kalman_row16(const PT &P, int r, double *kp, int x_off, int xi_off, int p_off, const double *pyp_k,
+                                             const double *tab, double *xch, double &xi_old, double &xi_new)
+{
+    using RT = Row16Tab<NX, NU, NY, ND>;
+    constexpr int NE = RT::NE;
+    const bool row = r < NE;
+    const int rr = row ? r : 0;
+    const double *e = tab + rr * RT::ESZ;
+    double xi[NE], innov[NY];
+    MPC_UNROLL for (int i = 0; i < NE; i++) xi[i] = kp[xi_off + i];
+    MPC_UNROLL for (int i = 0; i < NY; i++) {       // yhat = Fy_model(xhat, dhat) :524, y = Fy_p(x) + pyp :531-534
+        double yh = P.fyc[i], yy = pyp_k[i];
+        MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+        MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * kp[x_off + j];
+        innov[i] = yy - yh;
+    }
+    xi_old = kp[xi_off + rr];
+    double Kr[NY];
+    if (P.estimator == MPC_EST_KALMAN) {
+        double Pr[NE], PCt[NY];
+        MPC_UNROLL for (int j = 0; j < NE; j++) Pr[j] = kp[p_off + rr * NE + j];
+        MPC_UNROLL for (int j = 0; j < NY; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += Pr[l] * P.Ca[j][l]; PCt[j] = a; }
+        if (row) { MPC_UNROLL for (int j = 0; j < NY; j++) xch[r * NY + j] = PCt[j]; }
+        __syncthreads();
+        double all[NE][NY], S[NY][NY];
+        MPC_UNROLL for (int l = 0; l < NE; l++) { MPC_UNROLL for (int j = 0; j < NY; j++) all[l][j] = xch[l * NY + j]; }
+        MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < NY; j++) { double a = P.Rkf[i][j]; MPC_UNROLL for (int l = 0; l < NE; l++) a += P.Ca[i][l] * all[l][j]; S[i][j] = a; } }
+        MPC_UNROLL for (int i = 0; i < NY; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (S[i][j] + S[j][i]); S[i][j] = a; S[j][i] = a; } }
+        sym_inverse<NY>(S);                                   // K = P C' S^-1   (Estimator.py:297)
+        MPC_UNROLL for (int j = 0; j < NY; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) a += PCt[l] * S[l][j]; Kr[j] = a; }
+        // P_corr = (I - K C) P :300 (C P = (P C')' up to the rounding of P's symmetry); U = P_corr Aa'; P+ = Aa U + Q :309
+        double Pc[NE], U[NE];
+        MPC_UNROLL for (int j = 0; j < NE; j++) { double a = Pr[j]; MPC_UNROLL for (int m = 0; m < NY; m++) a -= Kr[m] * all[j][m]; Pc[j] = a; }
+        MPC_UNROLL for (int j = 0; j < NE; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NE; l++) a += Pc[l] * P.Aa[j][l]; U[j] = a; }
+        double *xu = xch + NE * NY;
+        if (row) { MPC_UNROLL for (int j = 0; j < NE; j++) xu[r * NE + j] = U[j]; }
+        __syncthreads();
+        double Pn[NE];
+        MPC_UNROLL for (int j = 0; j < NE; j++) Pn[j] = e[RT::E_Q + j];
+        MPC_UNROLL for (int l = 0; l < NE; l++) { const double al = e[RT::E_A + l]; MPC_UNROLL for (int j = 0; j < NE; j++) Pn[j] += al * xu[l * NE + j]; }
+        if (row) { MPC_UNROLL for (int j = 0; j < NE; j++) kp[p_off + r * NE + j] = Pn[j]; }
+    } else {
+        MPC_UNROLL for (int j = 0; j < NY; j++) Kr[j] = e[RT::E_K + j];
+    }
+    double v = xi_old;
+    MPC_UNROLL for (int l = 0; l < NY; l++) v += Kr[l] * innov[l];                                     // :303-306
+    if (P.has_dsat && r >= NX) v = dmin(dmax(v, e[RT::E_DMIN]), e[RT::E_DMAX]);                     // MPC_code.py:655-668
+    xi_new = v;
+    __syncthreads();      // everybody has read the old xi
+    if (row) kp[xi_off + r] = v;
+}
+
+// Target problem (Target_Calc.py:20-161 + MPC_code.py:693-718) reduced to the null space of [A-I, B], one
+// constraint row per lane.  dh / us_prev: this instance's data (the same in its 16 lanes); tw: its warm-start record in LDS
+// (y[NR] l_lo[NC] l_hi[NC] gr[NR] w0[NC]) with validity flag twv.  Returns the status (the same in the 16 lanes); v_out = row r of
+// [xs; us; ys] of the final point.
+template <int NX, int NU, int NY, int ND, class PT>
+__device__ __forceinline__ int target_row16(const PT &P, int r, const double *tab, const double *usp, const double *ysp, const double *dh,
+                                            const double *us_prev, double *tw, int *twv, bool inst_on, double &v_out, int &iters)
+{
+    using RT = Row16Tab<NX, NU, NY, ND>;
+    constexpr int NV = NX + NU, NC = RT::NCT, NR = NU, NE = RT::NE;
+    const bool row = r < NC;
+    const int rr = row ? r : 0;
+    const double *t = tab + NE * RT::ESZ + rr * RT::TSZ;
+    double Wr[NR];
+    MPC_UNROLL for (int c = 0; c < NR; c++) Wr[c] = row ? t[RT::T_W + c] : 0.0;
+    const double tlo = t[RT::T_LO], thi = t[RT::T_HI];
+    const bool fl = row && fin(tlo), fh = row && fin(thi);
+    const double lo = fl ? tlo : 0.0, hi = fh ? thi : 0.0;
+    double cx[NX], e[NY], vp[NV], yp[NY], gr[NR], y[NR];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { double a = P.fxc[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += P.Bd[i][j] * dh[j]; cx[i] = a; }
+    MPC_UNROLL for (int i = 0; i < NY; i++) { double a = P.fyc[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += P.Cd[i][j] * dh[j]; e[i] = a; }
+    MPC_UNROLL for (int q = 0; q < NV; q++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NX; j++) a -= P.Ep[q][j] * cx[j]; vp[q] = a; }
+    MPC_UNROLL for (int i = 0; i < NY; i++) { double a = e[i]; MPC_UNROLL for (int j = 0; j < NX; j++) a += P.Cm[i][j] * vp[j]; yp[i] = a; }
+    MPC_UNROLL for (int c = 0; c < NR; c++) {
+        double a = 0.0;
+        MPC_UNROLL for (int i = 0; i < NY; i++) { double qi = 0.0; MPC_UNROLL for (int j = 0; j < NY; j++) qi += P.Qss[i][j] * (yp[j] - ysp[j]); a += qi * P.CZx[i][c]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) {
+            double ri = 0.0;
+            MPC_UNROLL for (int j = 0; j < NU; j++) ri += P.Rss[i][j] * (vp[NX + j] - (P.duss_form ? us_prev[j] : usp[j]));
+            a += ri * P.Zn[NX + i][c];
+        }
+        gr[c] = a;
+    }
+    double w0 = 0.0;      // this lane's row of [vp; yp]
+    MPC_UNROLL for (int q = 0; q < NV; q++) w0 = r == q ? vp[q] : w0;
+    MPC_UNROLL for (int i = 0; i < NY; i++) w0 = r == NV + i ? yp[i] : w0;
+    const double ncon = row16_sum((fl ? 1.0 : 0.0) + (fh ? 1.0 : 0.0));
+    const double inv_ncon = 1.0 / dmax(ncon, 1.0);
+    {
+        double Hi[NR][NR];
+        MPC_UNROLL for (int i = 0; i < NR; i++) { MPC_UNROLL for (int j = 0; j < NR; j++) Hi[i][j] = P.Hr[i][j]; }
+        sym_inverse<NR>(Hi);
+        MPC_UNROLL for (int i = 0; i < NR; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NR; j++) a += Hi[i][j] * gr[j]; y[i] = -a; }
+    }
+    double s_lo, s_hi, l_lo, l_hi;
+    {
+        double v = w0; MPC_UNROLL for (int c = 0; c < NR; c++) v += Wr[c] * y[c];
+        s_lo = fl ? dmax(v - lo, kSMin) : 1.0; s_hi = fh ? dmax(hi - v, kSMin) : 1.0;
+        l_lo = fl ? kMu0 * frcp(s_lo) : 0.0; l_hi = fh ? kMu0 * frcp(s_hi) : 0.0;
+    }
+    if (*twv != 0) {
+        double dl = row ? fabs(w0 - tw[2 * NR + 2 * NC + rr]) : 0.0;
+        MPC_UNROLL for (int c = 0; c < NR; c++) dl = dmax(dl, fabs(gr[c] - tw[NR + 2 * NC + c]));
+        const double delta = row16_max(dl);
+        if (delta <= kWsDelta) {
+            const double smin = dmin(dmax(kWsKappa * delta, kWsSMinLo), kWsSMinHi), wmu = kWsMuFactor * smin * smin;
+            MPC_UNROLL for (int c = 0; c < NR; c++) y[c] = tw[c];
+            double v = w0; MPC_UNROLL for (int c = 0; c < NR; c++) v += Wr[c] * y[c];
+            s_lo = fl ? dmax(v - lo, smin) : 1.0; s_hi = fh ? dmax(hi - v, smin) : 1.0;
+            l_lo = fl ? dmax(tw[NR + rr], wmu * frcp(s_lo)) : 0.0; l_hi = fh ? dmax(tw[NR + NC + rr], wmu * frcp(s_hi)) : 0.0;
+        }
+    }
+    double gscale = 1.0; int stall = 0, status = kMaxIter;
+    MPC_UNROLL for (int c = 0; c < NR; c++) gscale = dmax(gscale, fabs(gr[c]));
+    bool on = inst_on;
+    iters = 0;
+    for (int it = 0;; it++) {
+        if (!__any(on ? 1 : 0)) break;      // the four instances of the wave have their verdicts
+        // reciprocals of the slacks once per iteration (v_rcp_f64 + Newton, mpc::frcp) instead of IEEE divisions
+        double v = w0; MPC_UNROLL for (int c = 0; c < NR; c++) v += Wr[c] * y[c];
+        const double r_lo = fl ? v - s_lo - lo : 0.0, r_hi = fh ? v + s_hi - hi : 0.0;
+        const double is_lo = frcp(s_lo), is_hi = frcp(s_hi);
+        const double sig = l_lo * is_lo + l_hi * is_hi;
+        const double mu = row16_sum(s_lo * l_lo + s_hi * l_hi) * inv_ncon;
+        const double res_p = row16_max(dmax(fabs(r_lo), fabs(r_hi)));
+        const double cres = row16_max(dmax(comp_measure(s_lo, l_lo), comp_measure(s_hi, l_hi)));
+        const double lmax = row16_max(dmax(l_lo, l_hi));
+        double grad[NR], res_s = 0.0;
+        MPC_UNROLL for (int c = 0; c < NR; c++) {
+            double a = gr[c]; MPC_UNROLL for (int j = 0; j < NR; j++) a += P.Hr[c][j] * y[j];
+            a += row16_sum((l_hi - l_lo) * Wr[c]);
+            grad[c] = a; res_s = dmax(res_s, fabs(a));
+        }
+        if (on) {
+            iters = it;
+            const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
+            stall = ok_cp ? stall + 1 : 0;
+            if (ok_cp && (res_s <= kTolStat * gscale || (stall > kStallMax && res_s <= kTolStatAcc * gscale))) { status = kSolved; on = false; }
+            else if (lmax > kInfeasZ * gscale || !(fabs(mu) < 1.0e300)) { status = kInfeasible; on = false; }
+            else if (it == P.max_iter) { status = kMaxIter; on = false; }
+        }
+        double Ht[NR][NR];
+        MPC_UNROLL for (int i = 0; i < NR; i++) { MPC_UNROLL for (int j = 0; j <= i; j++) { const double a = P.Hr[i][j] + row16_sum(sig * Wr[i] * Wr[j]); Ht[i][j] = a; Ht[j][i] = a; } }
+        const bool pd = sym_inverse<NR>(Ht);
+        if (on && !pd) { status = kInfeasible; on = false; }
+        double dy[NR], ds_lo = 0.0, ds_hi = 0.0, dl_lo = 0.0, dl_hi = 0.0, sm = 0.0, alpha = 1.0;
+        MPC_UNROLL for (int pass = 0; pass < 2; pass++) {
+            double rc_lo, rc_hi, rhs[NR];
+            if (pass == 0) { rc_lo = fl ? s_lo * l_lo : 0.0; rc_hi = fh ? s_hi * l_hi : 0.0; }
+            else {
+                rc_lo = fl ? s_lo * l_lo - dmax(sm, l_lo * kSFloor) + ds_lo * dl_lo : 0.0;
+                rc_hi = fh ? s_hi * l_hi - dmax(sm, l_hi * kSFloor) + ds_hi * dl_hi : 0.0;
+            }
+            const double h = (-rc_hi + l_hi * r_hi) * is_hi + (rc_lo + l_lo * r_lo) * is_lo;
+            MPC_UNROLL for (int c = 0; c < NR; c++) rhs[c] = grad[c] + row16_sum(h * Wr[c]);
+            MPC_UNROLL for (int i = 0; i < NR; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NR; j++) a += Ht[i][j] * rhs[j]; dy[i] = -a; }
+            // step to the boundary = 1 / m with m = max_i (-d_i / x_i); predictor capped at 1 (m >= 1), corrector at 1 / tau
+            double dv = 0.0; MPC_UNROLL for (int c = 0; c < NR; c++) dv += Wr[c] * dy[c];
+            ds_hi = fh ? -r_hi - dv : 0.0; ds_lo = fl ? r_lo + dv : 0.0;
+            dl_hi = fh ? (-rc_hi - l_hi * ds_hi) * is_hi : 0.0;
+            dl_lo = fl ? (-rc_lo - l_lo * ds_lo) * is_lo : 0.0;
+            double m = dmax(pass == 0 ? 1.0 : kTau, dmax(-ds_lo * is_lo, -ds_hi * is_hi));
+            if (fl) m = dmax(m, -dl_lo * frcp_approx(l_lo));
+            if (fh) m = dmax(m, -dl_hi * frcp_approx(l_hi));
+            m = row16_max(m);
+            if (pass == 0) {
+                const double amax = frcp(m);
+                // rows without a bound carry s = 1, l = 0, ds = dl = 0: they add nothing
+                const double s1 = row16_sum((s_lo + amax * ds_lo) * (l_lo + amax * dl_lo) + (s_hi + amax * ds_hi) * (l_hi + amax * dl_hi));
+                const double mu_aff = s1 * inv_ncon, rat = mu > 0.0 ? mu_aff * frcp(mu) : 0.0;
+                sm = dmax(rat * rat * rat * mu, kMuFloor);
+            } else alpha = m <= kTau ? 1.0 : kTau * frcp(m);
+        }
+        if (on) {
+            MPC_UNROLL for (int c = 0; c < NR; c++) y[c] += alpha * dy[c];
+            s_lo += alpha * ds_lo; s_hi += alpha * ds_hi; l_lo += alpha * dl_lo; l_hi += alpha * dl_hi;
+        }
+    }
+    {
+        double v = w0; MPC_UNROLL for (int c = 0; c < NR; c++) v += Wr[c] * y[c];
+        v_out = v;
+    }
+    if (inst_on) {
+        if (row) { tw[NR + r] = l_lo; tw[NR + NC + r] = l_hi; tw[2 * NR + 2 * NC + r] = w0; }
+        if (r == 0) { MPC_UNROLL for (int c = 0; c < NR; c++) { tw[c] = y[c]; tw[NR + 2 * NC + c] = gr[c]; } *twv = status == kSolved ? 1 : 0; }
+    }
+    return status;
 }
 
 }  // namespace mpc
