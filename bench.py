@@ -6,18 +6,22 @@
 A *step* is one closed-loop step (estimator + target + OCP + plant, reference MPC_code.py:485-827)
 of every instance of the per-GPU batch.  Workload at N=1: BASELINE.json configs[1] - the shipped
 Ex_LMPC_CSTR problem, batch 4096 initial states drawn as BASELINE.md section 3 says.  For N>1 the driver
-launches this file once per GPU under torch.distributed.run; each rank owns its own 4096 instances
+launches this file once per GPU (torch.distributed.run is only the process launcher: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT are read from the environment); each rank owns its own 4096 instances
 (weak scaling), the only exchange is the all-gather of the optimal controls U at the end of the
-timed region (RCCL).  PyTorch is used for rendezvous, barrier, the collective and device-wide
-synchronisation only; the solver is libmpc_amd.so through ctypes.
+timed region - RCCL inside libmpc_amd.so (mpc_allgather_log).  No PyTorch anywhere: the solver, the
+collective, the barrier and the device synchronisation are all the library's, through ctypes.
 
-The timed region holds exactly K steps from t = 0 with all inputs resident in HBM; the W warm-up
-steps run before it from the same initial state, which is then restored (untimed).
+Timing.  The K steps from t = 0 (inputs resident in HBM) are bracketed by barrier + device sync on both
+sides, maximum over the ranks.  One such region lasts a few milliseconds, so it is repeated R times
+from the restored initial state (restore untimed) until about a second of GPU time has been spent;
+`value` and `ms_per_step` are the MEDIAN region, `repeats` = R.  The W warm-up steps run first.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the fused closed-loop kernel against HBM with the
-algorithmic bytes of DESIGN.md section 6 (this path is latency / fp64-issue bound, not HBM bound);
-`cpu_baseline` times oracle/mpc_oracle.c (a C port of the same algorithm - the reference's own
-CasADi/IPOPT path cannot run here) on the host cores.
+algorithmic bytes of SURVEY.md section 8d (4 968 B per instance-step); `traffic` is the measured HBM-side
+traffic per launch, scaled from the per-instance-step figure of the committed PMC summary of this kernel.
+`cpu_baseline` times oracle/mpc_oracle.c (a C port of the same algorithm, -O3 -march=native -fopenmp
+- the reference's own CasADi/IPOPT path cannot run here) on all host cores and on one.
 """
 from __future__ import annotations
 
@@ -32,57 +36,76 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KERNEL_NAMES = {1: "loop_kernel (one instance per lane)", 2: "loop_kernel_tp (horizon-parallel)"}
+KERNEL_NAMES = {1: "loop_kernel (one instance per lane)", 2: "loop_kernel_tp (horizon-parallel)", 3: "loop_kernel_wv (wave-autonomous)"}
 B_PER_GPU = 4096
 SEED = 20250614
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def alg_bytes_per_step(p) -> int:
-    """Algorithmic HBM bytes per closed-loop step per instance.
-
-    State in/out as SURVEY 8d (920 B for the CSTR) plus the warm starts this solver carries between steps, in and
-    out: for the OCP the inputs and the bound multipliers per stage (the reference carries the primal w,
-    MPC_code.py:764), for the target problem its reduced optimum, multipliers and the QP vectors they belong to."""
+    """Algorithmic HBM bytes per closed-loop step per instance, SURVEY.md section 8d / BASELINE.md section 3: state in
+    (x_p, xhat, dhat, P, u_prev, set-points, previous target) and out (x_p, xhat, dhat, P, u, xs, us, ys) plus the primal
+    warm start w the reference carries between steps (MPC_code.py:764), in and out.  CSTR: 920 + 4048 = 4968 B."""
     ne = p.nx + p.nd
-    n_in = p.nxp + p.nx + p.nd + (ne * ne if p.estimator == "kal" else 0) + p.nu + (p.ny + p.nu + p.nx) + (p.nx + p.nu)
-    n_out = p.nxp + p.nx + p.nd + (ne * ne if p.estimator == "kal" else 0) + p.nu + p.nx + p.nu + p.ny
+    pk = ne * ne if p.estimator == "kal" else 0
+    n_in = p.nxp + p.nx + p.nd + pk + p.nu + (p.ny + p.nu + p.nx) + (p.nx + p.nu)
+    n_out = p.nxp + p.nx + p.nd + pk + p.nu + p.nx + p.nu + p.ny
+    return 8 * (n_in + n_out + 2 * p.nw)
+
+
+def carried_bytes_per_step(p) -> int:
+    """What THIS solver would move per instance-step if nothing stayed on chip: the state as above plus its own warm starts
+    (inputs and bound multipliers per stage, reduced target optimum) - reported next to the section-8d figure."""
+    ne = p.nx + p.nd
+    pk = ne * ne if p.estimator == "kal" else 0
+    n_in = p.nxp + p.nx + p.nd + pk + p.nu + (p.ny + p.nu + p.nx) + (p.nx + p.nu)
+    n_out = p.nxp + p.nx + p.nd + pk + p.nu + p.nx + p.nu + p.ny
     nbounded = p.nu + (p.nx if (np.isfinite(p.xmin).any() or np.isfinite(p.xmax).any() or p.y_bounded) else 0)
-    warm_ocp = 2 * p.N * (p.nu + 2 * nbounded)
-    warm_target = 2 * (2 * p.nu + 3 * (p.nx + p.nu + p.ny))
-    return 8 * (n_in + n_out + warm_ocp + warm_target)
+    return 8 * (n_in + n_out + 2 * p.N * (p.nu + 2 * nbounded) + 2 * (2 * p.nu + 3 * (p.nx + p.nu + p.ny)))
 
 
-def measured_traffic():
-    """HBM bytes per launch of the closed-loop kernel from the committed PMC summary (rocprofv3 cannot run inside
-    this process); None if the summary is missing."""
-    f = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+def measured_traffic(kernel_name: str, instance_steps_per_launch: float):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC summary (the counters cannot be read from inside this
+    process): the summary stores bytes per instance-step of the named kernel; a launch of this run moves that times its
+    instance-steps.  Returns (bytes, source)."""
     try:
-        return float(json.load(open(f))["hbm_bytes_per_launch"])
+        d = json.load(open(PMC_SUMMARY))
     except Exception:
-        return None
+        return None, "profiles/r02_pmc_summary.json missing"
+    per = d.get("hbm_bytes_per_instance_step")
+    src = (f"profiles/r02_pmc_summary.json: kernel {d.get('kernel')}, {per:.0f} B per instance-step = (2*FETCH_SIZE + WRITE_SIZE) KiB of "
+           f"separate rocprofv3 --pmc passes of `{d.get('command')}` / its instance-steps; scaled to this run's {instance_steps_per_launch:.0f} instance-steps per launch")
+    if d.get("kernel_short") and d["kernel_short"] not in kernel_name:
+        src += f" (NOTE: summary is for {d['kernel_short']}, this run used {kernel_name})"
+    return per * instance_steps_per_launch, src
 
 
-def cpu_baseline(problem, x0, nsteps, target_seconds=10.0, max_seconds=40.0):
+def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     """Time the oracle's C restatement on the host cores: the same closed loop (same instances, same steps, from
-    t=0), repeated until about `target_seconds` of wall time have been spent (at least once, bounded above)."""
+    t=0), on all cores and on one, each a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
-    oc = oracle_c.OracleC(problem)
+    oc = oracle_c.OracleC(problem, lib_path=oracle_c.build_fast())
     nthr = oc.max_threads()
-    nb = len(x0)
-    t0 = time.perf_counter(); oc.closed_loop(min(nsteps, 10), x0[:min(nb, 256)], x0[:min(nb, 256)], logs=False); t1 = time.perf_counter() - t0
-    rate = min(nb, 256) * min(nsteps, 10) / max(t1, 1e-6)            # rough, only to bound the sample
-    if nb * nsteps / rate > max_seconds:                             # slow host: shrink the sample, say so
-        nb = max(64, int(max_seconds * rate / nsteps))
-    reps, spent = 0, 0.0
-    while reps == 0 or (spent < target_seconds and spent * (reps + 1) / reps < max_seconds):
-        t0 = time.perf_counter(); oc.closed_loop(nsteps, x0[:nb], x0[:nb], logs=False); spent += time.perf_counter() - t0
-        reps += 1
-    return dict(value=reps * nb * nsteps / spent, unit="steps/s", cores=nthr, kind="port",
-                sample=f"{nb} instances x {nsteps} closed-loop steps from t=0 of the same workload, {reps} repetitions, {spent:.1f} s wall: "
-                       f"oracle/mpc_oracle.c (C port of the same Riccati-PDIP with the same warm start, gcc -O2 -fopenmp, {nthr} threads); "
-                       "the reference's own CasADi/IPOPT path is not installable here")
+
+    def run(nb, threads, budget):
+        reps, spent = 0, 0.0
+        while reps == 0 or (spent < budget and spent * (reps + 1) / reps < max_seconds):
+            t0 = time.perf_counter(); oc.closed_loop(nsteps, x0[:nb], x0[:nb], logs=False, nthreads=threads); spent += time.perf_counter() - t0
+            reps += 1
+        return reps * nb * nsteps / spent, reps, spent
+
+    t0 = time.perf_counter(); oc.closed_loop(min(nsteps, 10), x0[:256], x0[:256], logs=False, nthreads=1); t1 = time.perf_counter() - t0
+    rate1 = 256 * min(nsteps, 10) / max(t1, 1e-6)                       # one core, rough: only to size the samples
+    nb1 = int(min(len(x0), max(16, 4.0 * rate1 / nsteps)))              # about 4 s on one core
+    v1, r1, s1 = run(nb1, 1, 4.0)
+    nbn = int(min(len(x0), max(64, max_seconds * rate1 * nthr * 0.5 / nsteps)))
+    vn, rn, sn = run(nbn, 0, target_seconds)
+    return dict(value=vn, unit="steps/s", cores=nthr, kind="port", single_core_value=v1,
+                sample=f"{nbn} instances x {nsteps} closed-loop steps from t=0 of the same workload, {rn} repetitions, {sn:.1f} s wall on {nthr} threads "
+                       f"(single core: {nb1} instances, {r1} repetitions, {s1:.1f} s): oracle/mpc_oracle.c, a C port of the same Riccati-PDIP with the "
+                       f"same warm start, gcc -O3 -march=native -fopenmp built on this host; the reference's own CasADi/IPOPT path is not installable here")
 
 
 def main():
@@ -92,9 +115,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="instances per GPU (default: BASELINE configs[1])")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="closed-loop steps per kernel launch (0: library default)")
-    ap.add_argument("--loop-kernel", type=int, default=0, help="0: library default (by batch size), 1: instance per lane, 2: horizon-parallel")
+    ap.add_argument("--loop-kernel", type=int, default=0, help="0: library default, 1: instance per lane, 2: horizon-parallel, 3: wave-autonomous")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions (0: as many as fill --min-seconds)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="GPU time to spend in timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true", help="create the RCCL communicator even for one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,25 +128,17 @@ def main():
     K, W, B = args.steps, args.warmup, args.batch
     use_dist = world > 1 or args.force_dist
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     import mpc_code_amd as m
-    from mpc_code_amd import capi
+    from mpc_code_amd import capi, shard
     prob = m.load_problem(m.example_path("cstr_lmpc.py"))
-    if rank == 0:
+    if local_rank == 0:
         capi.build_library()          # no-op when the in-tree .so is current; one rank only (no concurrent hipcc)
-    if use_dist:
-        dist.barrier()
-    solver = capi.Solver(prob, device=local_rank)
+    else:
+        t0 = time.time()
+        while not os.path.exists(capi.LIB_PATH) and time.time() - t0 < 900:
+            time.sleep(0.5)
+    solver = capi.Solver(prob, device=local_rank)      # raises if the HIP library or the GPU is missing: no CPU fallback
+    comm = shard.RcclComm(solver, rank, world) if use_dist else None
     if args.steps_per_launch > 0:
         solver.set_option("steps_per_launch", args.steps_per_launch)
     solver.set_option("loop_kernel", args.loop_kernel)
@@ -131,54 +148,48 @@ def main():
     x0_all = rng.uniform([-0.5, -8.0, -5.0], [0.5, 8.0, 5.0], size=(B * world, 3))
     x0 = x0_all[rank * B:(rank + 1) * B]
     nsched = max(K, W, 1)
-    sched = prob.schedules(nsched)
     solver.loop_alloc(B, nsched, capi.LOG_U)
-    solver.loop_set_schedule(sched)
+    solver.loop_set_schedule(prob.schedules(nsched))
 
     def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # gather buffers for U: [K][nu][Bpad] per rank
-    _, bpad = solver.dev_ptr("U")
-    send = torch.empty((K, prob.nu, bpad), dtype=torch.float64, device="cuda")
-    recv = torch.empty((world,) + tuple(send.shape), dtype=torch.float64, device="cuda") if use_dist else None
+        solver.comm_barrier()          # every rank's stream drained (+ one all-reduce when there is a communicator)
 
     # warm-up (untimed), then restore the initial state
     solver.loop_set_state(x0, x0)
     if W > 0:
         solver.loop_run(0, W)
+        solver.allgather_log("U", 0, W, to_host=False)
         solver.loop_sync()
-    if use_dist:
-        dist.all_gather_into_tensor(recv, send)
-    solver.loop_set_state(x0, x0)
-
-    barrier()
-    t0 = time.perf_counter()
-    solver.loop_run(0, K)
-    solver.pack_log("U", 0, K, send.data_ptr())
-    solver.loop_sync()
-    if use_dist:
-        dist.all_gather_into_tensor(recv, send)
-    barrier()
-    dt = time.perf_counter() - t0
-
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kernel_ms, n_launch = solver.last_kernel_ms()
+    times, kernel_ms, n_launch = [], [], 1
+    gpu_spent = 0.0
+    while True:
+        solver.loop_set_state(x0, x0)       # untimed: t = 0 again
+        barrier()
+        t0 = time.perf_counter()
+        solver.loop_run(0, K)
+        solver.allgather_log("U", 0, K, to_host=False)      # all ranks' controls, device to device (RCCL for N > 1)
+        barrier()
+        dt = time.perf_counter() - t0
+        if comm is not None:
+            dt = comm.max(dt)               # the slowest rank's region: every rank takes the same decision below
+        times.append(dt)
+        ms, n_launch = solver.last_kernel_ms()
+        kernel_ms.append(ms)
+        gpu_spent += dt
+        if (args.repeats > 0 and len(times) >= args.repeats) or (args.repeats == 0 and (gpu_spent >= args.min_seconds or len(times) >= 2000)):
+            break
+    dt = float(np.median(times))
     loop_kernel = int(solver.get_option("loop_kernel"))
 
     if rank == 0:
         st = solver.loop_get_log("STATUS_DYN")[:K]
         it = solver.loop_get_log("ITERS_DYN")[:K]
         steps_total = B * world * K
-        per_launch_s = kernel_ms * 1e-3 / max(n_launch, 1)
-        steps_per_launch = B * K / max(n_launch, 1)
+        per_launch_s = float(np.mean(kernel_ms)) * 1e-3 / max(n_launch, 1)
+        inst_steps_per_launch = B * K / max(n_launch, 1)
         ab = alg_bytes_per_step(prob)
-        achieved = ab * steps_per_launch / per_launch_s / 1e9
+        achieved = ab * inst_steps_per_launch / per_launch_s / 1e9
+        traffic, traffic_src = measured_traffic(KERNEL_NAMES[loop_kernel], inst_steps_per_launch)
         out = {
             "metric": "closed-loop MPC steps/sec over batch, LMPC-CSTR N=50",
             "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -187,14 +198,15 @@ def main():
             "config": {"workload": "Ex_LMPC_CSTR (nx=3,nu=2,ny=3,nd=3), N=50, batch=%d per GPU, x0~U([-0.5,0.5]x[-8,8]x[-5,5]) seed %d, "
                                    "closed loop from t=0: Kalman filter + target QP + OCP (Riccati-PDIP) + plant per step" % (B, SEED),
                        "batch_per_gpu": B, "horizon": prob.N, "steps_per_launch": K / max(n_launch, 1), "loop_kernel": KERNEL_NAMES[loop_kernel],
-                       "parallelism": "instances sharded over %d GPU(s), all-gather of U at the end" % world},
+                       "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U (mpc_allgather_log) inside the timed region" % world,
+                       "repeats": len(times), "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (measured_traffic() if (B == B_PER_GPU and K == 100) else None),
-                         "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_loop.py --batch 4096 --steps 100; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, per launch)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
-                         "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
-                         "note": "bound by single-wave instruction issue in the sequential recursions (Riccati factorisation of four instances per wave on the fp64 matrix cores, vector recursions on one wave per 16 instances), not by HBM (SURVEY.md 8d)"},
+                         "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab, "carried_bytes_per_step": carried_bytes_per_step(prob),
+                         "note": "HIP events on the handle's stream around each timed region's launches, mean over the repeats. The path is bound by dependent "
+                                 "fp64 issue of one wave per SIMD (Riccati recursion on the matrix cores, four instances per wave), not by HBM "
+                                 "(SURVEY.md 8d): iterates and loop state stay in registers / LDS for a whole launch"},
             "solver": {"mean_iters": float(it[st != 2].mean()) if (st != 2).any() else None, "max_iters": int(it.max()),
                        "frac_solved": float((st == 0).mean()), "frac_maxiter": float((st == 1).mean()),
                        "frac_infeasible_hold": float((st == 2).mean())},
@@ -202,13 +214,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, x0, K)
         print(json.dumps(out), flush=True)
-    if use_dist and rank == 0:      # the gathered block of this rank must be what the kernel logged
-        mine = recv[rank].cpu().numpy()[:, :, :B]
-        assert np.array_equal(np.moveaxis(mine, 2, 1), solver.loop_get_log("U")[:K]), "all-gather of U corrupted the data"
+    if use_dist:      # the gathered block of this rank must be what the kernel logged
+        allU = solver.allgather_log("U", 0, K)
+        assert np.array_equal(allU[rank], solver.loop_get_log("U")[:K]), "all-gather of U corrupted the data"
+        comm.barrier()
     solver.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

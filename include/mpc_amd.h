@@ -151,12 +151,35 @@ int mpc_pack_u(mpc_handle *h, void *dst_dev /* [B][nu] float64 */);
  * (asynchronous on the handle's stream) - the send buffer of the end-of-run all-gather of U */
 int mpc_pack_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, void *dst_dev);
 
+/* ---- multi-GPU: one process per GPU of one node, RCCL over xGMI -------------------------------------------------
+ * Replaces nothing in the reference (it has no parallelism): the batch shards over the ranks with no
+ * data-path collective; what is exchanged are the optimal controls.  Rendezvous: rank 0 calls mpc_comm_unique_id and hands the
+ * 128 bytes to the other ranks by any means (mpc-code_amd/shard.py: a file under /tmp keyed by the launcher's pid); every rank
+ * then calls mpc_comm_init on its handle (= its GPU).  Without a communicator every call below behaves as world size 1.
+ *   mpc_allgather_u      ncclAllGather of u*[B][nu] of the last step (what MPC_code.py:798 reads out of sol["x"], over all ranks)
+ *   mpc_allgather_log    the same for steps [k0, k0+nsteps) of a float64 log ("U", ...), device to device from the log
+ *   mpc_comm_allgather   all-gather of equal-sized host buffers (statuses, ragged shards padded by the caller)
+ *   mpc_comm_barrier     every rank's stream drained + one all-reduce: the bracket of a timed region
+ *   mpc_comm_allreduce_max  maximum over the ranks of host doubles (slowest rank's time)                                               */
+#define MPC_COMM_ID_BYTES 128
+int mpc_comm_unique_id(char *out128);
+int mpc_comm_init(mpc_handle *h, int32_t rank, int32_t world, const char *id128);
+int mpc_comm_destroy(mpc_handle *h);
+int mpc_comm_rank(mpc_handle *h, int32_t *rank, int32_t *world);
+int mpc_comm_allgather(mpc_handle *h, const void *send, size_t bytes, void *recv /* [world][bytes] */);
+int mpc_comm_allreduce_max(mpc_handle *h, double *inout, int32_t n);
+int mpc_comm_barrier(mpc_handle *h);
+int mpc_allgather_u(mpc_handle *h, double *u_all /* host [world][B][nu] or NULL: result stays on the device, mpc_dev_ptr "coll_recv" */);
+int mpc_allgather_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, double *out /* host [world][nsteps][B][dim] or NULL */);
+
 /* Tunables of the resident closed loop (mpc_loop_run); they never change results beyond rounding.
  *   "steps_per_launch"  closed-loop steps per kernel launch (default 50; a launch starts with cold caches)
- *   "loop_kernel"       0 = choose by batch size (default), 1 = one instance per lane, 2 = horizon-parallel
- *                       (one wave per instance and block-parallel element-wise work; needs N <= 64)            */
+ *   "loop_kernel"       0 = choose by problem and batch size (default), 1 = one instance per lane, 2 = horizon-parallel
+ *                       (eight waves share sixteen instances, block-parallel element-wise work; needs N <= 64),
+ *                       3 = wave-autonomous (one wave owns four instances for the whole launch, iterates resident in registers,
+ *                       every recursion on the fp64 matrix cores; needs N <= 64, stage state <= 4, nu <= 2; the default there) */
 int mpc_set_option(mpc_handle *h, const char *name, double value);
-/* Current value; for "loop_kernel" the kernel mpc_loop_run will use for the allocated batch (1 or 2). */
+/* Current value; for "loop_kernel" the kernel mpc_loop_run will use for the allocated batch (1, 2 or 3). */
 int mpc_get_option(mpc_handle *h, const char *name, double *value);
 
 /* Library self-description: "gfx950;dims=3/2/3/3/3/0,4/2/2/2/4/1;..." */

@@ -6,7 +6,7 @@ Layout
 ``problem``  namespace -> numeric :class:`LinearMPCProblem` (DARE, bounds, estimator gains)
 ``capi``     ctypes binding of ``include/mpc_amd.h`` (``libmpc_amd.so``, hand-written HIP, gfx950)
 ``driver``   the closed loop of the reference's ``MPC_code.py:485-875`` over a batch of instances
-``shard``    batch partition across ranks + the all-gather of u* (``torch.distributed``: RCCL / gloo)
+``shard``    batch partition across ranks, rendezvous and host side of the all-gather of u* (RCCL inside the library)
 ``csrc/``    the HIP kernels and the C-ABI
 
 Nothing here imports ``oracle/`` - that directory is test infrastructure.

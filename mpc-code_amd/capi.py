@@ -96,6 +96,15 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     lib.mpc_target_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5 + [_dp, _dp, _dp, _ip, _ip]
     lib.mpc_kf_update.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp, _dp]
     lib.mpc_closed_loop.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32] + [_dp] * 13
+    lib.mpc_comm_unique_id.argtypes = [ct.c_char_p]
+    lib.mpc_comm_init.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_char_p]
+    lib.mpc_comm_destroy.argtypes = [ct.c_void_p]
+    lib.mpc_comm_rank.argtypes = [ct.c_void_p, _ip, _ip]
+    lib.mpc_comm_allgather.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_void_p]
+    lib.mpc_comm_allreduce_max.argtypes = [ct.c_void_p, _dp, ct.c_int32]
+    lib.mpc_comm_barrier.argtypes = [ct.c_void_p]
+    lib.mpc_allgather_u.argtypes = [ct.c_void_p, _dp]
+    lib.mpc_allgather_log.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.c_int32, _dp]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -104,7 +113,9 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
 EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update",
            "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_run",
            "mpc_loop_sync", "mpc_loop_get_log", "mpc_closed_loop", "mpc_last_kernel_ms", "mpc_stream", "mpc_dev_ptr",
-           "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_get_option", "mpc_build_info")
+           "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_get_option", "mpc_build_info",
+           "mpc_comm_unique_id", "mpc_comm_init", "mpc_comm_destroy", "mpc_comm_rank", "mpc_comm_allgather",
+           "mpc_comm_allreduce_max", "mpc_comm_barrier", "mpc_allgather_u", "mpc_allgather_log")
 
 
 def _c(a, shape=None):
@@ -198,6 +209,53 @@ class Solver:
 
     def pack_log(self, name: str, k0: int, nsteps: int, dst_ptr: int):
         self._chk(self.lib.mpc_pack_log(self.h, name.encode(), int(k0), int(nsteps), ct.c_void_p(dst_ptr)), "mpc_pack_log")
+
+    # ------------------------------------------------------------------ multi-GPU (RCCL inside the library)
+    def comm_unique_id(self) -> bytes:
+        buf = ct.create_string_buffer(128)
+        self._chk(self.lib.mpc_comm_unique_id(buf), "mpc_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        self._chk(self.lib.mpc_comm_init(self.h, int(rank), int(world), unique_id), "mpc_comm_init")
+
+    def comm_rank(self):
+        r, w = ct.c_int32(0), ct.c_int32(1)
+        self._chk(self.lib.mpc_comm_rank(self.h, ct.byref(r), ct.byref(w)), "mpc_comm_rank")
+        return r.value, w.value
+
+    def comm_barrier(self):
+        self._chk(self.lib.mpc_comm_barrier(self.h), "mpc_comm_barrier")
+
+    def comm_allreduce_max(self, values):
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._chk(self.lib.mpc_comm_allreduce_max(self.h, _p(v), int(v.size)), "mpc_comm_allreduce_max")
+        return v
+
+    def comm_allgather(self, send: np.ndarray) -> np.ndarray:
+        """Equal-sized host arrays of every rank -> [world, ...] on every rank."""
+        send = np.ascontiguousarray(send)
+        _, world = self.comm_rank()
+        recv = np.empty((world,) + send.shape, dtype=send.dtype)
+        self._chk(self.lib.mpc_comm_allgather(self.h, send.ctypes.data_as(ct.c_void_p), send.nbytes, recv.ctypes.data_as(ct.c_void_p)),
+                  "mpc_comm_allgather")
+        return recv
+
+    def allgather_u(self, to_host: bool = True):
+        """u* of the last step of every rank, [world, B, nu]; None when left on the device."""
+        _, world = self.comm_rank()
+        out = np.empty((world, self._loop_B, self.p.nu)) if to_host else None
+        self._chk(self.lib.mpc_allgather_u(self.h, _p(out)), "mpc_allgather_u")
+        return out
+
+    def allgather_log(self, name: str, k0: int, nsteps: int, to_host: bool = True):
+        """Steps [k0, k0+nsteps) of a float64 log of every rank, [world, nsteps, B, dim]; None when left on the device."""
+        p = self.p
+        dims = dict(U=p.nu, X_HAT=p.nx, XS=p.nx, US=p.nu, YS=p.ny, Xp=p.nxp, D_HAT=p.nd)
+        _, world = self.comm_rank()
+        out = np.empty((world, int(nsteps), self._loop_B, dims[name])) if to_host else None
+        self._chk(self.lib.mpc_allgather_log(self.h, name.encode(), int(k0), int(nsteps), _p(out)), "mpc_allgather_log")
+        return out
 
     # ------------------------------------------------------------------ per-step calls
     def ocp_solve(self, xhat, xs, us, dhat, u_prev, want_w=False):

@@ -10,6 +10,8 @@
 #include "mpc_wave.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -837,8 +839,12 @@ struct mpc_handle {
     DevBuf scratch, ws;
     // loop state
     int B = 0; size_t Bs = 0; int max_steps = 0, log_level = 0, sched_steps = 0, last_k0 = 0, last_n = 0;
+    bool state_set = false;     // mpc_loop_set_state has supplied the whole state since the last mpc_loop_alloc
     DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
+    // multi-GPU (one process per GPU): RCCL communicator over the ranks of the job, staging buffers of the collectives
+    ncclComm_t comm = nullptr; int rank = 0, world = 1;
+    DevBuf coll_send, coll_recv;
 };
 
 static size_t pad64(size_t b) { return (b + 63) / 64 * 64; }
@@ -1073,11 +1079,15 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
     return 0;
 }
 
+extern "C" int mpc_comm_destroy(mpc_handle *h);
+
 extern "C" void mpc_destroy(mpc_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)mpc_comm_destroy(h);
+    h->coll_send.release(); h->coll_recv.release();
     for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1090,7 +1100,7 @@ extern "C" const char *mpc_build_info(void)
 {
     static std::string s;
     if (s.empty()) {
-        s = "gfx950;loop_kernels=horizon-parallel(N<=64;mfma-riccati:ns<=4&nu<=2,else-batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
+        s = "gfx950;loop_kernels=wave-autonomous(N<=64&ns<=4&nu<=2),horizon-parallel(N<=64;mfma-riccati:ns<=4&nu<=2,else-batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU, NG) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU "/" #NG ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
@@ -1308,7 +1318,13 @@ extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32
         h->st_Kg.ensure((size_t)ne * P.ny * Bs * 8) || h->st_Pn.ensure((size_t)ne * ne * Bs * 8) ||
         h->st_tw.ensure((size_t)(2 * P.nu + 3 * (P.nx + P.nu + P.ny)) * Bs * 8))
         return -10;
-    HIP_TRY(hipMemset(h->st_flag.p, 0, 3 * Bs * 4));      // [0,Bs): OCP warm start valid, [Bs,2Bs): filter look-ahead valid, [2Bs,3Bs): target warm start valid
+    // [0,Bs): OCP warm start valid, [Bs,2Bs): filter look-ahead valid, [2Bs,3Bs): target warm start valid.  All resident state is
+    // cleared on the handle's (non-blocking) stream: nothing a kernel reads is ever uninitialised, whatever the caller sets later
+    HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * Bs * 4, h->stream));
+    for (DevBuf *b : {&h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_Kg, &h->st_Pn, &h->st_tw})
+        HIP_TRY(hipMemsetAsync(b->p, 0, b->bytes, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->state_set = false;
     if (ensure_ws(h, Bs)) return -10;
     const int sdim = P.ny + P.nu + P.nxp + P.ny;   // ysp usp pxp pyp
     if (h->sch.ensure((size_t)max_steps * sdim * 8)) return -10;
@@ -1354,9 +1370,12 @@ extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double
     HIP_TRY(hipSetDevice(h->device));
     const DevProblem &P = h->hp;
     const int ne = P.nx + P.nd;
-    if (P.estimator == MPC_EST_KALMAN && !Pk) {
-        // a fresh filter needs a covariance; refuse to guess
-        // (the reference falls back to zeros when P0 is absent, MPC_code.py:455-458: pass zeros explicitly)
+    if (!h->state_set) {
+        // first call after mpc_loop_alloc: the whole state, nothing is guessed (the reference falls back to zeros when P0 is
+        // absent, MPC_code.py:455-458: pass zeros explicitly).  Later calls may update a subset (NULL = keep).
+        if (!x_p || !xhat || !u || !xs || !us) return fail(-1, "the first mpc_loop_set_state after mpc_loop_alloc needs x_p, xhat, u, xs and us");
+        if (P.nd > 0 && !dhat) return fail(-1, "the first mpc_loop_set_state after mpc_loop_alloc needs dhat (nd = %d)", P.nd);
+        if (P.estimator == MPC_EST_KALMAN && !Pk) return fail(-1, "the first mpc_loop_set_state after mpc_loop_alloc needs the covariance P (MPC_EST_KALMAN)");
     }
     int rc = 0;
     rc |= up_state(h, h->st_x, x_p, P.nxp); rc |= up_state(h, h->st_xhat, xhat, P.nx); rc |= up_state(h, h->st_dhat, dhat, P.nd);
@@ -1365,7 +1384,9 @@ extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double
     // a new state invalidates the warm start: the next OCP of every instance starts cold
     HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * h->Bs * 4, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return rc ? -10 : 0;
+    if (rc) return -10;
+    h->state_set = true;
+    return 0;
 }
 
 extern "C" int mpc_loop_get_state(mpc_handle *h, double *x_p, double *xhat, double *dhat, double *Pk, double *u,
@@ -1417,6 +1438,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
 {
     if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
     if (k0 < 0 || nsteps < 1 || k0 + nsteps > h->sched_steps) return fail(-1, "steps [%d,%d) outside the schedule of %d steps", k0, k0 + nsteps, h->sched_steps);
+    if (!h->state_set) return fail(-1, "mpc_loop_set_state first (the resident state is all zeros after mpc_loop_alloc)");
     HIP_TRY(hipSetDevice(h->device));
     const DevProblem &P = h->hp;
     const size_t Bs = h->Bs, ms = h->max_steps;
@@ -1502,6 +1524,7 @@ extern "C" void *mpc_dev_ptr(mpc_handle *h, const char *name, int64_t *bpad)
     if (n == "u") return h->st_u.p;
     if (n == "xs") return h->st_xs.p;
     if (n == "us") return h->st_us.p;
+    if (n == "coll_recv") return h->coll_recv.p;
     auto it = h->log_off.find(n);
     if (it == h->log_off.end()) return nullptr;
     if (it->second.second > 0) return (double *)h->logs.p + it->second.first;
@@ -1514,6 +1537,166 @@ extern "C" int mpc_pack_u(mpc_handle *h, void *dst_dev)
     HIP_TRY(hipSetDevice(h->device));
     hipLaunchKernelGGL(pack_u_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (const double *)h->st_u.p, (double *)dst_dev, h->B, h->Bs, h->hp.nu);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU: one process per GPU, RCCL over xGMI.  Instances are independent, so the only
+// exchanges are the all-gather of the controls (per step: mpc_allgather_u; per run: mpc_allgather_log) and the
+// job-level barrier / reductions of the benchmark harness.  librccl is opened on first use: a single-GPU user of
+// the library never loads it.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load()
+{
+    if (g_rccl.lib) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    if (!lib) return fail(-12, "librccl.so not found: %s", dlerror());
+#define MPC_RCCL_SYM(field, sym) *(void **)(&g_rccl.field) = dlsym(lib, sym); if (!g_rccl.field) { dlclose(lib); return fail(-12, "librccl lacks %s", sym); }
+    MPC_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") MPC_RCCL_SYM(CommInitRank, "ncclCommInitRank") MPC_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    MPC_RCCL_SYM(AllGather, "ncclAllGather") MPC_RCCL_SYM(AllReduce, "ncclAllReduce") MPC_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef MPC_RCCL_SYM
+    g_rccl.lib = lib;
+    return 0;
+}
+}  // namespace
+#define RCCL_TRY(x)                                                                                      \
+    do {                                                                                                 \
+        ncclResult_t r_ = (x);                                                                           \
+        if (r_ != ncclSuccess) return fail(-12, "%s failed: %s (%s:%d)", #x, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int mpc_comm_unique_id(char *out128)
+{
+    if (!out128) return fail(-1, "null argument");
+    if (rccl_load()) return -12;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == MPC_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int mpc_comm_init(mpc_handle *h, int32_t rank, int32_t world, const char *id128)
+{
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(-1, "bad argument");
+    if (h->comm) return fail(-1, "the handle already has a communicator");
+    if (rccl_load()) return -12;
+    HIP_TRY(hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCL_TRY(g_rccl.CommInitRank(&h->comm, world, id, rank));
+    h->rank = rank; h->world = world;
+    return 0;
+}
+
+extern "C" int mpc_comm_destroy(mpc_handle *h)
+{
+    if (!h || !h->comm) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->rank = 0; h->world = 1;
+    return 0;
+}
+
+extern "C" int mpc_comm_rank(mpc_handle *h, int32_t *rank, int32_t *world)
+{
+    if (!h) return fail(-1, "null handle");
+    if (rank) *rank = h->rank;
+    if (world) *world = h->world;
+    return 0;
+}
+
+// all-gather of `bytes` bytes per rank between host buffers, staged through device memory (rank r's block lands at recv + r * bytes)
+extern "C" int mpc_comm_allgather(mpc_handle *h, const void *send, size_t bytes, void *recv)
+{
+    if (!h || !send || !recv || bytes == 0) return fail(-1, "bad argument");
+    if (!h->comm) { std::memcpy(recv, send, bytes); return 0; }
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->coll_send.ensure(bytes) || h->coll_recv.ensure(bytes * h->world)) return -10;
+    HIP_TRY(hipMemcpyAsync(h->coll_send.p, send, bytes, hipMemcpyHostToDevice, h->stream));
+    RCCL_TRY(g_rccl.AllGather(h->coll_send.p, h->coll_recv.p, bytes, ncclChar, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(recv, h->coll_recv.p, bytes * h->world, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// max over the ranks of n host doubles, in place
+extern "C" int mpc_comm_allreduce_max(mpc_handle *h, double *inout, int32_t n)
+{
+    if (!h || !inout || n < 1) return fail(-1, "bad argument");
+    if (!h->comm) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->coll_send.ensure(sizeof(double) * n)) return -10;
+    HIP_TRY(hipMemcpyAsync(h->coll_send.p, inout, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    RCCL_TRY(g_rccl.AllReduce(h->coll_send.p, h->coll_send.p, n, ncclDouble, ncclMax, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(inout, h->coll_send.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// everything queued on this handle's stream on every rank has completed when this returns
+extern "C" int mpc_comm_barrier(mpc_handle *h)
+{
+    if (!h) return fail(-1, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->comm) { double one = 1.0; const int rc = mpc_comm_allreduce_max(h, &one, 1); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// u* of the last closed-loop step of every rank: ncclAllGather(u_local[B][nu]).  u_all (host, optional)
+// receives [world][B][nu]; the gathered block also stays on the device (mpc_dev_ptr "coll_recv").
+extern "C" int mpc_allgather_u(mpc_handle *h, double *u_all)
+{
+    if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->B * h->hp.nu, bytes = n * sizeof(double);
+    if (h->coll_send.ensure(bytes) || h->coll_recv.ensure(bytes * h->world)) return -10;
+    hipLaunchKernelGGL(pack_u_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (const double *)h->st_u.p, (double *)h->coll_send.p, h->B, h->Bs, h->hp.nu);
+    HIP_TRY(hipGetLastError());
+    if (h->comm) RCCL_TRY(g_rccl.AllGather(h->coll_send.p, h->coll_recv.p, n, ncclDouble, h->comm, h->stream));
+    else HIP_TRY(hipMemcpyAsync(h->coll_recv.p, h->coll_send.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (u_all) { HIP_TRY(hipMemcpyAsync(u_all, h->coll_recv.p, bytes * h->world, hipMemcpyDeviceToHost, h->stream)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+    return 0;
+}
+
+// steps [k0, k0 + nsteps) of a float64 log of every rank, gathered device to device straight from the log ([step][dim][Bpad] per
+// rank, asynchronous on the handle's stream); out (host, optional) receives [world][nsteps][B][dim]
+extern "C" int mpc_allgather_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, double *out)
+{
+    if (!h || h->B == 0 || !name) return fail(-1, "bad argument");
+    auto it = h->log_off.find(name);
+    if (it == h->log_off.end() || it->second.second == 0) return fail(-8, "float64 log '%s' was not enabled in mpc_loop_alloc", name);
+    if (k0 < 0 || nsteps < 1 || k0 + nsteps > h->max_steps) return fail(-1, "steps out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const int d = it->second.second;
+    const size_t row = (size_t)d * h->Bs, n = (size_t)nsteps * row;
+    if (h->coll_recv.ensure(n * sizeof(double) * h->world)) return -10;
+    const double *src = (const double *)h->logs.p + it->second.first + (size_t)k0 * row;
+    if (h->comm) RCCL_TRY(g_rccl.AllGather(src, h->coll_recv.p, n, ncclDouble, h->comm, h->stream));
+    else HIP_TRY(hipMemcpyAsync(h->coll_recv.p, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (out) {
+        std::vector<double> st(n * h->world);
+        HIP_TRY(hipMemcpyAsync(st.data(), h->coll_recv.p, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int r = 0; r < h->world; r++)
+            for (int k = 0; k < nsteps; k++)
+                from_soa(st.data() + ((size_t)r * nsteps + k) * row, h->B, d, h->Bs, out + (((size_t)r * nsteps + k) * h->B) * d);
+    }
     return 0;
 }
 

@@ -26,7 +26,9 @@ def _bcast(v, B, d):
 
 
 def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[capi.Solver] = None,
-                    fused: bool = True, device: int = 0, gather: bool = False, total: Optional[int] = None) -> Dict[str, np.ndarray]:
+                    fused: bool = True, device: int = 0, gather: bool = False, total: Optional[int] = None, comm=None) -> Dict[str, np.ndarray]:
+    """``gather=True``: this rank ran its shard of a batch of ``total`` instances; every result array is all-gathered over the
+    ranks of ``comm`` (mpc-code_amd/shard.py).  ``total`` is required then: a shard does not know the size of the whole."""
     p = problem
     nsteps = p.Nsim if nsteps is None else int(nsteps)
     x0_p = p.x0_p[None] if x0_p is None else np.atleast_2d(x0_p)
@@ -52,7 +54,11 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
         if own:
             s.close()
     if gather:
-        out = {k: np.moveaxis(allgather_rows(np.moveaxis(v, 1, 0), total if total is not None else B), 0, 1) for k, v in out.items()}
+        if total is None:
+            if comm is not None and comm.world > 1:
+                raise ValueError("run_closed_loop(gather=True) over several ranks needs total= (the size of the whole batch)")
+            total = B
+        out = {k: np.moveaxis(allgather_rows(np.moveaxis(v, 1, 0), total, comm), 0, 1) for k, v in out.items()}
     return out
 
 
@@ -71,7 +77,7 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched):
         if p.estimator != "none":
             xi, Pk = s.kf_update(y, np.hstack([xhat, dhat]), Pk)          # :577-650
             xhat, dhat = xi[:, :n].copy(), xi[:, n:].copy()
-            if p.dmin is not None:
+            if p.dmin is not None and p.dmax is not None:                # both or neither (problem.py refuses one-sided)
                 dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)       # :660-665
         log["D_HAT"].append(dhat.copy())
         t = s.target_solve(sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_k)   # :704-709

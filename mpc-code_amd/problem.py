@@ -201,7 +201,11 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
             raise UnsupportedProblem(f"flag {flag}=True is outside the batched linear hot path")
     if not ns.get("LinPar", True):
         raise UnsupportedProblem("LinPar=False")
-    nl_plant = _has(ns, "User_fxp_Cont") and ns["User_fxp_Cont"] is not None      # plant only: the controller stays linear
+    # plant only: the controller stays linear.  The reference tests 'Ap' first and falls through to the user plant only when it
+    # is absent (MPC_code.py:176-199): an Ex-file that defines both simulates the linear plant
+    nl_plant = _has(ns, "User_fxp_Cont") and ns["User_fxp_Cont"] is not None and not (_has(ns, "Ap") and ns["Ap"] is not None)
+    if (ns.get("dmin") is None) != (ns.get("dmax") is None):
+        raise UnsupportedProblem("dmin and dmax come as a pair (the reference saturates dhat with both, MPC_code.py:655-668)")
     for req in ("A", "B", "C", "Cp", "Q", "Qss", "N", "h", "Nsim", "x", "u", "y", "d", "xp") + (() if nl_plant else ("Ap", "Bp")):
         if not _has(ns, req):
             raise UnsupportedProblem(f"'{req}' missing: not a matrix-defined linear example")

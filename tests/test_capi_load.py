@@ -60,3 +60,15 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "mpc_oracle" not in src and "riccati_np" not in src and "oracle_c" not in src, os.path.join(dp, f)
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dp, f)
+
+
+def test_product_and_bench_do_not_use_pytorch():
+    """north_star: host side is Python + ctypes, no PyTorch; the collective is RCCL inside the library."""
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for dp, _, fs in os.walk(os.path.join(ROOT, "mpc-code_amd")):
+        files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".hip", ".hpp", ".h"))]
+    for f in files:
+        src = open(f, errors="ignore").read()
+        assert not re.search(r"^\s*(from|import)\s+torch", src, re.M), f
+    hip = open(os.path.join(ROOT, "mpc-code_amd", "csrc", "mpc_amd.hip")).read()
+    assert "ncclAllGather" in hip and "ncclCommInitRank" in hip

@@ -101,7 +101,7 @@ def test_target_and_estimator_match_c_restatement(which, cstr, wb, oracle_c, sol
         assert np.abs(b - b2.reshape(B, ne, ne)).max() < 1e-12
 
 
-LOOP_KERNELS = [pytest.param(1, id="lane"), pytest.param(2, id="horizon")]      # the two closed-loop kernels (mpc_set_option "loop_kernel")
+LOOP_KERNELS = [pytest.param(1, id="lane"), pytest.param(2, id="horizon"), pytest.param(3, id="wave")]      # the closed-loop kernels (mpc_set_option "loop_kernel")
 
 
 @pytest.mark.parametrize("lk", LOOP_KERNELS)
@@ -203,22 +203,33 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
     with pytest.raises(capi.MpcAmdError):
         s.loop_run(0, 1)                                       # before mpc_loop_alloc
     with pytest.raises(capi.MpcAmdError):
-        s.set_option("loop_kernel", 3)
+        s.set_option("loop_kernel", 4)
     with pytest.raises(capi.MpcAmdError):
         s.set_option("no_such_option", 1)
+    # the resident loop refuses to run on a state nobody supplied, and a fresh Kalman filter needs its covariance
+    s.loop_alloc(4, 2, capi.LOG_NONE); s.loop_set_schedule(cstr.schedules(2))
+    with pytest.raises(capi.MpcAmdError):
+        s.loop_run(0, 1)
+    x4, u4 = np.zeros((4, 3)), np.zeros((4, 2))
+    rc = s.lib.mpc_loop_set_state(s.h, dp(x4), dp(x4), dp(x4), None, dp(u4), dp(x4), dp(u4))
+    assert rc != 0 and b"covariance" in s.lib.mpc_last_error()
+    rc = s.lib.mpc_loop_set_state(s.h, dp(x4), dp(x4), dp(x4), dp(np.zeros((4, 6, 6))), None, dp(x4), dp(u4))
+    assert rc != 0 and b"needs x_p, xhat, u" in s.lib.mpc_last_error()
 
 
 def test_loop_kernel_choice(cstr, wb, solver_factory):
-    """mpc_loop_run picks the horizon-parallel kernel whenever its factorisation runs on the matrix cores (stage fits a 4x4
-    tile: CSTR), otherwise (Wood-Berry, stage state 6) for small batches only; the lane kernel for long horizons;
-    steps_per_launch defaults to 50."""
+    """mpc_loop_run picks the wave-autonomous kernel whenever the stage fits a 4x4 tile (CSTR) and N <= 64; otherwise
+    (Wood-Berry, stage state 6) the horizon-parallel kernel for small batches and the lane kernel for large ones; the lane
+    kernel for long horizons; steps_per_launch defaults to 50."""
     import copy
     from mpc_code_amd import capi
     s = solver_factory(cstr)
     assert s.get_option("steps_per_launch") == 50
-    s.loop_alloc(100, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 2
-    s.loop_alloc(20000, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 2
+    s.loop_alloc(100, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 3
+    s.loop_alloc(20000, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 3
     sw = solver_factory(wb)
+    with pytest.raises(capi.MpcAmdError):
+        sw.set_option("loop_kernel", 3)                          # stage state 6 does not fit a 4x4 tile
     sw.loop_alloc(100, 2, capi.LOG_NONE); assert sw.get_option("loop_kernel") == 2
     sw.loop_alloc(20000, 2, capi.LOG_NONE); assert sw.get_option("loop_kernel") == 1
     s.set_option("loop_kernel", 2); assert s.get_option("loop_kernel") == 2
@@ -229,6 +240,8 @@ def test_loop_kernel_choice(cstr, wb, solver_factory):
         t.loop_alloc(100, 2, capi.LOG_NONE); assert t.get_option("loop_kernel") == 1
         with pytest.raises(capi.MpcAmdError):
             t.set_option("loop_kernel", 2)
+        with pytest.raises(capi.MpcAmdError):
+            t.set_option("loop_kernel", 3)
         x0 = bench_x0(100, 3)
         t.loop_set_schedule(q.schedules(2)); t.loop_set_state(x0, x0); t.loop_run(0, 2); t.loop_sync()
     finally:
@@ -300,7 +313,7 @@ def test_short_horizon_and_double_integrator(pkg, oracle_c, solver_factory):
         from mpc_code_amd.driver import run_closed_loop
         x0 = rng.uniform(-0.4, 0.4, (37, 2))
         cl = oracle_c.OracleC(p).closed_loop(8, x0, x0)
-        for lk in (1, 2):
+        for lk in (1, 2, 3):
             gl = run_closed_loop(p, x0, x0, 8, solver=solver_factory(p, lk))
             assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), (N, lk)
             assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, (N, lk)
@@ -388,14 +401,17 @@ def test_both_kernels_leave_the_same_resident_state(cstr, solver_factory):
     B, K = 50, 7
     x0 = bench_x0(B, 123)
     fin = []
-    for lk in (1, 2):
+    for lk in (1, 2, 3):
         s = solver_factory(cstr, lk)
         s.loop_alloc(B, K, capi.LOG_U); s.loop_set_schedule(cstr.schedules(K)); s.loop_set_state(x0, x0)
         s.loop_run(0, 3); s.loop_run(3, K - 3); s.loop_sync()
         fin.append(s.loop_get_state())
-    for k in ("x_p", "xhat", "dhat", "u", "xs", "us"):
-        assert np.abs(fin[0][k] - fin[1][k]).max() < 1e-6, k
+    for other in fin[1:]:
+        for k in ("x_p", "xhat", "dhat", "u", "xs", "us"):
+            assert np.abs(fin[0][k] - other[k]).max() < 1e-6, k
     assert np.array_equal(fin[0]["P"], fin[1]["P"])                     # same operations on the same numbers
+    # the wave-autonomous kernel forms (I - K C) P with P C' transposed and A (P_corr A') instead of (A P_corr) A': rounding only
+    assert np.abs(fin[0]["P"] - fin[2]["P"]).max() <= 1e-12 * np.abs(fin[0]["P"]).max()
 
 
 def test_general_output_rows(dint_yrow, xp_nlplant, oracle_c, solver_factory):
@@ -420,7 +436,7 @@ def test_general_output_rows(dint_yrow, xp_nlplant, oracle_c, solver_factory):
     assert y.max() <= p.ymax[0] + 1e-7 and y.min() >= p.ymin[0] - 1e-7 and (y.max(axis=1) > p.ymax[0] - 1e-5).sum() > 20      # the row binds
     x0 = rng.uniform(-0.2, 0.2, (150, 2))
     cl = oc.closed_loop(25, x0, x0)
-    for lk in (1, 2):
+    for lk in (1, 2, 3):
         gl = run_closed_loop(p, x0, x0, 25, solver=solver_factory(p, lk))
         assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), lk
         assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, lk
@@ -460,7 +476,7 @@ def test_kernel_variants_of_the_bound_sets(cstr, oracle_c, solver_factory):
             setattr(p, k, v)
         cl = oracle_c.OracleC(p).closed_loop(25, x0, x0)
         assert (cl["STATUS_DYN"] == 0).mean() > 0.9, name
-        for lk in (1, 2):
+        for lk in (1, 2, 3):
             gl = run_closed_loop(p, x0, x0, 25, solver=solver_factory(p, lk))
             assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), (name, lk)
             assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, (name, lk)

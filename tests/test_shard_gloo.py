@@ -1,7 +1,9 @@
 """Multi-rank path on CPU: world_size 2, gloo.  The batch shards with no data-path collective and the
-controls are collected with one all-gather; here the per-rank compute is the oracle's C
-restatement standing in for the GPU (there is none in this container) - the sharding and gathering code is the
-product's own (mpc-code_amd/shard.py)."""
+controls are collected with one all-gather.  The product's host side of that path
+(mpc-code_amd/shard.py: who owns which rows, padding and stitching of ragged shards, the file rendezvous that
+carries rank 0's 128-byte RCCL id) runs here unchanged; what is substituted is the transport (a gloo process group
+behind shard.py's communicator interface instead of RCCL inside libmpc_amd.so) and the per-rank compute (the oracle's
+C restatement instead of the GPU - there is none in this container)."""
 import os
 import socket
 import subprocess
@@ -21,12 +23,25 @@ WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+    import torch
     import torch.distributed as dist
     import mpc_code_amd as m
-    from mpc_code_amd.shard import shard, shard_bounds, allgather_rows
+    from mpc_code_amd.shard import shard, shard_bounds, allgather_rows, exchange_unique_id
     import oracle_c
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
     rank = dist.get_rank()
+
+    class GlooComm:      # shard.py's communicator interface over gloo
+        rank, world = dist.get_rank(), dist.get_world_size()
+        def allgather(self, a):
+            send = torch.from_numpy(np.ascontiguousarray(a))
+            recv = [torch.empty_like(send) for _ in range(self.world)]
+            dist.all_gather(recv, send)
+            return np.stack([r.numpy() for r in recv])
+    comm = GlooComm()
+    # the rendezvous that carries rank 0's RCCL id: 128 bytes through a file, atomically
+    uid = exchange_unique_id((lambda: bytes(range(128))) if rank == 0 else None, rank, 2, {out!r} + ".id", timeout=60)
+    assert uid == bytes(range(128))
     p = m.load_problem(m.example_path("cstr_lmpc.py"))
     total = 37                                     # ragged: 19 + 18
     rng = np.random.default_rng(20250614)
@@ -35,8 +50,13 @@ WORKER = textwrap.dedent("""
     assert mine.shape[0] == (19 if rank == 0 else 18)
     L = oracle_c.OracleC(p).closed_loop(6, mine, mine, nthreads=2)
     U_local = np.moveaxis(L["U"], 1, 0)            # [B_local][step][nu]
-    U_all = allgather_rows(np.ascontiguousarray(U_local), total)
-    st_all = allgather_rows(np.ascontiguousarray(L["STATUS_DYN"].T), total)
+    U_all = allgather_rows(np.ascontiguousarray(U_local), total, comm)
+    st_all = allgather_rows(np.ascontiguousarray(L["STATUS_DYN"].T), total, comm)
+    try:                                           # a shard of the wrong size is an error, not a silent truncation
+        allgather_rows(U_local[:-1], total, comm)
+        raise SystemExit("allgather_rows accepted a short shard")
+    except ValueError:
+        pass
     np.savez({out!r} + str(rank) + ".npz", U=U_all, st=st_all)
     dist.barrier(); dist.destroy_process_group()
 """)
@@ -58,6 +78,15 @@ def test_two_ranks_shard_and_allgather(tmp_path, cstr, oracle_c):
         assert g["U"].shape == (37, 6, 2)
         assert np.array_equal(g["U"], np.moveaxis(ref["U"], 1, 0))          # same code, same inputs: bit-identical
         assert np.array_equal(g["st"], ref["STATUS_DYN"].T)
+
+
+def test_single_rank_gather_checks_the_total():
+    import pytest
+    from mpc_code_amd.shard import allgather_rows
+    a = np.arange(12.0).reshape(6, 2)
+    assert np.array_equal(allgather_rows(a, 6), a)
+    with pytest.raises(ValueError):
+        allgather_rows(a, 7)
 
 
 def test_shard_bounds_cover_the_batch():
