@@ -101,7 +101,7 @@ def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     nb1 = int(min(len(x0), max(16, 4.0 * rate1 / nsteps)))              # about 4 s on one core
     v1, r1, s1 = run(nb1, 1, 4.0)
     nbn = int(min(len(x0), max(64, max_seconds * rate1 * nthr * 0.5 / nsteps)))
-    vn, rn, sn = run(nbn, 0, target_seconds)
+    vn, rn, sn = run(nbn, nthr, target_seconds)      # explicit: orc_closed_loop's thread count is sticky (omp_set_num_threads)
     return dict(value=vn, unit="steps/s", cores=nthr, kind="port", single_core_value=v1,
                 sample=f"{nbn} instances x {nsteps} closed-loop steps from t=0 of the same workload, {rn} repetitions, {sn:.1f} s wall on {nthr} threads "
                        f"(single core: {nb1} instances, {r1} repetitions, {s1:.1f} s): oracle/mpc_oracle.c, a C port of the same Riccati-PDIP with the "
