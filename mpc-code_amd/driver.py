@@ -2,8 +2,11 @@
 
 ``run_closed_loop`` is what "python MPC_code.py" does after its set-up section, for B instances
 that share the Ex-file and differ in their initial state; the result arrays carry the reference's
-names (``MPC_code.py:877-895``): ``U, X_HAT, XS, US, YS, Xp, D_HAT`` plus the solver status /
-iteration words per step.  Two modes:
+names (``MPC_code.py:877-895``): ``U, X_HAT, Y_HAT, XS, US, YS, Xp, Yp, D_HAT, TIME_SS, TIME_DYN`` plus the solver
+status / iteration words per step.  ``Yp`` is the measurement ``Fy_p(x_k) + pyp`` (``:531-534``), ``Y_HAT`` the prediction
+``Fy_model(xhat_k, dhat_k)`` of it from the prior estimate (``:524``).  ``TIME_SS`` / ``TIME_DYN`` are the reference's
+wall-clock pair around the two solver calls (``:703-711``, ``:775-783``) in the call-by-call mode; the fused kernel cannot
+separate them: there ``TIME_DYN`` is the kernel time of a whole step (HIP events / steps) and ``TIME_SS`` is zero.  Two modes:
 
 * ``fused=True``  - ``mpc_loop_run``: one kernel launch advances all instances one or more steps
   (estimator, target, OCP, plant fused), state resident in HBM.
@@ -48,6 +51,13 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
             s.loop_sync()
             out = {k: s.loop_get_log(k) for k in ("U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT", "STATUS_DYN",
                                                   "STATUS_SS", "ITERS_DYN", "ITERS_SS") if not (k == "D_HAT" and p.nd == 0)}
+            out["Yp"] = out["Xp"] @ p.Cp.T + sched["pyp"][:nsteps, None, :]                                   # :531-534
+            d_prior = np.zeros((nsteps, B, p.nd))
+            if p.nd:                                                 # dhat is carried unchanged between steps (:655-668)
+                d_prior[0] = _bcast(p.dhat0, B, p.nd); d_prior[1:] = out["D_HAT"][:-1]
+            out["Y_HAT"] = out["X_HAT"] @ p.C.T + p.fy_const + (d_prior @ p.Cd.T if p.nd else 0.0)             # :524
+            ms, _ = s.last_kernel_ms()
+            out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
         else:
             out = _stepwise(p, s, x0_p, x0_m, nsteps, sched)
     finally:
@@ -58,7 +68,7 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
             if comm is not None and comm.world > 1:
                 raise ValueError("run_closed_loop(gather=True) over several ranks needs total= (the size of the whole batch)")
             total = B
-        out = {k: np.moveaxis(allgather_rows(np.moveaxis(v, 1, 0), total, comm), 0, 1) for k, v in out.items()}
+        out = {k: (np.moveaxis(allgather_rows(np.moveaxis(v, 1, 0), total, comm), 0, 1) if np.ndim(v) >= 2 else v) for k, v in out.items()}
     return out
 
 
@@ -69,23 +79,30 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched):
     u = _bcast(p.u0, B, p.nu).copy(); dhat = _bcast(p.dhat0, B, p.nd).copy() if p.nd else np.zeros((B, 0))
     Pk = np.broadcast_to(p.P0, (B,) + p.P0.shape).copy() if p.estimator == "kal" else None
     us_k, xs_k = u.copy(), x0_m.copy()                                   # :682-684
-    keys = ("U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS")
+    import time
+    keys = ("U", "X_HAT", "Y_HAT", "XS", "US", "YS", "Xp", "Yp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "TIME_SS", "TIME_DYN")
     log = {k: [] for k in keys}
     for k in range(nsteps):
         log["Xp"].append(x.copy()); log["X_HAT"].append(xhat.copy())      # :519-520
+        log["Y_HAT"].append(xhat @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0))   # :524
         y = x @ p.Cp.T + sched["pyp"][k]                                  # :534
+        log["Yp"].append(y.copy())
         if p.estimator != "none":
             xi, Pk = s.kf_update(y, np.hstack([xhat, dhat]), Pk)          # :577-650
             xhat, dhat = xi[:, :n].copy(), xi[:, n:].copy()
             if p.dmin is not None and p.dmax is not None:                # both or neither (problem.py refuses one-sided)
                 dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)       # :660-665
         log["D_HAT"].append(dhat.copy())
+        t0 = time.time()                                                                     # :703
         t = s.target_solve(sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_k)   # :704-709
+        log["TIME_SS"].append(time.time() - t0)                                              # :711,729
         ok = (t["status"] != capi.STATUS_INFEASIBLE)[:, None]
         xs_k = np.where(ok, t["xs"], xs_k); us_k = np.where(ok, t["us"], us_k)               # :714-718
         log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy())
         log["YS"].append(xs_k @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0))      # :730
+        t0 = time.time()                                                                     # :775
         o = s.ocp_solve(xhat, xs_k, us_k, dhat, u)                                           # :776-781
+        log["TIME_DYN"].append(time.time() - t0)                                             # :783,810
         ok = (o["status"] != capi.STATUS_INFEASIBLE)[:, None]
         hold = xhat @ p.A.T + u @ p.B.T + p.fx_const + (dhat @ p.Bd.T if p.nd else 0.0)      # :804-805
         u = np.where(ok, o["u0"], u); xhat = np.where(ok, o["x1"], hold)                     # :798-799

@@ -101,6 +101,33 @@ def test_target_and_estimator_match_c_restatement(which, cstr, wb, oracle_c, sol
         assert np.abs(b - b2.reshape(B, ne, ne)).max() < 1e-12
 
 
+def assert_same_closed_loop(g, c, p, tol, keys=("U", "XS", "US", "X_HAT", "Xp", "D_HAT", "YS"), max_flipped=0.005):
+    """Two closed loops of the same instances: equal status words and values within tol.  An instance whose feasibility label
+    differs at some step is compared up to that step only, and the difference has to be *explained*: one of the two labels is
+    'infeasible' and the stage-0 feasibility test is borderline (an output row of the given state next to its bound,
+    Control_Calc.py:128-151 / SURVEY.md App. C; judged on the logged prior estimate, hence the loose 1e-3) - anything else fails.  At most max_flipped of the instances may be borderline."""
+    K, B = g["STATUS_DYN"].shape
+    same = g["STATUS_DYN"] == c["STATUS_DYN"]
+    first = np.where(same.all(axis=0), K, np.argmin(same, axis=0))          # first step with a different label, per instance
+    flipped = np.where(first < K)[0]
+    assert len(flipped) <= max_flipped * B, f"{len(flipped)} of {B} instances change their feasibility label"
+    for b in flipped:
+        k = first[b]
+        assert {int(g["STATUS_DYN"][k, b]), int(c["STATUS_DYN"][k, b])} & {2}, (b, k, "labels differ but neither is 'infeasible'")
+        dh = g["D_HAT"][k, b] if "D_HAT" in g and p.nd else np.zeros(0)
+        y0 = p.C @ g["X_HAT"][k, b] + p.fy_const + (p.Cd @ dh if p.nd else 0.0)      # prior estimate; the test uses the corrected one
+        margin = min(np.abs(y0 - p.ymin).min(), np.abs(y0 - p.ymax).min())
+        assert margin < 1e-3, (b, k, "label flip away from every output bound", margin)
+    step = np.arange(K)[:, None]
+    mask = step < first[None, :]                                                  # compare everything before the first flip
+    for key in keys:
+        if key in g and key in c and g[key].size:
+            d = np.abs(g[key] - c[key]).max(axis=2)
+            assert d[mask].max() < tol, (key, d[mask].max())
+    assert np.array_equal(g["STATUS_SS"][mask], c["STATUS_SS"][mask])
+    return len(flipped)
+
+
 LOOP_KERNELS = [pytest.param(1, id="lane"), pytest.param(2, id="horizon"), pytest.param(3, id="wave")]      # the closed-loop kernels (mpc_set_option "loop_kernel")
 
 
@@ -112,13 +139,7 @@ def test_fused_closed_loop_matches_c_restatement(which, B, nst, lk, cstr, wb, or
     x0 = bench_x0(B, 9) if p is cstr else 0.05 * np.random.default_rng(9).standard_normal((B, p.nx))
     g = run_closed_loop(p, x0, x0, nst, solver=solver_factory(p, lk), fused=True)
     c = oracle_c.OracleC(p).closed_loop(nst, x0, x0)
-    same = g["STATUS_DYN"] == c["STATUS_DYN"]
-    assert same.mean() > 0.999
-    good = same.all(axis=0)                                   # instances whose feasibility labels never flipped
-    assert good.mean() > 0.97
-    for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT", "YS"):
-        assert np.abs(g[k] - c[k])[:, good].max() < 1e-6, k
-    assert np.array_equal(g["STATUS_SS"][:, good], c["STATUS_SS"][:, good])
+    assert_same_closed_loop(g, c, p, 1e-6)
 
 
 @pytest.mark.parametrize("lk", LOOP_KERNELS)
@@ -131,8 +152,11 @@ def test_stepwise_calls_equal_fused_kernel(lk, cstr, solver_factory):
     a = run_closed_loop(cstr, x0, x0, 12, solver=s, fused=True)
     b = run_closed_loop(cstr, x0, x0, 12, solver=s, fused=False)
     assert np.array_equal(a["STATUS_DYN"], b["STATUS_DYN"])
-    for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT"):
+    for k in ("U", "XS", "US", "X_HAT", "Y_HAT", "Xp", "Yp", "D_HAT"):      # the reference's result arrays, MPC_code.py:877-895
         assert np.abs(a[k] - b[k]).max() < 5e-6, k
+    assert a["TIME_DYN"].shape == (12,) and b["TIME_SS"].shape == (12,) and (b["TIME_DYN"] > 0).all()
+    sched = cstr.schedules(12)
+    assert np.abs(a["Yp"] - (a["Xp"] @ cstr.Cp.T + sched["pyp"][:, None, :])).max() == 0.0
     assert b["ITERS_DYN"][6:].mean() > 1.5 * a["ITERS_DYN"][6:].mean()      # the warm start is doing its job
 
 
@@ -142,11 +166,10 @@ def test_shipped_scenarios_follow_the_golden_closed_loop(lk, cstr, wb, solver_fa
     for p, name in ((cstr, "cstr_shipped"), (wb, "wb_shipped")):
         g = np.load(os.path.join(GOLD, name + ".npz"))
         r = run_closed_loop(p, nsteps=100, solver=solver_factory(p, lk))
-        same = ((r["STATUS_DYN"] == 2) == (g["STATUS_DYN"] == 2)).all(axis=1)
-        upto = int(np.argmin(same)) if not same.all() else 100
-        assert upto >= 20
-        assert np.abs(r["U"][:upto] - g["U"][:upto]).max() < 5e-6
-        assert np.abs(r["X_HAT"][:upto] - g["X_HAT"][:upto]).max() < 5e-6
+        # all 100 steps: the same feasibility labels as the exact golden loop, and its values (measured: 5.7e-8 / 3e-9)
+        assert np.array_equal(r["STATUS_DYN"] == 2, g["STATUS_DYN"] == 2)
+        assert np.abs(r["U"] - g["U"]).max() < 1e-6
+        assert np.abs(r["X_HAT"] - g["X_HAT"]).max() < 1e-6
     # the shipped CSTR run starts infeasible: u is held at u0 = 0 for steps 0-2
     r = run_closed_loop(cstr, nsteps=4, solver=solver_factory(cstr, lk))
     assert (r["STATUS_DYN"][:3, 0] == 2).all() and r["STATUS_DYN"][3, 0] == 0 and np.all(r["U"][:3] == 0.0)
@@ -321,20 +344,16 @@ def test_short_horizon_and_double_integrator(pkg, oracle_c, solver_factory):
 
 @pytest.mark.parametrize("lk", LOOP_KERNELS)
 def test_full_size_closed_loop(lk, cstr, oracle_c, solver_factory):
-    """The benchmark workload itself (4096 instances, first 30 steps incl. the set-point change): every status word and
-    a sample of trajectories against the C restatement; invariants on all of them."""
+    """The benchmark workload itself (BASELINE.json configs[1]: 4096 instances, 100 steps from t = 0): EVERY instance and step
+    against the C restatement - all 409 600 status words and all trajectories (measured: no label differs, 5e-9) - and
+    invariants on all of them."""
     from mpc_code_amd.driver import run_closed_loop
     p = cstr
-    B, K = 4096, 30
+    B, K = 4096, 100
     x0 = bench_x0(B)
     g = run_closed_loop(p, x0, x0, K, solver=solver_factory(p, lk))
-    pick = np.arange(0, B, 61)
-    c = oracle_c.OracleC(p).closed_loop(K, x0[pick], x0[pick])
-    same = g["STATUS_DYN"][:, pick] == c["STATUS_DYN"]
-    assert same.mean() > 0.999
-    good = same.all(axis=0)
-    assert np.abs(g["U"][:, pick][:, good] - c["U"][:, good]).max() < 1e-6
-    assert np.abs(g["X_HAT"][:, pick][:, good] - c["X_HAT"][:, good]).max() < 1e-6
+    c = oracle_c.OracleC(p).closed_loop(K, x0, x0)
+    assert assert_same_closed_loop(g, c, p, 1e-7, max_flipped=0.001) <= 4
     # invariants on all 4096: inputs inside their box; the plant log obeys the plant; held steps keep u
     assert (g["U"] >= p.umin - 1e-9).all() and (g["U"] <= p.umax + 1e-9).all()
     sched = p.schedules(K)
