@@ -44,21 +44,37 @@ class _Desc(ct.Structure):
                                    "dmin", "dmax", "Q_kf", "R_kf", "K")]
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile ``csrc/mpc_amd.hip`` for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+def jit_library_path(dims) -> str:
+    return os.path.join(CSRC, "jit", "libmpc_amd_" + "_".join(str(int(v)) for v in dims) + ".so")
+
+
+def build_library(force: bool = False, verbose: bool = False, dims=None) -> str:
+    """Compile ``csrc/mpc_amd.hip`` for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    ``dims = (nx, nu, ny, nd, nxp, du_form, general_output_rows)``: a library holding the kernels of exactly that
+    dimension set (every kernel is a template on the problem dimensions; the default library carries the sets of the
+    shipped examples, ``mpc_build_info()``), written to ``csrc/jit/`` and reused while the sources are unchanged."""
     srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp", "mpc_tp.hpp", "mpc_wave.hpp")] + \
            [os.path.join(os.path.dirname(PKG_DIR), "include", "mpc_amd.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
-        return LIB_PATH
+    out = LIB_PATH if dims is None else jit_library_path(dims)
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0]]
+    flags = list(HIPCC_FLAGS)
+    if dims is not None:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        flags.append("-DMPC_DIM_LIST(X)=X(" + ",".join(str(int(v)) for v in dims) + ")")
+    tmp = out + f".{os.getpid()}.tmp"
+    cmd = [hipcc] + flags + ["-o", tmp, srcs[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB_PATH
+    os.replace(tmp, out)
+    return out
 
 
 _lib = None
+_libs = {}
 
 
 def load_library(path: Optional[str] = None) -> ct.CDLL:
@@ -66,6 +82,8 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise MpcAmdError(f"{path} not found: build it with mpc_code_amd.capi.build_library() (needs hipcc); "
                           "there is no CPU fallback")
@@ -107,6 +125,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     lib.mpc_allgather_log.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int32, ct.c_int32, _dp]
     if path == LIB_PATH:
         _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -136,7 +155,7 @@ def _pi(a):
 class Solver:
     """A problem resident on one GPU.  ``problem`` is a :class:`LinearMPCProblem`."""
 
-    def __init__(self, problem, device: int = 0, lib_path: Optional[str] = None):
+    def __init__(self, problem, device: int = 0, lib_path: Optional[str] = None, jit: bool = True):
         self.lib = load_library(lib_path)
         self.p = p = problem
         self._keep = {}
@@ -158,6 +177,14 @@ class Solver:
                 setattr(d, k, _p(a))
         self.h = ct.c_void_p()
         rc = self.lib.mpc_lin_create(ct.byref(d), ct.byref(self.h))
+        if rc == -5 and lib_path is None and jit and not os.environ.get("MPC_AMD_NO_JIT"):
+            # no kernel compiled for these dimensions: build the library of exactly this set (about a minute of hipcc, then cached
+            # under csrc/jit/) - the kernels are templates on the dimensions, any stage state <= 8 and nu <= 4 compiles
+            import re
+            m = re.search(r"nx=(\d+) nu=(\d+) ny=(\d+) nd=(\d+) nxp=(\d+) du_form=(\d+) general_output_rows=(\d+)", self.lib.mpc_last_error().decode())
+            if m:
+                self.lib = load_library(build_library(dims=tuple(int(v) for v in m.groups())))
+                rc = self.lib.mpc_lin_create(ct.byref(d), ct.byref(self.h))
         if rc != 0:
             self.h = None
             raise MpcAmdError(f"mpc_lin_create failed ({rc}): {self.lib.mpc_last_error().decode()}")

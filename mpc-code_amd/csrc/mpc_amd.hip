@@ -166,6 +166,7 @@ struct LoopArgs {
     double *tw; int32_t *tw_valid;                   // warm start of the target solve: [2*nu + 3*(nx+nu+ny)][Bs], [Bs]
     double *ws;
     int B, nsteps; size_t Bs;
+    int N;                                           // horizon (host side: sizes the dynamic LDS of the wave-autonomous kernel)
 };
 
 template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
@@ -479,18 +480,20 @@ struct WvKernelCfg {
     // per-instance state kept in LDS across the steps of a launch
     static constexpr int K_X = 0, K_XH = NXP, K_DH = K_XH + NX, K_U = K_DH + NDD, K_XS = K_U + NU, K_US = K_XS + NX, K_P = K_US + NU,
                          K_TW = K_P + NE * NE, KEEP = K_TW + NTW;
-    static constexpr size_t lds_bytes() { return sizeof(double) * (Cfg::lds_doubles(KEEP) + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 16; }
+    static constexpr size_t lds_bytes(int N) { return sizeof(double) * (Cfg::lds_doubles(KEEP, N) + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 16; }
     static constexpr int ni() { return NI; }
 };
 
 template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED, int NI>
-__global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const DevProblem *__restrict__ Pp, LoopArgs a)
+__global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__restrict__ Pp, LoopArgs a)
 {
     using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
     using Cfg = typename KC::Cfg;
     constexpr int NS = KC::NS, NE = KC::NE, NDD = KC::NDD, NTW = KC::NTW, KEEP = KC::KEEP;
     extern __shared__ double wv_smem[];
-    double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::T_DOUBLES, *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
+    const DevProblem &P0 = *Pp;
+    const int LD = Cfg::ld(P0.N);
+    double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::t_doubles(P0.N), *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
     int *const iflag = (int *)(keep + NI * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
     using RT = Row16Tab<NX, NU, NY, ND>;
     double *const tab = (double *)(wsv + 8);      // per-row constants of the 16-lanes-per-instance phases
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(64, (NI <= 2 ? 2 : 1)) void loop_kernel_wv(const De
         for (int f = 0; f < NTW; f++) kp[KC::K_TW + f] = (a.tw + (size_t)f * Bs)[b];
         twv[lane] = a.tw_valid[b]; wsv[lane] = a.ws_valid[b];
     } else if (lane < NI) { twv[lane] = 0; wsv[lane] = 0; }
-    for (int i = lane; i < NI * Cfg::LD; i += 64) T[Cfg::RZ * NI * Cfg::LD + i] = 0.0;      // the zero row of the tile view
+    for (int i = lane; i < NI * LD; i += 64) T[Cfg::RZ * NI * LD + i] = 0.0;      // the zero row of the tile view
     if (lane < Cfg::GUARD) wv_smem[lane] = 0.0;
     if (RT::fits) row16_fill_tables<NX, NU, NY, ND>(P, tab, lane);
     __syncthreads();
@@ -774,13 +777,13 @@ static Launchers make_launchers_mode()
         }
     }
     l.loop_wv = nullptr; l.wv_ws_per_inst = 0; l.wv_lds = 0;
-    if constexpr (NX + (DU ? NU : 0) + NG <= 4 && NU <= 2) {
-#ifndef MPC_WV_NI
-#define MPC_WV_NI 4
-#endif
-        constexpr int NI = MPC_WV_NI;      // instances per wave of the wave-autonomous kernel
+    if constexpr (NX + (DU ? NU : 0) + NG <= 8 && NU <= 2) {
+        // instances per wave: four (one per tile of a matrix-core product) when their resident iterates fit the 256 accumulation
+        // registers they are parked in (4 NC slacks / multipliers + NV primal + NC predictor direction, two registers each), else two
+        constexpr int NSZ_ = NX + (DU ? NU : 0) + NG;
+        constexpr int NI = (5 * NC + NSZ_ + NU) * 2 * 4 <= 248 ? 4 : 2;
         using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
-        constexpr size_t lds = KC::lds_bytes();
+        constexpr size_t lds = KC::lds_bytes(64);      // the longest horizon; a launch asks for what its own horizon needs
         l.wv_lds = lds; l.wv_ws_per_inst = sizeof(double) * 64 * KC::Cfg::ROWS_WS;
         if (lds <= 160 * 1024) {
             l.loop_wv = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
@@ -792,7 +795,7 @@ static Launchers make_launchers_mode()
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
                     attr_set[dev] = true;
                 }
-                hipLaunchKernelGGL(kern, dim3((a.B + NI - 1) / NI), dim3(64), lds, s, p, a);
+                hipLaunchKernelGGL(kern, dim3((a.B + NI - 1) / NI), dim3(64), KC::lds_bytes(a.N), s, p, a);
                 return 0;
             };
         }
@@ -1100,7 +1103,7 @@ extern "C" const char *mpc_build_info(void)
 {
     static std::string s;
     if (s.empty()) {
-        s = "gfx950;loop_kernels=wave-autonomous(N<=64&ns<=4&nu<=2),horizon-parallel(N<=64;mfma-riccati:ns<=4&nu<=2,else-batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
+        s = "gfx950;loop_kernels=wave-autonomous(N<=64&ns<=8&nu<=2),horizon-parallel(N<=64;mfma-riccati:ns<=4&nu<=2,else-batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU, NG) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU "/" #NG ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
@@ -1116,7 +1119,7 @@ extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
     if (!std::strcmp(name, "loop_kernel")) {
         const int v = (int)value;
         if (v < 0 || v > 3) return fail(-1, "loop_kernel must be 0 (auto), 1 (instance per lane), 2 (horizon-parallel) or 3 (wave-autonomous)");
-        if (v == 3 && (!h->L.loop_wv || h->hp.N > 64)) return fail(-8, "the wave-autonomous kernel needs N <= 64 and a stage that fits a 4x4 tile (stage state <= 4, nu <= 2)");
+        if (v == 3 && (!h->L.loop_wv || h->hp.N > 64)) return fail(-8, "the wave-autonomous kernel needs N <= 64, stage state <= 8 and nu <= 2");
         if (v == 2 && (!h->L.loop_tp || h->hp.N > 64)) return fail(-8, "the horizon-parallel kernel needs N <= 64 and a problem that fits the LDS");
         h->loop_kernel_opt = v;
         return 0;
@@ -1469,7 +1472,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         } else a.st_dyn = a.st_ss = a.it_dyn = a.it_ss = nullptr;
         a.ws_valid = (int32_t *)h->st_flag.p; a.kf_valid = a.ws_valid + Bs; a.Kg = (double *)h->st_Kg.p; a.Pn = (double *)h->st_Pn.p;
         a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
-        a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs;
+        a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs; a.N = P.N;
         if (mode == 3) { if (h->L.loop_wv(h->dp, a, h->stream)) return fail(-9, "cannot configure the wave-autonomous kernel (LDS %zu bytes)", h->L.wv_lds); }
         else if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);

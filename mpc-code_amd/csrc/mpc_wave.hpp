@@ -38,13 +38,14 @@ struct WvCfg {
     //   RZ: zeros, written once in the kernel's prologue
     static constexpr int RA = 0, RA_SZ = (NC > NKF + NLI ? NC : NKF + NLI);
     static constexpr int RG = RA_SZ, RK = RG + NV, RZ = RK + NU, ROWS = RZ + 1;      // RZ: a row of zeros (tile lanes without a datum read it)
-    static constexpr int LD = 65;                                      // odd: the tile view (row, instance) -> distinct banks
-    static constexpr int GUARD = 8;                                    // cells in front of T: run-on reads of the backward loops, stores of idle lanes
-    static constexpr int T_DOUBLES = GUARD + ROWS * NI * LD;
+    // row stride: the horizon + 1, made odd: the tile view (row, instance) then hits distinct banks; 65 for the longest horizon
+    __host__ __device__ static constexpr int ld(int N) { return (N + 1) | 1; }
+    static constexpr int GUARD = 8;                                    // cells in front of T: look-ahead reads of the backward loops, stores of idle lanes
+    __host__ __device__ static constexpr int t_doubles(int N) { return GUARD + ROWS * NI * ld(N); }
     static constexpr int QN = 5 * NS + 2 * NU + 1;                     // z0 zr c zlo zhi | ur us | ws_delta
     static constexpr int ROWS_WS = NU + 2 * NC;                        // warm start kept in HBM between launches: u | l_lo | l_hi
     static constexpr int OUT = NU + NS;                                // first input / next state of the final iterate
-    __host__ __device__ static constexpr size_t lds_doubles(int keep_per_inst) { return (size_t)T_DOUBLES + NI * QN + NI * OUT + NI * keep_per_inst; }
+    __host__ __device__ static constexpr size_t lds_doubles(int keep_per_inst, int N) { return (size_t)t_doubles(N) + NI * QN + NI * OUT + NI * keep_per_inst; }
 };
 
 template <int NS, int NU, int NC>
@@ -116,9 +117,9 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
 {
     using Cfg = WvCfg<NS, NU, NC, NI>;
     using Iter = WvIter<NS, NU, NC>;
-    constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK, LD = Cfg::LD;
-    static_assert(NS <= 4 && NU <= 2 && NI >= 1 && NI <= 4, "the stage has to fit one 4x4 tile; at most four tiles per product");
-    const int lane = threadIdx.x, N = P.N;
+    constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK;
+    static_assert(NS <= 8 && NU <= 2 && NI >= 1 && NI <= 4, "stage state <= 8 (2 x 2 tiles of 4 x 4), nu <= 2 (closed-form inverse of Lambda); at most four instances per product");
+    const int lane = threadIdx.x, N = P.N, LD = Cfg::ld(N);
     const int k = lane;
     const bool blk_on = k < N, last = k == N - 1;
     auto tk = [&](int row, int inst) -> double & { return T[(row * NI + inst) * LD + k]; };      // lane = block view
@@ -174,7 +175,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             const double rh = Bd.fh[i] ? v + Xj.sh[i] - Bd.hi[i] : 0.0, rl = Bd.fl[i] ? v - Xj.sl[i] - Bd.lo[i] : 0.0;
             const double isl = frcp(Xj.sl[i]), ish = frcp(Xj.sh[i]);
             mu_p += Xj.sl[i] * Xj.ll[i] + Xj.sh[i] * Xj.lh[i];
-            tk(RA + i, j) = Xj.ll[i] * isl + Xj.lh[i] * ish;
+            if (blk_on) tk(RA + i, j) = Xj.ll[i] * isl + Xj.lh[i] * ish;      // lanes beyond the horizon would land in the next row (stride N + 1)
             hb[i] = Xj.lh[i] * (rh * ish - 1.0) + Xj.ll[i] * (rl * isl + 1.0);
             resp_p = dmax(resp_p, dmax(fabs(rl), fabs(rh)));
             cres_p = dmax(cres_p, dmax(comp_measure(Xj.sl[i], Xj.ll[i]), comp_measure(Xj.sh[i], Xj.lh[i])));
@@ -182,8 +183,11 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         }
         double gu[NU], gz[NS], pi[NS];
         gradient(Pl, j, Xj, gu, gz);
-        MPC_UNROLL for (int i = 0; i < NU; i++) tk(RG + i, j) = gu[i] + hb[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { tk(RG + NU + i, j) = gz[i] + (NU + i < NC ? hb[NU + i < NC ? NU + i : 0] : 0.0); pi[i] = blk_on ? gz[i] : 0.0; }
+        if (blk_on) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) tk(RG + i, j) = gu[i] + hb[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + (NU + i < NC ? hb[NU + i < NC ? NU + i : 0] : 0.0);
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = blk_on ? gz[i] : 0.0;
         MPC_UNROLL for (int e = 0; e < 6; e++) {
             const int d = 1 << e;
             if (d < N) {
@@ -300,7 +304,9 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
 
     MPC_TSTAMP(1);
     // ---- tile view ------------------------------------------------------------------------------------------------------
-    // lane 16 r + 4 b + c holds element (r, c) of the tile of instance b; mm(M, S, C) = M'S + C on all four tiles at once.
+    // lane 16 r + 4 b + c holds element (r, c) of a 4x4 tile of instance b; mm(M, S, C) = M'S + C on all four instances' tiles at
+    // once.  A stage with more than four states is a grid of SB x SB such tiles (SB = 2 up to stage state 8: Wood-Berry's Delta-u
+    // form, general output rows); the input block stays one tile (nu <= 2: the 2 x 2 inverse of Lambda is closed-form).
     // One wave alone on a SIMD issues one instruction every four cycles whatever its kind, so these loops are written for the
     // lowest instruction count per block:
     //   * a lane that has no use for a quantity reads the zero row RZ instead (never written after the kernel's prologue): no masks;
@@ -310,13 +316,14 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
     //   * per field one address register stepped once per group, the blocks of a group at immediate offsets.
     auto mm = [](double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); };
     constexpr int RZ = Cfg::RZ;
+    constexpr int SB = (NS + 3) / 4;      // tiles per side of a state matrix
     // Everything a pass needs per lane is rebuilt at its start from a lane index the compiler cannot see through: as loop
-    // invariants of the iteration loop these ~70 registers would stay live across the element-wise phases (and spill there).
+    // invariants of the iteration loop these registers would stay live across the element-wise phases (and spill there).
     struct TileCtx {
-        int tr, tc; bool live, in_ss, in_su, in_us, in_uu;
+        int tr, tc; bool live;
         double *Tt, *trash;
-        double Ar, Atr, Br, Btr;
-        double *p_hu, *p_hz, *p_kf, *p_k, *p_kt, *p_li;
+        double Ar[SB][SB], Atr[SB][SB], Br[SB], Btr[SB];      // A, A', B, B' as tiles: Ar[i][j](r, c) = A[4i + r][4j + c], Btr[j](r, c) = B[4j + c][r]
+        double *p_hu, *p_hz[SB], *p_kf, *p_k[SB], *p_kt[SB], *p_li;
     };
     auto tile_ctx = [&](const PT &Pl) {
         int lo = threadIdx.x;
@@ -327,62 +334,112 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         c.live = tbq < NI;                                                 // tiles >= NI carry zeros (their lanes read RZ, store to the guard)
         const int tb = c.live ? tbq : 0;
         const int tr = c.tr, tc = c.tc;
-        c.in_ss = tr < NS && tc < NS; c.in_su = tr < NS && tc < NU; c.in_us = tr < NU && tc < NS; c.in_uu = tr < NU && tc < NU;
         c.Tt = T + tb * LD; c.trash = T - Cfg::GUARD;
-        c.Ar = c.in_ss ? Pl.A[tr][tc] : 0.0; c.Atr = c.in_ss ? Pl.A[tc][tr] : 0.0; c.Br = c.in_su ? Pl.B[tr][tc] : 0.0; c.Btr = c.in_us ? Pl.B[tc][tr] : 0.0;
         auto trow = [&](int row) -> double * { return c.Tt + (c.live ? row : RZ) * (NI * LD); };
-        // vectors live in column-replicated tiles: hu / hz / kff rows of this lane
-        c.p_hu = trow(tr < NU ? RG + tr : RZ); c.p_hz = trow(tr < NS ? RG + NU + tr : RZ); c.p_kf = trow(tr < NU ? RK + tr : RZ);
-        // K (rows < NU, columns < NS), K' and -Lambda^-1 (symmetric, rows / columns < NU) as tiles
+        MPC_UNROLL for (int i = 0; i < SB; i++) {
+            const int ri = 4 * i + tr, ci = 4 * i + tc;
+            MPC_UNROLL for (int j = 0; j < SB; j++) {
+                const int cj = 4 * j + tc, rj = 4 * j + tr;
+                c.Ar[i][j] = (ri < NS && cj < NS) ? Pl.A[ri < NS ? ri : 0][cj < NS ? cj : 0] : 0.0;
+                c.Atr[i][j] = (ri < NS && cj < NS) ? Pl.A[cj < NS ? cj : 0][ri < NS ? ri : 0] : 0.0;
+                (void)rj;
+            }
+            c.Br[i] = (ri < NS && tc < NU) ? Pl.B[ri < NS ? ri : 0][tc < NU ? tc : 0] : 0.0;
+            c.Btr[i] = (tr < NU && ci < NS) ? Pl.B[ci < NS ? ci : 0][tr < NU ? tr : 0] : 0.0;
+            // vectors live in column-replicated tiles: hz rows of this lane; K (rows < NU, state columns) and K' as tiles
+            c.p_hz[i] = trow(ri < NS ? RG + NU + ri : RZ);
+            c.p_k[i] = trow((tr < NU && ci < NS) ? RA + tr * NS + ci : RZ);
+            c.p_kt[i] = trow((ri < NS && tc < NU) ? RA + tc * NS + ri : RZ);
+        }
+        c.p_hu = trow(tr < NU ? RG + tr : RZ); c.p_kf = trow(tr < NU ? RK + tr : RZ);
+        // -Lambda^-1 (symmetric, rows / columns < NU) as a tile
         const int li_i = tr > tc ? tr : tc, li_j = tr > tc ? tc : tr;
-        c.p_k = trow(c.in_us ? RA + tr * NS + tc : RZ); c.p_kt = trow(c.in_su ? RA + tc * NS + tr : RZ);
-        c.p_li = trow(c.in_uu ? RA + NKF + li_i * (li_i + 1) / 2 + li_j : RZ);
+        c.p_li = trow((tr < NU && tc < NU) ? RA + NKF + li_i * (li_i + 1) / 2 + li_j : RZ);
         return c;
     };
     double pd_min = 1.0;        // smallest pivot / determinant of this lane's instance so far: <= 0 means a Lambda lost definiteness
-    constexpr int PD = 4;       // blocks per group
+    constexpr int PD = SB == 1 ? 4 : 2;       // blocks per group
 
     // backward: Riccati factorisation (sigma -> K, -Lambda^-1) with the right-hand-side recursion of the predictor behind it
     auto tile_factor = [&]() {
         const PT &Pl = launder(P);
         const TileCtx c = tile_ctx(Pl);
-        const int tr = c.tr, tc = c.tc; const bool live = c.live, in_ss = c.in_ss, in_us = c.in_us, in_uu = c.in_uu;
-        const double Ar = c.Ar, Br = c.Br, Btr = c.Btr; double *const trash = c.trash, *const p_hu = c.p_hu, *const p_hz = c.p_hz, *const p_kf = c.p_kf;
+        const int tr = c.tr, tc = c.tc; const bool live = c.live;
+        double *const trash = c.trash;
         auto trow = [&](int row) -> double * { return c.Tt + (live ? row : RZ) * (NI * LD); };
-        const double Rr = in_uu ? Pl.R[tr][tc] : 0.0, Qr = in_ss ? Pl.Q[tr][tc] : 0.0, Mtr = (HASM && in_us) ? Pl.M[tc][tr] : 0.0;
-        // rows 0 / 1 of Lambda = R~ + B'PB broadcast over all tile rows, straight from PB: (B E_i)' PB + E_i' R~
-        const double BE0 = tr < NS ? Pl.B[tr][0] : 0.0, BE1 = (NU > 1 && tr < NS) ? Pl.B[tr][NU > 1 ? 1 : 0] : 0.0;
+        const bool in_uu = tr < NU && tc < NU;
+        const double Rr = in_uu ? Pl.R[tr][tc] : 0.0;
+        double Qr[SB][SB], Mtr[SB], BE0[SB], BE1[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) {
+            const int ri = 4 * i + tr, ci = 4 * i + tc;
+            MPC_UNROLL for (int j = 0; j < SB; j++) { const int cj = 4 * j + tc; Qr[i][j] = (ri < NS && cj < NS) ? Pl.Q[ri < NS ? ri : 0][cj < NS ? cj : 0] : 0.0; }
+            Mtr[i] = (HASM && tr < NU && ci < NS) ? Pl.M[ci < NS ? ci : 0][tr < NU ? tr : 0] : 0.0;
+            // rows 0 / 1 of Lambda = R~ + B'PB broadcast over all tile rows, straight from PB: (B E_i)' PB + E_i' R~
+            BE0[i] = ri < NS ? Pl.B[ri < NS ? ri : 0][0] : 0.0; BE1[i] = (NU > 1 && ri < NS) ? Pl.B[ri < NS ? ri : 0][NU > 1 ? 1 : 0] : 0.0;
+        }
         const double RE0 = tc < NU ? Pl.R[0][tc] : 0.0, RE1 = (NU > 1 && tc < NU) ? Pl.R[NU > 1 ? 1 : 0][tc] : 0.0;
         const double Ir = tr == tc ? 1.0 : 0.0;
-        // barrier weights: sigma_z[r] on the diagonal of P, sigma_u[r] on the diagonal of R~, sigma_u[i] at (., i) of broadcast row i
-        const bool dz_on = tr == tc && tr < NS && NU + tr < NC, du_on = tr == tc && tr < NU;
-        const double *q_sz = trow(dz_on ? RA + NU + tr : RZ) + (N - 1), *q_su = trow(du_on ? RA + tr : RZ) + (N - 1);
+        // barrier weights: sigma_z on the diagonal of P's diagonal tiles, sigma_u[r] on the diagonal of R~, sigma_u[i] at (., i) of broadcast row i
+        const double *q_sz[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) { const int ri = 4 * i + tr; q_sz[i] = trow((tr == tc && ri < NS && NU + ri < NC) ? RA + NU + ri : RZ) + (N - 1); }
+        const double *q_su = trow((tr == tc && tr < NU) ? RA + tr : RZ) + (N - 1);
         const double *q_s0 = trow(tc == 0 ? RA : RZ) + (N - 1), *q_s1 = trow((NU > 1 && tc == 1) ? RA + 1 : RZ) + (N - 1);
-        const double *q_hu = p_hu + (N - 1), *q_hz = p_hz + (N - 1);
+        const double *q_hu = c.p_hu + (N - 1);
+        const double *q_hz[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) q_hz[i] = c.p_hz[i] + (N - 1);
         // this lane's element of -adj(Lambda) as a combination of a = L00, d = L11, off = L01 (2 x 2), element (r mod 2, c):
         //   (0,0): -d   (1,1): -a   (0,1), (1,0): +off;  -Lambda^-1 = that / det.  NU = 1: -1 in column 0.
-        const int ri = tr & 1;
-        const double c_a = (NU > 1 && tc == 1 && ri == 1) ? -1.0 : 0.0, c_d = (NU > 1 && tc == 0 && ri == 0) ? -1.0 : 0.0;
-        const double c_o = (NU > 1 && tc < 2 && ri != tc) ? 1.0 : 0.0, c_1 = (NU == 1 && tc == 0) ? -1.0 : 0.0;
+        const int ri2 = tr & 1;
+        const double c_a = (NU > 1 && tc == 1 && ri2 == 1) ? -1.0 : 0.0, c_d = (NU > 1 && tc == 0 && ri2 == 0) ? -1.0 : 0.0;
+        const double c_o = (NU > 1 && tc < 2 && ri2 != tc) ? 1.0 : 0.0, c_1 = (NU == 1 && tc == 0) ? -1.0 : 0.0;
         const double w_top = tr < NU ? 1.0 : 0.0;
         const double k_a = c_a * w_top, k_d = c_d * w_top, k_o = c_o * w_top, k_1 = c_1 * w_top;      // the same, rows < NU only (the K product)
-        // K goes to LDS from the lanes that hold it (rows < NU of the tile), -Lambda^-1 from rows 2..3, which compute it as well, kff
-        // (valid in rows < NU of every column) from column 3 when the state leaves it free: one store per block
-        const bool st_k = in_us, st_l = tr >= 2 && tc < NU && tc <= tr - 2 && tr - 2 < NU, st_f3 = NS < 4 && tr < NU && tc == 3;
-        const bool st_any = live && (st_k || st_l || st_f3), st_f = live && NS >= 4 && tr < NU && tc == 0;
-        double *q_st = st_any ? trow(st_k ? RA + tr * NS + tc : (st_l ? RA + NKF + (tr - 2) * (tr - 1) / 2 + tc : RK + (tr < NU ? tr : 0))) + (N - 1) : trash + PD;
-        double *q_sf = st_f ? p_kf + (N - 1) : trash + PD;
-        const int stp = st_any ? PD : 0, stpf = st_f ? PD : 0;
-        double Pm = in_ss ? Pl.Pf[tr][tc] : 0.0, PC = 0.0;
-        double f[PD][6];
-        MPC_UNROLL for (int d = 0; d < PD; d++) { f[d][0] = q_sz[-d]; f[d][1] = q_su[-d]; f[d][2] = q_s0[-d]; f[d][3] = NU > 1 ? q_s1[-d] : 0.0; f[d][4] = q_hu[-d]; f[d][5] = q_hz[-d]; }
+        // stores per block: K from the lanes that hold it (rows < NU of each state tile); -Lambda^-1 from rows 2..3 of tile 0, which
+        // compute it as well; kff (valid in rows < NU of every column) from column 3 of tile 0 when the state leaves it free - else its own store
+        const bool st_l = tr >= 2 && tc < NU && tc <= tr - 2 && tr - 2 < NU, st_f3 = NS < 4 && tr < NU && tc == 3;
+        double *q_st[SB]; int stp[SB];
+        MPC_UNROLL for (int j = 0; j < SB; j++) {
+            const int cj = 4 * j + tc;
+            const bool st_k = tr < NU && cj < NS;
+            const bool any = live && (st_k || (j == 0 && (st_l || st_f3)));
+            q_st[j] = any ? trow(st_k ? RA + tr * NS + cj : (st_l ? RA + NKF + (tr - 2) * (tr - 1) / 2 + tc : RK + (tr < NU ? tr : 0))) + (N - 1) : trash + PD;
+            stp[j] = any ? PD : 0;
+        }
+        const bool sel_k0 = tr < NU && tc < NS;      // tile 0 lanes that store K (the others of tile 0 store -Lambda^-1 or kff)
+        const bool st_f = live && NS >= 4 && tr < NU && tc == 0;
+        double *q_sf = st_f ? c.p_kf + (N - 1) : trash + PD;
+        const int stpf = st_f ? PD : 0;
+        double Pm[SB][SB], PC[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) {
+            const int ri = 4 * i + tr;
+            MPC_UNROLL for (int j = 0; j < SB; j++) { const int cj = 4 * j + tc; Pm[i][j] = (ri < NS && cj < NS) ? Pl.Pf[ri < NS ? ri : 0][cj < NS ? cj : 0] : 0.0; }
+            PC[i] = 0.0;
+        }
+        constexpr int NF = 2 * SB + 4;      // sigma_z[SB] sigma_u s0 s1 hu hz[SB]
+        double f[PD][NF];
+        auto fetch = [&](int d, int off) {
+            MPC_UNROLL for (int i = 0; i < SB; i++) { f[d][i] = q_sz[i][off]; f[d][SB + 4 + i] = q_hz[i][off]; }
+            f[d][SB] = q_su[off]; f[d][SB + 1] = q_s0[off]; f[d][SB + 2] = NU > 1 ? q_s1[off] : 0.0; f[d][SB + 3] = q_hu[off];
+        };
+        MPC_UNROLL for (int d = 0; d < PD; d++) fetch(d, -d);
         auto block = [&](int d, bool more) {
-            const double sz = f[d][0], su = f[d][1], s0 = f[d][2], s1 = f[d][3], HU = f[d][4], HZ = f[d][5];
-            if (more) { f[d][0] = q_sz[-PD - d]; f[d][1] = q_su[-PD - d]; f[d][2] = q_s0[-PD - d]; if (NU > 1) f[d][3] = q_s1[-PD - d]; f[d][4] = q_hu[-PD - d]; f[d][5] = q_hz[-PD - d]; }
-            Pm += sz;
-            const double PB = mm(Pm, Br, 0.0), PA = mm(Pm, Ar, 0.0), BtP = mm(Br, Pm, 0.0);
-            const double X0 = mm(BE0, PB, RE0 + s0), X1 = NU > 1 ? mm(BE1, PB, RE1 + s1) : 0.0;
-            const double Psi = mm(Br, PA, Mtr);                             // M' + B'PA
+            double sz[SB], HZ[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { sz[i] = f[d][i]; HZ[i] = f[d][SB + 4 + i]; }
+            const double su = f[d][SB], s0 = f[d][SB + 1], s1 = f[d][SB + 2], HU = f[d][SB + 3];
+            if (more) fetch(d, -PD - d);
+            MPC_UNROLL for (int i = 0; i < SB; i++) Pm[i][i] += sz[i];
+            // P A, P B, B'P (P symmetric: P' = P)
+            double PA[SB][SB], PB[SB], BtP[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) {
+                double pb = 0.0, bp = 0.0;
+                MPC_UNROLL for (int l = 0; l < SB; l++) { pb = mm(Pm[l][i], c.Br[l], pb); bp = mm(c.Br[l], Pm[l][i], bp); }
+                PB[i] = pb; BtP[i] = bp;
+                MPC_UNROLL for (int j = 0; j < SB; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < SB; l++) a = mm(Pm[l][i], c.Ar[l][j], a); PA[i][j] = a; }
+            }
+            double X0 = RE0 + s0, X1 = RE1 + s1;
+            MPC_UNROLL for (int l = 0; l < SB; l++) { X0 = mm(BE0[l], PB[l], X0); if (NU > 1) X1 = mm(BE1[l], PB[l], X1); }
+            double Psi[SB];
+            MPC_UNROLL for (int j = 0; j < SB; j++) { double a = Mtr[j]; MPC_UNROLL for (int l = 0; l < SB; l++) a = mm(c.Br[l], PA[l][j], a); Psi[j] = a; }      // M' + B'PA
             const double Rs = Rr + su;
             // every lane gets the numbers Lambda is made of (columns via the quad)
             const double a = dpp_move<0x00, 0xF>(X0, X0);
@@ -395,26 +452,45 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 adjm = __builtin_fma(c_d, dd, __builtin_fma(c_a, a, c_o * off));
                 pd_min = dmin(pd_min, dmin(a, det));
             }
-            // K = -Lambda^-1 Psi = (-adj Psi) / det: the product runs while the reciprocal is refined
-            const double Kraw = mm(adjk, Psi, 0.0);
+            // K = -Lambda^-1 Psi = (-adj Psi) / det: the products run while the reciprocal is refined
+            double Kk[SB];
+            MPC_UNROLL for (int j = 0; j < SB; j++) Kk[j] = mm(adjk, Psi[j], 0.0);
             const double rdet = frcp(det);
-            const double Kk = Kraw * rdet, mL = adjm * rdet, mLi = adjk * rdet;
+            MPC_UNROLL for (int j = 0; j < SB; j++) Kk[j] *= rdet;
+            const double mL = adjm * rdet, mLi = adjk * rdet;
             // right-hand side of the predictor for this block (off the chain of the matrix recursion)
-            const double PV = HZ + PC;
-            const double KFF = mm(mLi, mm(Br, PV, HU), 0.0);                // -Lambda^-1 (hu + B'(hz + p+)), in every column
-            q_st[-d] = st_k ? Kk : (st_l ? mL : KFF);
+            double PV[SB], psv = HU;
+            MPC_UNROLL for (int i = 0; i < SB; i++) { PV[i] = HZ[i] + PC[i]; psv = mm(c.Br[i], PV[i], psv); }      // hu + B'(hz + p+)
+            const double KFF = mm(mLi, psv, 0.0);                           // -Lambda^-1 psi, in every column
+            q_st[0][-d] = sel_k0 ? Kk[0] : (st_l ? mL : KFF);
+            MPC_UNROLL for (int j = 1; j < SB; j++) q_st[j][-d] = Kk[j];
             if (NS >= 4) q_sf[-d] = KFF;
             // closed-loop (Joseph) form: Q + Acl' P Acl + K' R~ K (+ M K + K' M'); wasted (and harmless) for block 0
-            const double Acl = mm(Btr, Kk, Ar), RK_ = mm(Rs, Kk, 0.0), Tm = mm(BtP, Kk, PA);      // A + B K,  R~ K,  P Acl = PA + PB K
-            double Pn = mm(Acl, Tm, 0.0) + mm(Kk, RK_, Qr);
-            if (HASM) { const double MK = mm(Mtr, Kk, 0.0); Pn = mm(MK, Ir, Pn + MK); }
-            Pm = Pn;      // symmetric up to rounding; the recursion does not amplify the difference
-            PC = mm(Acl, PV, mm(Kk, HU, 0.0));      // Acl'(hz + p+) + K' hu
+            double Acl[SB][SB], Tm[SB][SB], RK_[SB], MK[SB][SB];
+            MPC_UNROLL for (int j = 0; j < SB; j++) RK_[j] = mm(Rs, Kk[j], 0.0);                                // R~ K
+            MPC_UNROLL for (int i = 0; i < SB; i++) {
+                MPC_UNROLL for (int j = 0; j < SB; j++) {
+                    Acl[i][j] = mm(c.Btr[i], Kk[j], c.Ar[i][j]);            // A + B K
+                    Tm[i][j] = mm(BtP[i], Kk[j], PA[i][j]);                 // P Acl = PA + PB K
+                    if (HASM) MK[i][j] = mm(Mtr[i], Kk[j], 0.0);            // M K
+                }
+            }
+            MPC_UNROLL for (int i = 0; i < SB; i++) {
+                MPC_UNROLL for (int j = 0; j < SB; j++) {
+                    double acc = mm(Kk[i], RK_[j], Qr[i][j]), acc2 = 0.0;
+                    MPC_UNROLL for (int l = 0; l < SB; l++) acc2 = mm(Acl[l][i], Tm[l][j], acc2);
+                    double pn = acc + acc2;
+                    if (HASM) pn = mm(MK[j][i], Ir, pn + MK[i][j]);          // + M K + (M K)'
+                    Pm[i][j] = pn;      // symmetric up to rounding; the recursion does not amplify the difference
+                }
+            }
+            MPC_UNROLL for (int i = 0; i < SB; i++) { double a2 = mm(Kk[i], HU, 0.0); MPC_UNROLL for (int l = 0; l < SB; l++) a2 = mm(Acl[l][i], PV[l], a2); PC[i] = a2; }      // Acl'(hz + p+) + K' hu
         };
         const int G = N / PD, rem = N - G * PD;
         for (int g = 0; g < G; g++) {       // full groups: the reads of the next group (or of the remainder) are in flight
             MPC_UNROLL for (int d = 0; d < PD; d++) block(d, true);
-            q_sz -= PD; q_su -= PD; q_s0 -= PD; q_s1 -= PD; q_hu -= PD; q_hz -= PD; q_st -= stp; q_sf -= stpf;
+            MPC_UNROLL for (int i = 0; i < SB; i++) { q_sz[i] -= PD; q_hz[i] -= PD; q_st[i] -= stp[i]; }
+            q_su -= PD; q_s0 -= PD; q_s1 -= PD; q_hu -= PD; q_sf -= stpf;
         }
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
@@ -423,25 +499,44 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         const PT &Pl = launder(P);
         const TileCtx c = tile_ctx(Pl);
         const int tr = c.tr, tc = c.tc; const bool live = c.live;
-        const double Ar = c.Ar, Br = c.Br, Btr = c.Btr; double *const trash = c.trash, *const p_hu = c.p_hu, *const p_hz = c.p_hz, *const p_kf = c.p_kf, *const p_k = c.p_k, *const p_li = c.p_li;
+        double *const trash = c.trash;
         const bool st_any = live && tr < NU && tc == 0;
-        const double *q_hu = p_hu + (N - 1), *q_hz = p_hz + (N - 1), *q_k = p_k + (N - 1), *q_li = p_li + (N - 1);
-        double *q_st = st_any ? p_kf + (N - 1) : trash + PD;
+        const double *q_hu = c.p_hu + (N - 1), *q_li = c.p_li + (N - 1);
+        const double *q_hz[SB], *q_k[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) { q_hz[i] = c.p_hz[i] + (N - 1); q_k[i] = c.p_k[i] + (N - 1); }
+        double *q_st = st_any ? c.p_kf + (N - 1) : trash + PD;
         const int stp = st_any ? PD : 0;
-        double PC = 0.0;
-        double f[PD][4];
-        MPC_UNROLL for (int d = 0; d < PD; d++) { f[d][0] = q_hu[-d]; f[d][1] = q_hz[-d]; f[d][2] = q_k[-d]; f[d][3] = q_li[-d]; }
+        double PC[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) PC[i] = 0.0;
+        constexpr int NF = 2 * SB + 2;      // hu li hz[SB] k[SB]
+        double f[PD][NF];
+        auto fetch = [&](int d, int off) {
+            f[d][0] = q_hu[off]; f[d][1] = q_li[off];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { f[d][2 + i] = q_hz[i][off]; f[d][2 + SB + i] = q_k[i][off]; }
+        };
+        MPC_UNROLL for (int d = 0; d < PD; d++) fetch(d, -d);
         auto block = [&](int d, bool more) {
-            const double HU = f[d][0], HZ = f[d][1], Kk = f[d][2], mLi = f[d][3];
-            if (more) { f[d][0] = q_hu[-PD - d]; f[d][1] = q_hz[-PD - d]; f[d][2] = q_k[-PD - d]; f[d][3] = q_li[-PD - d]; }
-            q_st[-d] = mm(mLi, mm(Br, HZ + PC, HU), 0.0);
-            const double Acl = mm(Btr, Kk, Ar);
-            PC = mm(Acl, PC, mm(Acl, HZ, mm(Kk, HU, 0.0)));
+            const double HU = f[d][0], mLi = f[d][1];
+            double HZ[SB], Kk[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { HZ[i] = f[d][2 + i]; Kk[i] = f[d][2 + SB + i]; }
+            if (more) fetch(d, -PD - d);
+            double psv = HU;
+            MPC_UNROLL for (int i = 0; i < SB; i++) psv = mm(c.Br[i], HZ[i] + PC[i], psv);
+            q_st[-d] = mm(mLi, psv, 0.0);
+            double Acl[SB][SB], PCn[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { MPC_UNROLL for (int j = 0; j < SB; j++) Acl[i][j] = mm(c.Btr[i], Kk[j], c.Ar[i][j]); }
+            MPC_UNROLL for (int i = 0; i < SB; i++) {
+                double cst = mm(Kk[i], HU, 0.0), dyn = 0.0;
+                MPC_UNROLL for (int l = 0; l < SB; l++) { cst = mm(Acl[l][i], HZ[l], cst); dyn = mm(Acl[l][i], PC[l], dyn); }
+                PCn[i] = cst + dyn;
+            }
+            MPC_UNROLL for (int i = 0; i < SB; i++) PC[i] = PCn[i];
         };
         const int G = N / PD, rem = N - G * PD;
         for (int g = 0; g < G; g++) {
             MPC_UNROLL for (int d = 0; d < PD; d++) block(d, true);
-            q_hu -= PD; q_hz -= PD; q_k -= PD; q_li -= PD; q_st -= stp;
+            MPC_UNROLL for (int i = 0; i < SB; i++) { q_hz[i] -= PD; q_k[i] -= PD; }
+            q_hu -= PD; q_li -= PD; q_st -= stp;
         }
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
@@ -450,29 +545,52 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         const PT &Pl = launder(P);
         const TileCtx c = tile_ctx(Pl);
         const int tr = c.tr, tc = c.tc; const bool live = c.live;
-        const double Atr = c.Atr, Btr = c.Btr; double *const trash = c.trash, *const p_kf = c.p_kf, *const p_k = c.p_k, *const p_kt = c.p_kt;
+        double *const trash = c.trash;
         auto trow = [&](int row) -> double * { return c.Tt + (live ? row : RZ) * (NI * LD); };
-        const bool st_u = tr < NU && tc == 0, st_z = tr < NS && tc == 1;
-        const double *q_k = p_k, *q_kt = p_kt, *q_kf = p_kf;
-        const bool st_any = live && (st_u || st_z);
-        double *q_st = st_any ? trow(st_u ? RG + tr : RG + NU + (tr < NS ? tr : 0)) : trash;
-        const int stp = st_any ? PD : 0;
-        double DZ = 0.0;
-        double f[PD][3];
-        MPC_UNROLL for (int d = 0; d < PD; d++) { f[d][0] = q_k[d]; f[d][1] = q_kt[d]; f[d][2] = q_kf[d]; }
+        // stores: du from column 0 of the rows < NU and dz (state tile 0) from column 1 in one store; further state tiles from their column 1
+        const bool st_u = tr < NU && tc == 0;
+        double *q_st[SB]; int stp[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) {
+            const int ri = 4 * i + tr;
+            const bool st_z = ri < NS && tc == 1;
+            const bool any = live && (st_z || (i == 0 && st_u));
+            q_st[i] = any ? trow((i == 0 && st_u) ? RG + tr : RG + NU + (ri < NS ? ri : 0)) : trash;
+            stp[i] = any ? PD : 0;
+        }
+        const double *q_kf = c.p_kf;
+        const double *q_k[SB], *q_kt[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) { q_k[i] = c.p_k[i]; q_kt[i] = c.p_kt[i]; }
+        double DZ[SB];
+        MPC_UNROLL for (int i = 0; i < SB; i++) DZ[i] = 0.0;
+        constexpr int NF = 2 * SB + 1;      // kff k[SB] kt[SB]
+        double f[PD][NF];
+        auto fetch = [&](int d, int off) {
+            f[d][0] = q_kf[off];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { f[d][1 + i] = q_k[i][off]; f[d][1 + SB + i] = q_kt[i][off]; }
+        };
+        MPC_UNROLL for (int d = 0; d < PD; d++) fetch(d, d);
         auto block = [&](int d, bool more) {
-            const double Kk = f[d][0], KkT = f[d][1], KFF = f[d][2];
-            if (more) { f[d][0] = q_k[PD + d]; f[d][1] = q_kt[PD + d]; f[d][2] = q_kf[PD + d]; }
-            const double DU = mm(KkT, DZ, KFF);                       // K dz + kff
-            const double AclT = mm(Kk, Btr, Atr);                     // (A + B K)'
-            const double DZn = mm(AclT, DZ, mm(Btr, KFF, 0.0));       // Acl dz + B kff
-            q_st[d] = st_u ? DU : DZn;
-            DZ = DZn;
+            const double KFF = f[d][0];
+            double Kk[SB], KkT[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { Kk[i] = f[d][1 + i]; KkT[i] = f[d][1 + SB + i]; }
+            if (more) fetch(d, PD + d);
+            double DU = KFF;
+            MPC_UNROLL for (int j = 0; j < SB; j++) DU = mm(KkT[j], DZ[j], DU);                      // K dz + kff
+            double DZn[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) {
+                double a = mm(c.Btr[i], KFF, 0.0);                                               // B kff
+                MPC_UNROLL for (int j = 0; j < SB; j++) a = mm(mm(Kk[j], c.Btr[i], c.Atr[j][i]), DZ[j], a);      // (A + B K)'[j][i]' dz_j = Acl[i][j] dz_j
+                DZn[i] = a;
+            }
+            q_st[0][d] = st_u ? DU : DZn[0];
+            MPC_UNROLL for (int i = 1; i < SB; i++) q_st[i][d] = DZn[i];
+            MPC_UNROLL for (int i = 0; i < SB; i++) DZ[i] = DZn[i];
         };
         const int G = N / PD, rem = N - G * PD;
         for (int g = 0; g < G; g++) {
             MPC_UNROLL for (int d = 0; d < PD; d++) block(d, true);
-            q_k += PD; q_kt += PD; q_kf += PD; q_st += stp;
+            MPC_UNROLL for (int i = 0; i < SB; i++) { q_k[i] += PD; q_kt[i] += PD; q_st[i] += stp[i]; }
+            q_kf += PD;
         }
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
@@ -535,8 +653,10 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     const double rcl = Bd.fl[i] ? Xj.sl[i] * Xj.ll[i] - dmax(Sj.sm, Xj.ll[i] * kSFloor) + pl[i] : 0.0;
                     hc[i] = (-rch + Xj.lh[i] * rh) * ish + (rcl + Xj.ll[i] * rl) * isl;
                 }
-                MPC_UNROLL for (int i = 0; i < NU; i++) tk(RG + i, j) = gu[i] + hc[i];
-                MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + hc[NU + i];
+                if (blk_on) {
+                    MPC_UNROLL for (int i = 0; i < NU; i++) tk(RG + i, j) = gu[i] + hc[i];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + hc[NU + i];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

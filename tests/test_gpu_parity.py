@@ -221,7 +221,7 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
     import copy
     q = copy.copy(cstr); q.nd = 2; q.Bd = cstr.Bd[:, :2]; q.Cd = cstr.Cd[:, :2]; q.dhat0 = np.zeros(2); q.estimator = "none"
     with pytest.raises(capi.MpcAmdError) as e:
-        capi.Solver(q)
+        capi.Solver(q, jit=False)                               # (with jit=True the library of this dimension set would be built)
     assert "no kernel compiled" in str(e.value)
     with pytest.raises(capi.MpcAmdError):
         s.loop_run(0, 1)                                       # before mpc_loop_alloc
@@ -241,9 +241,8 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
 
 
 def test_loop_kernel_choice(cstr, wb, solver_factory):
-    """mpc_loop_run picks the wave-autonomous kernel whenever the stage fits a 4x4 tile (CSTR) and N <= 64; otherwise
-    (Wood-Berry, stage state 6) the horizon-parallel kernel for small batches and the lane kernel for large ones; the lane
-    kernel for long horizons; steps_per_launch defaults to 50."""
+    """mpc_loop_run picks the wave-autonomous kernel whenever it exists for the problem (stage state <= 8 as 2 x 2 tiles, nu <= 2,
+    N <= 64: CSTR and Wood-Berry alike), the lane kernel for long horizons; steps_per_launch defaults to 50."""
     import copy
     from mpc_code_amd import capi
     s = solver_factory(cstr)
@@ -251,10 +250,8 @@ def test_loop_kernel_choice(cstr, wb, solver_factory):
     s.loop_alloc(100, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 3
     s.loop_alloc(20000, 2, capi.LOG_NONE); assert s.get_option("loop_kernel") == 3
     sw = solver_factory(wb)
-    with pytest.raises(capi.MpcAmdError):
-        sw.set_option("loop_kernel", 3)                          # stage state 6 does not fit a 4x4 tile
-    sw.loop_alloc(100, 2, capi.LOG_NONE); assert sw.get_option("loop_kernel") == 2
-    sw.loop_alloc(20000, 2, capi.LOG_NONE); assert sw.get_option("loop_kernel") == 1
+    sw.loop_alloc(100, 2, capi.LOG_NONE); assert sw.get_option("loop_kernel") == 3      # stage state 6: 2 x 2 tiles
+    sw.loop_alloc(20000, 2, capi.LOG_NONE); assert sw.get_option("loop_kernel") == 3
     s.set_option("loop_kernel", 2); assert s.get_option("loop_kernel") == 2
     s.set_option("loop_kernel", 0)
     q = copy.copy(cstr); q.N = 70                               # N > 64 does not fit a wave: lane kernel, and 2 is refused
@@ -499,3 +496,22 @@ def test_kernel_variants_of_the_bound_sets(cstr, oracle_c, solver_factory):
             gl = run_closed_loop(p, x0, x0, 25, solver=solver_factory(p, lk))
             assert np.array_equal(gl["STATUS_DYN"], cl["STATUS_DYN"]), (name, lk)
             assert np.abs(gl["U"] - cl["U"]).max() < TOL_PORT and np.abs(gl["X_HAT"] - cl["X_HAT"]).max() < TOL_PORT, (name, lk)
+
+
+def test_other_dimensions_through_the_jit_library(five_state, oracle_c, solver_factory):
+    """A dimension set the default library does not carry (nx = 5, nu = 2: stage blocks of 2 x 2 tiles on the matrix cores):
+    capi.Solver builds the library of exactly that set (csrc/jit/, prebuilt in the build container so that it ships) and the
+    three closed-loop kernels agree with the C restatement."""
+    from mpc_code_amd import capi
+    from mpc_code_amd.driver import run_closed_loop
+    p = five_state
+    assert "5/2/2/2/5/0/0" not in capi.load_library().mpc_build_info().decode()
+    rng = np.random.default_rng(12)
+    x0 = rng.uniform(-1.0, 1.0, (203, 5))
+    c = oracle_c.OracleC(p).closed_loop(20, x0, x0)
+    assert (c["STATUS_DYN"] == 0).mean() > 0.9 and c["ITERS_DYN"].max() > 3
+    for lk in (1, 2, 3):
+        s = solver_factory(p, lk)
+        assert "5/2/2/2/5/0/0" in s.build_info()
+        g = run_closed_loop(p, x0, x0, 20, solver=s)
+        assert_same_closed_loop(g, c, p, TOL_PORT)
