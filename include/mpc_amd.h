@@ -63,6 +63,9 @@ typedef struct mpc_lin_desc {
     const double *dmin, *dmax; /* saturation of the disturbance estimate, MPC_code.py:660-665; NULL = none */
     /* estimator data: Q_kf,R_kf [nx+nd]^2,[ny]^2 for MPC_EST_KALMAN; K [nx+nd,ny] for MPC_EST_FIXED_GAIN */
     const double *Q_kf, *R_kf, *K;
+    /* bounds on u_k - u_{k-1} (k = 0: u_0 - u_prev), the g2 rows of opt_dyn, Control_Calc.py:163-169,241-243; NULL = none.  The
+     * problem then runs in the stage form with input v = u_k - u_{k-1} and state [x; u_prev] (kernel set du = 1) */
+    const double *Dumin, *Dumax;
 } mpc_lin_desc;
 
 /* Replaces the construction nlpsol('solver','ipopt',...) of Control_Calc.py:256-258 and

@@ -41,7 +41,7 @@ class _Desc(ct.Structure):
                [(k, _dp) for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp",
                                    "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax",
                                    "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss",
-                                   "dmin", "dmax", "Q_kf", "R_kf", "K")]
+                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")]
 
 
 def jit_library_path(dims) -> str:
@@ -165,8 +165,8 @@ class Solver:
         d.estimator, d.max_iter, d.device = _EST[p.estimator], int(p.max_iter), int(device)
         for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp", "Q", "R", "P", "Qss", "Rss",
                   "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss",
-                  "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf", "K"):
-            v = getattr(p, k)
+                  "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax"):
+            v = getattr(p, k, None)
             if v is None:
                 setattr(d, k, None)
             else:

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
-        MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * a.Bs + b] = u0[i];
+        MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * a.Bs + b] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];      // input v = u - u_prev: u is the u_prev part of z_1
         MPC_UNROLL for (int i = 0; i < NX; i++) a.xnext_out[i * a.Bs + b] = z1[i];
     }
 }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, delta, u0, z1, res, it_dyn);
         ws_valid = st_dyn == kSolved;
         if (st_dyn != kInfeasible) {
-            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = u0[i];          // :798
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];          // :798
             MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
         } else {                                                           // :804-805 hold u, propagate the model
             double xn[NX];
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (a.u + (size_t)(i) * Bs)[bq];
             if (st_dyn != kInfeasible) {
                 const double *fin_rows = wsg + (size_t)lane * Cfg::ROWS_ST * 64;     // final iterate, block 0
-                MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = fin_rows[(Cfg::ST_U + i) * 64];          // :798
+                MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? fin_rows[(Cfg::ST_Z + (DU ? NX + i : 0)) * 64] : fin_rows[(Cfg::ST_U + i) * 64];          // :798
                 MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = fin_rows[(Cfg::ST_Z + i) * 64];         // :799
             } else {                                                           // :804-805 hold u, propagate the model
                 double xo[NX], dh[ND > 0 ? ND : 1];
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             }
             double xi_old = 0.0, xi_new = 0.0;
             if (P.estimator != MPC_EST_NONE)
-                kalman_row16<NX, NY, ND, NXP, NU>(P, r16, kq, KC::K_X, KC::K_XH, KC::K_P, a.pyp + k * NY, tab, T + b16c * RT::XCH, xi_old, xi_new);
+                kalman_row16<NX, NY, ND, NXP, NU>(P, r16, b16 < NI, kq, KC::K_X, KC::K_XH, KC::K_P, a.pyp + k * NY, tab, T + b16c * RT::XCH, xi_old, xi_new);
             if (inst16 && a.DHAT && r16 >= NX && r16 < NE) (a.DHAT + (size_t)((size_t)k * ND + (r16 - NX)) * Bs)[bi] = xi_new;
             double delta = row16_max(r16 < NE ? fabs(xi_new - xi_old) : 0.0);      // warm-start test: estimate against its prediction
             __syncthreads();
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             int it_ss; double vrow;
             const int st_ss = target_row16<NX, NU, NY, ND>(P, r16, tab, a.usp + k * NU, a.ysp + k * NY, dh, usv, kq + KC::K_TW, twv + b16c, inst16, vrow, it_ss);
             // accept, or keep the previous target when infeasible (MPC_code.py:714-718); rows 0..NX-1 = xs, NX..NX+NU-1 = us
-            const bool trow = r16 < NX + NU;
+            const bool trow = r16 < NX + NU && b16 < NI;      // lanes of unused instance slots (NI < 4) alias slot 0: they must not write
             const double prev = trow ? kq[KC::K_XS + r16] : 0.0;      // K_XS.. and K_US.. are adjacent
             const double tnew = (st_ss != kInfeasible && trow) ? vrow : prev;
             delta = dmax(delta, row16_max(fabs(tnew - prev)));
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
                 if (a.US && r16 >= NX && trow) (a.US + (size_t)((size_t)k * NU + (r16 - NX)) * Bs)[bi] = tnew;
                 if (a.st_dyn && r16 == 0) { (a.st_ss + (size_t)k * Bs)[bi] = st_ss; (a.it_ss + (size_t)k * Bs)[bi] = it_ss; }
             }
-            if (r16 == 0) outv[b16c * Cfg::OUT] = delta;
+            if (r16 == 0 && b16 < NI) outv[b16c * Cfg::OUT] = delta;
             __syncthreads();
         }
         if (valid) {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = kp[KC::K_U + i];
             if (st_dyn != kInfeasible) {
-                MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = outv[lane * Cfg::OUT + i];               // :798
+                MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? outv[lane * Cfg::OUT + NU + (DU ? NX + i : 0)] : outv[lane * Cfg::OUT + i];               // :798
                 MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = outv[lane * Cfg::OUT + NU + i];         // :799
             } else {                                                           // :804-805 hold u, propagate the model
                 double xo[NX], dh[NDD];
@@ -946,6 +946,11 @@ static int build_target(const mpc_lin_desc *d, DevProblem &P)
     return 0;
 }
 
+// the g2 rows exist (DuFree False, Control_Calc.py:64-67)
+static bool du_bounded(const mpc_lin_desc *d) { return d->Dumin != nullptr || d->Dumax != nullptr; }
+// the stage state carries u_prev: cost on u_k - u_{k-1}, or bounds on it
+static bool stage_has_uprev(const mpc_lin_desc *d) { return d->du_form != 0 || du_bounded(d); }
+
 static int build_problem(const mpc_lin_desc *d, DevProblem &P)
 {
     std::memset(&P, 0, sizeof(P));
@@ -964,7 +969,19 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
         for (int j = 0; j < m; j++) P.R[i][j] = d->R[i * m + j];
         P.ulo[i] = d->umin[i]; P.uhi[i] = d->umax[i];
     }
-    if (d->du_form) {   // z = [x; u_prev]  (Control_Calc.py:163-166,180-181)
+    if (du_bounded(d)) {
+        // Bounds on u_k - u_{k-1} (g2 rows, Control_Calc.py:163-169,241-243): stage form with input v_k = u_k - u_{k-1} and state
+        // z = [x; u_prev]:  z+ = [[A, B], [0, I]] z + [B; I] v.  The g2 rows are the box on the input, the u bounds a box on the
+        // u_prev part of z_1..z_N (z_{k+1}'s is u_k), the cost on u - us couples z_u and v (M), the cost on u_k - u_{k-1} is v'Sv.
+        P.in_is_du = 1; P.zr_us = d->du_form ? 0 : 1;
+        for (int i = 0; i < m; i++) {
+            P.ulo[i] = d->Dumin ? d->Dumin[i] : -INFINITY; P.uhi[i] = d->Dumax ? d->Dumax[i] : INFINITY;
+            P.B[n0 + i][i] = 1.0; P.A[n0 + i][n0 + i] = 1.0;
+            for (int r = 0; r < n0; r++) P.A[r][n0 + i] = d->B[r * m + i];
+            if (!d->du_form) { for (int j = 0; j < m; j++) { P.Q[n0 + i][n0 + j] = d->R[i * m + j]; P.M[n0 + i][j] = d->R[i * m + j]; } }
+            P.zlo_m[n0 + i] = P.zlo_e[n0 + i] = d->umin[i]; P.zhi_m[n0 + i] = P.zhi_e[n0 + i] = d->umax[i];
+        }
+    } else if (d->du_form) {   // z = [x; u_prev], input u  (Control_Calc.py:163-166,180-181)
         for (int i = 0; i < m; i++) {
             P.B[n0 + i][i] = 1.0;
             for (int j = 0; j < m; j++) { P.Q[n0 + i][n0 + j] = d->R[i * m + j]; P.M[n0 + i][j] = -d->R[i * m + j]; }
@@ -988,7 +1005,7 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
     // at k = 1..N-1 (the terminal state has no output row); no cost on w.
     P.ng = general_output_rows(d, P.yg_row);
     if (d->y_bounded) {
-        const int nb = n0 + (d->du_form ? m : 0);
+        const int nb = n0 + (stage_has_uprev(d) ? m : 0);
         for (int i = 0; i < q; i++) {
             P.ymap_idx[i] = -1;       // unbounded rows and rows that are identically zero: nothing to map
             for (int j = 0; j < n0; j++) if (d->C[i * n0 + j] != 0.0) { P.ymap_idx[i] = j; P.ymap_scale[i] = d->C[i * n0 + j]; }
@@ -1039,6 +1056,7 @@ static int bound_mode(const mpc_lin_desc *d)
     }
     bool y_any = false;
     if (d->y_bounded) for (int i = 0; i < d->ny; i++) y_any = y_any || std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]);
+    if (du_bounded(d)) return kBoundsGeneric;
     if (u_all && x_all && !d->du_form) return kBoundsAllFinite;        // Delta-u form carries unbounded u_prev states
     if (u_all && x_none && !y_any) return kBoundsInputsOnly;
     return kBoundsGeneric;
@@ -1048,7 +1066,7 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
 {
     if (!d || !out) return fail(-1, "null argument");
     *out = nullptr;
-    const int ns = d->nx + (d->du_form ? d->nu : 0) + general_output_rows(d, nullptr);
+    const int ns = d->nx + (stage_has_uprev(d) ? d->nu : 0) + general_output_rows(d, nullptr);
     if (d->nx < 1 || d->nu < 1 || ns > kMaxN || d->nu > kMaxM || d->ny > kMaxY || d->nd > kMaxD || d->nxp > kMaxN || d->N < 2 || d->N > 512)
         return fail(-2, "dimensions out of range (stage state <= %d, nu <= %d, ny <= %d, nd <= %d, 2 <= N <= 512)", kMaxN, kMaxM, kMaxY, kMaxD);
     int ndev = 0;
@@ -1058,7 +1076,7 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
     bool found = false;
     const int ng = general_output_rows(d, nullptr);
 #define MPC_TRY_DIM(NX, NU, NY, ND, NXP, DU, NG)                                                              \
-    if (!found && d->nx == NX && d->nu == NU && d->ny == NY && d->nd == ND && d->nxp == NXP && (d->du_form != 0) == (DU != 0) && ng == NG) { \
+    if (!found && d->nx == NX && d->nu == NU && d->ny == NY && d->nd == ND && d->nxp == NXP && stage_has_uprev(d) == (DU != 0) && ng == NG) { \
         h->L = make_launchers<NX, NU, NY, ND, NXP, (DU != 0), NG>(bound_mode(d));                             \
         found = true;                                                                                         \
     }
@@ -1066,7 +1084,7 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
 #undef MPC_TRY_DIM
     if (!found) {
         delete h;
-        return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d general_output_rows=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, d->du_form, ng, mpc_build_info());
+        return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d general_output_rows=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, (int)stage_has_uprev(d), ng, mpc_build_info());
     }
     int rc = build_problem(d, h->hp);
     if (rc != 0) { delete h; return rc; }
@@ -1214,7 +1232,7 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
         if (kkt_res) for (int i = 0; i < 3; i++) kkt_res[(size_t)b * 3 + i] = o[(size_t)(nu + nx + i) * Bs + b];
     }
     if (w_out) {   // primal trajectory in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) from the workspace
-        const int N = P.N, ns = nx + (P.du_form ? nu : 0), nv = ns + nu, nxu = nx + nu;
+        const int N = P.N, ns = nx + ((P.du_form || P.in_is_du) ? nu : 0), nv = ns + nu, nxu = nx + nu;
         const int slots = h->L.ws_rows / 2, slotU = 4 * h->L.nc, slotZ = slotU + (nu + 1) / 2; (void)nv;
         std::vector<double> wsh((size_t)h->L.ws_rows * (N + 2) * Bs);
         HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1224,7 +1242,7 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
             double *w = w_out + (size_t)b * (nx * (N + 1) + nu * N);
             for (int i = 0; i < nx; i++) w[i] = xhat[(size_t)b * nx + i];
             for (int k = 0; k < N; k++) {
-                for (int i = 0; i < nu; i++) w[k * nxu + nx + i] = at(b, k, slotU + i / 2, i % 2);
+                for (int i = 0; i < nu; i++) w[k * nxu + nx + i] = P.in_is_du ? at(b, k, slotZ + (nx + i) / 2, (nx + i) % 2) : at(b, k, slotU + i / 2, i % 2);
                 for (int i = 0; i < nx; i++) w[(k + 1) * nxu + i] = at(b, k, slotZ + i / 2, i % 2);
             }
         }

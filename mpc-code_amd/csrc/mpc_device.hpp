@@ -47,6 +47,7 @@ enum : int { kSolved = 0, kMaxIter = 1, kInfeasible = 2 };
 // is a scalar load, whatever the kernel has stored to global memory in between
 struct DevProblem {
     int nx, nu, ny, nd, nxp, N, du_form, duss_form, y_bounded, estimator, max_iter, has_dsat;
+    int in_is_du, zr_us;      // stage input is v = u - u_prev (bounds on it exist); reference of the u_prev states is us (cost on u - us)
     // stage form (z = x, or [x; u_prev] when du_form)
     double A[kMaxN][kMaxN], B[kMaxN][kMaxM], Q[kMaxN][kMaxN], M[kMaxN][kMaxM], R[kMaxM][kMaxM], Pf[kMaxN][kMaxN];
     double ulo[kMaxM], uhi[kMaxM], zlo_m[kMaxN], zhi_m[kMaxN], zlo_e[kMaxN], zhi_e[kMaxN];
@@ -213,6 +214,9 @@ __device__ __forceinline__ void build_inst(const PT &P, const double (&xhat)[NX]
     MPC_UNROLL for (int i = 0; i < NU; i++) { q.us[i] = us[i]; q.ur[i] = DU ? 0.0 : us[i]; }
     if (DU) {
         MPC_UNROLL for (int i = 0; i < NU; i++) { q.z0[NX + i] = u_prev[i]; q.zr[NX + i] = 0.0; q.c[NX + i] = 0.0; }
+        if (P.in_is_du) {      // input v = u - u_prev: cold start v = 0; the cost on u - us makes us the reference of the u_prev states
+            MPC_UNROLL for (int i = 0; i < NU; i++) { q.us[i] = 0.0; if (P.zr_us) q.zr[NX + i] = us[i]; }
+        }
     }
     MPC_UNROLL for (int g = 0; g < NG; g++) {      // output-row states w = C_i x: initial value, reference, affine term
         const int r = P.yg_row[g];

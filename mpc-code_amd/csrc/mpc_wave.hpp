@@ -749,14 +749,15 @@ __device__ __forceinline__ void row16_fill_tables(const PT &P, double *tab, int 
 
 // Estimator step (MPC_code.py:524-534, 577-668; kalman(): Estimator.py:297-309): xi = [xhat; dhat] at kp[xi_off + r], plant state at
 // kp[x_off..], covariance rows at kp[p_off + r * NE ..].  On return lane r < NE holds xi_old / xi_new of its row (also written back).
+// slot_on: this lane's instance slot exists (lanes of unused slots compute along on slot 0's data and write nothing).
 template <int NX, int NY, int ND, int NXP, int NU, class PT>
-__device__ __forceinline__ void kalman_row16(const PT &P, int r, double *kp, int x_off, int xi_off, int p_off, const double *pyp_k,
+__device__ __forceinline__ void kalman_row16(const PT &P, int r, bool slot_on, double *kp, int x_off, int xi_off, int p_off, const double *pyp_k,
                                              const double *tab, double *xch, double &xi_old, double &xi_new)
 {
     using RT = Row16Tab<NX, NU, NY, ND>;
     constexpr int NE = RT::NE;
-    const bool row = r < NE;
-    const int rr = row ? r : 0;
+    const bool row = r < NE && slot_on;      // lanes of an unused instance slot (fewer than four instances per wave) alias slot 0: read only
+    const int rr = r < NE ? r : 0;
     const double *e = tab + rr * RT::ESZ;
     double xi[NE], innov[NY];
     MPC_UNROLL for (int i = 0; i < NE; i++) xi[i] = kp[xi_off + i];

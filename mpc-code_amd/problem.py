@@ -96,6 +96,9 @@ class LinearMPCProblem:
     ymax_ss: np.ndarray = None
     dmin: Optional[np.ndarray] = None
     dmax: Optional[np.ndarray] = None
+    # bounds on u_k - u_{k-1} (u_0 - u_prev for k = 0): the g2 rows of opt_dyn, Control_Calc.py:163-169,241-243; None = absent
+    Dumin: Optional[np.ndarray] = None
+    Dumax: Optional[np.ndarray] = None
     # estimator
     estimator: str = "none"   # 'kal' (Estimator.py:263-311) | 'kalss' (:231-261, also for lue) | 'none'
     Q_kf: Optional[np.ndarray] = None
@@ -272,8 +275,7 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
     y_dyn_lo = ns.get("ymin_dyn") if ns.get("ymin_dyn") is not None else ns.get("ymin")
     y_dyn_hi = ns.get("ymax_dyn") if ns.get("ymax_dyn") is not None else ns.get("ymax")
     y_bounded = not (y_dyn_lo is None and y_dyn_hi is None)   # Control_Calc.py:60-63
-    if ns.get("Dumin") is not None or ns.get("Dumax") is not None:
-        raise UnsupportedProblem("Delta-u bounds (g2 rows) are a later scope row")
+    du_bounded = ns.get("Dumin") is not None or ns.get("Dumax") is not None      # DuFree False, Control_Calc.py:64-67
 
     if ns.get("kal", False):
         est = "kal"
@@ -312,6 +314,7 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         ymin_ss=pick("ymin", "_ss", ny, -INF), ymax_ss=pick("ymax", "_ss", ny, INF),
         dmin=None if ns.get("dmin") is None else _vec(ns["dmin"], nd, -INF),
         dmax=None if ns.get("dmax") is None else _vec(ns["dmax"], nd, INF),
+        Dumin=_vec(ns.get("Dumin"), nu, -INF) if du_bounded else None, Dumax=_vec(ns.get("Dumax"), nu, INF) if du_bounded else None,
         estimator=est, Q_kf=Q_kf, R_kf=R_kf, P0=P0, K=K,
         x0_p=_vec(ns["x0_p"], nxp, 0.0), x0_m=_vec(ns["x0_m"], nx, 0.0), u0=_vec(ns["u0"], nu, 0.0),
         dhat0=_vec(ns.get("dhat0"), nd, 0.0) if _has(ns, "dhat0") else np.zeros(nd),

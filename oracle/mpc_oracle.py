@@ -146,6 +146,17 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
                 if np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i]):
                     row = np.zeros(nw); row[ix(k)] = p.C[i]
                     rows.append(row); lo.append(p.ymin[i] - yc[i]); hi.append(p.ymax[i] - yc[i])
+    if getattr(p, "Dumin", None) is not None or getattr(p, "Dumax", None) is not None:
+        # g2 rows: DU_k = U[k] - um1 (k = 0) | U[k] - U[k-1], Control_Calc.py:163-169, bounds tiled :241-243
+        dlo = p.Dumin if p.Dumin is not None else np.full(m, -np.inf); dhi = p.Dumax if p.Dumax is not None else np.full(m, np.inf)
+        for k in range(N):
+            for i in range(m):
+                if np.isfinite(dlo[i]) or np.isfinite(dhi[i]):
+                    row = np.zeros(nw); row[nxu * k + n + i] = 1.0
+                    off = u_prev[i] if k == 0 else 0.0
+                    if k > 0:
+                        row[nxu * (k - 1) + n + i] = -1.0
+                    rows.append(row); lo.append(dlo[i] + off); hi.append(dhi[i] + off)
     G = np.array(rows) if rows else np.zeros((0, nw))
     return H, g, E, e, G, np.array(lo, dtype=float), np.array(hi, dtype=float)
 

@@ -515,3 +515,48 @@ def test_other_dimensions_through_the_jit_library(five_state, oracle_c, solver_f
         assert "5/2/2/2/5/0/0" in s.build_info()
         g = run_closed_loop(p, x0, x0, 20, solver=s)
         assert_same_closed_loop(g, c, p, TOL_PORT)
+
+
+def test_du_bounds_against_the_dense_statement(cstr, wb, solver_factory):
+    """Bounds on u_k - u_{k-1} (g2 rows, Control_Calc.py:163-169,241-243) run in the stage form with input v = u_k - u_{k-1} and
+    state [x; u_prev] (mpc_amd.hip:build_problem).  Per call and in the closed loop of each kernel against the dense statement
+    of opt_dyn with the rows as plain inequalities (oracle/mpc_oracle.py), cost on u - us (CSTR) and on u_k - u_{k-1} (Wood-Berry)."""
+    import copy
+    import mpc_oracle as o
+    from mpc_code_amd.driver import run_closed_loop
+    rng = np.random.default_rng(31)
+    pc = copy.copy(cstr); pc.Dumin = np.array([-0.5, -1.0]); pc.Dumax = np.array([0.5, 1.0])
+    pw = copy.copy(wb); pw.Dumin = np.array([-0.02, -0.05]); pw.Dumax = np.array([0.03, 0.05])
+    for p, B in ((pc, 24), (pw, 12)):
+        if p is pc:
+            xh = bench_x0(B, 5) * [1.0, 0.3, 0.6]; xs = np.zeros((B, 3)); us = np.zeros((B, 2))
+            d = 0.02 * rng.standard_normal((B, 3)); up = rng.uniform(-1.0, 1.0, (B, 2))
+        else:
+            xh = 0.3 * rng.standard_normal((B, 4)); xs = 0.1 * rng.standard_normal((B, 4)); us = 0.05 * rng.standard_normal((B, 2))
+            d = 0.05 * rng.standard_normal((B, 2)); up = rng.uniform(-0.3, 0.3, (B, 2))
+        s = solver_factory(p)
+        g = s.ocp_solve(xh, xs, us, d, up, want_w=True)
+        nxu = p.nx + p.nu
+        bound = 0
+        for b in range(B):
+            r = o.ocp_solve_exact(p, xh[b], xs[b], us[b], d[b], up[b])
+            assert g["status"][b] == r["status"], (p.name, b)
+            if r["status"] != 0:
+                continue
+            assert np.abs(g["u0"][b] - r["u0"]).max() < 1e-6 and np.abs(g["x1"][b] - r["x1"]).max() < 1e-6, (p.name, b)
+            assert np.abs(g["w"][b] - r["w"]).max() < 1e-5, (p.name, b)                    # the whole trajectory, in opt_dyn's order
+            U = np.array([g["w"][b][nxu * k + p.nx:nxu * (k + 1)] for k in range(p.N)])
+            dU = np.diff(np.vstack([up[b], U]), axis=0)
+            assert (dU >= p.Dumin - 1e-7).all() and (dU <= p.Dumax + 1e-7).all()
+            bound += int(((np.abs(dU - p.Dumax) < 1e-6) | (np.abs(dU - p.Dumin) < 1e-6)).any())
+        assert bound >= B // 3, (p.name, bound)                                          # the rows bind
+    # closed loop, every kernel, against the dense closed loop (exact optimum per step)
+    x0 = bench_x0(3, 8) * [1.0, 0.3, 0.6]
+    ref = [o.closed_loop(pc, 10, x0_p=x, x0_m=x, ocp=o.ocp_solve_exact, target=o.target_solve_exact) for x in x0]
+    for lk in (1, 2, 3):
+        gl = run_closed_loop(pc, x0, x0, 10, solver=solver_factory(pc, lk))
+        for b, r in enumerate(ref):
+            assert np.array_equal(gl["STATUS_DYN"][:, b], r["STATUS_DYN"]), (lk, b)
+            assert np.abs(gl["U"][:, b] - r["U"]).max() < 5e-6 and np.abs(gl["X_HAT"][:, b] - r["X_HAT"]).max() < 5e-6, (lk, b)
+            dU = np.diff(np.vstack([pc.u0, gl["U"][:, b]]), axis=0)
+            assert (dU >= pc.Dumin - 1e-7).all() and (dU <= pc.Dumax + 1e-7).all()

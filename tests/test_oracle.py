@@ -190,3 +190,21 @@ def test_ipopt_vectors_if_present(cstr, wb):
     if not found:
         pytest.skip("no IPOPT vectors in tests/golden (casadi was not importable where the fixtures were made): parity is pinned by "
                     "the KKT certificates of make_golden.py instead")
+
+
+def test_du_bounds_rows_of_the_dense_statement(cstr):
+    """g2 rows (Control_Calc.py:163-169,241-243): with bounds on u_k - u_{k-1} the exact optimum respects them (also against
+    u_prev at k = 0), they bind, and the optimum without them violates them - i.e. the rows are there and they matter."""
+    import copy
+    p = copy.copy(cstr); p.Dumin = np.array([-0.5, -1.0]); p.Dumax = np.array([0.5, 1.0])
+    xh = np.array([0.2, -1.5, 3.0]); xs = np.zeros(3); us = np.zeros(2); d = np.zeros(3); up = np.array([0.3, -0.2])
+    r = o.ocp_solve_exact(p, xh, xs, us, d, up)
+    assert r["status"] == 0 and r["exact"] and o.kkt_max(r["res"]) < 1e-9
+    nxu = p.nx + p.nu
+    U = np.array([r["w"][nxu * k + p.nx:nxu * (k + 1)] for k in range(p.N)])
+    dU = np.diff(np.vstack([up, U]), axis=0)
+    assert (dU >= p.Dumin - 1e-9).all() and (dU <= p.Dumax + 1e-9).all()
+    assert (np.abs(dU - p.Dumax) < 1e-8).sum() + (np.abs(dU - p.Dumin) < 1e-8).sum() >= 3
+    r0 = o.ocp_solve_exact(cstr, xh, xs, us, d, up)
+    U0 = np.array([r0["w"][nxu * k + p.nx:nxu * (k + 1)] for k in range(p.N)])
+    assert np.abs(np.diff(np.vstack([up, U0]), axis=0)).max() > 1.5
