@@ -80,13 +80,17 @@ const char *mpc_last_error(void);
  * x_0 fixed to xhat (:734), parameters par[0:13] = xhat,xs,us,dhat,u_prev (:772, Control_Calc.py:44-48),
  * read-out u* = w[nx:nx+nu], xhat+ = w[nx+nu:2nx+nu] (:798-799).
  *   px, py    time-varying model parameters [B][N][nx|ny]; must be NULL (def_px/def_py are a later scope row)
- *   w_out     optional [B][nx*(N+1)+nu*N]: primal optimum in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37)
+ *   w_inout   optional [B][nx*(N+1)+nu*N]: on return the primal optimum in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37).
+ *             With mpc_set_option("ocp_warm_start", 1) it is also read: the caller's guess x0= of the reference call (the shifted
+ *             previous optimum, MPC_code.py:740-764) supplies the inputs of the starting point; the bound multipliers of the previous
+ *             mpc_ocp_solve call of the same batch stay in the handle and are shifted by one stage whenever the
+ *             problem data moved little.  A first element that is not finite means "no guess".  Default: cold start, content ignored.
  *   u_out [B][nu], xnext_out [B][nx]: untouched for instances with status 2
  *   kkt_res   optional [B][3]: stationarity, bound residual, mean complementarity at the returned point
  */
 int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
                   const double *dhat, const double *u_prev, const double *px, const double *py,
-                  double *w_out, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
+                  double *w_inout, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
                   double *kkt_res);
 
 /* One solver_ss(...) call per instance, MPC_code.py:693-718 (par_ss = usp,ysp,xsp,dhat,us_prev, :693). */
@@ -175,7 +179,10 @@ int mpc_comm_barrier(mpc_handle *h);
 int mpc_allgather_u(mpc_handle *h, double *u_all /* host [world][B][nu] or NULL: result stays on the device, mpc_dev_ptr "coll_recv" */);
 int mpc_allgather_log(mpc_handle *h, const char *name, int32_t k0, int32_t nsteps, double *out /* host [world][nsteps][B][dim] or NULL */);
 
-/* Tunables of the resident closed loop (mpc_loop_run); they never change results beyond rounding.
+/* Tunables; they never change results beyond rounding.
+ *   "ocp_warm_start"    0 (default) / 1: mpc_ocp_solve warm-starts from the caller's guess and its own previous call (see above)
+ *   "ocp_kernel"        0 = auto, 1 = one instance per lane, 3 = wave-autonomous solver (N <= 64, stage state <= 8, nu <= 2)
+ * of the resident closed loop (mpc_loop_run):
  *   "steps_per_launch"  closed-loop steps per kernel launch (default 50; a launch starts with cold caches)
  *   "loop_kernel"       0 = choose by problem and batch size (default), 1 = one instance per lane, 2 = horizon-parallel
  *                       (eight waves share sixteen instances, block-parallel element-wise work; needs N <= 64),

@@ -285,15 +285,19 @@ class Solver:
         return out
 
     # ------------------------------------------------------------------ per-step calls
-    def ocp_solve(self, xhat, xs, us, dhat, u_prev, want_w=False):
-        """``solver(...)`` of MPC_code.py:776-781 for a batch; returns dict(u0, x1, status, iters, res[, w])."""
+    def ocp_solve(self, xhat, xs, us, dhat, u_prev, want_w=False, w_guess=None):
+        """``solver(...)`` of MPC_code.py:776-781 for a batch; returns dict(u0, x1, status, iters, res[, w]).
+
+        ``w_guess`` [B, nw]: the reference's ``x0=`` (MPC_code.py:740-764); read only after ``set_option("ocp_warm_start", 1)``."""
         p = self.p
         xhat = _c(np.atleast_2d(xhat)); B = xhat.shape[0]
         xs, us = _c(xs, (B, p.nx)), _c(us, (B, p.nu))
         dhat, u_prev = _c(dhat, (B, p.nd)), _c(u_prev, (B, p.nu))
         u0 = np.full((B, p.nu), np.nan); x1 = np.full((B, p.nx), np.nan)
         st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); res = np.zeros((B, 3))
-        w = np.full((B, p.nw), np.nan) if want_w else None
+        w = np.full((B, p.nw), np.nan) if (want_w or w_guess is not None) else None
+        if w_guess is not None:
+            w[:] = np.broadcast_to(np.asarray(w_guess, dtype=np.float64), (B, p.nw))
         self._chk(self.lib.mpc_ocp_solve(self.h, B, _p(xhat), _p(xs), _p(us), _p(dhat) if p.nd else None, _p(u_prev),
                                          None, None, _p(w), _p(u0), _p(x1), _pi(st), _pi(it), _p(res)), "mpc_ocp_solve")
         return dict(u0=u0, x1=x1, status=st, iters=it, res=res, w=w)

@@ -712,6 +712,103 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
     }
 }
 
+// One solver(...) call per instance (MPC_code.py:776-781) on the wave-autonomous solver: the per-call entry point mpc_ocp_solve.
+// With the warm start on (option "ocp_warm_start") the bound multipliers of the previous call stay in the handle's workspace and
+// are shifted by one stage like the closed loop does; the inputs come from the caller's guess w when there is
+// one (the reference hands IPOPT the shifted previous optimum, MPC_code.py:740-764), else from the previous call as well.
+struct OcpWvArgs {
+    OcpArgs o;
+    const double *u_guess;      // [B][nu][64] inputs of the caller's guess (lane = stage), or nullptr
+    double *traj;               // [B][nu + ns][64] final iterate: u | z rows (lane = stage), or nullptr
+    double *prev;               // [2 nx + nd + nu][Bs] data of the previous call: x1 prediction, dhat, xs, us
+    int32_t *valid;             // [Bs] the workspace holds the multipliers of a solved previous call
+    int warm_on;
+};
+
+template <int NX, int NU, int NY, int ND, bool DU, int NG, int NC, bool MASKED, int NI>
+__global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restrict__ Pp, OcpWvArgs w)
+{
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NDD = ND > 0 ? ND : 1;
+    using Cfg = WvCfg<NS, NU, NC, NI>;
+    const OcpArgs &a = w.o;
+    extern __shared__ double wv_smem[];
+    const ConstProblem &P = *(const ConstProblem *)Pp;
+    const int N = Pp->N, LD = Cfg::ld(N);
+    double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::t_doubles(N), *const outv = q + NI * Cfg::QN;
+    int *const iflag = (int *)(outv + NI * Cfg::OUT);
+    const size_t Bs = a.Bs;
+    const int lane = threadIdx.x;
+    const int il = lane < NI ? lane : 0;
+    const int b = blockIdx.x * NI + il;
+    const bool valid = lane < NI && b < a.B;
+    for (int i = lane; i < NI * LD; i += 64) T[Cfg::RZ * NI * LD + i] = 0.0;
+    if (lane < Cfg::GUARD) wv_smem[lane] = 0.0;
+    if (valid) {
+        double xh[NX], xs[NX], us[NU], up[NU], dh[NDD];
+        MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { us[i] = a.us[i * Bs + b]; up[i] = a.u_prev[i * Bs + b]; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+        OcpInst<NS, NU> qi;
+        build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, up, qi);
+        // warm-start test against the previous call's data: estimate vs its prediction, disturbance, target
+        double delta = 0.0;
+        MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - w.prev[i * Bs + b]), fabs(xs[i] - w.prev[(NX + ND + i) * Bs + b])));
+        MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - w.prev[(NX + i) * Bs + b]));
+        MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - w.prev[(2 * NX + ND + i) * Bs + b]));
+        const bool warm = w.warm_on && w.valid[b] != 0 && delta <= kWsDelta;
+        double *qd = q + lane * Cfg::QN;
+        MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = qi.ur[i]; qd[5 * NS + NU + i] = qi.us[i]; }
+        qd[5 * NS + 2 * NU] = delta;
+        iflag[lane] = kWvValid | (qi.ok0 ? kWvOk0 : 0) | (warm ? kWvWarm : 0) | ((warm && w.u_guess) ? kWvKeepU : 0);
+        MPC_UNROLL for (int i = 0; i < ND; i++) w.prev[(NX + i) * Bs + b] = dh[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) w.prev[(NX + ND + i) * Bs + b] = xs[i];
+        MPC_UNROLL for (int i = 0; i < NU; i++) w.prev[(2 * NX + ND + i) * Bs + b] = us[i];
+    } else if (lane < NI) iflag[lane] = 0;
+    __syncthreads();
+    WvIterA<NS, NU, NC> X[NI];
+    WvInst S[NI];
+    MPC_UNROLL for (int j = 0; j < NI; j++) {
+        const size_t bj = (size_t)blockIdx.x * NI + j;
+        const double *rows = a.ws + (bj * Cfg::ROWS_WS) * 64;
+        const int fl = __builtin_amdgcn_readfirstlane(iflag[j]);
+        const bool wm = (fl & kWvWarm) != 0, ku = (fl & kWvKeepU) != 0;
+        WvIter<NS, NU, NC> X0;
+        MPC_UNROLL for (int i = 0; i < NU; i++) X0.u[i] = wm ? (ku ? w.u_guess[(bj * NU + i) * 64 + lane] : rows[i * 64 + lane]) : 0.0;
+        MPC_UNROLL for (int i = 0; i < NC; i++) { X0.ll[i] = wm ? rows[(NU + i) * 64 + lane] : 0.0; X0.lh[i] = wm ? rows[(NU + NC + i) * 64 + lane] : 0.0; X0.sl[i] = 1.0; X0.sh[i] = 1.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) X0.z[i] = 0.0;
+        X[j].put(X0);
+    }
+    wv_solve<NS, NU, DU, NC, MASKED, NI>(P, T, q, iflag, X, S, P.max_iter);
+    MPC_UNROLL for (int j = 0; j < NI; j++) {
+        const size_t bj = (size_t)blockIdx.x * NI + j;
+        double *rows = a.ws + (bj * Cfg::ROWS_WS) * 64;
+        WvIter<NS, NU, NC> Xf; X[j].get(Xf);
+        MPC_UNROLL for (int i = 0; i < NU; i++) rows[i * 64 + lane] = Xf.u[i];
+        MPC_UNROLL for (int i = 0; i < NC; i++) { rows[(NU + i) * 64 + lane] = Xf.ll[i]; rows[(NU + NC + i) * 64 + lane] = Xf.lh[i]; }
+        if (w.traj) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) w.traj[(bj * (NU + NS) + i) * 64 + lane] = Xf.u[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) w.traj[(bj * (NU + NS) + NU + i) * 64 + lane] = Xf.z[i];
+        }
+        if (lane == 0) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) outv[j * Cfg::OUT + i] = Xf.u[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = Xf.z[i];
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        int st = S[0].status, it = S[0].iters; double r0 = S[0].res_s, r1 = S[0].res_p, r2 = S[0].mu;
+        MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st = S[j].status; it = S[j].iters; r0 = S[j].res_s; r1 = S[j].res_p; r2 = S[j].mu; } }
+        a.status[b] = st; a.iters[b] = it;
+        a.res[0 * Bs + b] = r0; a.res[1 * Bs + b] = r1; a.res[2 * Bs + b] = r2;
+        w.valid[b] = st == kSolved ? 1 : 0;
+        if (st != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * Bs + b] = (DU && P.in_is_du) ? outv[lane * Cfg::OUT + NU + (DU ? NX + i : 0)] : outv[lane * Cfg::OUT + i];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { const double v = outv[lane * Cfg::OUT + NU + i]; a.xnext_out[i * Bs + b] = v; w.prev[i * Bs + b] = v; }
+        }
+    }
+}
+
 // dense [B][nu] copy of u for the all-gather of u* 
 __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__ dst, int B, size_t Bs, int nu)
 {
@@ -729,7 +826,9 @@ struct Launchers {
     void (*kf)(const DevProblem *, KfArgs, hipStream_t);
     void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
     int (*loop_tp)(const DevProblem *, LoopArgs, hipStream_t);     // horizon-parallel variant (N <= 64), nullptr if it does not fit
-    int (*loop_wv)(const DevProblem *, LoopArgs, hipStream_t);     // wave-autonomous variant (N <= 64, stage fits a 4x4 tile), nullptr otherwise
+    int (*loop_wv)(const DevProblem *, LoopArgs, hipStream_t);     // wave-autonomous variant (N <= 64, stage state <= 8, nu <= 2), nullptr otherwise
+    int (*ocp_wv)(const DevProblem *, OcpWvArgs, int, hipStream_t);    // the per-call solve on the same solver
+    int wv_ns;
     size_t wv_ws_per_inst, wv_lds;
     int ws_rows, nc, tp_ni;
     int tp_max_batch;           // auto choice of the loop kernel: largest batch the horizon-parallel kernel is preferred for
@@ -776,7 +875,7 @@ static Launchers make_launchers_mode()
             };
         }
     }
-    l.loop_wv = nullptr; l.wv_ws_per_inst = 0; l.wv_lds = 0;
+    l.loop_wv = nullptr; l.ocp_wv = nullptr; l.wv_ns = 0; l.wv_ws_per_inst = 0; l.wv_lds = 0;
     if constexpr (NX + (DU ? NU : 0) + NG <= 8 && NU <= 2) {
         // instances per wave: four (one per tile of a matrix-core product) when their resident iterates fit the 256 accumulation
         // registers they are parked in (4 NC slacks / multipliers + NV primal + NC predictor direction, two registers each), else two
@@ -796,6 +895,21 @@ static Launchers make_launchers_mode()
                     attr_set[dev] = true;
                 }
                 hipLaunchKernelGGL(kern, dim3((a.B + NI - 1) / NI), dim3(64), KC::lds_bytes(a.N), s, p, a);
+                return 0;
+            };
+            l.wv_ns = NSZ_;
+            l.ocp_wv = [](const DevProblem *p, OcpWvArgs a, int N, hipStream_t s) -> int {
+                auto kern = ocp_kernel_wv<NX, NU, NY, ND, DU, NG, NC, MASKED, NI>;
+                static bool attr_set[64] = {};
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+                if (!attr_set[dev]) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+                    attr_set[dev] = true;
+                }
+                using Cfg = typename KC::Cfg;
+                const size_t bytes = sizeof(double) * ((size_t)Cfg::t_doubles(N) + NI * Cfg::QN + NI * Cfg::OUT) + sizeof(int) * 8;
+                hipLaunchKernelGGL(kern, dim3((a.o.B + NI - 1) / NI), dim3(64), bytes, s, p, a);
                 return 0;
             };
         }
@@ -843,6 +957,9 @@ struct mpc_handle {
     // loop state
     int B = 0; size_t Bs = 0; int max_steps = 0, log_level = 0, sched_steps = 0, last_k0 = 0, last_n = 0;
     bool state_set = false;     // mpc_loop_set_state has supplied the whole state since the last mpc_loop_alloc
+    // per-call OCP on the wave-autonomous solver: data of the previous call (warm start), caller's guess, final trajectory
+    int ocp_warm = 0, ocp_kernel_opt = 0, pc_B = 0;
+    DevBuf pc_prev, pc_valid, pc_guess, pc_traj;
     DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
     // multi-GPU (one process per GPU): RCCL communicator over the ranks of the job, staging buffers of the collectives
@@ -1109,6 +1226,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)mpc_comm_destroy(h);
     h->coll_send.release(); h->coll_recv.release();
+    h->pc_prev.release(); h->pc_valid.release(); h->pc_guess.release(); h->pc_traj.release();
     for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1142,16 +1260,27 @@ extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
         h->loop_kernel_opt = v;
         return 0;
     }
+    if (!std::strcmp(name, "ocp_warm_start")) { h->ocp_warm = value != 0.0; h->pc_B = 0; return 0; }
+    if (!std::strcmp(name, "ocp_kernel")) {
+        const int v = (int)value;
+        if (v != 0 && v != 1 && v != 3) return fail(-1, "ocp_kernel must be 0 (auto), 1 (instance per lane) or 3 (wave-autonomous)");
+        if (v == 3 && (!h->L.ocp_wv || h->hp.N > 64)) return fail(-8, "the wave-autonomous solver needs N <= 64, stage state <= 8 and nu <= 2");
+        h->ocp_kernel_opt = v;
+        return 0;
+    }
     return fail(-1, "unknown option '%s'", name);
 }
 
 static int loop_mode(const mpc_handle *h);
+static bool ocp_uses_wave(const mpc_handle *h);
 
 extern "C" int mpc_get_option(mpc_handle *h, const char *name, double *value)
 {
     if (!h || !name || !value) return fail(-1, "null argument");
     if (!std::strcmp(name, "steps_per_launch")) { *value = h->steps_per_launch; return 0; }
     if (!std::strcmp(name, "loop_kernel")) { *value = loop_mode(h); return 0; }
+    if (!std::strcmp(name, "ocp_warm_start")) { *value = h->ocp_warm; return 0; }
+    if (!std::strcmp(name, "ocp_kernel")) { *value = ocp_uses_wave(h) ? 3 : 1; return 0; }
     return fail(-1, "unknown option '%s'", name);
 }
 
@@ -1180,9 +1309,22 @@ static int ensure_ws(mpc_handle *h, size_t Bs)
     return h->ws.ensure(std::max(std::max(lane_bytes, tp_bytes), wv_bytes));
 }
 
+// Which solver mpc_ocp_solve runs on: the wave-autonomous one where it exists, except (auto) for models whose open-loop response
+// over the horizon is violently unstable (|A^32| > 1e4, e.g. Ex_LMPC_nlplant with |eig A|^50 ~ 1e12): its initial trajectory and
+// costates come from lane scans with A^(2^e), which lose about three more digits there than the lane kernel's sequential sweeps
+// (measured: 1e-7 relative on u* instead of 3e-9).
+static bool ocp_uses_wave(const mpc_handle *h)
+{
+    if (!h->L.ocp_wv || h->hp.N > 64 || h->ocp_kernel_opt == 1) return false;
+    if (h->ocp_kernel_opt == 3) return true;
+    double nrm = 0.0;
+    for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));
+    return nrm <= 1e4;
+}
+
 extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs, const double *us,
                              const double *dhat, const double *u_prev, const double *px, const double *py,
-                             double *w_out, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
+                             double *w_inout, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
                              double *kkt_res)
 {
     if (!h || B < 1 || !xhat || !xs || !us || !u_prev || !u_out || !xnext_out || !status) return fail(-1, "null argument");
@@ -1192,6 +1334,7 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     HIP_TRY(hipSetDevice(h->device));
     const size_t Bs = pad64(B);
     const int nx = P.nx, nu = P.nu, nd = P.nd;
+    double *const w_out = w_inout;
     // layout of the scratch buffer (doubles): in: xhat xs us dhat u_prev | out: u x1 res | ints: status iters
     const size_t n_in = (size_t)(2 * nx + 2 * nu + nd) * Bs, n_out = (size_t)(nu + nx + 3) * Bs;
     const size_t bytes = (n_in + n_out) * sizeof(double) + 2 * Bs * sizeof(int32_t);
@@ -1212,8 +1355,48 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     a.status = (int32_t *)(d + n_in + n_out); a.iters = a.status + Bs;
     a.ws = (double *)h->ws.p; a.B = B; a.Bs = Bs;
     HIP_TRY(hipMemsetAsync(a.u_out, 0, n_out * sizeof(double), h->stream));
-    HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    h->L.ocp(h->dp, a, h->stream);
+    const bool wave = ocp_uses_wave(h);
+    const int ns_w = h->L.wv_ns, N = P.N;
+    std::vector<double> guess;
+    if (wave) {
+        // resident data of the previous call (warm start): reset when the batch changes
+        const size_t nprev = (size_t)(2 * nx + nd + nu) * Bs;
+        if (h->pc_prev.ensure(nprev * sizeof(double)) || h->pc_valid.ensure(Bs * sizeof(int32_t))) return -10;
+        if (h->pc_B != B) {
+            HIP_TRY(hipMemsetAsync(h->pc_prev.p, 0, nprev * sizeof(double), h->stream));
+            HIP_TRY(hipMemsetAsync(h->pc_valid.p, 0, Bs * sizeof(int32_t), h->stream));
+            h->pc_B = B;
+        }
+        OcpWvArgs wa;
+        wa.o = a; wa.prev = (double *)h->pc_prev.p; wa.valid = (int32_t *)h->pc_valid.p; wa.warm_on = h->ocp_warm;
+        wa.u_guess = nullptr; wa.traj = nullptr;
+        const int nxu = nx + nu, nw = nx * (N + 1) + nu * N;
+        if (w_out && h->ocp_warm && std::isfinite(w_out[0])) {
+            // the caller's guess (MPC_code.py:740-764 hands the shifted previous optimum): its inputs, as the solver's own input
+            // variable (u, or v = u_k - u_{k-1} when bounds on it exist), lane = stage
+            guess.assign((size_t)Bs * nu * 64, 0.0);
+            for (int b = 0; b < B; b++) {
+                const double *w = w_out + (size_t)b * nw;
+                for (int k = 0; k < N; k++)
+                    for (int i = 0; i < nu; i++) {
+                        const double uk = w[k * nxu + nx + i], um = k > 0 ? w[(k - 1) * nxu + nx + i] : u_prev[(size_t)b * nu + i];
+                        guess[((size_t)b * nu + i) * 64 + k] = P.in_is_du ? uk - um : uk;
+                    }
+            }
+            if (h->pc_guess.ensure(guess.size() * sizeof(double))) return -10;
+            HIP_TRY(hipMemcpyAsync(h->pc_guess.p, guess.data(), guess.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            wa.u_guess = (const double *)h->pc_guess.p;
+        }
+        if (w_out) {
+            if (h->pc_traj.ensure((size_t)Bs * (nu + ns_w) * 64 * sizeof(double))) return -10;
+            wa.traj = (double *)h->pc_traj.p;
+        }
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        if (h->L.ocp_wv(h->dp, wa, N, h->stream)) return fail(-9, "cannot configure the wave-autonomous solver");
+    } else {
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        h->L.ocp(h->dp, a, h->stream);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true; h->n_launches = 1;
@@ -1231,8 +1414,22 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
         }
         if (kkt_res) for (int i = 0; i < 3; i++) kkt_res[(size_t)b * 3 + i] = o[(size_t)(nu + nx + i) * Bs + b];
     }
-    if (w_out) {   // primal trajectory in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) from the workspace
-        const int N = P.N, ns = nx + ((P.du_form || P.in_is_du) ? nu : 0), nv = ns + nu, nxu = nx + nu;
+    if (w_out && wave) {   // primal trajectory in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37) from the final iterate's rows
+        const int nxu = nx + nu, nrow = nu + ns_w;
+        std::vector<double> tr((size_t)Bs * nrow * 64);
+        HIP_TRY(hipMemcpy(tr.data(), h->pc_traj.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; b++) {
+            if (ist[b] == kInfeasible) continue;
+            double *w = w_out + (size_t)b * (nx * (N + 1) + nu * N);
+            const double *r = tr.data() + (size_t)b * nrow * 64;
+            for (int i = 0; i < nx; i++) w[i] = xhat[(size_t)b * nx + i];
+            for (int k = 0; k < N; k++) {
+                for (int i = 0; i < nu; i++) w[k * nxu + nx + i] = P.in_is_du ? r[(nu + nx + i) * 64 + k] : r[i * 64 + k];
+                for (int i = 0; i < nx; i++) w[(k + 1) * nxu + i] = r[(nu + i) * 64 + k];
+            }
+        }
+    } else if (w_out) {   // the same from the lane kernel's workspace
+        const int ns = nx + ((P.du_form || P.in_is_du) ? nu : 0), nv = ns + nu, nxu = nx + nu;
         const int slots = h->L.ws_rows / 2, slotU = 4 * h->L.nc, slotZ = slotU + (nu + 1) / 2; (void)nv;
         std::vector<double> wsh((size_t)h->L.ws_rows * (N + 2) * Bs);
         HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));

@@ -86,9 +86,9 @@ struct WvIterA {
     }
 };
 
-struct WvInst { double mu, mu_sum, sm, inv_ncon, gscale; int stall, iters, status; bool on, warm; };
+struct WvInst { double mu, mu_sum, sm, inv_ncon, gscale, res_s, res_p; int stall, iters, status; bool on, warm, keep_u; };
 
-enum : int { kWvOk0 = 1, kWvWarm = 2, kWvValid = 4 };
+enum : int { kWvOk0 = 1, kWvWarm = 2, kWvValid = 4, kWvKeepU = 8 };      // KeepU: warm start whose inputs are a caller's guess for THIS problem (not to be shifted)
 
 // sums / maxima over the 16 lanes of a DPP row (= one instance of the target problem's constraint rows); result in every lane
 __device__ __forceinline__ double row16_sum(double v)
@@ -201,7 +201,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         Sj.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
         const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
         const double res_s = wave_max(blk_on ? rs_p : 0.0);
-        Sj.mu = Sj.mu_sum * Sj.inv_ncon;
+        Sj.mu = Sj.mu_sum * Sj.inv_ncon; Sj.res_s = res_s; Sj.res_p = res_p;
         if (it == 0) Sj.gscale = dmax(1.0, res_s);
         const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         Sj.stall = ok_cp ? Sj.stall + 1 : 0;
@@ -221,7 +221,8 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         const int myflag = __builtin_amdgcn_readfirstlane(iflag[j]);
         Sj.on = (myflag & kWvValid) && (myflag & kWvOk0);
         Sj.warm = (myflag & kWvWarm) != 0;
-        Sj.mu = 0.0; Sj.mu_sum = 0.0; Sj.sm = 0.0; Sj.gscale = 1.0; Sj.stall = 0; Sj.iters = 0;
+        Sj.mu = 0.0; Sj.mu_sum = 0.0; Sj.sm = 0.0; Sj.gscale = 1.0; Sj.stall = 0; Sj.iters = 0; Sj.res_s = 0.0; Sj.res_p = 0.0;
+        Sj.keep_u = (myflag & kWvKeepU) != 0;
         Sj.status = ((myflag & kWvValid) && !(myflag & kWvOk0)) ? kInfeasible : kMaxIter;
         double ncon = 0.0;
         MPC_UNROLL for (int i = 0; i < NC; i++) {
@@ -245,7 +246,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 double v;
                 if (Sj.warm) {
                     const double t = __shfl_down(Xj.u[i], 1, 64);
-                    v = rep ? Xj.u[i] : t;
+                    v = (rep || Sj.keep_u) ? Xj.u[i] : t;
                     if (f_lo) v = dmax(v, ulo);
                     if (f_hi) v = dmin(v, uhi);
                 } else {

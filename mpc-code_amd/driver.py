@@ -29,9 +29,12 @@ def _bcast(v, B, d):
 
 
 def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[capi.Solver] = None,
-                    fused: bool = True, device: int = 0, gather: bool = False, total: Optional[int] = None, comm=None) -> Dict[str, np.ndarray]:
+                    fused: bool = True, device: int = 0, gather: bool = False, total: Optional[int] = None, comm=None,
+                    warm_start: bool = False) -> Dict[str, np.ndarray]:
     """``gather=True``: this rank ran its shard of a batch of ``total`` instances; every result array is all-gathered over the
-    ranks of ``comm`` (mpc-code_amd/shard.py).  ``total`` is required then: a shard does not know the size of the whole."""
+    ranks of ``comm`` (mpc-code_amd/shard.py).  ``total`` is required then: a shard does not know the size of the whole.
+    ``warm_start`` (call-by-call mode): hand ``mpc_ocp_solve`` the shifted previous optimum as the reference hands it to IPOPT
+    (``MPC_code.py:740-764``) and let it keep its multipliers between calls (``ocp_warm_start``); the fused loop always does."""
     p = problem
     nsteps = p.Nsim if nsteps is None else int(nsteps)
     x0_p = p.x0_p[None] if x0_p is None else np.atleast_2d(x0_p)
@@ -59,7 +62,7 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
             ms, _ = s.last_kernel_ms()
             out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
         else:
-            out = _stepwise(p, s, x0_p, x0_m, nsteps, sched)
+            out = _stepwise(p, s, x0_p, x0_m, nsteps, sched, warm_start=warm_start)
     finally:
         if own:
             s.close()
@@ -72,7 +75,7 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
     return out
 
 
-def _stepwise(p, s, x0_p, x0_m, nsteps, sched):
+def _stepwise(p, s, x0_p, x0_m, nsteps, sched, warm_start=False):
     """The reference's call sequence, MPC_code.py:519-816, with each solver call going through the C-ABI."""
     B, n = x0_p.shape[0], p.nx
     x, xhat = x0_p.copy(), x0_m.copy()
@@ -82,6 +85,10 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched):
     import time
     keys = ("U", "X_HAT", "Y_HAT", "XS", "US", "YS", "Xp", "Yp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "TIME_SS", "TIME_DYN")
     log = {k: [] for k in keys}
+    s.set_option("ocp_warm_start", 1 if warm_start else 0)
+    # The reference builds x0= for IPOPT itself (first guess (x0_m, u0) tiled :740-756, then the previous optimum shifted by one
+    # stage :760-764).  mpc_ocp_solve keeps the previous optimum and its multipliers in the handle and shifts them on the device, so
+    # nothing has to travel; an explicit guess can still be passed (capi.Solver.ocp_solve(w_guess=...)).
     for k in range(nsteps):
         log["Xp"].append(x.copy()); log["X_HAT"].append(xhat.copy())      # :519-520
         log["Y_HAT"].append(xhat @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0))   # :524

@@ -158,6 +158,49 @@ def test_stepwise_calls_equal_fused_kernel(lk, cstr, solver_factory):
     sched = cstr.schedules(12)
     assert np.abs(a["Yp"] - (a["Xp"] @ cstr.Cp.T + sched["pyp"][:, None, :])).max() == 0.0
     assert b["ITERS_DYN"][6:].mean() > 1.5 * a["ITERS_DYN"][6:].mean()      # the warm start is doing its job
+    # ... and the per-call entry point honours one too (option "ocp_warm_start": previous optimum and multipliers stay in the handle,
+    # MPC_code.py:740-764): same closed loop, the fused loop's iteration counts
+    c = run_closed_loop(cstr, x0, x0, 12, solver=s, fused=False, warm_start=True)
+    assert np.array_equal(a["STATUS_DYN"], c["STATUS_DYN"])
+    for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT"):
+        assert np.abs(a[k] - c[k]).max() < 5e-6, k
+    assert abs(c["ITERS_DYN"].mean() - a["ITERS_DYN"].mean()) < 0.05 * a["ITERS_DYN"].mean()
+    s.set_option("ocp_warm_start", 0)
+
+
+def test_per_call_solver_kernels_and_explicit_guess(cstr, oracle_c, solver_factory):
+    """mpc_ocp_solve on the wave-autonomous solver (default where it exists) and on the lane kernel give the C restatement's
+    answers; with "ocp_warm_start" a caller's guess x0= (the reference hands IPOPT the shifted previous optimum) is read: same
+    optimum, fewer iterations; a guess that is not finite means none."""
+    p = cstr
+    s, oc = solver_factory(p), oracle_c.OracleC(p)
+    B = 300
+    xh, xs, us, d, up = _rand_inputs(p, B, 21)
+    c = oc.ocp_solve(xh, xs, us, d, up, want_w=True)
+    ok = c["status"] == 0
+    assert s.get_option("ocp_kernel") == 3
+    res = {}
+    for kern in (3, 1):
+        s.set_option("ocp_kernel", kern)
+        g = s.ocp_solve(xh, xs, us, d, up, want_w=True)
+        assert np.array_equal(g["status"], c["status"]) and np.abs(g["u0"] - c["u0"])[ok].max() < TOL_PORT and np.abs(g["w"] - c["w"])[ok].max() < 1e-6, kern
+        assert (np.abs(g["res"][ok, 0]) < 1e-5).all() and (g["res"][ok, 1] < 1e-8).all()
+        res[kern] = g
+    s.set_option("ocp_kernel", 0); s.set_option("ocp_warm_start", 1)
+    cold = s.ocp_solve(xh, xs, us, d, up, want_w=True)                       # first call of the batch: nothing to start from
+    assert np.array_equal(cold["iters"], res[3]["iters"])
+    # the "next step" of every instance: state moved along the optimum, guess = optimum shifted by one stage (MPC_code.py:764)
+    nxu = p.nx + p.nu
+    xh2 = np.where(ok[:, None], cold["x1"], xh); up2 = np.where(ok[:, None], cold["u0"], up)
+    guess = np.hstack([np.nan_to_num(cold["w"][:, nxu:]), us, xs])
+    warm = s.ocp_solve(xh2, xs, us, d, up2, w_guess=guess)
+    ref = oc.ocp_solve(xh2, xs, us, d, up2)
+    ok2 = ok & (ref["status"] == 0)
+    assert np.array_equal(warm["status"][ok], ref["status"][ok]) and np.abs(warm["u0"] - ref["u0"])[ok2].max() < TOL_PORT
+    assert warm["iters"][ok2].mean() < 0.5 * ref["iters"][ok2].mean()
+    nog = s.ocp_solve(xh2, xs, us, d, up2, w_guess=np.full((B, p.nw), np.nan))    # no guess: the handle's own previous optimum, shifted
+    assert np.array_equal(nog["status"][ok], ref["status"][ok]) and np.abs(nog["u0"] - ref["u0"])[ok2].max() < TOL_PORT
+    s.set_option("ocp_warm_start", 0)
 
 
 @pytest.mark.parametrize("lk", LOOP_KERNELS)
