@@ -1,0 +1,64 @@
+/*
+ * mpc_nmpc.h - C-ABI of the non-linear MPC path (libmpc_nmpc_<model>.so): SURVEY.md section 8f rank 1, BASELINE config 3.
+ *
+ * The library is built per model: the Ex-file's User_fxm_Cont / User_fym / User_fxp_Cont / User_fyp are traced and emitted
+ * as device functions (mpc-code_amd/nlcodegen.py), the kernels of csrc/mpc_nmpc.hip are compiled against them for gfx950.
+ * It replaces, for a batch of instances, the loop body of the reference with a non-linear model (MPC_code.py:485-827):
+ *   defEstimator(...) -> ekf()                 Estimator.py:313-386, MPC_code.py:577-650
+ *   solver_ss(...) on the NLP of opt_ss        Target_Calc.py:20-161, MPC_code.py:693-718      (SQP on the linear target QP)
+ *   solver(...) on the NLP of opt_dyn          Control_Calc.py:20-260, MPC_code.py:733-805     (SQP on the Riccati-PDIP solver:
+ *                                              max_sqp = 1 is one real-time iteration per step, a larger value iterates to the
+ *                                              NLP's KKT point)
+ *   Fx_p / Fy_p                                Utilities.py:21-100, MPC_code.py:531-534,813-816
+ * Conventions as mpc_amd.h: caller-owned contiguous float64 host arrays, one row per instance [B][dim]; status words 0 solved,
+ * 1 iteration limit (accepted), 2 infeasible (hold rule); 0 on success, negative code + nmpc_last_error() otherwise; no CPU path.
+ */
+#ifndef MPC_NMPC_H
+#define MPC_NMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmpc_handle nmpc_handle;
+
+typedef struct nmpc_desc {
+    int32_t nx, nu, ny, nd, nxp; /* must equal the dimensions the library was generated for */
+    int32_t N;                   /* horizon (<= 512) */
+    int32_t max_iter;            /* interior-point iterations per QP (Sol_itmax) */
+    int32_t device;
+    double h;                    /* sampling interval */
+    const double *Q, *R;         /* stage cost on x - xs, u - us (no terminal cost: Utilities.py:398-399) */
+    const double *Qss, *Rss;     /* target cost */
+    const double *umin, *umax, *xmin, *xmax, *ymin, *ymax;                         /* +-INFINITY = absent */
+    const double *umin_ss, *umax_ss, *xmin_ss, *xmax_ss, *ymin_ss, *ymax_ss;
+    const double *dmin, *dmax;   /* saturation of dhat, or NULL */
+    const double *Q_kf, *R_kf;   /* EKF covariances [nx+nd]^2, [ny]^2 */
+    const int32_t *ycols;        /* output row i is state ycols[i] (-1: not a single state; then it must be unbounded) */
+} nmpc_desc;
+
+int nmpc_create(const nmpc_desc *desc, nmpc_handle **out);
+void nmpc_destroy(nmpc_handle *h);
+const char *nmpc_last_error(void);
+const char *nmpc_build_info(void);      /* "gfx950;nmpc;dims=nx/nu/ny/nd/nxp;mx=.." */
+
+/* resident closed loop, as mpc_loop_* of mpc_amd.h */
+int nmpc_alloc(nmpc_handle *h, int32_t B, int32_t max_steps);
+int nmpc_set_state(nmpc_handle *h, const double *x_p, const double *xhat, const double *dhat, const double *P, const double *u,
+                   const double *xs, const double *us);
+int nmpc_set_schedule(nmpc_handle *h, int32_t nsteps, const double *ysp /* [nsteps][ny] */, const double *usp /* [nsteps][nu] */);
+/* steps [k0, k0+nsteps); asynchronous.  max_sqp SQP iterations per OCP (1 = real-time iteration), stopped early when the
+ * trajectory moves less than sqp_tol */
+int nmpc_run(nmpc_handle *h, int32_t k0, int32_t nsteps, int32_t max_sqp, double sqp_tol);
+int nmpc_sync(nmpc_handle *h);
+/* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT"; [nsteps][B] int32: "STATUS_DYN","STATUS_SS","ITERS_DYN"
+ * (interior-point iterations of the last QP),"SQP_DYN","SQP_SS" */
+int nmpc_get_log(nmpc_handle *h, const char *name, void *out);
+float nmpc_last_kernel_ms(nmpc_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_NMPC_H */

@@ -4,6 +4,8 @@ Layout
 ------
 ``exfile``   run an unmodified Ex-style problem file without CasADi -> namespace
 ``problem``  namespace -> numeric :class:`LinearMPCProblem` (DARE, bounds, estimator gains)
+``symtrace`` / ``nlproblem``  non-linear examples: the Ex-file's model functions traced into expression DAGs
+             (:class:`NonlinearMPCProblem`), differentiated and emitted as device code
 ``capi``     ctypes binding of ``include/mpc_amd.h`` (``libmpc_amd.so``, hand-written HIP, gfx950)
 ``driver``   the closed loop of the reference's ``MPC_code.py:485-875`` over a batch of instances
 ``shard``    batch partition across ranks, rendezvous and host side of the all-gather of u* (RCCL inside the library)
@@ -18,11 +20,15 @@ EXAMPLES_DIR = _os.path.join(PKG_DIR, "examples")
 
 from .exfile import load_exfile, DEFAULTS  # noqa: E402,F401
 from .problem import LinearMPCProblem, UnsupportedProblem, problem_from_namespace  # noqa: E402,F401
+from .nlproblem import NonlinearMPCProblem, nl_problem_from_namespace  # noqa: E402,F401
 
 
 def load_problem(path, overrides=None):
-    """Ex-style file -> :class:`LinearMPCProblem`."""
+    """Ex-style file -> :class:`LinearMPCProblem`, or :class:`NonlinearMPCProblem` when the model is a user function
+    (``User_fxm_Cont``: the reference's own test, MPC_code.py:94)."""
     ns = load_exfile(path, overrides)
+    if ns.get("User_fxm_Cont") is not None:
+        return nl_problem_from_namespace(ns)
     return problem_from_namespace(ns)
 
 

@@ -271,12 +271,39 @@ __device__ __forceinline__ void load_stage_const(const DevProblem &P, StageConst
     MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) C.R[i][j] = vreg(P.R[i][j]); }
 }
 
+// picks the per-block copy (LTV) or the constant matrix, as a reference of the right type
+template <bool LTV, class TL, class TC>
+__device__ __forceinline__ const auto &ab_pick(const TL &l, const TC &c)
+{
+    if constexpr (LTV) return l; else return c;
+}
+
 // NC = number of bounded variables per block (NU: inputs only, NS+NU: inputs and states); MASKED = some of
 // those bounds may be absent (+-inf).  The host picks the cheapest variant the problem allows.
-template <int NS, int NU, bool HASM, int NC, bool MASKED>
+// LTV: the stage matrices differ from block to block (the QP of one SQP iteration of the non-linear path, x+ = A_k x + B_k u + c_k):
+// ltv points at this lane's column of [block][A (NS*NS) | B (NS*NU) | c (NS) | ...][64 lanes], ltv_stride entries per block; shift = 0 then warm-starts from the same
+// stage of the workspace (an SQP iteration of the same step) instead of the next one.
+template <int NS, int NU, bool HASM, int NC, bool MASKED, bool LTV = false>
 __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, const OcpInst<NS, NU> &q, const Ws &ws,
-                          int max_iter, bool warm, double ws_delta, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters)
+                          int max_iter, bool warm, double ws_delta, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters,
+                          const double *ltv = nullptr, int shift = 1, int ltv_stride = NS * (NS + NU + 1))
 {
+    const int NLTV = ltv_stride;      // entries per block of the ltv slab (A | B | c first)
+    // per-block matrices: loaded into (Al, Bl) for LTV; the constant ones are used in place otherwise
+    auto load_ab = [&](int k, double (&Al)[NS][NS], double (&Bl)[NS][NU]) {
+        if (LTV) {
+            const double *blk = ltv + (size_t)k * NLTV * 64;
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NS; j++) Al[i][j] = blk[(i * NS + j) * 64];
+                MPC_UNROLL for (int j = 0; j < NU; j++) Bl[i][j] = blk[(NS * NS + i * NU + j) * 64];
+            }
+        }
+    };
+#define MPC_LOAD_AB(k)                                                                     \
+    double Al_[LTV ? NS : 1][LTV ? NS : 1], Bl_[LTV ? NS : 1][LTV ? NU : 1];               \
+    if constexpr (LTV) load_ab(k, Al_, Bl_);                                               \
+    const auto &AA = ab_pick<LTV>(Al_, C.A);                                               \
+    const auto &BB = ab_pick<LTV>(Bl_, C.B);
     using L = BlkLayout<NS, NU, NC>;
     constexpr int NV = NS + NU;
     static_assert(NC == NU || NC == NV, "bounded variables: inputs, or inputs and states");
@@ -329,7 +356,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         for (int k = 0; k < N; k++) {
             if (k == N - 1) use_end();
             const BlkPtr b = ws.blk(k);
-            const BlkPtr src = ws.blk(k + 1 < N ? k + 1 : k);      // previous step's block k+1 (read before block k is written)
+            const BlkPtr src = ws.blk((shift && k + 1 < N) ? k + 1 : k);      // previous step's block k+1 (read before block k is written)
+            MPC_LOAD_AB(k)
             double uk[NU], uprev[NU];
             v2d lprev[NC];
             ld_field<NU>(src, L::U, uprev);
@@ -342,9 +370,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             }
             double zn[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                double a = q.c[i];
-                MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * z[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * uk[j];
+                double a = LTV ? ltv[((size_t)k * NLTV + NS * NS + NS * NU + i) * 64] : q.c[i];
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += AA[i][j] * z[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) a += BB[i][j] * uk[j];
                 zn[i] = a;
             }
             MPC_UNROLL for (int i = 0; i < NS; i++) z[i] = zn[i];
@@ -372,7 +400,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
     for (int it = 0;; it++) {
         // ======================= sweep B1 (backward) =================================================
         double mu_sum = 0.0, res_p = 0.0, res_s = 0.0, cres = 0.0, lmax = 0.0;
-        double pi[NS], Pm[NS][NS], pcar[NS], unext_dev[NU];
+        double pi[NS], Pm[NS][NS], pcar[NS], unext_dev[NU], Anext_[LTV ? NS : 1][LTV ? NS : 1];
+        if constexpr (LTV) { MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Anext_[i][j] = 0.0; } }
+        const auto &Anext = ab_pick<LTV>(Anext_, C.A);      // LTI: A' pi with pi = 0 at the last block is the same thing
         bool pd_ok = true;
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             pi[i] = 0.0; pcar[i] = 0.0;
@@ -439,14 +469,15 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             load_b1(k - 1, cur);     // k-1 = -1 is a guard block
             // ---- phase B: Riccati step.  P_{k+1} completed with the barrier weights of z_{k+1} -----------
             MPC_UNROLL for (int i = 0; i < NS; i++) Pm[i][i] += sig[NU + i];
+            MPC_LOAD_AB(k)
             double PB[NS][NU], PA[NS][NS], Lam[NU][NU], Psi[NU][NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * C.B[l][j]; PB[i][j] = a; }
-                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * C.A[l][j]; PA[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * BB[l][j]; PB[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * AA[l][j]; PA[i][j] = a; }
             }
             MPC_UNROLL for (int i = 0; i < NU; i++) {
-                MPC_UNROLL for (int j = 0; j <= i; j++) { double a = C.R[i][j] + (i == j ? sig[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += C.B[l][i] * PB[l][j]; Lam[i][j] = a; Lam[j][i] = a; }
-                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = HASM ? C.M[j][i] : 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += C.B[l][i] * PA[l][j]; Psi[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j <= i; j++) { double a = C.R[i][j] + (i == j ? sig[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += BB[l][i] * PB[l][j]; Lam[i][j] = a; Lam[j][i] = a; }
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = HASM ? C.M[j][i] : 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += BB[l][i] * PA[l][j]; Psi[i][j] = a; }
             }
             pd_ok = sym_inverse<NU>(Lam) && pd_ok;     // Lam now holds Li
             double Kk[NU][NS], Acl[NS][NS];
@@ -459,7 +490,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 st_field<NU * NS>(b, L::K, kflat); st_field<NU * (NU + 1) / 2>(b, L::LI, liflat);
             }
             if (k > 0) {
-                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = C.A[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += C.B[i][l] * Kk[l][j]; Acl[i][j] = a; } }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = AA[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += BB[i][l] * Kk[l][j]; Acl[i][j] = a; } }
                 // closed-loop (Joseph) form: P_k = Q + Acl' P Acl + K' Rt K + M K + K' M'  (no cancellation)
                 double T[NS][NS], RK[NU][NS];
                 MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pm[i][l] * Acl[l][j]; T[i][j] = a; } }
@@ -504,23 +535,25 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             // adjoint pi_{k+1} = gz_{k+1} + A' pi_{k+2};  stationarity residual r_u,k = gu_k + B' pi_{k+1}
             {
                 double pn[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = gz1[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pi[j]; pn[i] = a; }
+                // the costate of z_{k+1} passes through the dynamics of the NEXT block (z_{k+2} = A_{k+1} z_{k+1} + ..)
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = gz1[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Anext[j][i] * pi[j]; pn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = pn[i];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pi[j]; res_s = dmax(res_s, fabs(a)); }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += BB[j][i] * pi[j]; res_s = dmax(res_s, fabs(a)); }
+                if constexpr (LTV) { MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Anext_[i][j] = AA[i][j]; } }
             }
             double pv[NS], qu[NU];
             MPC_UNROLL for (int i = 0; i < NS; i++) pv[i] = gz1[i] + haff[NU + i] + pcar[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) qu[i] = gu[i] + haff[i];
             {
                 double psi[NU], kff[NU];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += BB[j][i] * pv[j]; psi[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Lam[i][j] * psi[j]; kff[i] = -a; }
                 st_field<NU>(b, L::KFF, kff);
                 if (k > 0) {     // p_k carry = Acl' pv + K' qu = A' pv + K' psi
                     double pn[NS];
                     MPC_UNROLL for (int i = 0; i < NS; i++) {
                         double a = 0.0;
-                        MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
+                        MPC_UNROLL for (int j = 0; j < NS; j++) a += AA[j][i] * pv[j];
                         MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j][i] * psi[j];
                         pn[i] = a;
                     }
@@ -562,9 +595,10 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 const BlkPtr b = ws.blk(k);
                 const BlkPtr nb = ws.blk(k + 1);      // block N is a guard block; every field is reloaded in place
                 double ddu[NU], dzn[NS];                 // right after its last use (rolling prefetch, no second buffer)
+                MPC_LOAD_AB(k)
                 MPC_UNROLL for (int i = 0; i < NU; i++) { double a = c1.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += c1.K[i * NS + j] * dz[j]; ddu[i] = a; }
                 ld_field<NU>(nb, L::KFF, c1.kff); ld_field<NU * NS>(nb, L::K, c1.K);
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += AA[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += BB[i][j] * ddu[j]; dzn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
                 MPC_UNROLL for (int i = 0; i < NC; i++) {
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
@@ -658,14 +692,15 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 }
                 {
                     double psi[NU], kff[NU];
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.B[j][i] * pv[j]; psi[i] = a; }
+                    MPC_LOAD_AB(k)
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { double a = qu[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += BB[j][i] * pv[j]; psi[i] = a; }
                     MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a += Li[i][j] * psi[j]; kff[i] = -a; }
                     st_field<NU>(b, L::KFF, kff);
                     if (k > 0) {     // p_k carry = Acl' pv + K' qu = A' pv + K' psi
                         double pn[NS];
                         MPC_UNROLL for (int i = 0; i < NS; i++) {
                             double a = 0.0;
-                            MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[j][i] * pv[j];
+                            MPC_UNROLL for (int j = 0; j < NS; j++) a += AA[j][i] * pv[j];
                             MPC_UNROLL for (int j = 0; j < NU; j++) a += Kk[j * NS + i] * psi[j];
                             pn[i] = a;
                         }
@@ -695,9 +730,10 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 const BlkPtr b = ws.blk(k);
                 const BlkPtr nb = ws.blk(k + 1);
                 double ddu[NU], dzn[NS];
+                MPC_LOAD_AB(k)
                 MPC_UNROLL for (int i = 0; i < NU; i++) { double a = c3.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += c3.K[i * NS + j] * dz[j]; ddu[i] = a; }
                 ld_field<NU>(nb, L::KFF, c3.kff); ld_field<NU * NS>(nb, L::K, c3.K);
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += C.A[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += C.B[i][j] * ddu[j]; dzn[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += AA[i][j] * dz[j]; MPC_UNROLL for (int j = 0; j < NU; j++) a += BB[i][j] * ddu[j]; dzn[i] = a; }
                 MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = dzn[i];
                 st_field<NU>(b, L::DU, ddu); st_field<NS>(b, L::DZ, dz);
                 MPC_UNROLL for (int i = 0; i < NC; i++) {
@@ -723,6 +759,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         MPC_STAMP(4);  // F2
     }
 #undef MPC_BOUNDS
+#undef MPC_LOAD_AB
     return status;
 }
 

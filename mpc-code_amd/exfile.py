@@ -90,9 +90,13 @@ class SymVec:
 
 def _vertcat(*parts):
     """Numeric ``vertcat``: stacks scalars / arrays along axis 0 (the state index), broadcasting over trailing batch
-    axes, so that a user plant function written for CasADi evaluates on ``x[nx, B]`` arrays; shape objects pass through."""
+    axes, so that a user plant function written for CasADi evaluates on ``x[nx, B]`` arrays; shape objects pass through;
+    traced expressions (:mod:`symtrace`) come back as a flat list of nodes."""
+    from .symtrace import Sym, flatten
     if any(isinstance(a, SymVec) for a in parts):
         return list(parts)
+    if any(isinstance(a, Sym) or (isinstance(a, list) and a and isinstance(a[0], Sym)) for a in parts):
+        return flatten(parts)
     rows = [np.asarray(a, dtype=np.float64) for a in parts]
     tail = np.broadcast_shapes(*[r.shape[1:] if r.ndim >= 2 else r.shape for r in rows])
     out = []
@@ -122,8 +126,14 @@ def _make_standins() -> Dict[str, types.ModuleType]:
     cas.mtimes = lambda *a: NotImplemented
     cas.pi = math.pi
     cas.inf = math.inf
-    for fn in ("exp", "log", "sqrt", "sin", "cos", "tan", "fabs", "tanh"):      # NumPy's: scalars and arrays alike
-        setattr(cas, fn, getattr(np, fn))
+    from . import symtrace
+
+    def _elementwise(fn):      # NumPy's on numbers and arrays; the node's own method on a traced expression
+        npf = getattr(np, fn)
+        return lambda v: getattr(v, fn)() if isinstance(v, symtrace.Sym) else npf(v)
+    for fn in ("exp", "log", "sqrt", "sin", "cos", "tan", "fabs", "tanh"):
+        setattr(cas, fn, _elementwise(fn))
+    cas.if_else = symtrace.if_else
     cas.__all__ = [k for k in vars(cas) if not k.startswith("_")]
     tools = types.ModuleType("casadi.tools")
     tools.__all__ = []

@@ -1,0 +1,186 @@
+"""Problem descriptor of the non-linear MPC path (BASELINE config 3: ``Ex_NMPC.py``).
+
+The reference builds a non-linear example symbolically: ``defF_model`` integrates the Ex-file's continuous model
+``User_fxm_Cont(x,u,d,t,px)`` with ``Mx`` classical Runge-Kutta steps per sampling interval (``Utilities.py:157-183``,
+``casadi.simpleRK``), takes ``User_fym`` as output map, ``defF_p`` does the same for the plant (``:58-82``), and IPOPT
+differentiates the unrolled graphs.  Here the same Ex-file functions are *traced* (:mod:`symtrace`): the expression
+DAGs of model, output, plant and their Jacobians are what the device code generator and the host-side simulation use.
+
+Covered: continuous-time model and plant (``User_fxm_Cont``, ``User_fym``, ``User_fxp_Cont``, ``User_fyp``), disturbance
+entering the model non-linearly (``offree = "nl"``: the estimate ``dhat`` is an argument of the model, ``Utilities.py:126-129``),
+quadratic stage cost on ``x - xs`` and ``u - us`` (``Q``, ``R``; no terminal cost: ``defVfin`` returns 0 without ``A``,
+``Utilities.py:398-399``), quadratic target cost (``Qss``, ``Rss``), bounds on u, x, y (outputs that are single states),
+saturation of ``dhat``, extended Kalman filter (``Estimator.py:313-386``).  Anything else raises ``UnsupportedProblem``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+
+from . import symtrace as st
+from .problem import UnsupportedProblem, _mat, _vec
+
+INF = float("inf")
+
+
+@dataclass
+class NonlinearMPCProblem:
+    nx: int
+    nu: int
+    ny: int
+    nd: int
+    nxp: int
+    N: int
+    h: float
+    Nsim: int
+    Mx: int
+    # traced expressions in the variables x[i], u[i], d[i], t (model) / xp[i], u[i], t (plant)
+    f: List[st.Sym] = None          # model: dx/dt
+    hy: List[st.Sym] = None         # model output
+    fp: List[st.Sym] = None         # plant: dxp/dt
+    hp: List[st.Sym] = None         # plant output
+    Q: np.ndarray = None
+    R: np.ndarray = None
+    Qss: np.ndarray = None
+    Rss: np.ndarray = None
+    umin: np.ndarray = None
+    umax: np.ndarray = None
+    xmin: np.ndarray = None
+    xmax: np.ndarray = None
+    ymin: np.ndarray = None
+    ymax: np.ndarray = None
+    umin_ss: np.ndarray = None
+    umax_ss: np.ndarray = None
+    xmin_ss: np.ndarray = None
+    xmax_ss: np.ndarray = None
+    ymin_ss: np.ndarray = None
+    ymax_ss: np.ndarray = None
+    dmin: Optional[np.ndarray] = None
+    dmax: Optional[np.ndarray] = None
+    Q_kf: np.ndarray = None
+    R_kf: np.ndarray = None
+    P0: np.ndarray = None
+    x0_p: np.ndarray = None
+    x0_m: np.ndarray = None
+    u0: np.ndarray = None
+    dhat0: np.ndarray = None
+    max_iter: int = 100
+    defSP: Optional[Callable] = None
+    name: str = ""
+    ycols: List[int] = None         # output row i is state ycols[i] (bounded outputs are boxes on states)
+    funcs: Dict[str, Any] = field(default_factory=dict)      # the Ex-file's own Python functions (host-side checks)
+
+    # ------------------------------------------------------------------ derived symbolic Jacobians
+    def __post_init__(self):
+        self.vx, self.vu, self.vd = st.symvec("x", self.nx), st.symvec("u", self.nu), st.symvec("d", self.nd)
+        self.vxp = st.symvec("xp", self.nxp)
+        self.vt = st.Sym.var("t")
+        if self.f is not None:
+            self.f_x = st.jacobian(self.f, self.vx); self.f_u = st.jacobian(self.f, self.vu); self.f_d = st.jacobian(self.f, self.vd)
+            self.h_x = st.jacobian(self.hy, self.vx); self.h_d = st.jacobian(self.hy, self.vd)
+
+    @property
+    def nw(self) -> int:
+        return self.nx * (self.N + 1) + self.nu * self.N
+
+    def schedules(self, nsteps: int, k0: int = 0) -> Dict[str, np.ndarray]:
+        ysp = np.zeros((nsteps, self.ny)); usp = np.zeros((nsteps, self.nu)); xsp = np.zeros((nsteps, self.nx))
+        for i in range(nsteps):
+            if self.defSP is not None:
+                a, b, c = self.defSP((k0 + i) * self.h)
+                ysp[i], usp[i], xsp[i] = np.ravel(a), np.ravel(b), np.ravel(c)
+        return dict(ysp=ysp, usp=usp, xsp=xsp)
+
+    # ------------------------------------------------------------------ host-side evaluation (NumPy, batch [B, .])
+    def _vals(self, x=None, u=None, d=None, t=0.0, xp=None):
+        v = {"t": t}
+        if x is not None: v.update({f"x[{i}]": x[..., i] for i in range(self.nx)})
+        if xp is not None: v.update({f"xp[{i}]": xp[..., i] for i in range(self.nxp)})
+        if u is not None: v.update({f"u[{i}]": u[..., i] for i in range(self.nu)})
+        if d is not None: v.update({f"d[{i}]": d[..., i] for i in range(self.nd)})
+        return v
+
+    @staticmethod
+    def _stack(vals, shape):
+        return np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), shape) for v in vals], axis=-1)
+
+    def plant_step(self, xp, u, t):
+        """x_p(t + h): ``Mx`` classical RK4 steps of the plant with time as a state (Utilities.py:58-82)."""
+        xp = np.array(xp, dtype=np.float64); dt = self.h / self.Mx
+        f = lambda x_, t_: self._stack(st.evaluate(self.fp, self._vals(xp=x_, u=u, t=t_)), x_.shape[:-1])
+        for s in range(self.Mx):
+            ts = t + s * dt
+            k1 = f(xp, ts); k2 = f(xp + 0.5 * dt * k1, ts + 0.5 * dt); k3 = f(xp + 0.5 * dt * k2, ts + 0.5 * dt); k4 = f(xp + dt * k3, ts + dt)
+            xp = xp + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+        return xp
+
+    def plant_output(self, xp, u, t):
+        return self._stack(st.evaluate(self.hp, self._vals(xp=xp, u=u, t=t)), np.shape(xp)[:-1])
+
+
+def _trace(fn, args):
+    try:
+        return st.flatten(fn(*args))
+    except Exception as e:      # noqa: BLE001 - whatever the user function trips over
+        raise UnsupportedProblem(f"{getattr(fn, '__name__', fn)} cannot be traced: {e}") from e
+
+
+def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMPCProblem:
+    """Classify a non-linear Ex-file namespace (reference MPC_code.py:84-257 probes) and trace its functions."""
+    has = lambda k: k in ns and ns[k] is not None and not k.startswith("__")
+    for bad in ("User_fxm_Dis", "User_fxp_Dis", "User_fobj_Cont", "User_fobj_Dis", "User_fobj_Coll", "User_fssobj", "User_vfin",
+                "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "def_px", "def_py", "def_pxmp", "def_pymp",
+                "Dumin", "Dumax", "A", "S", "Sss"):
+        if has(bad):
+            raise UnsupportedProblem(f"'{bad}' is outside the non-linear path built so far")
+    for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks", "TermCons", "mhe", "ContForm",
+                 "DUFormEcon", "kal", "kalss", "lue"):
+        if ns.get(flag, False) is True:
+            raise UnsupportedProblem(f"flag {flag}=True is outside the non-linear path built so far")
+    for req in ("User_fxm_Cont", "User_fym", "User_fxp_Cont", "User_fyp", "Q", "R", "Qss", "N", "h", "Nsim", "x", "u", "y", "d", "xp", "Q_kf", "R_kf"):
+        if not has(req):
+            raise UnsupportedProblem(f"'{req}' missing: not a continuous-time non-linear example with EKF")
+    if not ns.get("ekf", False) or ns.get("offree", "no") != "nl":
+        raise UnsupportedProblem("the non-linear path needs ekf = True and offree = 'nl'")
+    nx, nu, ny, nd, nxp = ns["x"].size1(), ns["u"].size1(), ns["y"].size1(), ns["d"].size1(), ns["xp"].size1()
+    vx, vu, vd, vxp, vt = st.symvec("x", nx), st.symvec("u", nu), st.symvec("d", nd), st.symvec("xp", nxp), st.Sym.var("t")
+    zero = lambda n: [0.0] * n
+    f = _trace(ns["User_fxm_Cont"], (vx, vu, vd, vt, zero(nx)))            # Utilities.py:160
+    hy = _trace(ns["User_fym"], (vx, vu, vd, vt, zero(ny)))                # Utilities.py:229
+    fp = _trace(ns["User_fxp_Cont"], (vxp, vt, vu, zero(nxp), zero(nxp)))  # Utilities.py:61
+    hp = _trace(ns["User_fyp"], (vxp, vu, vt, zero(ny), zero(ny)))         # Utilities.py:94
+    if len(f) != nx or len(hy) != ny or len(fp) != nxp or len(hp) != ny:
+        raise UnsupportedProblem("a user function returns a vector of the wrong length")
+    ycols = []
+    for e in hy:        # bounded outputs have to be single states (then their bounds are boxes on states)
+        if e.op == "var" and e in vx:
+            ycols.append(vx.index(e))
+        else:
+            ycols.append(-1)
+
+    def pick(base, suffix, n, fill):
+        v = ns.get(base + suffix)
+        if v is None:
+            v = ns.get(base)
+        return _vec(v, n, fill)
+    y_lo, y_hi = pick("ymin", "_dyn", ny, -INF), pick("ymax", "_dyn", ny, INF)
+    if any(c < 0 and (np.isfinite(y_lo[i]) or np.isfinite(y_hi[i])) for i, c in enumerate(ycols)):
+        raise UnsupportedProblem("a bounded output is not a single state")
+    P0 = np.array(ns["P0"], dtype=np.float64) if has("P0") else np.zeros((nx + nd, nx + nd))
+    return NonlinearMPCProblem(
+        nx=nx, nu=nu, ny=ny, nd=nd, nxp=nxp, N=int(ns["N"]), h=float(ns["h"]), Nsim=int(ns["Nsim"]), Mx=int(ns.get("Mx", 10)),
+        f=f, hy=hy, fp=fp, hp=hp, Q=_mat(ns["Q"], nx, nx, "Q"), R=_mat(ns["R"], nu, nu, "R"),
+        Qss=_mat(ns["Qss"], ny, ny, "Qss"), Rss=_mat(ns["Rss"], nu, nu, "Rss") if has("Rss") else np.zeros((nu, nu)),
+        umin=pick("umin", "_dyn", nu, -INF), umax=pick("umax", "_dyn", nu, INF), xmin=pick("xmin", "_dyn", nx, -INF), xmax=pick("xmax", "_dyn", nx, INF),
+        ymin=y_lo, ymax=y_hi,
+        umin_ss=pick("umin", "_ss", nu, -INF), umax_ss=pick("umax", "_ss", nu, INF), xmin_ss=pick("xmin", "_ss", nx, -INF), xmax_ss=pick("xmax", "_ss", nx, INF),
+        ymin_ss=pick("ymin", "_ss", ny, -INF), ymax_ss=pick("ymax", "_ss", ny, INF),
+        dmin=None if ns.get("dmin") is None else _vec(ns["dmin"], nd, -INF), dmax=None if ns.get("dmax") is None else _vec(ns["dmax"], nd, INF),
+        Q_kf=_mat(ns["Q_kf"], nx + nd, nx + nd, "Q_kf"), R_kf=_mat(ns["R_kf"], ny, ny, "R_kf"), P0=P0,
+        x0_p=_vec(ns["x0_p"], nxp, 0.0), x0_m=_vec(ns["x0_m"], nx, 0.0), u0=_vec(ns["u0"], nu, 0.0),
+        dhat0=_vec(ns.get("dhat0"), nd, 0.0) if has("dhat0") else np.zeros(nd),
+        max_iter=int(ns.get("Sol_itmax", 100)), defSP=ns.get("defSP"), name=name or str(ns.get("__name__", "")), ycols=ycols,
+        funcs={k: ns[k] for k in ("User_fxm_Cont", "User_fym", "User_fxp_Cont", "User_fyp")},
+    )

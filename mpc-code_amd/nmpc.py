@@ -1,0 +1,178 @@
+"""ctypes binding of include/mpc_nmpc.h and the batched non-linear closed loop.
+
+``NmpcSolver`` owns one per-model library (built by :mod:`nlcodegen` from the traced Ex-file functions) and a handle on it;
+``run_nmpc_closed_loop`` is the loop body of the reference's ``MPC_code.py:485-827`` with a non-linear model, for B instances
+that differ in their initial state - one kernel launch, everything resident in HBM.  There is no CPU path: without a GPU
+``NmpcSolver`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import nlcodegen
+from .capi import MpcAmdError
+
+NMPC_EXPORTS = ("nmpc_create", "nmpc_destroy", "nmpc_last_error", "nmpc_build_info", "nmpc_alloc", "nmpc_set_state", "nmpc_set_schedule",
+                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms")
+
+_dp = ct.POINTER(ct.c_double)
+_ip = ct.POINTER(ct.c_int32)
+
+
+class _NDesc(ct.Structure):
+    _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "N", "max_iter", "device")] + [("h", ct.c_double)]
+                + [(k, _dp) for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss",
+                                      "xmax_ss", "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf")] + [("ycols", _ip)])
+
+
+_libs: Dict[str, ct.CDLL] = {}
+
+
+def load_nmpc_library(path: str) -> ct.CDLL:
+    if path in _libs:
+        return _libs[path]
+    lib = ct.CDLL(path)
+    vp = ct.c_void_p
+    lib.nmpc_create.argtypes = [ct.POINTER(_NDesc), ct.POINTER(vp)]; lib.nmpc_create.restype = ct.c_int
+    lib.nmpc_destroy.argtypes = [vp]; lib.nmpc_destroy.restype = None
+    lib.nmpc_last_error.restype = ct.c_char_p
+    lib.nmpc_build_info.restype = ct.c_char_p
+    lib.nmpc_alloc.argtypes = [vp, ct.c_int32, ct.c_int32]
+    lib.nmpc_set_state.argtypes = [vp] + [_dp] * 7
+    lib.nmpc_set_schedule.argtypes = [vp, ct.c_int32, _dp, _dp]
+    lib.nmpc_run.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
+    lib.nmpc_sync.argtypes = [vp]
+    lib.nmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
+    lib.nmpc_last_kernel_ms.argtypes = [vp]; lib.nmpc_last_kernel_ms.restype = ct.c_float
+    _libs[path] = lib
+    return lib
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+def _rows(v, B, d):
+    a = np.asarray(v, dtype=np.float64)
+    return np.ascontiguousarray(np.broadcast_to(a.reshape(-1, d) if a.ndim > 1 else a, (B, d)))
+
+
+class NmpcSolver:
+    """A non-linear problem (:class:`NonlinearMPCProblem`) resident on one GPU."""
+
+    LOGS = {"U": "nu", "X_HAT": "nx", "XS": "nx", "US": "nu", "Xp": "nxp", "D_HAT": "nd"}
+    ILOGS = ("STATUS_DYN", "STATUS_SS", "ITERS_DYN", "SQP_DYN", "SQP_SS")
+
+    def __init__(self, problem, device: int = 0, lib_path: Optional[str] = None):
+        self.p = p = problem
+        self.lib = load_nmpc_library(lib_path or nlcodegen.build_nmpc_library(p))
+        self._keep = {}
+        d = _NDesc()
+        d.nx, d.nu, d.ny, d.nd, d.nxp, d.N, d.max_iter, d.device, d.h = p.nx, p.nu, p.ny, p.nd, p.nxp, p.N, int(p.max_iter), int(device), float(p.h)
+        for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss",
+                  "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf"):
+            v = getattr(p, k, None)
+            if v is None:
+                setattr(d, k, None)
+            else:
+                a = _c(v)
+                self._keep[k] = a
+                setattr(d, k, a.ctypes.data_as(_dp))
+        yc = _c(p.ycols, np.int32); self._keep["ycols"] = yc; d.ycols = yc.ctypes.data_as(_ip)
+        self.h = ct.c_void_p()
+        rc = self.lib.nmpc_create(ct.byref(d), ct.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise MpcAmdError(f"nmpc_create failed ({rc}): {self.lib.nmpc_last_error().decode()}")
+        self.B = self.steps = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MpcAmdError(f"{what} failed ({rc}): {self.lib.nmpc_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_info(self) -> str:
+        return self.lib.nmpc_build_info().decode()
+
+    def alloc(self, B: int, max_steps: int):
+        self._chk(self.lib.nmpc_alloc(self.h, int(B), int(max_steps)), "nmpc_alloc")
+        self.B, self.steps = int(B), 0
+
+    def set_state(self, x0_p, x0_m, dhat=None, P=None, u=None, xs=None, us=None):
+        """Defaults are the reference's start-up values: dhat0, P0, u0, and xs = x0_m, us = u0 (MPC_code.py:446-476)."""
+        p, B = self.p, self.B
+        ne = p.nx + p.nd
+        a = [_rows(x0_p, B, p.nxp), _rows(x0_m, B, p.nx), _rows(p.dhat0 if dhat is None else dhat, B, max(p.nd, 1))[:, :max(p.nd, 1)],
+             np.ascontiguousarray(np.broadcast_to(np.asarray(p.P0 if P is None else P, dtype=np.float64).reshape(-1, ne * ne), (B, ne * ne))),
+             _rows(p.u0 if u is None else u, B, p.nu)]
+        a.append(a[1].copy() if xs is None else _rows(xs, B, p.nx))
+        a.append(a[4].copy() if us is None else _rows(us, B, p.nu))
+        self._chk(self.lib.nmpc_set_state(self.h, *[v.ctypes.data_as(_dp) for v in a]), "nmpc_set_state")
+
+    def set_schedule(self, sched: Dict[str, np.ndarray]):
+        ysp, usp = _c(sched["ysp"]), _c(sched["usp"])
+        self._chk(self.lib.nmpc_set_schedule(self.h, ysp.shape[0], ysp.ctypes.data_as(_dp), usp.ctypes.data_as(_dp)), "nmpc_set_schedule")
+        self.steps = ysp.shape[0]
+
+    def run(self, k0: int, nsteps: int, max_sqp: int = 1, sqp_tol: float = 1e-9):
+        self._chk(self.lib.nmpc_run(self.h, int(k0), int(nsteps), int(max_sqp), float(sqp_tol)), "nmpc_run")
+
+    def sync(self):
+        self._chk(self.lib.nmpc_sync(self.h), "nmpc_sync")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.nmpc_last_kernel_ms(self.h))
+
+    def get_log(self, name: str) -> np.ndarray:
+        if name in self.LOGS:
+            out = np.empty((self.steps, self.B, getattr(self.p, self.LOGS[name])))
+        elif name in self.ILOGS:
+            out = np.empty((self.steps, self.B), dtype=np.int32)
+        else:
+            raise KeyError(name)
+        if out.size:
+            self._chk(self.lib.nmpc_get_log(self.h, name.encode(), out.ctypes.data_as(ct.c_void_p)), "nmpc_get_log")
+        return out
+
+
+def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[NmpcSolver] = None,
+                         max_sqp: int = 1, sqp_tol: float = 1e-9, device: int = 0) -> Dict[str, np.ndarray]:
+    """``max_sqp = 1``: one real-time iteration per step (one linearisation along the shifted previous trajectory, one QP);
+    larger: iterate each OCP to the NLP's KKT point, what the reference's IPOPT call returns (``MPC_code.py:775-783``).
+    Result arrays carry the reference's names (``MPC_code.py:877-895``), shaped [nsteps, B, dim]."""
+    p = problem
+    nsteps = p.Nsim if nsteps is None else int(nsteps)
+    x0_p = p.x0_p[None] if x0_p is None else np.atleast_2d(x0_p)
+    x0_m = p.x0_m[None] if x0_m is None else np.atleast_2d(x0_m)
+    B = x0_p.shape[0]
+    own = solver is None
+    s = NmpcSolver(p, device=device) if own else solver
+    try:
+        s.alloc(B, nsteps)
+        s.set_state(x0_p, x0_m)
+        s.set_schedule(p.schedules(nsteps))
+        s.run(0, nsteps, max_sqp, sqp_tol)
+        s.sync()
+        out = {k: s.get_log(k) for k in list(s.LOGS) + list(s.ILOGS) if not (k == "D_HAT" and p.nd == 0)}
+        ms = s.last_kernel_ms()
+        out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
+        u_prev = np.concatenate([_rows(p.u0, B, p.nu)[None], out["U"][:-1]]) if nsteps else out["U"]
+        t = (np.arange(nsteps) * p.h)[:, None]
+        out["Yp"] = p.plant_output(out["Xp"], u_prev, t)                     # MPC_code.py:531-534
+    finally:
+        if own:
+            s.close()
+    return out

@@ -1,0 +1,291 @@
+"""ORACLE (test infrastructure, never shipped): the non-linear MPC loop of the reference, restated with NumPy.
+
+PARITY UNPINNED against the reference's own solver: CasADi/IPOPT cannot run here and the reference ships no vectors
+(SURVEY.md section 8c).  This file pins the GPU path to the *mathematics* of the reference's non-linear case instead:
+
+* model / plant      ``defF_model`` / ``defF_p``: ``Mx`` classical RK4 steps of the Ex-file's continuous functions per sampling
+                     interval, time carried as a state (``Utilities.py:157-183``, ``:58-82``; ``casadi.simpleRK``).  The
+                     Ex-file's own Python functions are called on NumPy arrays - no tracer, no generated code;
+* Jacobians          central finite differences of that discrete map (independent of the product's symbolic ones);
+* estimator          ``ekf`` (``Estimator.py:313-386``) on ``[x; d]`` with ``d+ = d`` (``MPC_code.py:546-561``);
+* target             the NLP of ``opt_ss`` (``Target_Calc.py:20-161``) for a non-linear model, by Newton-type SQP: every iteration
+                     is the linear target QP of ``oracle/mpc_oracle.py:target_qp`` with the model linearised at the iterate;
+* OCP                the NLP of ``opt_dyn`` (``Control_Calc.py:20-260``: multiple shooting, quadratic cost, no terminal cost -
+                     ``Utilities.py:398-399`` - bounds on x_1..x_N, u, and the output rows at k = 0..N-1), by SQP with the exact
+                     (Gauss-Newton = exact: the cost is quadratic) Hessian of the cost: each iteration a dense QP in opt_dyn's own
+                     variable order, solved by ``mpc_oracle.qp_ipm_dense``; iterated to a fixed point, which is a KKT point of the
+                     NLP whatever Hessian the iteration uses;
+* loop               ``MPC_code.py:485-827``: measure, estimate, target (previous target kept when infeasible), OCP (shifted
+                     warm start ``:764``, hold rule ``:804-805``), plant.
+
+``kkt_nlp`` certifies a returned OCP point against the NLP itself (stationarity with finite-difference constraint Jacobians).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import mpc_oracle as o
+
+STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# discrete maps from the Ex-file's continuous functions
+# ---------------------------------------------------------------------------------------------------
+def _col(v, n):
+    return np.asarray(v, dtype=np.float64).reshape(n)
+
+
+def model_fx(p, x, u, d, t=0.0):
+    """Fx_model(x,u,h,d,t): Mx RK4 steps of User_fxm_Cont over h (Utilities.py:160-172)."""
+    f = lambda x_, t_: _col(p.funcs["User_fxm_Cont"](x_, u, d, t_, np.zeros(p.nx)), p.nx)
+    dt = p.h / p.Mx
+    x = np.array(x, dtype=np.float64)
+    for s in range(p.Mx):
+        ts = t + s * dt
+        k1 = f(x, ts); k2 = f(x + 0.5 * dt * k1, ts + 0.5 * dt); k3 = f(x + 0.5 * dt * k2, ts + 0.5 * dt); k4 = f(x + dt * k3, ts + dt)
+        x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return x
+
+
+def model_fy(p, x, u, d, t=0.0):
+    return _col(p.funcs["User_fym"](x, u, d, t, np.zeros(p.ny)), p.ny)
+
+
+def plant_fx(p, xp, u, t):
+    f = lambda x_, t_: _col(p.funcs["User_fxp_Cont"](x_, t_, u, np.zeros(p.nxp), np.zeros(p.nxp)), p.nxp)
+    dt = p.h / p.Mx
+    x = np.array(xp, dtype=np.float64)
+    for s in range(p.Mx):
+        ts = t + s * dt
+        k1 = f(x, ts); k2 = f(x + 0.5 * dt * k1, ts + 0.5 * dt); k3 = f(x + 0.5 * dt * k2, ts + 0.5 * dt); k4 = f(x + dt * k3, ts + dt)
+        x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return x
+
+
+def plant_fy(p, xp, u, t):
+    return _col(p.funcs["User_fyp"](xp, u, t, np.zeros(p.ny), np.zeros(p.ny)), p.ny)
+
+
+def _fd(fun, v, rel=1e-6):
+    v = np.asarray(v, dtype=np.float64)
+    f0 = fun(v)
+    J = np.zeros((f0.size, v.size))
+    for j in range(v.size):
+        e = np.zeros(v.size); e[j] = rel * max(1.0, abs(v[j]))
+        J[:, j] = (fun(v + e) - fun(v - e)) / (2.0 * e[j])
+    return J
+
+
+def linearize(p, x, u, d, t=0.0):
+    """A = dF/dx, B = dF/du, G = dF/dd of the discrete model at (x,u,d), and F itself."""
+    z = np.concatenate([x, u, d])
+    J = _fd(lambda v: model_fx(p, v[:p.nx], v[p.nx:p.nx + p.nu], v[p.nx + p.nu:], t), z)
+    return J[:, :p.nx], J[:, p.nx:p.nx + p.nu], J[:, p.nx + p.nu:], model_fx(p, x, u, d, t)
+
+
+def output_jac(p, x, u, d, t=0.0):
+    z = np.concatenate([x, d])
+    J = _fd(lambda v: model_fy(p, v[:p.nx], u, v[p.nx:], t), z)
+    return J[:, :p.nx], J[:, p.nx:]
+
+
+# ---------------------------------------------------------------------------------------------------
+# estimator: Estimator.py:313-386
+# ---------------------------------------------------------------------------------------------------
+def ekf(p, xi, Pm, y, u, t=0.0):
+    n = p.nx
+    x, d = xi[:n], xi[n:]
+    yhat = model_fy(p, x, u, d, t)
+    Cx, Cd = output_jac(p, x, u, d, t)
+    C = np.hstack([Cx, Cd])
+    K = Pm @ C.T @ np.linalg.inv(C @ Pm @ C.T + p.R_kf)
+    Pc = Pm - K @ C @ Pm
+    xi_c = xi + K @ (y - yhat)
+    A, _, G, _ = linearize(p, xi_c[:n], u, xi_c[n:], t)
+    Aa = np.block([[A, G], [np.zeros((p.nd, n)), np.eye(p.nd)]])
+    return xi_c, Aa @ Pc @ Aa.T + p.Q_kf
+
+
+# ---------------------------------------------------------------------------------------------------
+# a linear stand-in problem object for mpc_oracle's dense QP builders
+# ---------------------------------------------------------------------------------------------------
+class _Lin:
+    pass
+
+
+def _linear_view(p, A, B, c, C, e):
+    """The linear problem 'x+ = A x + B u + c, y = C x + e' with p's costs and bounds, in the attribute names mpc_oracle expects."""
+    q = _Lin()
+    q.nx, q.nu, q.ny, q.nd, q.N = p.nx, p.nu, p.ny, 0, p.N
+    q.A, q.B, q.C, q.fx_const, q.fy_const = A, B, C, c, e
+    q.Bd, q.Cd = np.zeros((p.nx, 0)), np.zeros((p.ny, 0))
+    q.Q, q.R, q.P, q.DUForm = p.Q, p.R, np.zeros((p.nx, p.nx)), False
+    q.Qss, q.Rss, q.DUssForm = p.Qss, p.Rss, False
+    for k in ("umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss"):
+        setattr(q, k, getattr(p, k))
+    q.y_bounded = bool(np.isfinite(p.ymin).any() or np.isfinite(p.ymax).any())
+    q.Dumin = q.Dumax = None
+    return q
+
+
+# ---------------------------------------------------------------------------------------------------
+# target: opt_ss for a non-linear model (Target_Calc.py:20-161), SQP on the linear target QP
+# ---------------------------------------------------------------------------------------------------
+def target_solve(p, usp, ysp, d, xs0, us0, tol=1e-10, max_sqp=30, t=0.0):
+    xs, us = np.array(xs0, dtype=np.float64), np.array(us0, dtype=np.float64)
+    for it in range(max_sqp):
+        A, B, _, F = linearize(p, xs, us, d, t)
+        Cx, _ = output_jac(p, xs, us, d, t)
+        c = F - A @ xs - B @ us
+        e = model_fy(p, xs, us, d, t) - Cx @ xs
+        q = _linear_view(p, A, B, c, Cx, e)
+        H, g, E, ee, G, lo, hi = o.target_qp(q, usp, ysp, np.zeros(p.nx), np.zeros(0), us)
+        r = o.qp_ipm_dense(H, g, E, ee, G, lo, hi, tol=1e-12)
+        if r["status"] != STATUS_SOLVED:
+            return dict(xs=xs, us=us, status=r["status"], sqp_iters=it)
+        w = r["w"]
+        step = max(np.abs(w[:p.nx] - xs).max(), np.abs(w[p.nx:p.nx + p.nu] - us).max())
+        xs, us = w[:p.nx].copy(), w[p.nx:p.nx + p.nu].copy()
+        if step < tol:
+            return dict(xs=xs, us=us, ys=model_fy(p, xs, us, d, t), status=STATUS_SOLVED, sqp_iters=it + 1)
+    return dict(xs=xs, us=us, ys=model_fy(p, xs, us, d, t), status=STATUS_MAXITER, sqp_iters=max_sqp)
+
+
+# ---------------------------------------------------------------------------------------------------
+# OCP: opt_dyn for a non-linear model (Control_Calc.py:20-260), SQP on a dense QP in opt_dyn's own order
+# ---------------------------------------------------------------------------------------------------
+def ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us):
+    """QP of one SQP iteration: min sum_k 1/2 (x_k-xs)'Q(x_k-xs) + 1/2 (u_k-us)'R(u_k-us), x_0 = xhat,
+    x_{k+1} = A_k x_k + B_k u_k + c_k, bounds on x_1..x_N and u, output rows ymin <= C x_k + e <= ymax for k = 1..N-1
+    (the k = 0 row constrains the given x_0: feasibility test made by the caller)."""
+    n, m, N = p.nx, p.nu, p.N
+    nxu = n + m; nw = nxu * N + n
+    ix = lambda k: slice(nxu * k, nxu * k + n)
+    iu = lambda k: slice(nxu * k + n, nxu * k + nxu)
+    H = np.zeros((nw, nw)); g = np.zeros(nw)
+    for k in range(N):
+        H[ix(k), ix(k)] += p.Q; g[ix(k)] += -p.Q @ xs
+        H[iu(k), iu(k)] += p.R; g[iu(k)] += -p.R @ us
+    E = np.zeros((n * (N + 1), nw)); ee = np.zeros(n * (N + 1))
+    E[0:n, ix(0)] = np.eye(n); ee[0:n] = xhat
+    for k in range(N):
+        r = slice(n * (k + 1), n * (k + 2))
+        E[r, ix(k)] = Ak[k]; E[r, iu(k)] = Bk[k]; E[r, ix(k + 1)] = -np.eye(n); ee[r] = -ck[k]
+    rows, lo, hi = [], [], []
+    for k in range(1, N + 1):
+        for i in range(n):
+            if np.isfinite(p.xmin[i]) or np.isfinite(p.xmax[i]):
+                row = np.zeros(nw); row[nxu * k + i] = 1.0; rows.append(row); lo.append(p.xmin[i]); hi.append(p.xmax[i])
+    for k in range(N):
+        for i in range(m):
+            if np.isfinite(p.umin[i]) or np.isfinite(p.umax[i]):
+                row = np.zeros(nw); row[nxu * k + n + i] = 1.0; rows.append(row); lo.append(p.umin[i]); hi.append(p.umax[i])
+    for k in range(1, N):
+        for i in range(p.ny):
+            if np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i]):
+                row = np.zeros(nw); row[ix(k)] = C[i]; rows.append(row); lo.append(p.ymin[i] - e[i]); hi.append(p.ymax[i] - e[i])
+    G = np.array(rows) if rows else np.zeros((0, nw))
+    return H, g, E, ee, G, np.array(lo, dtype=float), np.array(hi, dtype=float)
+
+
+def ocp_solve(p, xhat, xs, us, d, w_guess, max_sqp=50, tol=1e-9, t=0.0):
+    """SQP from the trajectory ``w_guess`` (opt_dyn's order).  ``max_sqp = 1`` is one real-time iteration.
+    Returns dict(u0, x1, w, status, sqp_iters, step)."""
+    n, m, N = p.nx, p.nu, p.N
+    nxu = n + m
+    w = np.array(w_guess, dtype=np.float64); w[:n] = xhat
+    y0 = model_fy(p, xhat, us, d, t)
+    rl = o.BOUND_RELAX * np.maximum(1.0, np.abs(p.ymin)); rh = o.BOUND_RELAX * np.maximum(1.0, np.abs(p.ymax))
+    if np.any(y0 < p.ymin - rl) or np.any(y0 > p.ymax + rh):
+        return dict(u0=None, x1=None, w=w, status=STATUS_INFEASIBLE, sqp_iters=0, step=np.inf)
+    step = np.inf
+    for it in range(max_sqp):
+        Ak, Bk, ck = [], [], []
+        for k in range(N):
+            xk, uk = w[nxu * k:nxu * k + n], w[nxu * k + n:nxu * (k + 1)]
+            A, B, _, F = linearize(p, xk, uk, d, t)
+            Ak.append(A); Bk.append(B); ck.append(F - A @ xk - B @ uk)
+        C, _ = output_jac(p, xhat, us, d, t)                      # outputs that are single states: constant selection rows
+        e = model_fy(p, xhat, us, d, t) - C @ xhat
+        H, g, E, ee, G, lo, hi = ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us)
+        r = o.qp_ipm_dense(H, g, E, ee, G, lo, hi, tol=1e-11)
+        if r["status"] == STATUS_INFEASIBLE:
+            return dict(u0=None, x1=None, w=w, status=STATUS_INFEASIBLE, sqp_iters=it, step=step)
+        pol = o.qp_polish(H, g, E, ee, G, lo, hi, r["w"], r["z_lo"], r["z_hi"]) if r["status"] == STATUS_SOLVED else None
+        wn = pol["w"] if pol is not None else r["w"]
+        step = float(np.abs(wn - w).max())
+        w = wn
+        if step < tol:
+            break
+    return dict(u0=w[n:n + m].copy(), x1=w[n + m:2 * n + m].copy(), w=w, status=STATUS_SOLVED if step < tol or max_sqp == 1 else STATUS_MAXITER,
+                sqp_iters=it + 1, step=step)
+
+
+def kkt_nlp(p, w, xhat, xs, us, d, t=0.0):
+    """Certificate of an OCP point against the NLP itself: dynamics defects and the least-squares stationarity residual
+    |grad f + J' lambda + bound multipliers| with multipliers fitted on the active set (bounds within 1e-7)."""
+    n, m, N = p.nx, p.nu, p.N
+    nxu = n + m; nw = w.size
+    defect = 0.0
+    Ak, Bk = [], []
+    for k in range(N):
+        xk, uk = w[nxu * k:nxu * k + n], w[nxu * k + n:nxu * (k + 1)]
+        A, B, _, F = linearize(p, xk, uk, d, t)
+        Ak.append(A); Bk.append(B)
+        defect = max(defect, np.abs(F - w[nxu * (k + 1):nxu * (k + 1) + n]).max())
+    C, _ = output_jac(p, xhat, us, d, t)
+    H, g, E, ee, G, lo, hi = ocp_qp_ltv(p, Ak, Bk, [np.zeros(n)] * N, C, np.zeros(p.ny), xhat, xs, us)
+    grad = H @ w + g
+    Gw = G @ w
+    act = (np.abs(Gw - lo) < 1e-7) | (np.abs(Gw - hi) < 1e-7)
+    M = np.vstack([E, G[act]]).T
+    lam = np.linalg.lstsq(M, -grad, rcond=None)[0]
+    return dict(defect=defect, stationarity=float(np.abs(grad + M @ lam).max()), n_active=int(act.sum()),
+                bound_violation=float(max(0.0, (lo - Gw).max(initial=0.0), (Gw - hi).max(initial=0.0))))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the closed loop, one instance: MPC_code.py:485-827
+# ---------------------------------------------------------------------------------------------------
+def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certify=False):
+    n, m, N = p.nx, p.nu, p.N
+    nxu = n + m
+    x = np.array(p.x0_p if x0_p is None else x0_p, dtype=np.float64)
+    xhat = np.array(p.x0_m if x0_m is None else x0_m, dtype=np.float64)
+    u = p.u0.copy(); dhat = p.dhat0.copy(); Pk = p.P0.copy()
+    xs, us = xhat.copy(), u.copy()
+    sched = p.schedules(nsteps)
+    w = np.concatenate([np.tile(np.concatenate([xhat, u]), N), xhat])          # :740-756
+    L = {k: [] for k in ("U", "X_HAT", "XS", "US", "Xp", "Yp", "D_HAT", "STATUS_DYN", "STATUS_SS", "SQP_DYN", "SQP_SS", "W",
+                              "KKT_DEFECT", "KKT_STAT", "KKT_VIOL")}
+    for k in range(nsteps):
+        t = k * p.h
+        L["Xp"].append(x.copy()); L["X_HAT"].append(xhat.copy())
+        y = plant_fy(p, x, u, t)                                               # :531-534
+        L["Yp"].append(y.copy())
+        xi, Pk = ekf(p, np.concatenate([xhat, dhat]), Pk, y, u, t)             # :577-650
+        xhat, dhat = xi[:n].copy(), xi[n:].copy()
+        if p.dmin is not None:
+            dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)               # :655-668
+        L["D_HAT"].append(dhat.copy())
+        us_prev, xs_prev = us.copy(), xs.copy()
+        tg = target_solve(p, sched["usp"][k], sched["ysp"][k], dhat, xs, us, t=t)   # :693-718
+        if tg["status"] != STATUS_INFEASIBLE:
+            xs, us = tg["xs"], tg["us"]
+        L["XS"].append(xs.copy()); L["US"].append(us.copy()); L["STATUS_SS"].append(tg["status"]); L["SQP_SS"].append(tg["sqp_iters"])
+        r = ocp_solve(p, xhat, xs, us, dhat, w, max_sqp=max_sqp, tol=sqp_tol, t=t)    # :733-805
+        L["W"].append(r["w"].copy())
+        if certify and r["status"] == STATUS_SOLVED:
+            c = kkt_nlp(p, r["w"], xhat, xs, us, dhat, t)
+            L["KKT_DEFECT"].append(c["defect"]); L["KKT_STAT"].append(c["stationarity"]); L["KKT_VIOL"].append(c["bound_violation"])
+        else:
+            L["KKT_DEFECT"].append(np.nan); L["KKT_STAT"].append(np.nan); L["KKT_VIOL"].append(np.nan)
+        if r["status"] != STATUS_INFEASIBLE:
+            u, xhat = r["u0"], r["x1"]                                         # :798-799
+            w = np.concatenate([r["w"][nxu:], us_prev, xs_prev])               # :764
+        else:
+            xhat = model_fx(p, xhat, u, dhat, t)                              # :804-805
+        L["U"].append(u.copy()); L["STATUS_DYN"].append(r["status"]); L["SQP_DYN"].append(r["sqp_iters"])
+        x = plant_fx(p, x, u, t)                                               # :813-816
+    return {k: np.array(v) for k, v in L.items()}

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/nmpc_cstr.npz (run in the build container; about ten minutes).
+
+The non-linear path's reference run needs CasADi + IPOPT, which are not installable here, and the reference ships no
+vectors for it: PARITY UNPINNED against a reference run.  The fixture comes from oracle/nmpc_oracle.py - SQP whose QPs are
+solved by the dense interior point + exact active-set polish of oracle/mpc_oracle.py - and is self-certifying for the
+converged mode: every OCP row carries the residuals of the NLP's own KKT conditions (dynamics defect of the RK4 model,
+stationarity with multipliers fitted on the active set, bound violation), the conditions IPOPT terminates on.
+
+  rti_*   one real-time iteration per step (max_sqp = 1), 40 steps (crossing the feed-flow change at t = 5), 3 instances
+  sqp_*   every OCP iterated to its KKT point (tolerance 1e-9 on the trajectory step), 8 steps, 2 instances
+Instance 0 is the shipped start; the others start from perturbed plant/model states.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mpc_code_amd as m          # noqa: E402
+import nmpc_oracle as no          # noqa: E402
+
+
+def starts(p, n):
+    rng = np.random.default_rng(20240611)
+    x0 = np.tile(p.x0_p, (n, 1))
+    x0[1:] += rng.uniform(-1.0, 1.0, size=(n - 1, p.nx)) * np.array([0.02, 2.0, 0.02])
+    return x0
+
+
+def run(p, nsteps, x0s, **kw):
+    logs = [no.closed_loop(p, nsteps, x0_p=x0, x0_m=x0, **kw) for x0 in x0s]
+    return {k: np.stack([lg[k] for lg in logs], axis=1) for k in logs[0]}
+
+
+def main():
+    p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "cstr_nmpc.py"))
+    out = {}
+    t0 = time.time()
+    x0 = starts(p, 3)
+    r = run(p, 40, x0, max_sqp=1)
+    out.update({"rti_" + k: v for k, v in r.items()}); out["rti_x0"] = x0
+    print("rti", time.time() - t0, flush=True)
+    r = run(p, 8, x0[:2], max_sqp=50, sqp_tol=1e-9, certify=True)
+    out.update({"sqp_" + k: v for k, v in r.items()}); out["sqp_x0"] = x0[:2]
+    print("sqp", time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "nmpc_cstr.npz"), **out)
+    for k, v in out.items():
+        print(k, v.shape)
+    print("max KKT: defect", out["sqp_KKT_DEFECT"].max(), "stationarity", out["sqp_KKT_STAT"].max(), "violation", out["sqp_KKT_VIOL"].max())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,244 @@
+"""Non-linear path (BASELINE config 3): tracer, Ex-file loading, oracle against its committed
+vectors, and - on the GPU - libmpc_nmpc_<model>.so against them.
+
+tests/golden/nmpc_cstr.npz comes from oracle/nmpc_oracle.py (tests/golden/make_nmpc_golden.py); its converged rows carry the
+residuals of the NLP's own KKT conditions.  Parity against a reference run is unpinned: CasADi/IPOPT are absent here.
+"""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REF, ROOT, gpu_available
+
+GOLD = os.path.join(ROOT, "tests", "golden", "nmpc_cstr.npz")
+
+
+@pytest.fixture(scope="module")
+def nl(pkg):
+    return pkg.load_problem(pkg.example_path("cstr_nmpc.py"))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def sample(p, n=6, seed=0):
+    rng = np.random.default_rng(seed)
+    x = p.x0_m + rng.normal(size=(n, p.nx)) * [0.02, 3.0, 0.02]
+    u = p.u0 + rng.normal(size=(n, p.nu)) * [2.0, 0.02]
+    d = p.dhat0 + rng.normal(size=(n, p.nd)) * [0.01, 0.01]
+    return x, u, d
+
+
+# ------------------------------------------------------------------------------------------------- host logic (CPU)
+def test_example_is_classified_as_nonlinear(pkg, nl):
+    from mpc_code_amd.nlproblem import NonlinearMPCProblem
+    assert isinstance(nl, NonlinearMPCProblem)
+    assert (nl.nx, nl.nu, nl.ny, nl.nd, nl.nxp, nl.N, nl.h, nl.Mx, nl.Nsim) == (3, 2, 2, 2, 3, 30, 0.2, 10, 201)
+    assert nl.ycols == [0, 2] and nl.nw == 3 * 31 + 2 * 30
+    assert np.array_equal(nl.schedules(3)["ysp"], np.tile([0.874317, 0.6528], (3, 1)))
+
+
+def test_traced_model_equals_the_user_functions(nl):
+    """The DAG evaluated with NumPy gives what the Ex-file's own Python functions give on floats."""
+    import math
+    from mpc_code_amd import symtrace as st
+    x, u, d = sample(nl)
+    for i in range(x.shape[0]):
+        vals = nl._vals(x=x[i], u=u[i], d=d[i], t=0.3)
+        got = np.array([float(v) for v in st.evaluate(nl.f, vals)])
+        # the same balance equations written out directly
+        area = math.pi * 0.219 ** 2; k = 7.2e10 * math.exp(-8750 / 350) * math.exp(-8750 * (1 / x[i, 1] - 1 / 350)) * x[i, 0]
+        ref = np.array([d[i, 1] * (1.0 - x[i, 0]) / (area * x[i, 2]) - k,
+                        d[i, 1] * (350 - x[i, 1]) / (area * x[i, 2]) + 5.0e4 / (1000.0 * 0.239) * k + 2 * (915.6 * 60 / 1000) / (0.219 * 1000.0 * 0.239) * (u[i, 0] - x[i, 1]),
+                        (d[i, 1] - u[i, 1]) / area])
+        assert np.allclose(got, ref, rtol=1e-13, atol=0)
+
+
+def test_symbolic_jacobians_against_central_differences(nl):
+    from mpc_code_amd import symtrace as st
+    x, u, d = sample(nl, 3, seed=1)
+    for i in range(3):
+        f = lambda xx, uu, dd: np.array([float(v) for v in st.evaluate(nl.f, nl._vals(x=xx, u=uu, d=dd, t=0.0))])
+        J = np.array([[float(st.evaluate([e], nl._vals(x=x[i], u=u[i], d=d[i], t=0.0))[0]) for e in row] for row in nl.f_x])
+        for j in range(nl.nx):
+            hstep = 1e-6 * max(1.0, abs(x[i, j])); e = np.zeros(nl.nx); e[j] = hstep
+            fd = (f(x[i] + e, u[i], d[i]) - f(x[i] - e, u[i], d[i])) / (2 * hstep)
+            assert np.allclose(J[:, j], fd, rtol=1e-6, atol=1e-7)
+        Jd = np.array([[float(st.evaluate([e], nl._vals(x=x[i], u=u[i], d=d[i], t=0.0))[0]) for e in row] for row in nl.f_d])
+        for j in range(nl.nd):
+            hstep = 1e-7; e = np.zeros(nl.nd); e[j] = hstep
+            fd = (f(x[i], u[i], d[i] + e) - f(x[i], u[i], d[i] - e)) / (2 * hstep)
+            assert np.allclose(Jd[:, j], fd, rtol=1e-6, atol=1e-7)
+
+
+def test_if_else_is_traced_as_a_select(nl):
+    """The plant's feed flow steps at t = 5, 15, 25 (Ex_NMPC.py:55): the traced plant follows the schedule."""
+    x = nl.x0_p[None]; u = nl.u0[None]
+    a, b, c = (nl.plant_step(x, u, t)[0, 2] for t in (1.0, 8.0, 20.0))
+    assert abs(a - x[0, 2]) < 1e-12 and b > a + 1e-3 and c < a - 1e-3      # level: steady, filling (0.15 in), draining (0.08 in)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_same_problem_as_the_reference_example(pkg, nl):
+    """The reference's Ex_NMPC.py loads unmodified and defines the same problem as examples/cstr_nmpc.py."""
+    ref = pkg.load_problem(os.path.join(REF, "Ex_NMPC.py"), overrides={"N": 30})
+    for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "dmin", "dmax", "Q_kf", "R_kf", "P0", "x0_p", "x0_m",
+              "u0", "dhat0", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss"):
+        assert np.array_equal(getattr(ref, k), getattr(nl, k)), k
+    assert (ref.nx, ref.nu, ref.ny, ref.nd, ref.nxp, ref.h, ref.Mx, ref.Nsim, ref.ycols) == (nl.nx, nl.nu, nl.ny, nl.nd, nl.nxp, nl.h, nl.Mx, nl.Nsim, nl.ycols)
+    import nmpc_oracle as no
+    x, u, d = sample(nl, 4, seed=2)
+    for i in range(4):
+        assert np.allclose(no.model_fx(ref, x[i], u[i], d[i]), no.model_fx(nl, x[i], u[i], d[i]), rtol=1e-13, atol=0)
+        for t in (0.0, 7.0, 30.0):
+            assert np.allclose(no.plant_fx(ref, x[i], u[i], t), no.plant_fx(nl, x[i], u[i], t), rtol=1e-13, atol=0)
+
+
+def test_unsupported_nonlinear_features_are_refused(pkg, tmp_path):
+    src = open(pkg.example_path("cstr_nmpc.py")).read()
+    f = tmp_path / "ex_slacks.py"; f.write_text(src.replace("slacks = False", "slacks = True"))
+    with pytest.raises(pkg.UnsupportedProblem):
+        pkg.load_problem(str(f))
+    f = tmp_path / "ex_lin.py"; f.write_text(src.replace('offree = "nl"', 'offree = "no"'))
+    with pytest.raises(pkg.UnsupportedProblem):
+        pkg.load_problem(str(f))
+
+
+# ------------------------------------------------------------------------------------------------- oracle (CPU)
+def test_oracle_reproduces_its_golden_rows(nl, gold):
+    import nmpc_oracle as no
+    r = no.closed_loop(nl, 3, x0_p=gold["rti_x0"][1], x0_m=gold["rti_x0"][1], max_sqp=1)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        assert np.allclose(r[k], gold["rti_" + k][:3, 1], rtol=1e-10, atol=1e-10), k
+
+
+def test_golden_converged_rows_satisfy_the_nlp_kkt_conditions(nl, gold):
+    """Re-verify the certificate without trusting any solver: dynamics defect, stationarity and bounds of the NLP
+    (Control_Calc.py:20-260) at the stored trajectories."""
+    import nmpc_oracle as no
+    assert np.all(gold["sqp_STATUS_DYN"] == 0)
+    assert gold["sqp_KKT_DEFECT"].max() < 1e-10 and gold["sqp_KKT_STAT"].max() < 1e-8 and gold["sqp_KKT_VIOL"].max() < 1e-10
+    k, b = 0, 1
+    w = gold["sqp_W"][k, b]
+    c = no.kkt_nlp(nl, w, w[:nl.nx], gold["sqp_XS"][k, b], gold["sqp_US"][k, b], gold["sqp_D_HAT"][k, b], 0.0)
+    assert c["defect"] < 1e-10 and c["stationarity"] < 1e-8 and c["bound_violation"] < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------- generated code and the C-ABI (CPU)
+@pytest.fixture(scope="module")
+def nmpc_lib(nl):
+    from mpc_code_amd import nlcodegen
+    return nlcodegen.build_nmpc_library(nl)
+
+
+def test_generated_header_is_straight_line_code(nl):
+    from mpc_code_amd import nlcodegen
+    text = nlcodegen.emit_model_header(nl)
+    for fn in ("f(", "f_jac(", "h(", "h_jac(", "fp(", "hp("):
+        assert "void " + fn in text
+    assert "NX = 3, NU = 2, NY = 2, ND = 2, NXP = 3, MX = 10" in text
+    assert text.count("exp(") <= 8          # shared sub-expressions: one Arrhenius term per function, not one per use
+    assert "?" in text                      # the feed-flow schedule became selects
+
+
+def test_nmpc_library_exports_the_header(nmpc_lib):
+    from mpc_code_amd import nmpc
+    hdr = open(os.path.join(ROOT, "include", "mpc_nmpc.h")).read()
+    declared = set(re.findall(r"\b(nmpc_[a-z_]+)\s*\(", hdr))
+    assert declared == set(nmpc.NMPC_EXPORTS), declared ^ set(nmpc.NMPC_EXPORTS)
+    lib = ct.CDLL(nmpc_lib)
+    for s in declared:
+        assert hasattr(lib, s), s
+    lib.nmpc_build_info.restype = ct.c_char_p
+    assert lib.nmpc_build_info().decode() == "gfx950;nmpc;dims=3/2/2/2/3;mx=10"
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU error path")
+def test_nmpc_create_fails_loudly_without_a_gpu(nl, nmpc_lib):
+    from mpc_code_amd import nmpc
+    from mpc_code_amd.capi import MpcAmdError
+    with pytest.raises(MpcAmdError, match="no HIP device"):
+        nmpc.NmpcSolver(nl, lib_path=nmpc_lib)
+
+
+# ------------------------------------------------------------------------------------------------- GPU parity
+@pytest.fixture(scope="module")
+def solver(nl):
+    from mpc_code_amd import nmpc
+    s = nmpc.NmpcSolver(nl)
+    yield s
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,max_sqp", [("rti", 1), ("sqp", 50)])
+def test_gpu_closed_loop_equals_the_golden_vectors(nl, gold, solver, mode, max_sqp):
+    """Real-time iteration over 40 steps (feed-flow change at step 25 included) and converged SQP over 8 steps.
+    Tolerance: 1e-9 relative to 1 + |value| per step would be the solver tolerance; errors carry through the closed
+    loop, so 2e-7 over the whole run (measured: 3e-9 / 2e-10)."""
+    from mpc_code_amd import nmpc
+    x0 = gold[mode + "_x0"]; ns = gold[mode + "_U"].shape[0]
+    r = nmpc.run_nmpc_closed_loop(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=max_sqp, sqp_tol=1e-9)
+    assert np.array_equal(r["STATUS_DYN"], gold[mode + "_STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], gold[mode + "_STATUS_SS"])
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "Yp"):
+        g = gold[f"{mode}_{k}"]
+        assert np.max(np.abs(r[k] - g) / (1.0 + np.abs(g))) < 2e-7, k
+    if mode == "rti":
+        assert np.all(r["SQP_DYN"] == 1)
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_batch_properties(nl, gold, solver):
+    """BASELINE configs[3]: B = 16384, N = 30.  Instance 0 is the golden instance; the rest start in a box around it.
+    Properties: every status solved, inputs and predicted states within their bounds, results independent of the position in
+    the batch (bit for bit), the golden instance reproduced."""
+    from mpc_code_amd import nmpc
+    B, ns = 16384, 30
+    rng = np.random.default_rng(7)
+    x0 = np.tile(nl.x0_p, (B, 1)); x0[1:] += rng.uniform(-1, 1, size=(B - 1, 3)) * [0.02, 2.0, 0.02]
+    r = nmpc.run_nmpc_closed_loop(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=1)
+    assert np.all(r["STATUS_DYN"] == 0) and np.all(r["STATUS_SS"] == 0)
+    assert all(np.isfinite(r[k]).all() for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"))
+    assert np.all(r["U"] >= nl.umin - 1e-7) and np.all(r["U"] <= nl.umax + 1e-7)
+    assert np.all(r["XS"] >= nl.xmin_ss - 1e-7) and np.all(r["XS"] <= nl.xmax_ss + 1e-7)
+    g = gold["rti_U"][:ns, 0]
+    assert np.max(np.abs(r["U"][:, 0] - g) / (1 + np.abs(g))) < 2e-7
+    perm = rng.permutation(B)
+    r2 = nmpc.run_nmpc_closed_loop(nl, x0[perm], x0[perm], nsteps=ns, solver=solver, max_sqp=1)
+    for k in ("U", "X_HAT", "Xp", "D_HAT"):
+        assert np.array_equal(r2[k], r[k][:, perm]), k
+    # the feed-flow step at t = 5 is rejected: by the end of the run the level is back at its set point
+    assert np.abs(r["Xp"][-1, :, 2] - 0.6528).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_gpu_launch_chunks_continue_the_same_loop(nl, solver):
+    """Two launches of 5 steps continue the resident state exactly as one launch of 10."""
+    B = 128
+    rng = np.random.default_rng(3)
+    x0 = np.tile(nl.x0_p, (B, 1)) + rng.uniform(-1, 1, size=(B, 3)) * [0.02, 2.0, 0.02]
+    sched = nl.schedules(10)
+    solver.alloc(B, 10); solver.set_state(x0, x0); solver.set_schedule(sched)
+    solver.run(0, 10, 1, 1e-9); solver.sync()
+    a = solver.get_log("U").copy()
+    solver.alloc(B, 10); solver.set_state(x0, x0); solver.set_schedule(sched)
+    solver.run(0, 5, 1, 1e-9); solver.run(5, 5, 1, 1e-9); solver.sync()
+    assert np.array_equal(solver.get_log("U"), a)
+
+
+@pytest.mark.gpu
+def test_gpu_error_paths(nl, solver):
+    from mpc_code_amd.capi import MpcAmdError
+    solver.alloc(4, 3)
+    with pytest.raises(MpcAmdError, match="nmpc_set_state first"):
+        solver.set_schedule(nl.schedules(3)); solver.run(0, 3)
+    solver.set_state(np.tile(nl.x0_p, (4, 1)), np.tile(nl.x0_m, (4, 1)))
+    with pytest.raises(MpcAmdError, match="outside the schedule"):
+        solver.run(0, 4)
+    with pytest.raises(MpcAmdError, match="max_sqp"):
+        solver.run(0, 3, 0)
