@@ -194,13 +194,13 @@ def test_gpu_closed_loop_equals_the_golden_vectors(nl, gold, solver, mode, max_s
 
 @pytest.mark.gpu
 def test_gpu_full_size_batch_properties(nl, gold, solver):
-    """BASELINE configs[3]: B = 16384, N = 30.  Instance 0 is the golden instance; the rest start in a box around it.
+    """BASELINE configs[3]: B = 16384, N = 30.  Instance 0 is the golden instance; the rest start in the box of SURVEY.md 8d cfg 3.
     Properties: every status solved, inputs and predicted states within their bounds, results independent of the position in
     the batch (bit for bit), the golden instance reproduced."""
     from mpc_code_amd import nmpc
     B, ns = 16384, 30
     rng = np.random.default_rng(7)
-    x0 = np.tile(nl.x0_p, (B, 1)); x0[1:] += rng.uniform(-1, 1, size=(B - 1, 3)) * [0.02, 2.0, 0.02]
+    x0 = np.tile(nl.x0_p, (B, 1)); x0[1:] *= 1.0 + 0.02 * rng.uniform(-1, 1, size=(B - 1, 3))      # SURVEY.md 8d cfg 3
     r = nmpc.run_nmpc_closed_loop(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=1)
     assert np.all(r["STATUS_DYN"] == 0) and np.all(r["STATUS_SS"] == 0)
     assert all(np.isfinite(r[k]).all() for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"))
@@ -212,8 +212,9 @@ def test_gpu_full_size_batch_properties(nl, gold, solver):
     r2 = nmpc.run_nmpc_closed_loop(nl, x0[perm], x0[perm], nsteps=ns, solver=solver, max_sqp=1)
     for k in ("U", "X_HAT", "Xp", "D_HAT"):
         assert np.array_equal(r2[k], r[k][:, perm]), k
-    # the feed-flow step at t = 5 is rejected: by the end of the run the level is back at its set point
-    assert np.abs(r["Xp"][-1, :, 2] - 0.6528).max() < 0.02
+    # the controlled loop contracts: 30 steps on, the level of every instance follows the same response to the feed-flow step
+    # at t = 5, whatever its start in the box
+    assert np.ptp(r["Xp"][-1, :, 2]) < 1e-3 and np.ptp(x0[:, 2]) > 0.02
 
 
 @pytest.mark.gpu
