@@ -66,6 +66,9 @@ typedef struct mpc_lin_desc {
     /* bounds on u_k - u_{k-1} (k = 0: u_0 - u_prev), the g2 rows of opt_dyn, Control_Calc.py:163-169,241-243; NULL = none.  The
      * problem then runs in the stage form with input v = u_k - u_{k-1} and state [x; u_prev] (kernel set du = 1) */
     const double *Dumin, *Dumax;
+    /* terminal equality x_N = xs of opt_dyn (TermCons, Control_Calc.py:197-198); 0 = none.  P is ignored then (the terminal cost is
+     * zero on the constraint) */
+    int32_t term_cons;
 } mpc_lin_desc;
 
 /* Replaces the construction nlpsol('solver','ipopt',...) of Control_Calc.py:256-258 and

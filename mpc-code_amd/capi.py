@@ -41,7 +41,7 @@ class _Desc(ct.Structure):
                [(k, _dp) for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp",
                                    "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax",
                                    "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss",
-                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")]
+                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")] + [("term_cons", ct.c_int32)]
 
 
 def jit_library_path(dims) -> str:
@@ -163,6 +163,7 @@ class Solver:
         d.nx, d.nu, d.ny, d.nd, d.nxp, d.N = p.nx, p.nu, p.ny, p.nd, p.nxp, p.N
         d.du_form, d.duss_form, d.y_bounded = int(p.DUForm), int(p.DUssForm), int(p.y_bounded)
         d.estimator, d.max_iter, d.device = _EST[p.estimator], int(p.max_iter), int(device)
+        d.term_cons = int(bool(getattr(p, "TermCons", False)))
         for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp", "Q", "R", "P", "Qss", "Rss",
                   "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss",
                   "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax"):

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
     double u0[NU], z1[NS], res[3];
     int it;
-    const int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it);
+    int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it);
+    if (P.term_cons && st != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st = kInfeasible;
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
         MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
         const bool warm = ws_valid && delta <= kWsDelta;
-        const int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, delta, u0, z1, res, it_dyn);
+        int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, delta, u0, z1, res, it_dyn);
+        if (P.term_cons && st_dyn != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st_dyn = kInfeasible;
         ws_valid = st_dyn == kSolved;
         if (st_dyn != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];          // :798
@@ -425,6 +427,12 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
         int st_dyn, it_dyn;
         MPC_TSTAMP(0);
         tp_solve<NS, NU, DU, NC, MASKED, NW, IPW>(P, sh, wsg, P.max_iter, st_dyn, it_dyn);
+        if (valid && P.term_cons && st_dyn != kInfeasible) {      // terminal equality missed: unreachable (mpc_device.hpp:term_missed)
+            const double *fin_rows = wsg + (size_t)lane * Cfg::ROWS_ST * 64, *qd = sh.q + lane * Cfg::QN;
+            double v = 0.0;
+            MPC_UNROLL for (int i = 0; i < NX; i++) v = dmax(v, fabs(fin_rows[(Cfg::ST_Z + i) * 64 + P.N - 1] - qd[NS + i]) * frcp(dmax(1.0, fabs(qd[NS + i]))));
+            if (!(v <= P.term_tol)) st_dyn = kInfeasible;
+        }
         if (valid) {
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
             double x[NXP], xh[NX], u[NU];
@@ -658,11 +666,19 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
                 MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = a_get(X[j].z[i]);
             }
         }
+        if (P.term_cons && lane == P.N - 1) {      // terminal equality (mpc_device.hpp:term_missed): the last block is lane N - 1
+            MPC_UNROLL for (int j = 0; j < NI; j++) {
+                double v = 0.0;
+                MPC_UNROLL for (int i = 0; i < NX; i++) { const double zr = q[j * Cfg::QN + NS + i]; v = dmax(v, fabs(a_get(X[j].z[i]) - zr) * frcp(dmax(1.0, fabs(zr)))); }
+                outv[j * Cfg::OUT + NU + NS] = v;
+            }
+        }
         __syncthreads();
         if (valid) {
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
             int st_dyn = S[0].status, it_dyn = S[0].iters;
             MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st_dyn = S[j].status; it_dyn = S[j].iters; } }
+            if (P.term_cons && st_dyn != kInfeasible && !(outv[lane * Cfg::OUT + NU + NS] <= P.term_tol)) st_dyn = kInfeasible;
             double x[NXP], xh[NX], u[NU];
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = kp[KC::K_U + i];
@@ -794,11 +810,17 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
             MPC_UNROLL for (int i = 0; i < NU; i++) outv[j * Cfg::OUT + i] = Xf.u[i];
             MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = Xf.z[i];
         }
+        if (P.term_cons && lane == P.N - 1) {      // terminal equality (mpc_device.hpp:term_missed)
+            double v = 0.0;
+            MPC_UNROLL for (int i = 0; i < NX; i++) { const double zr = q[j * Cfg::QN + NS + i]; v = dmax(v, fabs(Xf.z[i] - zr) * frcp(dmax(1.0, fabs(zr)))); }
+            outv[j * Cfg::OUT + NU + NS] = v;
+        }
     }
     __syncthreads();
     if (valid) {
         int st = S[0].status, it = S[0].iters; double r0 = S[0].res_s, r1 = S[0].res_p, r2 = S[0].mu;
         MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st = S[j].status; it = S[j].iters; r0 = S[j].res_s; r1 = S[j].res_p; r2 = S[j].mu; } }
+        if (P.term_cons && st != kInfeasible && !(outv[lane * Cfg::OUT + NU + NS] <= P.term_tol)) st = kInfeasible;
         a.status[b] = st; a.iters[b] = it;
         a.res[0 * Bs + b] = r0; a.res[1 * Bs + b] = r1; a.res[2 * Bs + b] = r2;
         w.valid[b] = st == kSolved ? 1 : 0;
@@ -1085,6 +1107,16 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
     for (int i = 0; i < m; i++) {
         for (int j = 0; j < m; j++) P.R[i][j] = d->R[i * m + j];
         P.ulo[i] = d->umin[i]; P.uhi[i] = d->umax[i];
+    }
+    if (d->term_cons) {
+        // Terminal equality x_N = xs (Control_Calc.py:197-198) through the terminal weight: rho (x_N - xs) is the multiplier of the
+        // equality, the optimum is the constrained one up to |multiplier| / rho (mpc_device.hpp:term_missed decides "unreachable")
+        double scale = 1.0;
+        for (int i = 0; i < n0 * n0; i++) scale = std::fmax(scale, std::fabs(d->Q[i]));
+        for (int i = 0; i < m * m; i++) scale = std::fmax(scale, std::fabs(d->R[i]));
+        for (int i = 0; i < n0; i++) for (int j = 0; j < n0; j++) P.Pf[i][j] = i == j ? 1e12 * scale : 0.0;
+        P.term_cons = 1; P.term_tol = 1e-6; P.term_gcap = 1e3 * scale;
+        P.term_floor = 8.0 * 2.2e-16 * P.Pf[0][0];      // a few units in the last place of x_N (|x| of order one to ten) times the weight
     }
     if (du_bounded(d)) {
         // Bounds on u_k - u_{k-1} (g2 rows, Control_Calc.py:163-169,241-243): stage form with input v_k = u_k - u_{k-1} and state

@@ -47,6 +47,7 @@ enum : int { kSolved = 0, kMaxIter = 1, kInfeasible = 2 };
 // is a scalar load, whatever the kernel has stored to global memory in between
 struct DevProblem {
     int nx, nu, ny, nd, nxp, N, du_form, duss_form, y_bounded, estimator, max_iter, has_dsat;
+    int term_cons; double term_tol, term_gcap, term_floor;      // terminal equality x_N = xs (Control_Calc.py:197-198): Pf carries the weight that enforces it, the residual above term_tol means unreachable
     int in_is_du, zr_us;      // stage input is v = u - u_prev (bounds on it exist); reference of the u_prev states is us (cost on u - us)
     // stage form (z = x, or [x; u_prev] when du_form)
     double A[kMaxN][kMaxN], B[kMaxN][kMaxM], Q[kMaxN][kMaxN], M[kMaxN][kMaxM], R[kMaxM][kMaxM], Pf[kMaxN][kMaxN];
@@ -565,14 +566,18 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         MPC_STAMP(1);  // B1
         // ---- convergence / failure tests at the current iterate ------------------------------------
         const double mu = mu_sum * inv_ncon;
-        if (it == 0) gscale = dmax(1.0, res_s);
+        // the scale of the stationarity test is the first residual - without the terminal weight's share when that weight stands for
+        // the terminal equality (a shifted warm start misses xs by a little, times 1e14)
+        if (it == 0) gscale = dmax(1.0, P.term_cons ? dmin(res_s, P.term_gcap) : res_s);
         res[0] = res_s; res[1] = res_p; res[2] = mu;
         iters = it;
         MPC_UNROLL for (int i = 0; i < NU; i++) u0[i] = ublk[i];
         MPC_UNROLL for (int i = 0; i < NS; i++) z1[i] = zblk[i];
         const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         stall = ok_cp ? stall + 1 : 0;
-        if (ok_cp && (res_s <= kTolStat * gscale || (stall > kStallMax && res_s <= kTolStatAcc * gscale))) { status = kSolved; break; }
+        // term_floor (zero without a terminal equality): the terminal weight times one unit in the last place of x_N, below which
+        // the residual of a representable iterate cannot go
+        if (ok_cp && (res_s <= kTolStat * gscale + P.term_floor || (stall > kStallMax && res_s <= kTolStatAcc * gscale + P.term_floor))) { status = kSolved; break; }
         if (lmax > kInfeasZ * gscale || !(fabs(mu) < 1.0e300) || !pd_ok) { status = kInfeasible; break; }
         if (it == max_iter) { status = kMaxIter; break; }
 
@@ -761,6 +766,20 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
 #undef MPC_BOUNDS
 #undef MPC_LOAD_AB
     return status;
+}
+
+// Terminal equality x_N = xs (TermCons, Control_Calc.py:197-198).  It is imposed through the terminal weight (mpc_amd.hip:build_problem:
+// Pf = rho I on the model states, rho = 1e12 x the cost scale - the multiplier of the equality is then rho (x_N - xs), the optimum
+// differs from the equality-constrained one by |multiplier| / rho, below the solver's own tolerance); a final iterate that still
+// misses xs is the reference's 'Infeasible_Problem_Detected': the bounds do not let the horizon reach it.
+template <int NS, int NU, int NC, int NX>
+__device__ __forceinline__ bool term_missed(const DevProblem &P, const Ws &ws, const OcpInst<NS, NU> &q)
+{
+    using L = BlkLayout<NS, NU, NC>;
+    double zN[NS], v = 0.0;
+    ld_field<NS>(ws.blk(P.N - 1), L::Z, zN);
+    MPC_UNROLL for (int i = 0; i < NX; i++) v = dmax(v, fabs(zN[i] - q.zr[i]) * frcp(dmax(1.0, fabs(q.zr[i]))));
+    return !(v <= P.term_tol);
 }
 
 // --------------------------------------------------------------------------------------------------------

@@ -252,11 +252,11 @@ __device__ void tp_solve(const DevProblem &P, const TpShared<NS, NU, NC, NW, IPW
         const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
         const double res_s = wave_max(blk_on ? rs_p : 0.0);
         S.mu = S.mu_sum * S.inv_ncon;
-        if (it == 0) S.gscale = dmax(1.0, res_s);
+        if (it == 0) S.gscale = dmax(1.0, P.term_cons ? dmin(res_s, P.term_gcap) : res_s);      // mpc_device.hpp:rpdip_lane
         const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         S.stall = ok_cp ? S.stall + 1 : 0;
         int verdict = 0;
-        if (ok_cp && (res_s <= kTolStat * S.gscale || (S.stall > kStallMax && res_s <= kTolStatAcc * S.gscale))) verdict = 1 + kSolved;
+        if (ok_cp && (res_s <= kTolStat * S.gscale + P.term_floor || (S.stall > kStallMax && res_s <= kTolStatAcc * S.gscale + P.term_floor))) verdict = 1 + kSolved;
         else if (lmax > kInfeasZ * S.gscale || !(fabs(S.mu) < 1.0e300)) verdict = 1 + kInfeasible;
         else if (it == max_iter) verdict = 1 + kMaxIter;
         if (verdict != 0) S.on = false;

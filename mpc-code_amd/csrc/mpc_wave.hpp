@@ -44,7 +44,7 @@ struct WvCfg {
     __host__ __device__ static constexpr int t_doubles(int N) { return GUARD + ROWS * NI * ld(N); }
     static constexpr int QN = 5 * NS + 2 * NU + 1;                     // z0 zr c zlo zhi | ur us | ws_delta
     static constexpr int ROWS_WS = NU + 2 * NC;                        // warm start kept in HBM between launches: u | l_lo | l_hi
-    static constexpr int OUT = NU + NS;                                // first input / next state of the final iterate
+    static constexpr int OUT = NU + NS + 1;                            // first input / next state of the final iterate, terminal miss
     __host__ __device__ static constexpr size_t lds_doubles(int keep_per_inst, int N) { return (size_t)t_doubles(N) + NI * QN + NI * OUT + NI * keep_per_inst; }
 };
 
@@ -202,11 +202,11 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
         const double res_s = wave_max(blk_on ? rs_p : 0.0);
         Sj.mu = Sj.mu_sum * Sj.inv_ncon; Sj.res_s = res_s; Sj.res_p = res_p;
-        if (it == 0) Sj.gscale = dmax(1.0, res_s);
+        if (it == 0) Sj.gscale = dmax(1.0, P.term_cons ? dmin(res_s, P.term_gcap) : res_s);      // mpc_device.hpp:rpdip_lane
         const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         Sj.stall = ok_cp ? Sj.stall + 1 : 0;
         int verdict = -1;
-        if (ok_cp && (res_s <= kTolStat * Sj.gscale || (Sj.stall > kStallMax && res_s <= kTolStatAcc * Sj.gscale))) verdict = kSolved;
+        if (ok_cp && (res_s <= kTolStat * Sj.gscale + P.term_floor || (Sj.stall > kStallMax && res_s <= kTolStatAcc * Sj.gscale + P.term_floor))) verdict = kSolved;
         else if (lmax > kInfeasZ * Sj.gscale || !(fabs(Sj.mu) < 1.0e300)) verdict = kInfeasible;
         else if (it == max_iter) verdict = kMaxIter;
         if (verdict >= 0) { Sj.on = false; Sj.status = verdict; Sj.iters = it; }

@@ -121,6 +121,7 @@ class LinearMPCProblem:
     # with Mx sub-steps per sampling interval; the controller path (estimator, target, OCP) stays linear.
     plant_fx_cont: Optional[Callable] = None
     plant_Mx: int = 10
+    TermCons: bool = False    # terminal equality x_N = xs (Control_Calc.py:197-198)
 
     # ------------------------------------------------------------------ schedules
     def schedules(self, nsteps: int, k0: int = 0) -> Dict[str, np.ndarray]:
@@ -199,7 +200,7 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         if _has(ns, bad) and ns[bad] is not None:
             raise UnsupportedProblem(f"'{bad}' is outside the batched linear hot path (later scope row)")
     for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks",
-                 "TermCons", "mhe", "ekf", "estimating", "ContForm", "DUFormEcon"):
+                 "mhe", "ekf", "estimating", "ContForm", "DUFormEcon"):
         if ns.get(flag, False) is True:
             raise UnsupportedProblem(f"flag {flag}=True is outside the batched linear hot path")
     if not ns.get("LinPar", True):
@@ -322,5 +323,6 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         defSP=ns.get("defSP"), def_pxp=ns.get("def_pxp"), def_pyp=ns.get("def_pyp"),
         name=name or str(ns.get("__name__", "")),
         plant_fx_cont=ns["User_fxp_Cont"] if nl_plant else None, plant_Mx=int(ns.get("Mx", 10)),
+        TermCons=bool(ns.get("TermCons", False)),
     )
     return prob

@@ -127,6 +127,9 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
         E[r, iu(k)] = p.B
         E[r, ix(k + 1)] = -np.eye(n)
         e[r] = -c
+    if getattr(p, "TermCons", False):          # g.append(X[N] - xs), Control_Calc.py:193-198
+        Et = np.zeros((n, nw)); Et[:, ix(N)] = np.eye(n)
+        E = np.vstack([E, Et]); e = np.concatenate([e, xs])
     # inequalities
     rows, lo, hi = [], [], []
     for k in range(1, N + 1):

@@ -208,3 +208,19 @@ def test_du_bounds_rows_of_the_dense_statement(cstr):
     r0 = o.ocp_solve_exact(cstr, xh, xs, us, d, up)
     U0 = np.array([r0["w"][nxu * k + p.nx:nxu * (k + 1)] for k in range(p.N)])
     assert np.abs(np.diff(np.vstack([up, U0]), axis=0)).max() > 1.5
+
+
+def test_terminal_equality_rows(pkg):
+    """TermCons: g.append(X[N] - xs), Control_Calc.py:193-198 - the dense statement carries nx more equality rows, its optimum ends on
+    xs, and an unreachable xs is reported infeasible."""
+    import mpc_oracle as o
+    p = pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides={"N": 6, "TermCons": True})
+    q = pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides={"N": 6})
+    xs, us = np.array([0.02, -0.3, 0.2]), np.zeros(2)
+    t = o.target_solve(p, np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), np.zeros(3), np.zeros(2)); xs, us = t["xs"], t["us"]
+    Ep = o.ocp_qp(p, np.zeros(3), xs, us, np.zeros(3), np.zeros(2))[2]; Eq = o.ocp_qp(q, np.zeros(3), xs, us, np.zeros(3), np.zeros(2))[2]
+    assert Ep.shape[0] == Eq.shape[0] + 3
+    r = o.ocp_solve(p, np.array([0.1, 1.0, 1.0]), xs, us, np.zeros(3), np.zeros(2))
+    assert r["status"] == 0 and np.abs(r["w"][-3:] - xs).max() < 1e-10
+    far = o.ocp_solve(p, np.array([0.5, 8.0, -5.0]), xs, us, np.zeros(3), np.zeros(2))
+    assert far["status"] == 2 and o.ocp_solve(q, np.array([0.5, 8.0, -5.0]), xs, us, np.zeros(3), np.zeros(2))["status"] != 2
