@@ -82,7 +82,9 @@ const char *mpc_last_error(void);
  * One solver(lbx,ubx,x0,p,lbg,ubg) call per instance, MPC_code.py:776-781, with the driver's glue:
  * x_0 fixed to xhat (:734), parameters par[0:13] = xhat,xs,us,dhat,u_prev (:772, Control_Calc.py:44-48),
  * read-out u* = w[nx:nx+nu], xhat+ = w[nx+nu:2nx+nu] (:798-799).
- *   px, py    time-varying model parameters [B][N][nx|ny]; must be NULL (def_px/def_py are a later scope row)
+ *   px, py    time-varying model parameters over the horizon, [B][N][nx] / [B][N][ny] (def_px / def_py evaluated by the driver,
+ *             MPC_code.py:492-497; Control_Calc.py:43-57,161,150): x_{k+1} = A x_k + B u_k + Bd d + px_k, y_k = C x_k + Cd d + py_k.
+ *             NULL = zero.  Such a call runs on the instance-per-lane solver with per-stage data and starts cold
  *   w_inout   optional [B][nx*(N+1)+nu*N]: on return the primal optimum in opt_dyn's order [x0,u0,...,xN] (Control_Calc.py:31-37).
  *             With mpc_set_option("ocp_warm_start", 1) it is also read: the caller's guess x0= of the reference call (the shifted
  *             previous optimum, MPC_code.py:740-764) supplies the inputs of the starting point; the bound multipliers of the previous
@@ -100,6 +102,10 @@ int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs
 int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, const double *ysp, const double *xsp,
                      const double *dhat, const double *us_prev, double *xs, double *us, double *ys,
                      int32_t *status, int32_t *iters);
+
+/* This step's model parameters p_x_k = px[:,0], p_y_k = py[:,0] (MPC_code.py:500-501) for the following mpc_kf_update (predicted output,
+ * :524) and mpc_target_solve (par_ss, :693) calls of a batch of B: [B][nx], [B][ny]; NULL clears one. */
+int mpc_set_model_offsets(mpc_handle *h, int32_t B, const double *px0, const double *py0);
 
 /* defEstimator(...) -> kalman() / kalss(), MPC_code.py:577-650, Estimator.py:231-311.
  * xi = [xhat; dhat] [B][nx+nd] in/out; P [B][(nx+nd)^2] in/out (ignored for MPC_EST_FIXED_GAIN, may be NULL).

@@ -113,6 +113,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     lib.mpc_ocp_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 7 + [_dp, _dp, _dp, _ip, _ip, _dp]
     lib.mpc_target_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5 + [_dp, _dp, _dp, _ip, _ip]
     lib.mpc_kf_update.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp, _dp]
+    lib.mpc_set_model_offsets.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp]
     lib.mpc_closed_loop.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32] + [_dp] * 13
     lib.mpc_comm_unique_id.argtypes = [ct.c_char_p]
     lib.mpc_comm_init.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32, ct.c_char_p]
@@ -129,7 +130,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     return lib
 
 
-EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update",
+EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update", "mpc_set_model_offsets",
            "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_run",
            "mpc_loop_sync", "mpc_loop_get_log", "mpc_closed_loop", "mpc_last_kernel_ms", "mpc_stream", "mpc_dev_ptr",
            "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_get_option", "mpc_build_info",
@@ -286,8 +287,11 @@ class Solver:
         return out
 
     # ------------------------------------------------------------------ per-step calls
-    def ocp_solve(self, xhat, xs, us, dhat, u_prev, want_w=False, w_guess=None):
+    def ocp_solve(self, xhat, xs, us, dhat, u_prev, want_w=False, w_guess=None, px=None, py=None):
         """``solver(...)`` of MPC_code.py:776-781 for a batch; returns dict(u0, x1, status, iters, res[, w]).
+
+        ``px`` [B, N, nx] / ``py`` [B, N, ny] (or [N, .], shared): the model parameters over the horizon (``def_px`` / ``def_py``,
+        MPC_code.py:492-497).
 
         ``w_guess`` [B, nw]: the reference's ``x0=`` (MPC_code.py:740-764); read only after ``set_option("ocp_warm_start", 1)``."""
         p = self.p
@@ -299,8 +303,10 @@ class Solver:
         w = np.full((B, p.nw), np.nan) if (want_w or w_guess is not None) else None
         if w_guess is not None:
             w[:] = np.broadcast_to(np.asarray(w_guess, dtype=np.float64), (B, p.nw))
+        pxa = None if px is None else np.ascontiguousarray(np.broadcast_to(np.asarray(px, dtype=np.float64), (B, p.N, p.nx)))
+        pya = None if py is None else np.ascontiguousarray(np.broadcast_to(np.asarray(py, dtype=np.float64), (B, p.N, p.ny)))
         self._chk(self.lib.mpc_ocp_solve(self.h, B, _p(xhat), _p(xs), _p(us), _p(dhat) if p.nd else None, _p(u_prev),
-                                         None, None, _p(w), _p(u0), _p(x1), _pi(st), _pi(it), _p(res)), "mpc_ocp_solve")
+                                         _p(pxa), _p(pya), _p(w), _p(u0), _p(x1), _pi(st), _pi(it), _p(res)), "mpc_ocp_solve")
         return dict(u0=u0, x1=x1, status=st, iters=it, res=res, w=w)
 
     def target_solve(self, usp, ysp, xsp, dhat, us_prev):
@@ -313,6 +319,13 @@ class Solver:
         self._chk(self.lib.mpc_target_solve(self.h, B, _p(usp), _p(ysp), _p(xsp), _p(dhat) if p.nd else None, _p(us_prev),
                                             _p(xs), _p(us), _p(ys), _pi(st), _pi(it)), "mpc_target_solve")
         return dict(xs=xs, us=us, ys=ys, status=st, iters=it)
+
+    def set_model_offsets(self, B, px0=None, py0=None):
+        """This step's ``p_x_k`` [B, nx] / ``p_y_k`` [B, ny] (MPC_code.py:500-501) for the following kf_update / target_solve calls;
+        ``None`` clears."""
+        p = self.p
+        a = None if px0 is None else _c(px0, (B, p.nx)); b = None if py0 is None else _c(py0, (B, p.ny))
+        self._chk(self.lib.mpc_set_model_offsets(self.h, int(B), _p(a), _p(b)), "mpc_set_model_offsets")
 
     def kf_update(self, y, xi, P=None):
         """``defEstimator(...)`` of MPC_code.py:577-650; returns (xi_corrected, P_plus)."""

@@ -99,8 +99,86 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     }
 }
 
+// The same call with time-varying model parameters over the horizon (def_px / def_py, MPC_code.py:492-497, Control_Calc.py:43-57):
+// x_{k+1} = A x_k + B u_k + Bd d + px_k, y_k = C x_k + Cd d + py_k.  The stage form keeps its matrices; the affine term and the
+// boxes that stand for the output rows become per block, which is what the time-varying lane solver takes (mpc_device.hpp:
+// rpdip_lane<.., LTV>: slab [block][A | B | c | lo | hi][64 lanes]).  One instantiation per dimension set (all bounds maskable).
+struct OcpPxyArgs { OcpArgs o; const double *px, *py; double *lin; };      // px [N][NX][Bs], py [N][NY][Bs]; either may be null
+
+template <int NX, int NU, int NY, int ND, bool DU, int NG>
+__global__ __launch_bounds__(64) void ocp_kernel_pxy(const DevProblem *__restrict__ Pp, OcpPxyArgs w)
+{
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NB = NX + (DU ? NU : 0), NC = NS + NU, NLTV = NS * (NS + NU + 1), NLIN = NLTV + 2 * NS;
+    const OcpArgs &a = w.o;
+    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    const int N = P.N;
+    double xhat[NX], xs[NX], us[NU], up[NU], dh[ND > 0 ? ND : 1];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { xhat[i] = a.xhat[i * a.Bs + b]; xs[i] = a.xs[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { us[i] = a.us[i * a.Bs + b]; up[i] = a.u_prev[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
+    OcpInst<NS, NU> q;
+    build_inst<NX, NU, NY, ND, DU, NG>(P, xhat, xs, us, dh, up, q);
+    StageConst<NS, NU> C;
+    load_stage_const<NS, NU, DU>(P, C);
+    double e0[NY];      // output offsets without py
+    MPC_UNROLL for (int i = 0; i < NY; i++) { double e = P.fyc[i]; MPC_UNROLL for (int j = 0; j < ND; j++) e += P.Cd[i][j] * dh[j]; e0[i] = e; }
+    if (P.y_bounded && w.py) {      // the stage-0 row is a test of the given x_0 (Control_Calc.py:128-151), with py_0
+        q.ok0 = true;
+        MPC_UNROLL for (int i = 0; i < NY; i++) {
+            double y0 = e0[i] + w.py[(size_t)i * a.Bs + b];
+            MPC_UNROLL for (int j = 0; j < NX; j++) y0 += P.Cm[i][j] * xhat[j];
+            const double rl = kBoundRelax * dmax(1.0, fabs(P.ymin[i])), rh = kBoundRelax * dmax(1.0, fabs(P.ymax[i]));
+            if (!(y0 >= P.ymin[i] - rl) || !(y0 <= P.ymax[i] + rh)) q.ok0 = false;
+        }
+    }
+    double *const lin = w.lin + (size_t)blockIdx.x * N * NLIN * 64 + lane;
+    for (int k = 0; k < N; k++) {
+        double *lb = lin + (size_t)k * NLIN * 64;
+        double pxk[NX];
+        MPC_UNROLL for (int i = 0; i < NX; i++) pxk[i] = w.px ? w.px[((size_t)k * NX + i) * a.Bs + b] : 0.0;
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) lb[(i * NS + j) * 64] = C.A[i][j];
+            MPC_UNROLL for (int j = 0; j < NU; j++) lb[(NS * NS + i * NU + j) * 64] = C.B[i][j];
+            double c = q.c[i];
+            if (i < NX) c += pxk[i < NX ? i : 0];
+            if (i >= NB) { const int r = P.yg_row[i >= NB ? i - NB : 0]; MPC_UNROLL for (int j = 0; j < NX; j++) c += P.Cm[r][j] * pxk[j]; }      // w+ = C_i x+
+            lb[(NS * NS + NS * NU + i) * 64] = c;
+        }
+        // bounds of z_{k+1}: the constant boxes, cut by the output rows of stage k + 1 (none at the terminal state)
+        double lo[NS], hi[NS];
+        const bool end = k == N - 1;
+        MPC_UNROLL for (int i = 0; i < NS; i++) { lo[i] = end ? P.zlo_e[i] : P.zlo_m[i]; hi[i] = end ? P.zhi_e[i] : P.zhi_m[i]; }
+        if (P.y_bounded && !end) {
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                const double e = e0[i] + (w.py ? w.py[((size_t)(k + 1) * NY + i) * a.Bs + b] : 0.0);
+                const double sc = P.ymap_scale[i];
+                const double aa = (P.ymin[i] - e) / sc, bb = (P.ymax[i] - e) / sc;
+                const double l = sc > 0 ? aa : bb, h = sc > 0 ? bb : aa;
+                const int idx = P.ymap_idx[i];
+                MPC_UNROLL for (int j = 0; j < NS; j++)
+                    if (j == idx) { lo[j] = dmax(lo[j], l); hi[j] = dmin(hi[j], h); }
+            }
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { lb[(NLTV + i) * 64] = lo[i]; lb[(NLTV + NS + i) * 64] = hi[i]; }
+    }
+    constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
+    Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (N + 2) + 1) * SL * 64), N, SL, lane};
+    double u0[NU], z1[NS], res[3];
+    int it;
+    int st = rpdip_lane<NS, NU, DU, NC, true, true>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it, lin, 1, NLIN, NLTV);
+    if (P.term_cons && st != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st = kInfeasible;
+    a.status[b] = st; a.iters[b] = it;
+    MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
+    if (st != kInfeasible) {
+        MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * a.Bs + b] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) a.xnext_out[i * a.Bs + b] = z1[i];
+    }
+}
+
 struct TargetArgs {
-    const double *usp, *ysp, *dhat, *us_prev;
+    const double *usp, *ysp, *dhat, *us_prev, *px0, *py0;      // px0 / py0 [dim][Bs]: mpc_set_model_offsets, or null
     double *xs, *us, *ys;
     int32_t *status, *iters;
     int B; size_t Bs;
@@ -117,7 +195,10 @@ __global__ __launch_bounds__(64) void target_kernel(const DevProblem *__restrict
     MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[i * a.Bs + b];
     MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
     int it;
-    const int st = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, usprev, xs, us, ys, it);
+    double px0[NX], py0[NY];
+    if (a.px0) { MPC_UNROLL for (int i = 0; i < NX; i++) px0[i] = a.px0[i * a.Bs + b]; }
+    if (a.py0) { MPC_UNROLL for (int i = 0; i < NY; i++) py0[i] = a.py0[i * a.Bs + b]; }
+    const int st = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, usprev, xs, us, ys, it, nullptr, 0, nullptr, a.px0 ? px0 : nullptr, a.py0 ? py0 : nullptr);
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < NX; i++) a.xs[i * a.Bs + b] = xs[i];
     MPC_UNROLL for (int i = 0; i < NU; i++) a.us[i * a.Bs + b] = us[i];
@@ -125,7 +206,7 @@ __global__ __launch_bounds__(64) void target_kernel(const DevProblem *__restrict
 }
 
 struct KfArgs {
-    const double *y; double *xi, *Pk;
+    const double *y, *py0; double *xi, *Pk;
     int B; size_t Bs;
 };
 
@@ -139,7 +220,7 @@ __global__ __launch_bounds__(64) void kf_kernel(const DevProblem *__restrict__ P
     double xi[NE], innov[NY];
     MPC_UNROLL for (int i = 0; i < NE; i++) xi[i] = a.xi[i * a.Bs + b];
     MPC_UNROLL for (int i = 0; i < NY; i++) {       // yhat = Fy_model(xhat, dhat), MPC_code.py:524
-        double yh = P.fyc[i];
+        double yh = P.fyc[i] + (a.py0 ? a.py0[i * a.Bs + b] : 0.0);
         MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
         innov[i] = a.y[i * a.Bs + b] - yh;
     }
@@ -844,6 +925,8 @@ __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__
 // ---------------------------------------------------------------------------------------------------
 struct Launchers {
     void (*ocp)(const DevProblem *, OcpArgs, hipStream_t);
+    void (*ocp_pxy)(const DevProblem *, OcpPxyArgs, hipStream_t);      // time-varying px / py: one variant (all bounds maskable)
+    int pxy_ws_rows, pxy_nc, pxy_lin;                                  // its workspace rows / bounded variables / slab entries per block
     void (*target)(const DevProblem *, TargetArgs, hipStream_t);
     void (*kf)(const DevProblem *, KfArgs, hipStream_t);
     void (*loop)(const DevProblem *, LoopArgs, hipStream_t);
@@ -867,6 +950,11 @@ static Launchers make_launchers_mode()
 {
     Launchers l;
     l.ocp = [](const DevProblem *p, OcpArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel<NX, NU, NY, ND, DU, NG, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
+    {
+        constexpr int NSZ = NX + (DU ? NU : 0) + NG;
+        l.ocp_pxy = [](const DevProblem *p, OcpPxyArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel_pxy<NX, NU, NY, ND, DU, NG>), dim3((a.o.B + 63) / 64), dim3(64), 0, s, p, a); };
+        l.pxy_ws_rows = 2 * BlkLayout<NSZ, NU, NSZ + NU>::SLOTS; l.pxy_nc = NSZ + NU; l.pxy_lin = NSZ * (NSZ + NU + 1) + 2 * NSZ;
+    }
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.loop = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
@@ -982,6 +1070,9 @@ struct mpc_handle {
     // per-call OCP on the wave-autonomous solver: data of the previous call (warm start), caller's guess, final trajectory
     int ocp_warm = 0, ocp_kernel_opt = 0, pc_B = 0;
     DevBuf pc_prev, pc_valid, pc_guess, pc_traj;
+    // time-varying model parameters: horizon values of one mpc_ocp_solve call, its slab and workspace; this step's p_x_k / p_y_k for
+    // mpc_target_solve / mpc_kf_update (mpc_set_model_offsets)
+    DevBuf pxy_in, pxy_lin, pxy_ws, off_px, off_py; int off_B = 0; bool off_has_px = false, off_has_py = false;
     DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
     // multi-GPU (one process per GPU): RCCL communicator over the ranks of the job, staging buffers of the collectives
@@ -1259,6 +1350,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     (void)mpc_comm_destroy(h);
     h->coll_send.release(); h->coll_recv.release();
     h->pc_prev.release(); h->pc_valid.release(); h->pc_guess.release(); h->pc_traj.release();
+    h->pxy_in.release(); h->pxy_lin.release(); h->pxy_ws.release(); h->off_px.release(); h->off_py.release();
     for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1360,7 +1452,6 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
                              double *kkt_res)
 {
     if (!h || B < 1 || !xhat || !xs || !us || !u_prev || !u_out || !xnext_out || !status) return fail(-1, "null argument");
-    if (px || py) return fail(-6, "time-varying px/py (def_px/def_py) are not implemented");
     const DevProblem &P = h->hp;
     if (P.nd > 0 && !dhat) return fail(-1, "dhat is required when nd > 0");
     HIP_TRY(hipSetDevice(h->device));
@@ -1387,10 +1478,32 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     a.status = (int32_t *)(d + n_in + n_out); a.iters = a.status + Bs;
     a.ws = (double *)h->ws.p; a.B = B; a.Bs = Bs;
     HIP_TRY(hipMemsetAsync(a.u_out, 0, n_out * sizeof(double), h->stream));
-    const bool wave = ocp_uses_wave(h);
+    const bool pxy = px || py;
+    const bool wave = !pxy && ocp_uses_wave(h);
     const int ns_w = h->L.wv_ns, N = P.N;
     std::vector<double> guess;
-    if (wave) {
+    if (pxy) {
+        // horizon values [B][N][dim] -> [N][dim][Bs]; the lane solver with per-block affine terms and output boxes
+        const int ny = P.ny;
+        const size_t npx = px ? (size_t)N * nx * Bs : 0, npy = py ? (size_t)N * ny * Bs : 0;
+        std::vector<double> hv(npx + npy, 0.0);
+        for (int b = 0; b < B; b++)
+            for (int k = 0; k < N; k++) {
+                if (px) for (int i = 0; i < nx; i++) hv[((size_t)k * nx + i) * Bs + b] = px[((size_t)b * N + k) * nx + i];
+                if (py) for (int i = 0; i < ny; i++) hv[npx + ((size_t)k * ny + i) * Bs + b] = py[((size_t)b * N + k) * ny + i];
+            }
+        if (h->pxy_in.ensure(hv.size() * sizeof(double)) || h->pxy_lin.ensure((size_t)N * h->L.pxy_lin * Bs * sizeof(double)) ||
+            h->pxy_ws.ensure((size_t)h->L.pxy_ws_rows * (N + 2) * Bs * sizeof(double)))
+            return -10;
+        HIP_TRY(hipMemcpyAsync(h->pxy_in.p, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));      // hv leaves scope before the kernel would otherwise read the copy
+        OcpPxyArgs wa;
+        wa.o = a; wa.o.ws = (double *)h->pxy_ws.p;
+        wa.px = px ? (const double *)h->pxy_in.p : nullptr; wa.py = py ? (const double *)h->pxy_in.p + npx : nullptr;
+        wa.lin = (double *)h->pxy_lin.p;
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        h->L.ocp_pxy(h->dp, wa, h->stream);
+    } else if (wave) {
         // resident data of the previous call (warm start): reset when the batch changes
         const size_t nprev = (size_t)(2 * nx + nd + nu) * Bs;
         if (h->pc_prev.ensure(nprev * sizeof(double)) || h->pc_valid.ensure(Bs * sizeof(int32_t))) return -10;
@@ -1462,9 +1575,10 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
         }
     } else if (w_out) {   // the same from the lane kernel's workspace
         const int ns = nx + ((P.du_form || P.in_is_du) ? nu : 0), nv = ns + nu, nxu = nx + nu;
-        const int slots = h->L.ws_rows / 2, slotU = 4 * h->L.nc, slotZ = slotU + (nu + 1) / 2; (void)nv;
-        std::vector<double> wsh((size_t)h->L.ws_rows * (N + 2) * Bs);
-        HIP_TRY(hipMemcpy(wsh.data(), h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const int ws_rows = pxy ? h->L.pxy_ws_rows : h->L.ws_rows, nc = pxy ? h->L.pxy_nc : h->L.nc;
+        const int slots = ws_rows / 2, slotU = 4 * nc, slotZ = slotU + (nu + 1) / 2; (void)nv;
+        std::vector<double> wsh((size_t)ws_rows * (N + 2) * Bs);
+        HIP_TRY(hipMemcpy(wsh.data(), pxy ? h->pxy_ws.p : h->ws.p, wsh.size() * sizeof(double), hipMemcpyDeviceToHost));
         auto at = [&](int b, int k, int slot, int comp) { return wsh[((((size_t)(b / 64) * (N + 2) + k + 1) * slots + slot) * 64 + (b % 64)) * 2 + comp]; };
         for (int b = 0; b < B; b++) {
             if (ist[b] == kInfeasible) continue;
@@ -1503,6 +1617,8 @@ extern "C" int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, con
     a.usp = d; a.ysp = d + (size_t)nu * Bs; a.dhat = d + (size_t)(nu + ny) * Bs; a.us_prev = d + (size_t)(nu + ny + nd) * Bs;
     a.xs = d + n_in; a.us = a.xs + (size_t)nx * Bs; a.ys = a.us + (size_t)nu * Bs;
     a.status = (int32_t *)(d + n_in + n_out); a.iters = a.status + Bs; a.B = B; a.Bs = Bs;
+    if ((h->off_has_px || h->off_has_py) && h->off_B != B) return fail(-1, "mpc_set_model_offsets was called for a batch of %d, this call has %d", h->off_B, B);
+    a.px0 = h->off_has_px ? (const double *)h->off_px.p : nullptr; a.py0 = h->off_has_py ? (const double *)h->off_py.p : nullptr;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     h->L.target(h->dp, a, h->stream);
     HIP_TRY(hipGetLastError());
@@ -1515,6 +1631,29 @@ extern "C" int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, con
     from_soa(sp + n_in, B, nx, Bs, xs); from_soa(sp + n_in + (size_t)nx * Bs, B, nu, Bs, us);
     from_soa(sp + n_in + (size_t)(nx + nu) * Bs, B, ny, Bs, ys);
     for (int b = 0; b < B; b++) { status[b] = ist[b]; if (iters) iters[b] = ist[Bs + b]; }
+    return 0;
+}
+
+extern "C" int mpc_set_model_offsets(mpc_handle *h, int32_t B, const double *px0, const double *py0)
+{
+    if (!h || B < 1) return fail(-1, "bad argument");
+    const DevProblem &P = h->hp;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t Bs = pad64(B);
+    h->off_has_px = h->off_has_py = false; h->off_B = B;
+    std::vector<double> st;
+    if (px0) {
+        st.assign((size_t)P.nx * Bs, 0.0); to_soa(px0, B, P.nx, Bs, st.data());
+        if (h->off_px.ensure(st.size() * sizeof(double))) return -10;
+        HIP_TRY(hipMemcpy(h->off_px.p, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->off_has_px = true;
+    }
+    if (py0) {
+        st.assign((size_t)P.ny * Bs, 0.0); to_soa(py0, B, P.ny, Bs, st.data());
+        if (h->off_py.ensure(st.size() * sizeof(double))) return -10;
+        HIP_TRY(hipMemcpy(h->off_py.p, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->off_has_py = true;
+    }
     return 0;
 }
 
@@ -1536,7 +1675,8 @@ extern "C" int mpc_kf_update(mpc_handle *h, int32_t B, const double *y, double *
     if (kal) to_soa(Pk, B, ne * ne, Bs, sp + (size_t)(ny + ne) * Bs);
     double *d = (double *)h->scratch.p;
     HIP_TRY(hipMemcpyAsync(d, sp, n_all * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    KfArgs a{d, d + (size_t)ny * Bs, d + (size_t)(ny + ne) * Bs, B, Bs};
+    if (h->off_has_py && h->off_B != B) return fail(-1, "mpc_set_model_offsets was called for a batch of %d, this call has %d", h->off_B, B);
+    KfArgs a{d, h->off_has_py ? (const double *)h->off_py.p : nullptr, d + (size_t)ny * Bs, d + (size_t)(ny + ne) * Bs, B, Bs};
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     h->L.kf(h->dp, a, h->stream);
     HIP_TRY(hipGetLastError());

@@ -282,12 +282,12 @@ __device__ __forceinline__ const auto &ab_pick(const TL &l, const TC &c)
 // NC = number of bounded variables per block (NU: inputs only, NS+NU: inputs and states); MASKED = some of
 // those bounds may be absent (+-inf).  The host picks the cheapest variant the problem allows.
 // LTV: the stage matrices differ from block to block (the QP of one SQP iteration of the non-linear path, x+ = A_k x + B_k u + c_k):
-// ltv points at this lane's column of [block][A (NS*NS) | B (NS*NU) | c (NS) | ...][64 lanes], ltv_stride entries per block; shift = 0 then warm-starts from the same
+// ltv points at this lane's column of [block][A (NS*NS) | B (NS*NU) | c (NS) | ...][64 lanes], ltv_stride entries per block (ltv_boff >= 0: entries ltv_boff.. hold the block's own state bounds lo[NS] | hi[NS], finite where the constant ones are); shift = 0 then warm-starts from the same
 // stage of the workspace (an SQP iteration of the same step) instead of the next one.
 template <int NS, int NU, bool HASM, int NC, bool MASKED, bool LTV = false>
 __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, const OcpInst<NS, NU> &q, const Ws &ws,
                           int max_iter, bool warm, double ws_delta, double (&u0)[NU], double (&z1)[NS], double (&res)[3], int &iters,
-                          const double *ltv = nullptr, int shift = 1, int ltv_stride = NS * (NS + NU + 1))
+                          const double *ltv = nullptr, int shift = 1, int ltv_stride = NS * (NS + NU + 1), int ltv_boff = -1)
 {
     const int NLTV = ltv_stride;      // entries per block of the ltv slab (A | B | c first)
     // per-block matrices: loaded into (Al, Bl) for LTV; the constant ones are used in place otherwise
@@ -329,6 +329,16 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
     const double inv_ncon = 1.0 / dmax(ncon, 1.0);
     auto use_mid = [&]() { MPC_UNROLL for (int i = 0; i < NC; i++) { cur_lo[i] = lo_m[i]; cur_hi[i] = hi_m[i]; cur_fl[i] = fl_m[i]; cur_fh[i] = fh_m[i]; } };
     auto use_end = [&]() { MPC_UNROLL for (int i = 0; i < NC; i++) { cur_lo[i] = lo_e[i]; cur_hi[i] = hi_e[i]; cur_fl[i] = fl_e[i]; cur_fh[i] = fh_e[i]; } };
+    // per-block state bounds (time-varying output offsets py_k move the boxes that stand for output rows)
+    auto use_stage = [&](int k) {
+        if (LTV && ltv_boff >= 0 && NC > NU) {
+            const double *sb = ltv + ((size_t)k * NLTV + ltv_boff) * 64;
+            MPC_UNROLL for (int i = NU; i < NC; i++) {
+                if (cur_fl[i]) cur_lo[i] = sb[(i - NU) * 64];
+                if (cur_fh[i]) cur_hi[i] = sb[(NS + i - NU) * 64];
+            }
+        }
+    };
 #define MPC_BOUNDS(k, i, lo, hi, fl, fh)                                   \
     const double lo = cur_lo[i], hi = cur_hi[i];                           \
     const bool fl = MASKED ? cur_fl[i] : true, fh = MASKED ? cur_fh[i] : true;
@@ -356,6 +366,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         use_mid();
         for (int k = 0; k < N; k++) {
             if (k == N - 1) use_end();
+            use_stage(k);
             const BlkPtr b = ws.blk(k);
             const BlkPtr src = ws.blk((shift && k + 1 < N) ? k + 1 : k);      // previous step's block k+1 (read before block k is written)
             MPC_LOAD_AB(k)
@@ -427,6 +438,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
         use_end();
         for (int k = N - 1; k >= 0; k--) {
             if (k == N - 2) use_mid();
+            use_stage(k);
             const BlkPtr b = ws.blk(k);
             double sig[NV], dlm[NV], haff[NV];
             MPC_UNROLL for (int i = NC; i < NV; i++) { sig[i] = 0.0; dlm[i] = 0.0; haff[i] = 0.0; }
@@ -597,6 +609,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
                 if (k == N - 1) use_end();
+                use_stage(k);
                 const BlkPtr b = ws.blk(k);
                 const BlkPtr nb = ws.blk(k + 1);      // block N is a guard block; every field is reloaded in place
                 double ddu[NU], dzn[NS];                 // right after its last use (rolling prefetch, no second buffer)
@@ -650,6 +663,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NU; i++) und[i] = 0.0;
             for (int k = N - 1; k >= 0; k--) {
                 if (k == N - 2) use_mid();
+                use_stage(k);
                 const BlkPtr b = ws.blk(k);
                 const BlkPtr nb = ws.blk(k - 1);       // block -1 is a guard block
                 double hcc[NV], dlm[NV];
@@ -732,6 +746,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NS; i++) dz[i] = 0.0;
             for (int k = 0; k < N; k++) {
                 if (k == N - 1) use_end();
+                use_stage(k);
                 const BlkPtr b = ws.blk(k);
                 const BlkPtr nb = ws.blk(k + 1);
                 double ddu[NU], dzn[NS];
@@ -790,14 +805,15 @@ __device__ __forceinline__ bool term_missed(const DevProblem &P, const Ws &ws, c
 template <int NX, int NU, int NY, int ND, class PT>
 __device__ int target_lane(const PT &P, const double *usp, const double *ysp, const double *dhat,
                            const double (&us_prev)[NU], double (&xs)[NX], double (&us)[NU], double (&ys)[NY], int &iters,
-                           double *tw = nullptr, size_t tws = 0, int32_t *twv = nullptr)
+                           double *tw = nullptr, size_t tws = 0, int32_t *twv = nullptr, const double *px0 = nullptr, const double *py0 = nullptr)
 {
     constexpr int NV = NX + NU, NC = NV + NY, NR = NU;
     double cx[NX], e[NY], vp[NV], yp[NY], gr[NR], w0[NC], y[NR];
     double s_lo[NC], s_hi[NC], l_lo[NC], l_hi[NC], lo[NC], hi[NC];
     bool fl[NC], fh[NC];
-    MPC_UNROLL for (int i = 0; i < NX; i++) { double a = P.fxc[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += P.Bd[i][j] * dhat[j]; cx[i] = a; }
-    MPC_UNROLL for (int i = 0; i < NY; i++) { double a = P.fyc[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += P.Cd[i][j] * dhat[j]; e[i] = a; }
+    // px0 / py0: this step's model parameters p_x_k, p_y_k (def_px / def_py, MPC_code.py:492-501,693), per instance
+    MPC_UNROLL for (int i = 0; i < NX; i++) { double a = P.fxc[i] + (px0 ? px0[i] : 0.0); MPC_UNROLL for (int j = 0; j < ND; j++) a += P.Bd[i][j] * dhat[j]; cx[i] = a; }
+    MPC_UNROLL for (int i = 0; i < NY; i++) { double a = P.fyc[i] + (py0 ? py0[i] : 0.0); MPC_UNROLL for (int j = 0; j < ND; j++) a += P.Cd[i][j] * dhat[j]; e[i] = a; }
     MPC_UNROLL for (int r = 0; r < NV; r++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NX; j++) a -= P.Ep[r][j] * cx[j]; vp[r] = a; }
     MPC_UNROLL for (int i = 0; i < NY; i++) { double a = e[i]; MPC_UNROLL for (int j = 0; j < NX; j++) a += P.Cm[i][j] * vp[j]; yp[i] = a; }
     MPC_UNROLL for (int c = 0; c < NR; c++) {

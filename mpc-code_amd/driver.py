@@ -46,6 +46,8 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
         sched = p.schedules(nsteps)
         if fused and not p.plant_is_linear:
             raise ValueError("a non-linear plant (User_fxp_Cont) is simulated on the host: call run_closed_loop(..., fused=False)")
+        if fused and p.has_model_params:
+            raise ValueError("time-varying model parameters (def_px / def_py) go through the call-by-call mode: run_closed_loop(..., fused=False)")
         if fused:
             s.loop_alloc(B, nsteps, capi.LOG_ALL)
             s.loop_set_state(x0_p, x0_m)
@@ -89,10 +91,15 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched, warm_start=False):
     # The reference builds x0= for IPOPT itself (first guess (x0_m, u0) tiled :740-756, then the previous optimum shifted by one
     # stage :760-764).  mpc_ocp_solve keeps the previous optimum and its multipliers in the handle and shifts them on the device, so
     # nothing has to travel; an explicit guess can still be passed (capi.Solver.ocp_solve(w_guess=...)).
+    pxh = pyh = None; px0 = np.zeros(p.nx); py0 = np.zeros(p.ny)
     for k in range(nsteps):
+        if p.has_model_params:                                           # :492-510: p_xk, p_yk over the horizon; the plant gets p_x_k, p_y_k too
+            pxh, pyh = p.horizon_params(k * p.h)
+            px0, py0 = pxh[0], pyh[0]
+            s.set_model_offsets(B, px0 if p.def_px is not None else None, py0 if p.def_py is not None else None)
         log["Xp"].append(x.copy()); log["X_HAT"].append(xhat.copy())      # :519-520
-        log["Y_HAT"].append(xhat @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0))   # :524
-        y = x @ p.Cp.T + sched["pyp"][k]                                  # :534
+        log["Y_HAT"].append(xhat @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0) + py0)   # :524
+        y = x @ p.Cp.T + sched["pyp"][k] + py0                          # :534
         log["Yp"].append(y.copy())
         if p.estimator != "none":
             xi, Pk = s.kf_update(y, np.hstack([xhat, dhat]), Pk)          # :577-650
@@ -106,15 +113,15 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched, warm_start=False):
         ok = (t["status"] != capi.STATUS_INFEASIBLE)[:, None]
         xs_k = np.where(ok, t["xs"], xs_k); us_k = np.where(ok, t["us"], us_k)               # :714-718
         log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy())
-        log["YS"].append(xs_k @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0))      # :730
+        log["YS"].append(xs_k @ p.C.T + p.fy_const + (dhat @ p.Cd.T if p.nd else 0.0) + py0)      # :730
         t0 = time.time()                                                                     # :775
-        o = s.ocp_solve(xhat, xs_k, us_k, dhat, u)                                           # :776-781
+        o = s.ocp_solve(xhat, xs_k, us_k, dhat, u, px=pxh if p.def_px is not None else None, py=pyh if p.def_py is not None else None)   # :776-781
         log["TIME_DYN"].append(time.time() - t0)                                             # :783,810
         ok = (o["status"] != capi.STATUS_INFEASIBLE)[:, None]
-        hold = xhat @ p.A.T + u @ p.B.T + p.fx_const + (dhat @ p.Bd.T if p.nd else 0.0)      # :804-805
+        hold = xhat @ p.A.T + u @ p.B.T + p.fx_const + (dhat @ p.Bd.T if p.nd else 0.0) + px0      # :804-805
         u = np.where(ok, o["u0"], u); xhat = np.where(ok, o["x1"], hold)                     # :798-799
         log["U"].append(u.copy())
         log["STATUS_DYN"].append(o["status"]); log["STATUS_SS"].append(t["status"])
         log["ITERS_DYN"].append(o["iters"]); log["ITERS_SS"].append(t["iters"])
-        x = p.plant_step(x, u, k * p.h, sched["pxp"][k])                                     # :813-816
+        x = p.plant_step(x, u, k * p.h, sched["pxp"][k] + (px0 if p.has_model_params else 0.0))                               # :813-816 (p_xmp = p_x_k, :502-505)
     return {k: np.array(v) for k, v in log.items()}

@@ -122,6 +122,8 @@ class LinearMPCProblem:
     plant_fx_cont: Optional[Callable] = None
     plant_Mx: int = 10
     TermCons: bool = False    # terminal equality x_N = xs (Control_Calc.py:197-198)
+    def_px: Optional[Callable] = None     # time-varying model parameters over the horizon (MPC_code.py:492-497)
+    def_py: Optional[Callable] = None
 
     # ------------------------------------------------------------------ schedules
     def schedules(self, nsteps: int, k0: int = 0) -> Dict[str, np.ndarray]:
@@ -141,6 +143,22 @@ class LinearMPCProblem:
             if self.def_pyp is not None:
                 pyp[i] = np.ravel(self.def_pyp(t)[0])
         return dict(ysp=ysp, usp=usp, xsp=xsp, pxp=pxp, pyp=pyp)
+
+    @property
+    def has_model_params(self) -> bool:
+        return self.def_px is not None or self.def_py is not None
+
+    def horizon_params(self, t_k: float):
+        """``p_xk[:, i] = def_px(t_k + i)``, ``p_yk[:, i] = def_py(t_k + i)`` for i = 0..N-1 - the reference's own indexing
+        (time plus stage index, not stage index times h), MPC_code.py:492-497.  Returns (px [N, nx], py [N, ny]); zeros when a
+        callback is absent."""
+        px = np.zeros((self.N, self.nx)); py = np.zeros((self.N, self.ny))
+        for i in range(self.N):
+            if self.def_px is not None:
+                px[i] = np.ravel(self.def_px(t_k + i)[0])
+            if self.def_py is not None:
+                py[i] = np.ravel(self.def_py(t_k + i)[0])
+        return px, py
 
     # ------------------------------------------------------------------ plant
     @property
@@ -196,7 +214,7 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
     for bad in ("User_fxm_Cont", "User_fxm_Dis", "User_fym", "User_fxp_Dis", "User_fyp",
                 "User_fobj_Cont", "User_fobj_Dis", "User_fobj_Coll", "User_fssobj", "User_vfin",
                 "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y",
-                "def_px", "def_py", "def_pxmp", "def_pymp", "R_wn", "G_wn"):
+                "def_pxmp", "def_pymp", "R_wn", "G_wn"):
         if _has(ns, bad) and ns[bad] is not None:
             raise UnsupportedProblem(f"'{bad}' is outside the batched linear hot path (later scope row)")
     for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks",
@@ -323,6 +341,6 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         defSP=ns.get("defSP"), def_pxp=ns.get("def_pxp"), def_pyp=ns.get("def_pyp"),
         name=name or str(ns.get("__name__", "")),
         plant_fx_cont=ns["User_fxp_Cont"] if nl_plant else None, plant_Mx=int(ns.get("Mx", 10)),
-        TermCons=bool(ns.get("TermCons", False)),
+        TermCons=bool(ns.get("TermCons", False)), def_px=ns.get("def_px"), def_py=ns.get("def_py"),
     )
     return prob

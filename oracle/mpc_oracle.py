@@ -79,7 +79,7 @@ def plant_fy(p, xp, pyp):
 # ----------------------------------------------------------------------------------------
 # dense QP data in the reference's own layouts
 # ----------------------------------------------------------------------------------------
-def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
+def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False, px=None, py=None):
     """QP of ``opt_dyn`` in its own variable order w=[x0,u0,...,x_{N-1},u_{N-1},x_N].
 
     Returns ``H, g, E, e, G, lo, hi``:  min 1/2 w'Hw + g'w  s.t.  E w = e,  lo <= G w <= hi.
@@ -87,6 +87,8 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
     Inequality rows: variable bounds on x_1..x_N, u_0..u_{N-1} (:248-252; x_0 is fixed by
     ``w_lb[0:nx]=w_ub[0:nx]=xhat``, MPC_code.py:734, so its bound rows are dropped), then the
     ``g1`` rows ``ymin <= C x_k + Cd d + .. <= ymax`` for k=0..N-1 (:130,150-151,229-230).
+    ``px`` [N, nx] / ``py`` [N, ny]: the model parameters over the horizon, ``par_xmk[:, k]`` in the dynamics and ``par_ymk[:, k]`` in the
+    output rows (Control_Calc.py:43-57,130,161).
     ``drop_stage0_rows`` leaves out the k=0 rows: they constrain the given x_0, i.e. they are a feasibility
     test that :func:`ocp_solve` makes up front with IPOPT's bound relaxation.
     """
@@ -126,7 +128,7 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
         E[r, ix(k)] = p.A
         E[r, iu(k)] = p.B
         E[r, ix(k + 1)] = -np.eye(n)
-        e[r] = -c
+        e[r] = -(c + (px[k] if px is not None else 0.0))
     if getattr(p, "TermCons", False):          # g.append(X[N] - xs), Control_Calc.py:193-198
         Et = np.zeros((n, nw)); Et[:, ix(N)] = np.eye(n)
         E = np.vstack([E, Et]); e = np.concatenate([e, xs])
@@ -148,7 +150,8 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
             for i in range(p.ny):
                 if np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i]):
                     row = np.zeros(nw); row[ix(k)] = p.C[i]
-                    rows.append(row); lo.append(p.ymin[i] - yc[i]); hi.append(p.ymax[i] - yc[i])
+                    yk = yc[i] + (py[k][i] if py is not None else 0.0)
+                    rows.append(row); lo.append(p.ymin[i] - yk); hi.append(p.ymax[i] - yk)
     if getattr(p, "Dumin", None) is not None or getattr(p, "Dumax", None) is not None:
         # g2 rows: DU_k = U[k] - um1 (k = 0) | U[k] - U[k-1], Control_Calc.py:163-169, bounds tiled :241-243
         dlo = p.Dumin if p.Dumin is not None else np.full(m, -np.inf); dhi = p.Dumax if p.Dumax is not None else np.full(m, np.inf)
@@ -164,7 +167,7 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False):
     return H, g, E, e, G, np.array(lo, dtype=float), np.array(hi, dtype=float)
 
 
-def target_qp(p, usp, ysp, xsp, dhat, us_prev):
+def target_qp(p, usp, ysp, xsp, dhat, us_prev, px0=None, py0=None):
     """QP of ``opt_ss`` in its own variable order wss=[xs,us,ys] (Target_Calc.py:29-38).
 
     Cost 1/2 (ys-ysp)'Qss(ys-ysp) + 1/2 dus'Rss dus with dus = us-usp, or us-us_prev when
@@ -179,9 +182,9 @@ def target_qp(p, usp, ysp, xsp, dhat, us_prev):
     H[su, su] = p.Rss; g[su] = -p.Rss @ (us_prev if p.DUssForm else usp)
     E = np.zeros((n + q, nv)); e = np.zeros(n + q)
     E[:n, :n] = p.A - np.eye(n); E[:n, su] = p.B
-    e[:n] = -(p.fx_const + (p.Bd @ dhat if p.nd else 0.0))
+    e[:n] = -(p.fx_const + (p.Bd @ dhat if p.nd else 0.0) + (px0 if px0 is not None else 0.0))
     E[n:, :n] = p.C; E[n:, sy] = -np.eye(q)
-    e[n:] = -(p.fy_const + (p.Cd @ dhat if p.nd else 0.0))
+    e[n:] = -(p.fy_const + (p.Cd @ dhat if p.nd else 0.0) + (py0 if py0 is not None else 0.0))
     lo = np.concatenate([p.xmin_ss, p.umin_ss, p.ymin_ss])
     hi = np.concatenate([p.xmax_ss, p.umax_ss, p.ymax_ss])
     keep = np.isfinite(lo) | np.isfinite(hi)
@@ -324,17 +327,17 @@ def lp_feasible(E, e, G, lo, hi, slack=0.0):
 # ----------------------------------------------------------------------------------------
 # per-step building blocks with the reference's read-out rules
 # ----------------------------------------------------------------------------------------
-def ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=1e-11):
+def ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=1e-11, px=None, py=None):
     """One ``solver(...)`` call of MPC_code.py:776-781 + read-out ``:798-799``.
 
     Returns dict(u0, x1, w, status, iters, res).  x_0 sits on a g1 row too
     (Control_Calc.py:128-151): if ``C xhat + ..`` violates [ymin,ymax] the problem is infeasible
     whatever u is - reported as status 2 before any iteration.
     """
-    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True)
+    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True, px=px, py=py)
     n, m = p.nx, p.nu
     if p.y_bounded:
-        y0 = model_fy(p, xhat, dhat)
+        y0 = model_fy(p, xhat, dhat, None if py is None else py[0])
         rl = BOUND_RELAX * np.maximum(1.0, np.abs(p.ymin)); rh = BOUND_RELAX * np.maximum(1.0, np.abs(p.ymax))
         if np.any(y0 < p.ymin - rl) or np.any(y0 > p.ymax + rh):
             return dict(u0=None, x1=None, w=None, status=STATUS_INFEASIBLE, iters=0, res=None)
@@ -344,9 +347,9 @@ def ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=1e-11):
                 iters=r["iters"], res=r["res"], nu=r["nu"], z_lo=r["z_lo"], z_hi=r["z_hi"])
 
 
-def target_solve(p, usp, ysp, xsp, dhat, us_prev, tol=1e-11):
+def target_solve(p, usp, ysp, xsp, dhat, us_prev, tol=1e-11, px0=None, py0=None):
     """One ``solver_ss(...)`` call of MPC_code.py:704-709 + read-out ``:715-718``."""
-    H, g, E, e, G, lo, hi = target_qp(p, usp, ysp, xsp, dhat, us_prev)
+    H, g, E, e, G, lo, hi = target_qp(p, usp, ysp, xsp, dhat, us_prev, px0, py0)
     r = qp_ipm_dense(H, g, E, e, G, lo, hi, tol=tol)
     n, m = p.nx, p.nu
     w = r["w"]
@@ -398,10 +401,16 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, u0=None, dhat0=None, P0=None, s
                            "STATUS_SS", "STATUS_DYN", "KKT_DYN", "KKT_SS", "ITERS_DYN", "XHAT_C", "U_PREV",
                            "EXACT_DYN", "EXACT_SS")}
     n = p.nx
+    has_par = getattr(p, "def_px", None) is not None or getattr(p, "def_py", None) is not None
+    px0 = py0 = None; kw_t, kw_o = {}, {}
     for k in range(nsteps):
+        if has_par:        # MPC_code.py:492-510: parameters over the horizon; p_x_k, p_y_k also reach the plant (p_xmp, p_ymp)
+            pxh, pyh = p.horizon_params(k * p.h)
+            px0, py0 = pxh[0], pyh[0]
+            kw_t, kw_o = dict(px0=px0, py0=py0), dict(px=pxh, py=pyh)
         log["Xp"].append(x.copy()); log["X_HAT"].append(xhat.copy())
-        yhat = model_fy(p, xhat, dhat)
-        y = plant_fy(p, x, sched["pyp"][k])
+        yhat = model_fy(p, xhat, dhat, py0)
+        y = plant_fy(p, x, sched["pyp"][k] + (py0 if py0 is not None else 0.0))
         log["Yp"].append(y.copy()); log["Y_HAT"].append(yhat.copy())
         xi = np.concatenate([xhat, dhat])
         if p.estimator == "kal":
@@ -413,22 +422,22 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, u0=None, dhat0=None, P0=None, s
             dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)
         log["D_HAT"].append(dhat.copy()); log["XHAT_C"].append(xhat.copy()); log["U_PREV"].append(u.copy())
         us_prev = us_k
-        t = target(p, sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_prev, tol=tol)
+        t = target(p, sched["usp"][k], sched["ysp"][k], sched["xsp"][k], dhat, us_prev, tol=tol, **kw_t)
         if t["status"] != STATUS_INFEASIBLE:
             xs_k, us_k = t["xs"], t["us"]
         log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy())
-        log["YS"].append(model_fy(p, xs_k, dhat))
+        log["YS"].append(model_fy(p, xs_k, dhat, py0))
         log["STATUS_SS"].append(t["status"]); log["KKT_SS"].append(kkt_max(t["res"]))
         log["EXACT_SS"].append(bool(t.get("exact", False)))
-        o = ocp(p, xhat, xs_k, us_k, dhat, u, tol=tol)
+        o = ocp(p, xhat, xs_k, us_k, dhat, u, tol=tol, **kw_o)
         if o["status"] != STATUS_INFEASIBLE:
             u, xhat = o["u0"].copy(), o["x1"].copy()             # MPC_code.py:798-799
         else:
-            xhat = model_fx(p, xhat, u, dhat)                    # MPC_code.py:804-805
+            xhat = model_fx(p, xhat, u, dhat, px0)               # MPC_code.py:804-805
         log["U"].append(u.copy()); log["STATUS_DYN"].append(o["status"])
         log["KKT_DYN"].append(kkt_max(o["res"]) if o["res"] else np.nan)
         log["ITERS_DYN"].append(o["iters"]); log["EXACT_DYN"].append(bool(o.get("exact", False)))
-        x = plant_fx(p, x, u, sched["pxp"][k], k * p.h)                 # MPC_code.py:816
+        x = plant_fx(p, x, u, sched["pxp"][k] + (px0 if px0 is not None else 0.0), k * p.h)                 # MPC_code.py:816
     return {k: np.array(v) for k, v in log.items()}
 
 
@@ -474,13 +483,13 @@ def qp_polish(H, g, E, e, G, lo, hi, w, z_lo, z_hi, act_tol=None):
     return dict(w=w2, nu=nu, z_lo=zl, z_hi=zh, res=res, n_active=int(a_lo.sum() + a_hi.sum()))
 
 
-def ocp_solve_exact(p, xhat, xs, us, dhat, u_prev, tol=1e-11):
+def ocp_solve_exact(p, xhat, xs, us, dhat, u_prev, tol=1e-11, px=None, py=None):
     """:func:`ocp_solve` followed by :func:`qp_polish`; ``exact`` tells whether the polish verified."""
-    r = ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=tol)
+    r = ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=tol, px=px, py=py)
     r["exact"] = False
     if r["status"] != STATUS_SOLVED:
         return r
-    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True)
+    H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True, px=px, py=py)
     pol = qp_polish(H, g, E, e, G, lo, hi, r["w"], r["z_lo"], r["z_hi"])
     if pol is not None:
         n, m = p.nx, p.nu
@@ -490,8 +499,8 @@ def ocp_solve_exact(p, xhat, xs, us, dhat, u_prev, tol=1e-11):
     return r
 
 
-def target_solve_exact(p, usp, ysp, xsp, dhat, us_prev, tol=1e-11):
-    H, g, E, e, G, lo, hi = target_qp(p, usp, ysp, xsp, dhat, us_prev)
+def target_solve_exact(p, usp, ysp, xsp, dhat, us_prev, tol=1e-11, px0=None, py0=None):
+    H, g, E, e, G, lo, hi = target_qp(p, usp, ysp, xsp, dhat, us_prev, px0, py0)
     r = qp_ipm_dense(H, g, E, e, G, lo, hi, tol=tol)
     n, m = p.nx, p.nu
     exact = False

@@ -258,9 +258,13 @@ def test_error_paths_are_loud(cstr, solver_factory, pkg):
     s = solver_factory(cstr)
     one = np.zeros((1, 3)); two = np.zeros((1, 2)); st = np.zeros(1, np.int32)
     dp = lambda a: a.ctypes.data_as(ct.POINTER(ct.c_double))
-    rc = s.lib.mpc_ocp_solve(s.h, 1, dp(one), dp(one), dp(two), dp(one), dp(two), dp(one), None, None, dp(two), dp(one),
+    rc = s.lib.mpc_ocp_solve(s.h, 1, dp(one), dp(one), dp(two), None, dp(two), None, None, None, dp(two), dp(one),
                              st.ctypes.data_as(ct.POINTER(ct.c_int32)), None, None)
-    assert rc != 0 and b"def_px" in s.lib.mpc_last_error()
+    assert rc != 0 and b"dhat is required" in s.lib.mpc_last_error()
+    s.set_model_offsets(4, np.zeros(3), np.zeros(3))             # this step's p_x_k, p_y_k for a batch of 4 ...
+    with pytest.raises(capi.MpcAmdError, match="batch of 4"):
+        s.target_solve(np.zeros(2), np.zeros(3), np.zeros(3), np.zeros((1, 3)), np.zeros(2))      # ... do not fit a batch of 1
+    s.set_model_offsets(1, None, None)
     import copy
     q = copy.copy(cstr); q.nd = 2; q.Bd = cstr.Bd[:, :2]; q.Cd = cstr.Cd[:, :2]; q.dhat0 = np.zeros(2); q.estimator = "none"
     with pytest.raises(capi.MpcAmdError) as e:
@@ -641,3 +645,66 @@ def test_terminal_equality(pkg, solver_factory):
             r = run_closed_loop(p, x0, x0, 6, solver=solver_factory(p, lk))
             assert np.array_equal(r["STATUS_DYN"], ST), (N, lk)
             assert np.abs(r["U"] - U).max() < tol, (N, lk)
+
+
+def _with_model_params(pkg, N=20, **extra):
+    def def_px(t):
+        return [np.array([0.02 * np.sin(0.3 * t), 0.15 * np.cos(0.2 * t), 0.05 * np.sin(0.1 * t + 1.0)])]
+
+    def def_py(t):
+        return [np.array([0.03 * np.cos(0.25 * t), 0.4 * np.sin(0.15 * t), 0.0])]
+    ov = {"N": N, "def_px": def_px, "def_py": def_py}; ov.update(extra)
+    return pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides=ov)
+
+
+def test_model_parameters_over_the_horizon(pkg, solver_factory):
+    """def_px / def_py (MPC_code.py:492-510): px_k in the dynamics, py_k in the output rows of every stage, p_x_k / p_y_k in the
+    estimator's predicted output, the target equalities and the plant.  mpc_ocp_solve(px, py) and mpc_set_model_offsets against the
+    dense statements with par_xmk / par_ymk (oracle/mpc_oracle.py), per call and over a closed loop of the three calls."""
+    import mpc_oracle as o
+    from mpc_code_amd.driver import run_closed_loop
+    p = _with_model_params(pkg)
+    assert p.has_model_params
+    rng = np.random.default_rng(11)
+    B = 32
+    pxh, pyh = p.horizon_params(3.0)
+    assert np.allclose(pxh[4], p.def_px(3.0 + 4)[0]) and pxh.shape == (20, 3) and pyh.shape == (20, 3)      # t_k + i, not t_k + i h
+    xh = rng.uniform([-0.4, -6, -4], [0.4, 6, 4], size=(B, 3)); d = rng.normal(size=(B, 3)) * 0.02; up = np.zeros((B, 2))
+    s = solver_factory(p)
+    # target with p_x_k, p_y_k
+    s.set_model_offsets(B, pxh[0], pyh[0])
+    t = s.target_solve(np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), d, up)
+    tr = [o.target_solve_exact(p, np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), d[b], up[b], px0=pxh[0], py0=pyh[0]) for b in range(B)]
+    assert np.array_equal(t["status"], [r["status"] for r in tr]) and all(r["exact"] for r in tr)
+    # against the exact optimum (active-set polish verified); the bounds of this target are weakly active: 1e-6 (DESIGN.md section 5)
+    assert max(np.abs(t["xs"][b] - tr[b]["xs"]).max() for b in range(B)) < 1e-6 and max(np.abs(t["us"][b] - tr[b]["us"]).max() for b in range(B)) < 1e-6
+    t0 = s.target_solve(np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), d, up)
+    s.set_model_offsets(B, None, None)
+    t1 = s.target_solve(np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), d, up)
+    assert np.array_equal(t0["xs"], t["xs"]) and np.abs(t1["xs"] - t["xs"]).max() > 1e-3            # the offsets matter, and clear
+    # OCP with the horizon values, per instance different (shifted in time)
+    PX = np.stack([p.horizon_params(0.7 * b)[0] for b in range(B)]); PY = np.stack([p.horizon_params(0.7 * b)[1] for b in range(B)])
+    g = s.ocp_solve(xh, t["xs"], t["us"], d, up, want_w=True, px=PX, py=PY)
+    ref = [o.ocp_solve_exact(p, xh[b], t["xs"][b], t["us"][b], d[b], up[b], px=PX[b], py=PY[b]) for b in range(B)]
+    rst = np.array([r["status"] for r in ref])
+    assert np.array_equal(g["status"], rst) and (rst == 0).sum() > B // 2
+    good = np.flatnonzero(rst == 0)
+    assert max(np.abs(g["u0"][b] - ref[b]["u0"]).max() for b in good) < 1e-6 and max(np.abs(g["x1"][b] - ref[b]["x1"]).max() for b in good) < 1e-6
+    assert max(np.abs(g["w"][b] - ref[b]["w"]).max() for b in good) < 1e-5                        # the whole trajectory
+    plain = s.ocp_solve(xh, t["xs"], t["us"], d, up)
+    assert np.abs(plain["u0"][good] - g["u0"][good]).max() > 1e-3                                   # the parameters matter
+    # an output row moved by py_k binds somewhere: y_k = C x_k + py_k within [ymin, ymax] at every stage
+    w = g["w"][good].reshape(len(good), -1)
+    X = np.stack([w[:, k * 5:k * 5 + 3] for k in range(1, p.N)], axis=1)
+    Y = X @ p.C.T + p.fy_const + (d[good] @ p.Cd.T)[:, None, :] + PY[good][:, 1:p.N]
+    assert (Y <= p.ymax + 1e-7).all() and (Y >= p.ymin - 1e-7).all()
+    # closed loop of the three calls
+    x0 = rng.uniform([-0.3, -4, -3], [0.3, 4, 3], size=(5, 3))
+    cl = [o.closed_loop(p, 8, x0_p=x, x0_m=x, ocp=o.ocp_solve_exact, target=o.target_solve_exact) for x in x0]
+    r = run_closed_loop(p, x0, x0, 8, solver=s, fused=False)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "Yp", "D_HAT"):
+        ref_k = np.stack([c[k] for c in cl], axis=1)
+        assert np.abs(r[k] - ref_k).max() < 1e-6, k
+    assert np.array_equal(r["STATUS_DYN"], np.stack([c["STATUS_DYN"] for c in cl], axis=1))
+    with pytest.raises(ValueError, match="def_px"):
+        run_closed_loop(p, x0, x0, 4, solver=s, fused=True)

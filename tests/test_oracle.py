@@ -224,3 +224,26 @@ def test_terminal_equality_rows(pkg):
     assert r["status"] == 0 and np.abs(r["w"][-3:] - xs).max() < 1e-10
     far = o.ocp_solve(p, np.array([0.5, 8.0, -5.0]), xs, us, np.zeros(3), np.zeros(2))
     assert far["status"] == 2 and o.ocp_solve(q, np.array([0.5, 8.0, -5.0]), xs, us, np.zeros(3), np.zeros(2))["status"] != 2
+
+
+def test_model_parameters_enter_the_dense_statements(pkg):
+    """par_xmk[:, k] in the dynamics rows and par_ymk[:, k] in the output rows (Control_Calc.py:43-57,130,161); p_x_k / p_y_k in the
+    target equalities (Target_Calc.py:75-81)."""
+    import mpc_oracle as o
+    p = pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides={"N": 5})
+    rng = np.random.default_rng(0)
+    px, py = rng.normal(size=(5, 3)) * 0.1, rng.normal(size=(5, 3)) * 0.1
+    a = o.ocp_qp(p, np.zeros(3), np.zeros(3), np.zeros(2), np.zeros(3), np.zeros(2))
+    b = o.ocp_qp(p, np.zeros(3), np.zeros(3), np.zeros(2), np.zeros(3), np.zeros(2), px=px, py=py)
+    n = p.nx
+    for k in range(5):
+        assert np.allclose(a[3][n * (k + 1):n * (k + 2)] - b[3][n * (k + 1):n * (k + 2)], px[k])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4]) and not np.allclose(a[5], b[5])
+    r = o.ocp_solve(p, np.array([0.1, 1, 1.0]), np.zeros(3), np.zeros(2), np.zeros(3), np.zeros(2), px=px, py=py)
+    w = r["w"]
+    for k in range(5):      # the returned trajectory obeys the parameterised model
+        xk, uk, xn = w[5 * k:5 * k + 3], w[5 * k + 3:5 * k + 5], w[5 * (k + 1):5 * (k + 1) + 3]
+        assert np.allclose(xn, o.model_fx(p, xk, uk, np.zeros(3), px[k]), atol=1e-10)
+    t = o.target_solve(p, np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), np.zeros(3), np.zeros(2), px0=px[0], py0=py[0])
+    assert np.allclose(t["xs"], o.model_fx(p, t["xs"], t["us"], np.zeros(3), px[0]), atol=1e-10)
+    assert np.allclose(t["ys"], o.model_fy(p, t["xs"], np.zeros(3), py[0]), atol=1e-10)
