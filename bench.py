@@ -65,16 +65,17 @@ def carried_bytes_per_step(p) -> int:
     return 8 * (n_in + n_out + 2 * p.N * (p.nu + 2 * nbounded) + 2 * (2 * p.nu + 3 * (p.nx + p.nu + p.ny)))
 
 
-def measured_traffic(kernel_name: str, instance_steps_per_launch: float):
+def measured_traffic(kernel_name: str, instance_steps_per_launch: float, summary: str = PMC_SUMMARY):
     """HBM-side bytes per launch from the committed rocprofv3 PMC summary (the counters cannot be read from inside this
     process): the summary stores bytes per instance-step of the named kernel; a launch of this run moves that times its
     instance-steps.  Returns (bytes, source)."""
+    name = os.path.relpath(summary, ROOT)
     try:
-        d = json.load(open(PMC_SUMMARY))
+        d = json.load(open(summary))
     except Exception:
-        return None, "profiles/r02_pmc_summary.json missing"
+        return None, name + " missing"
     per = d.get("hbm_bytes_per_instance_step")
-    src = (f"profiles/r02_pmc_summary.json: kernel {d.get('kernel')}, {per:.0f} B per instance-step = (2*FETCH_SIZE + WRITE_SIZE) KiB of "
+    src = (f"{name}: kernel {d.get('kernel')}, {per:.0f} B per instance-step = (2*FETCH_SIZE + WRITE_SIZE) KiB of "
            f"separate rocprofv3 --pmc passes of `{d.get('command')}` / its instance-steps; scaled to this run's {instance_steps_per_launch:.0f} instance-steps per launch")
     if d.get("kernel_short") and d["kernel_short"] not in kernel_name:
         src += f" (NOTE: summary is for {d['kernel_short']}, this run used {kernel_name})"
@@ -142,6 +143,7 @@ def main_nmpc(args):
     ab = (2 * state + 2 * p.nw + p.ny + p.nu) * 8              # state in + out, shifted trajectory in + out, set points
     per_launch_s = float(np.mean(kms)) * 1e-3
     achieved = ab * B * K / per_launch_s / 1e9
+    traffic, traffic_src = measured_traffic("nmpc_loop_kernel", B * K, os.path.join(ROOT, "profiles", "r02_nmpc_pmc_summary.json"))
     out = {"metric": "closed-loop NMPC steps/sec over batch, Ex_NMPC N=30 (BASELINE configs[3])", "value": B * K / dt, "unit": "steps/s", "n_gpus": 1,
            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
@@ -149,10 +151,12 @@ def main_nmpc(args):
                                   "from t=0: EKF + target SQP + %s + plant per step" % (B, SEED, "one real-time SQP iteration" if args.max_sqp == 1 else "SQP (<= %d iterations)" % args.max_sqp),
                       "batch_per_gpu": B, "horizon": p.N, "steps_per_launch": K, "max_sqp": args.max_sqp, "repeats": len(times),
                       "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "nmpc_loop_kernel (one instance per lane)", "launches": 1, "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
-                        "note": "algorithmic bytes: resident state in and out + the shifted trajectory in and out + set points.  The kernel is bound by "
-                                "dependent fp64 arithmetic (RK4 sensitivities of 30 stages x 10 sub-steps per instance, then the Riccati recursion), not by HBM"},
+                        "note": "algorithmic bytes: resident state in and out + the shifted trajectory in and out + set points.  Measured traffic is two "
+                                "orders above them: this kernel is the instance-per-lane design, its Riccati workspace (20 KB per instance) and the "
+                                "linearisation slab (7 KB) stream through HBM in every sweep - about 2.5 TB/s over a launch, next to the dependent fp64 "
+                                "chains of the RK4 sensitivities; the on-chip (wave-autonomous) solver of the linear path is the next step (DESIGN.md section 8)"},
            "solver": {"frac_solved": float((st == 0).mean()), "frac_maxiter": float((st == 1).mean()), "frac_infeasible_hold": float((st == 2).mean()),
                       "mean_sqp": float(sqp.mean()), "mean_ipm_iters_last_qp": float(it.mean())}}
     if not args.no_cpu_baseline:
