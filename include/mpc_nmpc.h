@@ -37,6 +37,14 @@ typedef struct nmpc_desc {
     const double *dmin, *dmax;   /* saturation of dhat, or NULL */
     const double *Q_kf, *R_kf;   /* EKF covariances [nx+nd]^2, [ny]^2 */
     const int32_t *ycols;        /* output row i is state ycols[i] (-1: not a single state; then it must be unbounded) */
+    /* round-2 additions (discrete-time examples, Ex_NMPC_dis.py) */
+    const double *Pf;            /* terminal weight 1/2 (x_N - xs)' Pf (x_N - xs) (User_vfin when it is such a form), or NULL */
+    const double *Cd;            /* [ny][nd] of offree = 'lin' (y = h(x) + Cd d; the state part Bd d is inside the generated model), or NULL */
+    const double *K;             /* [nx+nd][ny] fixed observer gain (lue), with estimator = 1 */
+    int32_t estimator;           /* 0: extended Kalman filter (Q_kf, R_kf), 1: fixed gain xi+ = xi + K (y - yhat), Estimator.py:231-261 */
+    int32_t du_form;             /* R weighs u_k - u_{k-1} (the Ex-file's S), Control_Calc.py:163-166,180-181 */
+    int32_t duss_form;           /* Rss weighs us - us_prev (Sss), Target_Calc.py:121-122 */
+    const double *Dumin, *Dumax; /* bounds on u_k - u_{k-1} (g2 rows), or NULL.  du_form or these need a library generated with DUV */
 } nmpc_desc;
 
 int nmpc_create(const nmpc_desc *desc, nmpc_handle **out);
@@ -48,7 +56,9 @@ const char *nmpc_build_info(void);      /* "gfx950;nmpc;dims=nx/nu/ny/nd/nxp;mx=
 int nmpc_alloc(nmpc_handle *h, int32_t B, int32_t max_steps);
 int nmpc_set_state(nmpc_handle *h, const double *x_p, const double *xhat, const double *dhat, const double *P, const double *u,
                    const double *xs, const double *us);
-int nmpc_set_schedule(nmpc_handle *h, int32_t nsteps, const double *ysp /* [nsteps][ny] */, const double *usp /* [nsteps][nu] */);
+/* pxp [nsteps][nxp], pyp [nsteps][ny]: the plant's disturbances def_pxp(t), def_pyp(t) (MPC_code.py:512-515), or NULL */
+int nmpc_set_schedule(nmpc_handle *h, int32_t nsteps, const double *ysp /* [nsteps][ny] */, const double *usp /* [nsteps][nu] */,
+                      const double *pxp, const double *pyp);
 /* steps [k0, k0+nsteps); asynchronous.  max_sqp SQP iterations per OCP (1 = real-time iteration), stopped early when the
  * trajectory moves less than sqp_tol */
 int nmpc_run(nmpc_handle *h, int32_t k0, int32_t nsteps, int32_t max_sqp, double sqp_tol);

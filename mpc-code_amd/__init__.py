@@ -25,9 +25,9 @@ from .nlproblem import NonlinearMPCProblem, nl_problem_from_namespace  # noqa: E
 
 def load_problem(path, overrides=None):
     """Ex-style file -> :class:`LinearMPCProblem`, or :class:`NonlinearMPCProblem` when the model is a user function
-    (``User_fxm_Cont``: the reference's own test, MPC_code.py:94)."""
+    (``User_fxm_Cont`` / ``User_fxm_Dis``: the reference's own tests, MPC_code.py:94-111)."""
     ns = load_exfile(path, overrides)
-    if ns.get("User_fxm_Cont") is not None:
+    if ns.get("User_fxm_Cont") is not None or ns.get("User_fxm_Dis") is not None:
         return nl_problem_from_namespace(ns)
     return problem_from_namespace(ns)
 

@@ -23,6 +23,7 @@ template <class M>
 __device__ __noinline__ void rk4_model(const double *x0, const double *u, const double *d, double t, double h, double *xn)
 {
     constexpr int NX = M::NX;
+    if (M::DISCRETE) { M::f(x0, u, d, t, xn); return; }      // the user's map is the step (Utilities.py:186-198)
     const double dt = h / M::MX;
     double x[NX];
     MPC_UNROLL for (int i = 0; i < NX; i++) x[i] = x0[i];
@@ -45,6 +46,7 @@ template <class M>
 __device__ __noinline__ void rk4_plant(const double *x0, const double *u, double t, double h, double *xn)
 {
     constexpr int NX = M::NXP;
+    if (M::PLANT_DISCRETE) { M::fp(x0, u, t, xn); return; }
     const double dt = h / M::MX;
     double x[NX];
     MPC_UNROLL for (int i = 0; i < NX; i++) x[i] = x0[i];
@@ -70,6 +72,7 @@ __device__ __noinline__ void rk4_model_sens(const double *x0, const double *u, c
                                             double *xn, double (*A)[M::NX], double (*B)[M::NU], double (*G)[M::ND > 0 ? M::ND : 1])
 {
     constexpr int NX = M::NX, NU = M::NU, ND = M::ND, NDD = ND > 0 ? ND : 1, NP = NX + NU + ND;
+    if (M::DISCRETE) { M::f_jac(x0, u, d, t, xn, A, B, G); return; }
     const double dt = h / M::MX;
     double x[NX], S[NX][NP];
     MPC_UNROLL for (int i = 0; i < NX; i++) { x[i] = x0[i]; MPC_UNROLL for (int j = 0; j < NP; j++) S[i][j] = (i == j) ? 1.0 : 0.0; }

@@ -62,6 +62,14 @@ class SymVec:
     evaluates symbolic model code (the non-linear front end is a later scope row).
     """
 
+    def __new__(cls, name=None, n: int = 1, m: int = 1):
+        if isinstance(name, (int, np.integer)):      # SX(n, m): a zero matrix to be filled in (Ex_NMPC_dis.py:67,89)
+            from .symtrace import SymMat
+            return SymMat.zeros(name, n)
+        if isinstance(name, float):                  # SX(1.): a number
+            return name
+        return super().__new__(cls)
+
     def __init__(self, name: str, n: int = 1, m: int = 1):
         self.name, self._n, self._m = name, int(n), int(m)
 
@@ -92,11 +100,11 @@ def _vertcat(*parts):
     """Numeric ``vertcat``: stacks scalars / arrays along axis 0 (the state index), broadcasting over trailing batch
     axes, so that a user plant function written for CasADi evaluates on ``x[nx, B]`` arrays; shape objects pass through;
     traced expressions (:mod:`symtrace`) come back as a flat list of nodes."""
-    from .symtrace import Sym, flatten
+    from .symtrace import Sym, SymMat, flatten
     if any(isinstance(a, SymVec) for a in parts):
         return list(parts)
-    if any(isinstance(a, Sym) or (isinstance(a, list) and a and isinstance(a[0], Sym)) for a in parts):
-        return flatten(parts)
+    if any(isinstance(a, (Sym, SymMat)) or (isinstance(a, list) and a and isinstance(a[0], Sym)) for a in parts):
+        return SymMat.col(flatten(parts))
     rows = [np.asarray(a, dtype=np.float64) for a in parts]
     tail = np.broadcast_shapes(*[r.shape[1:] if r.ndim >= 2 else r.shape for r in rows])
     out = []
@@ -117,13 +125,14 @@ def _old_div(a, b):
 
 
 def _make_standins() -> Dict[str, types.ModuleType]:
+    from .symtrace import mtimes as symtrace_mtimes
     cas = types.ModuleType("casadi")
     cas.SX = SymVec
     cas.MX = SymVec
     cas.DM = np.asarray
     cas.vertcat = _vertcat
     cas.horzcat = lambda *a: list(a)
-    cas.mtimes = lambda *a: NotImplemented
+    cas.mtimes = symtrace_mtimes
     cas.pi = math.pi
     cas.inf = math.inf
     from . import symtrace

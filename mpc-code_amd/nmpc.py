@@ -25,7 +25,8 @@ _ip = ct.POINTER(ct.c_int32)
 class _NDesc(ct.Structure):
     _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "N", "max_iter", "device")] + [("h", ct.c_double)]
                 + [(k, _dp) for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss",
-                                      "xmax_ss", "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf")] + [("ycols", _ip)])
+                                      "xmax_ss", "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf")] + [("ycols", _ip)]
+                + [(k, _dp) for k in ("Pf", "Cd", "K")] + [(k, ct.c_int32) for k in ("estimator", "du_form", "duss_form")] + [(k, _dp) for k in ("Dumin", "Dumax")])
 
 
 _libs: Dict[str, ct.CDLL] = {}
@@ -42,7 +43,7 @@ def load_nmpc_library(path: str) -> ct.CDLL:
     lib.nmpc_build_info.restype = ct.c_char_p
     lib.nmpc_alloc.argtypes = [vp, ct.c_int32, ct.c_int32]
     lib.nmpc_set_state.argtypes = [vp] + [_dp] * 7
-    lib.nmpc_set_schedule.argtypes = [vp, ct.c_int32, _dp, _dp]
+    lib.nmpc_set_schedule.argtypes = [vp, ct.c_int32, _dp, _dp, _dp, _dp]
     lib.nmpc_run.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
     lib.nmpc_sync.argtypes = [vp]
     lib.nmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
@@ -72,8 +73,9 @@ class NmpcSolver:
         self._keep = {}
         d = _NDesc()
         d.nx, d.nu, d.ny, d.nd, d.nxp, d.N, d.max_iter, d.device, d.h = p.nx, p.nu, p.ny, p.nd, p.nxp, p.N, int(p.max_iter), int(device), float(p.h)
+        d.estimator, d.du_form, d.duss_form = int(p.estimator == "lue"), int(bool(p.DUForm)), int(bool(p.DUssForm))
         for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss",
-                  "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf"):
+                  "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf", "Pf", "Cd", "K", "Dumin", "Dumax"):
             v = getattr(p, k, None)
             if v is None:
                 setattr(d, k, None)
@@ -124,7 +126,9 @@ class NmpcSolver:
 
     def set_schedule(self, sched: Dict[str, np.ndarray]):
         ysp, usp = _c(sched["ysp"]), _c(sched["usp"])
-        self._chk(self.lib.nmpc_set_schedule(self.h, ysp.shape[0], ysp.ctypes.data_as(_dp), usp.ctypes.data_as(_dp)), "nmpc_set_schedule")
+        pxp = _c(sched["pxp"]) if sched.get("pxp") is not None else None; pyp = _c(sched["pyp"]) if sched.get("pyp") is not None else None
+        self._chk(self.lib.nmpc_set_schedule(self.h, ysp.shape[0], ysp.ctypes.data_as(_dp), usp.ctypes.data_as(_dp),
+                                             None if pxp is None else pxp.ctypes.data_as(_dp), None if pyp is None else pyp.ctypes.data_as(_dp)), "nmpc_set_schedule")
         self.steps = ysp.shape[0]
 
     def run(self, k0: int, nsteps: int, max_sqp: int = 1, sqp_tol: float = 1e-9):
@@ -171,7 +175,7 @@ def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = 
         out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
         u_prev = np.concatenate([_rows(p.u0, B, p.nu)[None], out["U"][:-1]]) if nsteps else out["U"]
         t = (np.arange(nsteps) * p.h)[:, None]
-        out["Yp"] = p.plant_output(out["Xp"], u_prev, t)                     # MPC_code.py:531-534
+        out["Yp"] = p.plant_output(out["Xp"], u_prev, t) + p.schedules(nsteps)["pyp"][:, None, :]      # MPC_code.py:531-534
     finally:
         if own:
             s.close()

@@ -111,6 +111,7 @@ class Sym:
         if o.is_const(1.0): return self
         if o.is_const(0.0): return Sym.const(1.0)
         if o.is_const(2.0): return self * self
+        if o.is_const(0.5): return self.sqrt()
         return Sym("pow", (self, o))
     __rpow__ = lambda self, o: Sym.lift(o).__pow__(self)
 
@@ -142,7 +143,7 @@ class Sym:
     def __repr__(self):
         if self.op == "const": return repr(self.val)
         if self.op == "var": return str(self.val)
-        return f"{self.op}({', '.join(map(repr, self.args))})"
+        return f"<{self.op} node {self._id}>"      # never the whole tree: shared sub-expressions make it exponentially long
 
 
 def if_else(cond, a, b):
@@ -159,12 +160,103 @@ def symvec(name: str, n: int) -> List[Sym]:
     return [Sym.var(f"{name}[{i}]") for i in range(n)]
 
 
+class SymMat:
+    """A small dense matrix of traced expressions / numbers with the part of ``casadi.SX``'s surface the Ex-files use inside their
+    functions: ``SX(n, m)`` zeros, element and slice reads (a slice is a COPY, as in CasADi), element and slice assignment, ``.T``,
+    ``.shape``, ``size1()``, element-wise arithmetic with numbers / NumPy arrays / other matrices, ``mtimes``.  A column vector
+    indexed with one integer gives the element itself."""
+    __array_priority__ = 1000      # NumPy lets our operators win: np.array * SymMat -> SymMat.__rmul__
+
+    def __init__(self, a):
+        arr = np.empty(np.shape(a), dtype=object)
+        arr[...] = a
+        self.a = arr.reshape(-1, 1) if arr.ndim < 2 else arr
+
+    @classmethod
+    def zeros(cls, n, m=1):
+        z = np.empty((int(n), int(m)), dtype=object); z[...] = 0.0
+        return cls(z)
+
+    @classmethod
+    def col(cls, items):
+        z = np.empty((len(items), 1), dtype=object)
+        for i, v in enumerate(items): z[i, 0] = v
+        return cls(z)
+
+    shape = property(lambda self: self.a.shape)
+    T = property(lambda self: SymMat(self.a.T.copy()))
+    def size1(self): return self.a.shape[0]
+    def size2(self): return self.a.shape[1]
+    def __len__(self): return self.a.shape[0]
+    def __iter__(self): return iter(self.a.ravel()) if self.a.shape[1] == 1 else iter(SymMat(r[None].copy()) for r in self.a)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)) and self.a.shape[1] == 1:
+            return self.a[idx, 0]
+        r = self.a[idx]
+        return SymMat(np.array(r, dtype=object).copy()) if isinstance(r, np.ndarray) else r
+
+    def __setitem__(self, idx, v):
+        if isinstance(v, SymMat): v = v.a
+        elif isinstance(v, (list, tuple)): v = SymMat.col(flatten(v)).a
+        if isinstance(idx, (int, np.integer)) and self.a.shape[1] == 1:
+            if isinstance(v, np.ndarray): v = v.ravel()[0]
+            self.a[idx, 0] = v
+        else:
+            tgt = self.a[idx]
+            if isinstance(v, np.ndarray) and isinstance(tgt, np.ndarray) and v.size == tgt.size: v = v.reshape(tgt.shape)
+            self.a[idx] = v
+
+    @staticmethod
+    def _arr(o):
+        if isinstance(o, SymMat): return o.a
+        if isinstance(o, (list, tuple)): return SymMat.col(flatten(o)).a
+        if isinstance(o, np.ndarray) and o.ndim == 1: return o.reshape(-1, 1)
+        return o
+
+    def _bin(self, o, f): return SymMat(f(self.a, SymMat._arr(o)))
+    __add__ = lambda self, o: self._bin(o, lambda a, b: a + b)
+    __radd__ = lambda self, o: self._bin(o, lambda a, b: b + a)
+    __sub__ = lambda self, o: self._bin(o, lambda a, b: a - b)
+    __rsub__ = lambda self, o: self._bin(o, lambda a, b: b - a)
+    __mul__ = lambda self, o: self._bin(o, lambda a, b: a * b)
+    __rmul__ = lambda self, o: self._bin(o, lambda a, b: b * a)
+    __truediv__ = lambda self, o: self._bin(o, lambda a, b: a / b)
+    __rtruediv__ = lambda self, o: self._bin(o, lambda a, b: b / a)
+    __pow__ = lambda self, o: self._bin(o, lambda a, b: a ** b)
+    __neg__ = lambda self: SymMat(-self.a)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.array(self.a.tolist(), dtype=np.float64 if dtype is None else dtype)
+
+    def __repr__(self):
+        return f"SymMat{self.a.shape}"
+
+
+def mtimes(*ms):
+    """``casadi.mtimes``: matrix product of numbers, NumPy arrays and :class:`SymMat`; a 1 x 1 result is returned as its element."""
+    def arr(m):
+        if isinstance(m, SymMat): return m.a
+        if isinstance(m, (list, tuple)): return SymMat.col(flatten(m)).a
+        m = np.asarray(m)
+        return m.reshape(-1, 1) if m.ndim == 1 else m
+    out = ms[0]
+    for m in ms[1:]:
+        a, b = arr(out), arr(m)
+        out = a * b if (np.ndim(a) == 0 or np.ndim(b) == 0) else SymMat(np.dot(a, b))
+    if isinstance(out, SymMat) and out.a.shape == (1, 1):
+        return out.a[0, 0]
+    return out
+
+
 def flatten(v) -> List[Sym]:
     """What a traced ``vertcat`` / list / scalar returns, as a flat list of nodes."""
     if isinstance(v, Sym):
         return [v]
-    if isinstance(v, (int, float)):
-        return [Sym.const(v)]
+    if isinstance(v, (int, float, np.floating, np.integer)):
+        return [Sym.const(float(v))]
+    if isinstance(v, SymMat):
+        return [Sym.lift(e) for e in v.a.ravel()]
     out: List[Sym] = []
     for a in v:
         out.extend(flatten(a))

@@ -25,6 +25,7 @@ from __future__ import annotations
 import numpy as np
 
 import mpc_oracle as o
+from mpc_code_amd import symtrace as st
 
 STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2
 
@@ -36,35 +37,47 @@ def _col(v, n):
     return np.asarray(v, dtype=np.float64).reshape(n)
 
 
-def model_fx(p, x, u, d, t=0.0):
-    """Fx_model(x,u,h,d,t): Mx RK4 steps of User_fxm_Cont over h (Utilities.py:160-172)."""
-    f = lambda x_, t_: _col(p.funcs["User_fxm_Cont"](x_, u, d, t_, np.zeros(p.nx)), p.nx)
-    dt = p.h / p.Mx
+def _sm(v):
+    """The container the Ex-file functions index, slice and assign into (numbers inside: no tracing here)."""
+    return st.SymMat.col([float(a) for a in np.ravel(v)])
+
+
+def _rk4(f, x, t, h, Mx):
+    dt = h / Mx
     x = np.array(x, dtype=np.float64)
-    for s in range(p.Mx):
+    for s in range(Mx):
         ts = t + s * dt
         k1 = f(x, ts); k2 = f(x + 0.5 * dt * k1, ts + 0.5 * dt); k3 = f(x + 0.5 * dt * k2, ts + 0.5 * dt); k4 = f(x + dt * k3, ts + dt)
         x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
     return x
+
+
+def model_fx(p, x, u, d, t=0.0):
+    """Fx_model(x,u,h,d,t): Mx RK4 steps of User_fxm_Cont over h (Utilities.py:160-172), or the user's discrete map
+    (User_fxm_Dis, :186-198); + Bd d when offree = 'lin' (:189-190)."""
+    if getattr(p, "discrete", False):
+        out = _col(p.funcs["User_fxm_Dis"](_sm(x), _sm(u), _sm(d), t, _sm(np.zeros(p.nx))), p.nx)
+    else:
+        out = _rk4(lambda x_, t_: _col(p.funcs["User_fxm_Cont"](x_, u, d, t_, np.zeros(p.nx)), p.nx), x, t, p.h, p.Mx)
+    return out + p.Bd @ d if getattr(p, "offree", "nl") == "lin" else out
 
 
 def model_fy(p, x, u, d, t=0.0):
-    return _col(p.funcs["User_fym"](x, u, d, t, np.zeros(p.ny)), p.ny)
+    out = _col(p.funcs["User_fym"](_sm(x), _sm(u), _sm(d), t, _sm(np.zeros(p.ny))), p.ny)
+    return out + p.Cd @ d if getattr(p, "offree", "nl") == "lin" else out
 
 
-def plant_fx(p, xp, u, t):
-    f = lambda x_, t_: _col(p.funcs["User_fxp_Cont"](x_, t_, u, np.zeros(p.nxp), np.zeros(p.nxp)), p.nxp)
-    dt = p.h / p.Mx
-    x = np.array(xp, dtype=np.float64)
-    for s in range(p.Mx):
-        ts = t + s * dt
-        k1 = f(x, ts); k2 = f(x + 0.5 * dt * k1, ts + 0.5 * dt); k3 = f(x + 0.5 * dt * k2, ts + 0.5 * dt); k4 = f(x + dt * k3, ts + dt)
-        x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
-    return x
+def plant_fx(p, xp, u, t, pxp=None):
+    if getattr(p, "plant_discrete", False):
+        out = _col(p.funcs["User_fxp_Dis"](_sm(xp), t, _sm(u), _sm(np.zeros(p.nxp)), _sm(np.zeros(p.nxp))), p.nxp)
+    else:
+        out = _rk4(lambda x_, t_: _col(p.funcs["User_fxp_Cont"](x_, t_, u, np.zeros(p.nxp), np.zeros(p.nxp)), p.nxp), xp, t, p.h, p.Mx)
+    return out if pxp is None else out + pxp                     # LinPar: + pxp (Utilities.py:78-82,86-87)
 
 
-def plant_fy(p, xp, u, t):
-    return _col(p.funcs["User_fyp"](xp, u, t, np.zeros(p.ny), np.zeros(p.ny)), p.ny)
+def plant_fy(p, xp, u, t, pyp=None):
+    out = _col(p.funcs["User_fyp"](_sm(xp), _sm(u), t, _sm(np.zeros(p.ny)), _sm(np.zeros(p.ny))), p.ny)
+    return out if pyp is None else out + pyp
 
 
 def _fd(fun, v, rel=1e-6):
@@ -121,7 +134,7 @@ def _linear_view(p, A, B, c, C, e):
     q.A, q.B, q.C, q.fx_const, q.fy_const = A, B, C, c, e
     q.Bd, q.Cd = np.zeros((p.nx, 0)), np.zeros((p.ny, 0))
     q.Q, q.R, q.P, q.DUForm = p.Q, p.R, np.zeros((p.nx, p.nx)), False
-    q.Qss, q.Rss, q.DUssForm = p.Qss, p.Rss, False
+    q.Qss, q.Rss, q.DUssForm = p.Qss, p.Rss, bool(getattr(p, "DUssForm", False))
     for k in ("umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss"):
         setattr(q, k, getattr(p, k))
     q.y_bounded = bool(np.isfinite(p.ymin).any() or np.isfinite(p.ymax).any())
@@ -132,7 +145,7 @@ def _linear_view(p, A, B, c, C, e):
 # ---------------------------------------------------------------------------------------------------
 # target: opt_ss for a non-linear model (Target_Calc.py:20-161), SQP on the linear target QP
 # ---------------------------------------------------------------------------------------------------
-def target_solve(p, usp, ysp, d, xs0, us0, tol=1e-10, max_sqp=30, t=0.0):
+def target_solve(p, usp, ysp, d, xs0, us0, tol=1e-10, max_sqp=30, t=0.0, us_prev=None):
     xs, us = np.array(xs0, dtype=np.float64), np.array(us0, dtype=np.float64)
     for it in range(max_sqp):
         A, B, _, F = linearize(p, xs, us, d, t)
@@ -140,7 +153,7 @@ def target_solve(p, usp, ysp, d, xs0, us0, tol=1e-10, max_sqp=30, t=0.0):
         c = F - A @ xs - B @ us
         e = model_fy(p, xs, us, d, t) - Cx @ xs
         q = _linear_view(p, A, B, c, Cx, e)
-        H, g, E, ee, G, lo, hi = o.target_qp(q, usp, ysp, np.zeros(p.nx), np.zeros(0), us)
+        H, g, E, ee, G, lo, hi = o.target_qp(q, usp, ysp, np.zeros(p.nx), np.zeros(0), us0 if us_prev is None else us_prev)
         r = o.qp_ipm_dense(H, g, E, ee, G, lo, hi, tol=1e-12)
         if r["status"] != STATUS_SOLVED:
             return dict(xs=xs, us=us, status=r["status"], sqp_iters=it)
@@ -155,7 +168,7 @@ def target_solve(p, usp, ysp, d, xs0, us0, tol=1e-10, max_sqp=30, t=0.0):
 # ---------------------------------------------------------------------------------------------------
 # OCP: opt_dyn for a non-linear model (Control_Calc.py:20-260), SQP on a dense QP in opt_dyn's own order
 # ---------------------------------------------------------------------------------------------------
-def ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us):
+def ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us, u_prev=None):
     """QP of one SQP iteration: min sum_k 1/2 (x_k-xs)'Q(x_k-xs) + 1/2 (u_k-us)'R(u_k-us), x_0 = xhat,
     x_{k+1} = A_k x_k + B_k u_k + c_k, bounds on x_1..x_N and u, output rows ymin <= C x_k + e <= ymax for k = 1..N-1
     (the k = 0 row constrains the given x_0: feasibility test made by the caller)."""
@@ -164,9 +177,19 @@ def ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us):
     ix = lambda k: slice(nxu * k, nxu * k + n)
     iu = lambda k: slice(nxu * k + n, nxu * k + nxu)
     H = np.zeros((nw, nw)); g = np.zeros(nw)
+    DU = bool(getattr(p, "DUForm", False))
     for k in range(N):
         H[ix(k), ix(k)] += p.Q; g[ix(k)] += -p.Q @ xs
-        H[iu(k), iu(k)] += p.R; g[iu(k)] += -p.R @ us
+        H[iu(k), iu(k)] += p.R
+        if not DU:
+            g[iu(k)] += -p.R @ us
+        elif k == 0:                       # du = U[0] - um1 (Control_Calc.py:163-166,180-181)
+            g[iu(k)] += -p.R @ u_prev
+        else:                              # du = U[k] - U[k-1]
+            H[iu(k - 1), iu(k - 1)] += p.R; H[iu(k), iu(k - 1)] -= p.R; H[iu(k - 1), iu(k)] -= p.R
+    Pf = getattr(p, "Pf", None)
+    if Pf is not None:                     # Vfin = 1/2 (x_N - xs)' Pf (x_N - xs)
+        H[ix(N), ix(N)] += Pf; g[ix(N)] += -Pf @ xs
     E = np.zeros((n * (N + 1), nw)); ee = np.zeros(n * (N + 1))
     E[0:n, ix(0)] = np.eye(n); ee[0:n] = xhat
     for k in range(N):
@@ -185,11 +208,21 @@ def ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us):
         for i in range(p.ny):
             if np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i]):
                 row = np.zeros(nw); row[ix(k)] = C[i]; rows.append(row); lo.append(p.ymin[i] - e[i]); hi.append(p.ymax[i] - e[i])
+    if getattr(p, "Dumin", None) is not None or getattr(p, "Dumax", None) is not None:      # g2 rows, Control_Calc.py:163-169,241-243
+        dlo = p.Dumin if p.Dumin is not None else np.full(m, -np.inf); dhi = p.Dumax if p.Dumax is not None else np.full(m, np.inf)
+        for k in range(N):
+            for i in range(m):
+                if np.isfinite(dlo[i]) or np.isfinite(dhi[i]):
+                    row = np.zeros(nw); row[nxu * k + n + i] = 1.0
+                    off = u_prev[i] if k == 0 else 0.0
+                    if k > 0:
+                        row[nxu * (k - 1) + n + i] = -1.0
+                    rows.append(row); lo.append(dlo[i] + off); hi.append(dhi[i] + off)
     G = np.array(rows) if rows else np.zeros((0, nw))
     return H, g, E, ee, G, np.array(lo, dtype=float), np.array(hi, dtype=float)
 
 
-def ocp_solve(p, xhat, xs, us, d, w_guess, max_sqp=50, tol=1e-9, t=0.0):
+def ocp_solve(p, xhat, xs, us, d, w_guess, max_sqp=50, tol=1e-9, t=0.0, u_prev=None):
     """SQP from the trajectory ``w_guess`` (opt_dyn's order).  ``max_sqp = 1`` is one real-time iteration.
     Returns dict(u0, x1, w, status, sqp_iters, step)."""
     n, m, N = p.nx, p.nu, p.N
@@ -208,7 +241,7 @@ def ocp_solve(p, xhat, xs, us, d, w_guess, max_sqp=50, tol=1e-9, t=0.0):
             Ak.append(A); Bk.append(B); ck.append(F - A @ xk - B @ uk)
         C, _ = output_jac(p, xhat, us, d, t)                      # outputs that are single states: constant selection rows
         e = model_fy(p, xhat, us, d, t) - C @ xhat
-        H, g, E, ee, G, lo, hi = ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us)
+        H, g, E, ee, G, lo, hi = ocp_qp_ltv(p, Ak, Bk, ck, C, e, xhat, xs, us, u_prev)
         r = o.qp_ipm_dense(H, g, E, ee, G, lo, hi, tol=1e-11)
         if r["status"] == STATUS_INFEASIBLE:
             return dict(u0=None, x1=None, w=w, status=STATUS_INFEASIBLE, sqp_iters=it, step=step)
@@ -222,7 +255,7 @@ def ocp_solve(p, xhat, xs, us, d, w_guess, max_sqp=50, tol=1e-9, t=0.0):
                 sqp_iters=it + 1, step=step)
 
 
-def kkt_nlp(p, w, xhat, xs, us, d, t=0.0):
+def kkt_nlp(p, w, xhat, xs, us, d, t=0.0, u_prev=None):
     """Certificate of an OCP point against the NLP itself: dynamics defects and the least-squares stationarity residual
     |grad f + J' lambda + bound multipliers| with multipliers fitted on the active set (bounds within 1e-7)."""
     n, m, N = p.nx, p.nu, p.N
@@ -235,7 +268,8 @@ def kkt_nlp(p, w, xhat, xs, us, d, t=0.0):
         Ak.append(A); Bk.append(B)
         defect = max(defect, np.abs(F - w[nxu * (k + 1):nxu * (k + 1) + n]).max())
     C, _ = output_jac(p, xhat, us, d, t)
-    H, g, E, ee, G, lo, hi = ocp_qp_ltv(p, Ak, Bk, [np.zeros(n)] * N, C, np.zeros(p.ny), xhat, xs, us)
+    e = model_fy(p, xhat, us, d, t) - C @ xhat
+    H, g, E, ee, G, lo, hi = ocp_qp_ltv(p, Ak, Bk, [np.zeros(n)] * N, C, e, xhat, xs, us, u_prev)
     grad = H @ w + g
     Gw = G @ w
     act = (np.abs(Gw - lo) < 1e-7) | (np.abs(Gw - hi) < 1e-7)
@@ -254,6 +288,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certi
     x = np.array(p.x0_p if x0_p is None else x0_p, dtype=np.float64)
     xhat = np.array(p.x0_m if x0_m is None else x0_m, dtype=np.float64)
     u = p.u0.copy(); dhat = p.dhat0.copy(); Pk = p.P0.copy()
+    lue = getattr(p, "estimator", "ekf") == "lue"
     xs, us = xhat.copy(), u.copy()
     sched = p.schedules(nsteps)
     w = np.concatenate([np.tile(np.concatenate([xhat, u]), N), xhat])          # :740-756
@@ -262,22 +297,25 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certi
     for k in range(nsteps):
         t = k * p.h
         L["Xp"].append(x.copy()); L["X_HAT"].append(xhat.copy())
-        y = plant_fy(p, x, u, t)                                               # :531-534
+        y = plant_fy(p, x, u, t, sched["pyp"][k])                              # :531-534
         L["Yp"].append(y.copy())
-        xi, Pk = ekf(p, np.concatenate([xhat, dhat]), Pk, y, u, t)             # :577-650
+        if lue:                                                               # xi+ = xi + K (y - yhat), Estimator.py:231-261
+            xi = np.concatenate([xhat, dhat]) + p.K @ (y - model_fy(p, xhat, u, dhat, t))
+        else:
+            xi, Pk = ekf(p, np.concatenate([xhat, dhat]), Pk, y, u, t)         # :577-650
         xhat, dhat = xi[:n].copy(), xi[n:].copy()
         if p.dmin is not None:
             dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)               # :655-668
         L["D_HAT"].append(dhat.copy())
         us_prev, xs_prev = us.copy(), xs.copy()
-        tg = target_solve(p, sched["usp"][k], sched["ysp"][k], dhat, xs, us, t=t)   # :693-718
+        tg = target_solve(p, sched["usp"][k], sched["ysp"][k], dhat, xs, us, t=t, us_prev=us_prev)   # :693-718
         if tg["status"] != STATUS_INFEASIBLE:
             xs, us = tg["xs"], tg["us"]
         L["XS"].append(xs.copy()); L["US"].append(us.copy()); L["STATUS_SS"].append(tg["status"]); L["SQP_SS"].append(tg["sqp_iters"])
-        r = ocp_solve(p, xhat, xs, us, dhat, w, max_sqp=max_sqp, tol=sqp_tol, t=t)    # :733-805
+        r = ocp_solve(p, xhat, xs, us, dhat, w, max_sqp=max_sqp, tol=sqp_tol, t=t, u_prev=u)    # :733-805
         L["W"].append(r["w"].copy())
         if certify and r["status"] == STATUS_SOLVED:
-            c = kkt_nlp(p, r["w"], xhat, xs, us, dhat, t)
+            c = kkt_nlp(p, r["w"], xhat, xs, us, dhat, t, u_prev=u)
             L["KKT_DEFECT"].append(c["defect"]); L["KKT_STAT"].append(c["stationarity"]); L["KKT_VIOL"].append(c["bound_violation"])
         else:
             L["KKT_DEFECT"].append(np.nan); L["KKT_STAT"].append(np.nan); L["KKT_VIOL"].append(np.nan)
@@ -287,5 +325,5 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certi
         else:
             xhat = model_fx(p, xhat, u, dhat, t)                              # :804-805
         L["U"].append(u.copy()); L["STATUS_DYN"].append(r["status"]); L["SQP_DYN"].append(r["sqp_iters"])
-        x = plant_fx(p, x, u, t)                                               # :813-816
+        x = plant_fx(p, x, u, t, sched["pxp"][k])                              # :813-816
     return {k: np.array(v) for k, v in L.items()}

@@ -37,7 +37,33 @@ def run(p, nsteps, x0s, **kw):
     return {k: np.stack([lg[k] for lg in logs], axis=1) for k in logs[0]}
 
 
+def quadtank():
+    """tests/golden/nmpc_quadtank.npz: the discrete-time quadruple tank (examples/quadtank_nmpc_dis.py, N = 20): real-time iteration
+    over 16 steps (plant disturbance from t = 0, the set-point change of tests/nmpc_cases.py at t > 30) for the shipped start and a perturbed one; 9 steps with
+    every OCP iterated to its KKT point."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from nmpc_cases import quadtank_mild_setpoints
+    p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "quadtank_nmpc_dis.py"), overrides={"defSP": quadtank_mild_setpoints})
+    rng = np.random.default_rng(20240612)
+    x0 = np.tile(p.x0_p, (2, 1)); x0[1, 2:] += rng.uniform(-1, 1, 4) * [1.0, 1.0, 0.3, 0.3]
+    out = {}
+    t0 = time.time()
+    r = run(p, 16, x0, max_sqp=1)
+    out.update({"rti_" + k: v for k, v in r.items()}); out["rti_x0"] = x0
+    print("quadtank rti", time.time() - t0, flush=True)
+    r = run(p, 9, x0[:1], max_sqp=50, sqp_tol=1e-9, certify=True)
+    out.update({"sqp_" + k: v for k, v in r.items()}); out["sqp_x0"] = x0[:1]
+    print("quadtank sqp", time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "nmpc_quadtank.npz"), **out)
+    W = out["rti_W"]; lev = np.stack([W[:, :, 8 * j + 2:8 * j + 6] for j in range(p.N + 1)], axis=2)
+    print("smallest predicted level", lev.min())
+    print("max KKT: defect", np.nanmax(out["sqp_KKT_DEFECT"]), "stationarity", np.nanmax(out["sqp_KKT_STAT"]), "violation", np.nanmax(out["sqp_KKT_VIOL"]),
+          "status", out["sqp_STATUS_DYN"].ravel(), out["rti_STATUS_DYN"].ravel())
+
+
 def main():
+    if "quadtank" in sys.argv:
+        return quadtank()
     p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "cstr_nmpc.py"))
     out = {}
     t0 = time.time()

@@ -57,7 +57,7 @@ def test_unmodified_reference_examples_load_to_the_same_problem(pkg, ours, their
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("name", ["Ex_ENMPC.py", "Ex_NMPC_dis.py"])
+@pytest.mark.parametrize("name", ["Ex_ENMPC.py"])
 def test_examples_outside_the_built_paths_are_refused_loudly(pkg, name):
     with pytest.raises(pkg.UnsupportedProblem):
         pkg.load_problem(os.path.join(REF, name))

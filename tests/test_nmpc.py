@@ -243,3 +243,107 @@ def test_gpu_error_paths(nl, solver):
         solver.run(0, 4)
     with pytest.raises(MpcAmdError, match="max_sqp"):
         solver.run(0, 3, 0)
+
+
+# ================================================================================================= discrete-time example (Ex_NMPC_dis.py)
+QGOLD = os.path.join(ROOT, "tests", "golden", "nmpc_quadtank.npz")
+
+
+@pytest.fixture(scope="module")
+def qt(pkg):
+    return pkg.load_problem(pkg.example_path("quadtank_nmpc_dis.py"))
+
+
+@pytest.fixture(scope="module")
+def qt_mild(pkg):
+    from nmpc_cases import quadtank_mild_setpoints
+    return pkg.load_problem(pkg.example_path("quadtank_nmpc_dis.py"), overrides={"defSP": quadtank_mild_setpoints})
+
+
+def test_discrete_example_is_classified(qt):
+    """User_fxm_Dis / User_fxp_Dis (the sampled map itself, Utilities.py:84-87,186-198), offree = 'lin' (+ Bd d, + Cd d), lue with K,
+    cost and bounds on the input moves (S, Dumin/Dumax), Sss, User_vfin = dx' 100 dx, plant disturbance schedule def_pxp."""
+    assert (qt.nx, qt.nu, qt.ny, qt.nd, qt.nxp, qt.N, qt.h) == (6, 2, 2, 2, 6, 20, 5.0)
+    assert qt.discrete and qt.plant_discrete and qt.offree == "lin" and qt.estimator == "lue" and qt.DUForm and qt.DUssForm
+    assert np.array_equal(qt.Dumin, [-50, -50]) and qt.ycols == [2, 3] and np.array_equal(qt.Pf, 200.0 * np.eye(6))
+    assert np.array_equal(qt.K, np.vstack([np.zeros((6, 2)), np.eye(2)])) and np.array_equal(qt.Cd, np.eye(2))
+    s = qt.schedules(12)
+    assert np.array_equal(s["pxp"][3], [0, 0, 0.5, 0, 0, 0]) and s["ysp"][10, 1] == 12.1883 and s["ysp"][11, 1] == 6.0      # t = 55 > 50
+
+
+def test_traced_discrete_model_equals_the_user_function(qt):
+    """Tracing (SymMat: SX(n, 1) zeros, slice copies, element assignment, ** 0.5, nested if_else) against the same function run on
+    numbers; the shipped start is a steady state of the sampled map; levels outside [0, 20] are clamped as the reference clamps them."""
+    import nmpc_oracle as no
+    from mpc_code_amd import symtrace as st
+    rng = np.random.default_rng(0)
+    for x in [qt.x0_m + rng.normal(size=6) * [3, 3, 2, 2, 0.5, 0.5] for _ in range(3)] + [np.array([50, 50, 25.0, -1.0, 0.2, 19.99])]:
+        u = qt.u0 + rng.normal(size=2) * 5; d = rng.normal(size=2) * 0.1
+        tr = np.array([float(v) for v in st.evaluate(qt.f, qt._vals(x=x, u=u, d=d, t=0.0))])
+        assert np.allclose(tr, no.model_fx(qt, x, u, d), rtol=1e-14, atol=1e-14)
+    assert np.abs(no.model_fx(qt, qt.x0_m, qt.u0, np.zeros(2)) - qt.x0_m).max() < 1e-5
+    J = np.array([[float(st.evaluate([e], qt._vals(x=qt.x0_m, u=qt.u0, d=np.zeros(2), t=0.0))[0]) for e in row] for row in qt.f_x])
+    A, B, G, _ = no.linearize(qt, qt.x0_m, qt.u0, np.zeros(2))
+    assert np.allclose(J, A, rtol=1e-6, atol=1e-8) and np.allclose(J[:2], 0.0) and np.allclose(G, qt.Bd)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_same_problem_as_the_reference_discrete_example(pkg, qt):
+    ref = pkg.load_problem(os.path.join(REF, "Ex_NMPC_dis.py"), overrides={"N": 20})
+    for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "Dumin", "Dumax", "K", "Pf", "Bd", "Cd", "x0_p", "x0_m", "u0", "dhat0"):
+        assert np.array_equal(getattr(ref, k), getattr(qt, k)), k
+    assert (ref.estimator, ref.DUForm, ref.DUssForm, ref.ycols, ref.Nsim, ref.discrete) == (qt.estimator, qt.DUForm, qt.DUssForm, qt.ycols, qt.Nsim, qt.discrete)
+    import nmpc_oracle as no
+    rng = np.random.default_rng(1)
+    for x in [qt.x0_m + rng.normal(size=6) * [3, 3, 2, 2, 0.5, 0.5] for _ in range(3)] + [np.array([50, 50, 25.0, -1.0, 0.2, 19.99]), np.array([50, 50, 19.9, 0.01, 22, 0.0])]:
+        u = qt.u0 + rng.normal(size=2) * 5
+        assert np.allclose(no.model_fx(ref, x, u, np.zeros(2)), no.model_fx(qt, x, u, np.zeros(2)), rtol=1e-13, atol=1e-13)       # clamping included
+        assert np.allclose(no.plant_fx(ref, x, u, 100.0), no.plant_fx(qt, x, u, 100.0), rtol=1e-13, atol=1e-13)
+    for t in (10, 60, 1500, 2500, 3500, 4500, 6000):
+        assert all(np.array_equal(a_, b_) for a_, b_ in zip(ref.defSP(t), qt.defSP(t))) and np.array_equal(ref.def_pxp(t)[0], qt.def_pxp(t)[0])
+
+
+def test_discrete_oracle_reproduces_its_golden_rows(qt_mild):
+    import nmpc_oracle as no
+    g = np.load(QGOLD)
+    r = no.closed_loop(qt_mild, 2, x0_p=g["rti_x0"][1], x0_m=g["rti_x0"][1], max_sqp=1)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        assert np.allclose(r[k], g["rti_" + k][:2, 1], rtol=1e-10, atol=1e-10), k
+    assert np.all(g["sqp_STATUS_DYN"] == 0) and np.nanmax(g["sqp_KKT_DEFECT"]) < 1e-8 and np.nanmax(g["sqp_KKT_STAT"]) < 1e-7 and np.nanmax(g["sqp_KKT_VIOL"]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,max_sqp", [("rti", 1), ("sqp", 50)])
+def test_gpu_discrete_example_equals_the_golden_vectors(qt_mild, mode, max_sqp):
+    """Discrete user model, fixed-gain observer, stage form with the input move as input (cost S and bounds Dumin/Dumax on it, the u
+    bounds on the carried input), terminal weight; real-time iteration over 16 steps with a set-point change, and 9 steps iterated
+    to the NLP's KKT point (measured 3e-8 / 1e-11 relative)."""
+    from mpc_code_amd import nmpc
+    g = np.load(QGOLD)
+    x0 = g[mode + "_x0"]; ns = g[mode + "_U"].shape[0]
+    s = nmpc.NmpcSolver(qt_mild)
+    assert s.build_info().endswith("discrete;duv")
+    r = nmpc.run_nmpc_closed_loop(qt_mild, x0, x0, nsteps=ns, solver=s, max_sqp=max_sqp, sqp_tol=1e-9)
+    s.close()
+    assert np.array_equal(r["STATUS_DYN"], g[mode + "_STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], g[mode + "_STATUS_SS"])
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "Yp"):
+        gg = g[f"{mode}_{k}"]
+        assert np.max(np.abs(r[k] - gg) / (1.0 + np.abs(gg))) < 1e-6, k
+    assert np.array_equal(r["SQP_DYN"], g[mode + "_SQP_DYN"])          # the SQP takes the same number of iterations as the dense restatement
+
+
+@pytest.mark.gpu
+def test_gpu_discrete_example_shipped_schedule_properties(qt):
+    """The shipped schedule (level 6 asked of tank 2 at t > 50: an upper tank runs empty in the prediction) for a batch: inputs and
+    input moves within their bounds, levels within [0, 20], finite everywhere, every status solved or iteration limit."""
+    from mpc_code_amd import nmpc
+    B, ns = 1024, 24
+    rng = np.random.default_rng(5)
+    x0 = np.tile(qt.x0_p, (B, 1)); x0[1:, 2:] *= 1.0 + 0.05 * rng.uniform(-1, 1, size=(B - 1, 4))
+    r = nmpc.run_nmpc_closed_loop(qt, x0, x0, nsteps=ns, max_sqp=1)
+    assert all(np.isfinite(r[k]).all() for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"))
+    assert np.isin(r["STATUS_DYN"], (0, 1)).all() and (r["STATUS_DYN"] == 0).mean() > 0.95
+    U = r["U"]; dU = np.diff(np.concatenate([np.tile(qt.u0, (1, B, 1)), U]), axis=0)
+    assert (U >= qt.umin - 1e-6).all() and (U <= qt.umax + 1e-6).all() and (dU >= qt.Dumin - 1e-6).all() and (dU <= qt.Dumax + 1e-6).all()
+    assert (r["Xp"][:, :, 2:] > -1e-9).all() and (r["Xp"][:, :, 2:] < 20.0).all()
+    assert (r["Xp"][-1, :, 3] < r["Xp"][10, :, 3] - 0.5).all()          # tank 2 is being drained towards its new set point
