@@ -69,6 +69,10 @@ typedef struct mpc_lin_desc {
     /* terminal equality x_N = xs of opt_dyn (TermCons, Control_Calc.py:197-198); 0 = none.  P is ignored then (the terminal cost is
      * zero on the constraint) */
     int32_t term_cons;
+    /* the simulated process is a user function (User_fxp_Cont, MPC_code.py:176-199) compiled into the library from the traced
+     * Ex-file function (one library per plant; capi.Solver builds it); Ap, Bp are ignored then */
+    int32_t nl_plant;
+    double h_sample;             /* sampling interval h (the time a user plant integrates over); 0 = 1 */
 } mpc_lin_desc;
 
 /* Replaces the construction nlpsol('solver','ipopt',...) of Control_Calc.py:256-258 and

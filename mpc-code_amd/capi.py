@@ -41,14 +41,19 @@ class _Desc(ct.Structure):
                [(k, _dp) for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp",
                                    "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax",
                                    "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss",
-                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")] + [("term_cons", ct.c_int32)]
+                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")] + [("term_cons", ct.c_int32), ("nl_plant", ct.c_int32), ("h_sample", ct.c_double)]
 
 
 def jit_library_path(dims) -> str:
     return os.path.join(CSRC, "jit", "libmpc_amd_" + "_".join(str(int(v)) for v in dims) + ".so")
 
 
-def build_library(force: bool = False, verbose: bool = False, dims=None) -> str:
+def plant_library_path(dims, header_text: str) -> str:
+    import hashlib
+    return os.path.join(CSRC, "jit", "libmpc_amd_" + "_".join(str(int(v)) for v in dims) + "_plant_" + hashlib.sha256(header_text.encode()).hexdigest()[:12] + ".so")
+
+
+def build_library(force: bool = False, verbose: bool = False, dims=None, plant_header: Optional[str] = None) -> str:
     """Compile ``csrc/mpc_amd.hip`` for gfx950 in-tree (hipcc cross-compiles without a GPU).
 
     ``dims = (nx, nu, ny, nd, nxp, du_form, general_output_rows)``: a library holding the kernels of exactly that
@@ -57,6 +62,11 @@ def build_library(force: bool = False, verbose: bool = False, dims=None) -> str:
     srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp", "mpc_tp.hpp", "mpc_wave.hpp")] + \
            [os.path.join(os.path.dirname(PKG_DIR), "include", "mpc_amd.h")]
     out = LIB_PATH if dims is None else jit_library_path(dims)
+    hdr = None
+    if plant_header is not None:       # the fused closed loop with the Ex-file's own plant function: one library per (dimension set, plant)
+        assert dims is not None
+        out = plant_library_path(dims, plant_header)
+        hdr = out[:-3] + "_model.hpp"
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs if os.path.exists(s)):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -64,6 +74,10 @@ def build_library(force: bool = False, verbose: bool = False, dims=None) -> str:
     if dims is not None:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags.append("-DMPC_DIM_LIST(X)=X(" + ",".join(str(int(v)) for v in dims) + ")")
+    if hdr is not None:
+        with open(hdr, "w") as fh:
+            fh.write(plant_header)
+        flags.append(f'-DMPC_NL_PLANT_HEADER="{hdr}"')
     tmp = out + f".{os.getpid()}.tmp"
     cmd = [hipcc] + flags + ["-o", tmp, srcs[0]]
     if verbose:
@@ -165,6 +179,21 @@ class Solver:
         d.du_form, d.duss_form, d.y_bounded = int(p.DUForm), int(p.DUssForm), int(p.y_bounded)
         d.estimator, d.max_iter, d.device = _EST[p.estimator], int(p.max_iter), int(device)
         d.term_cons = int(bool(getattr(p, "TermCons", False)))
+        d.h_sample = float(p.h)
+        self.fused_plant = False
+        if lib_path is None and not p.plant_is_linear and jit and not os.environ.get("MPC_AMD_NO_JIT"):
+            # the Ex-file's plant function, traced and compiled into a library of this problem's own (cached under csrc/jit/)
+            from . import nlcodegen
+            try:
+                hdr = nlcodegen.emit_plant_header(p)
+            except Exception:      # noqa: BLE001 - a plant the tracer cannot follow stays on the host (call-by-call mode)
+                hdr = None
+            if hdr is not None:
+                ng = sum(1 for i in range(p.ny) if p.y_bounded and (np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i])) and np.count_nonzero(p.C[i]) != 1)
+                dims = (p.nx, p.nu, p.ny, p.nd, p.nxp, int(p.DUForm or p.Dumin is not None or p.Dumax is not None), ng)
+                self.lib = load_library(build_library(dims=dims, plant_header=hdr))
+                d.nl_plant = 1
+                self.fused_plant = True
         for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp", "Q", "R", "P", "Qss", "Rss",
                   "umin", "umax", "xmin", "xmax", "ymin", "ymax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss",
                   "ymin_ss", "ymax_ss", "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax"):

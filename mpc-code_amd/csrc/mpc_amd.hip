@@ -8,6 +8,12 @@
 #include "mpc_device.hpp"
 #include "mpc_tp.hpp"
 #include "mpc_wave.hpp"
+#ifdef MPC_NL_PLANT_HEADER
+// A non-linear plant for the fused closed loop (Ex_LMPC_nlplant.py, Ex_LMPCxp_nlplant.py: linear controller, User_fxp_Cont as the
+// simulated process): struct NlPlant { NXP, NU, MX; __device__ static void f(x, u, t, xdot); } generated from the traced Ex-file
+// function (mpc-code_amd/nlcodegen.py:emit_plant_header); a library built with it carries exactly one dimension set.
+#include MPC_NL_PLANT_HEADER
+#endif
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -249,7 +255,43 @@ struct LoopArgs {
     double *ws;
     int B, nsteps; size_t Bs;
     int N;                                           // horizon (host side: sizes the dynamic LDS of the wave-autonomous kernel)
+    double t0, h;                                    // time of the launch's first step, sampling interval (a user plant integrates in time)
 };
+
+// x_p(t + h) (MPC_code.py:813-816).  Linear plant: Ap x + Bp u + pxp (Utilities.py:45-49).  User plant: MX classical RK4 steps of
+// dx/dt = f(x, u, t) over h with the inputs held and time carried along, then + pxp (Utilities.py:58-82, casadi.simpleRK; LinPar).
+template <int NXP, int NU, class PT>
+__device__ __forceinline__ void plant_next(const PT &P, const double (&x)[NXP], const double (&u)[NU], const double *pxp_k, double t, double h, double (&xn)[NXP])
+{
+#ifdef MPC_NL_PLANT_HEADER
+    static_assert(NlPlant::NXP == NXP && NlPlant::NU == NU, "the plant header belongs to another dimension set");
+    (void)P;
+    const double dt = h / NlPlant::MX;
+    double xx[NXP];
+    MPC_UNROLL for (int i = 0; i < NXP; i++) xx[i] = x[i];
+    for (int s = 0; s < NlPlant::MX; s++) {
+        const double ts = t + s * dt;
+        double k1[NXP], k2[NXP], k3[NXP], k4[NXP], xa[NXP];
+        NlPlant::f(xx, u, ts, k1);
+        MPC_UNROLL for (int i = 0; i < NXP; i++) xa[i] = xx[i] + 0.5 * dt * k1[i];
+        NlPlant::f(xa, u, ts + 0.5 * dt, k2);
+        MPC_UNROLL for (int i = 0; i < NXP; i++) xa[i] = xx[i] + 0.5 * dt * k2[i];
+        NlPlant::f(xa, u, ts + 0.5 * dt, k3);
+        MPC_UNROLL for (int i = 0; i < NXP; i++) xa[i] = xx[i] + dt * k3[i];
+        NlPlant::f(xa, u, ts + dt, k4);
+        MPC_UNROLL for (int i = 0; i < NXP; i++) xx[i] += dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    MPC_UNROLL for (int i = 0; i < NXP; i++) xn[i] = xx[i] + pxp_k[i];
+#else
+    (void)t; (void)h;
+    MPC_UNROLL for (int i = 0; i < NXP; i++) {
+        double v = pxp_k[i];
+        MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
+        MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
+        xn[i] = v;
+    }
+#endif
+}
 
 template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
 __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__ Pp, LoopArgs a)
@@ -329,7 +371,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - xh_pred[i]), fabs(xs[i] - xs_prev[i])));
         MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
         MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
-        const bool warm = ws_valid && delta <= kWsDelta;
+        const bool warm = ws_valid && delta <= kWsDelta && !P.no_warm;
         int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, delta, u0, z1, res, it_dyn);
         if (P.term_cons && st_dyn != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st_dyn = kInfeasible;
         ws_valid = st_dyn == kSolved;
@@ -352,12 +394,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         // ---- plant (MPC_code.py:813-816) -----------------------------------------------------------
         {
             double xn[NXP];
-            MPC_UNROLL for (int i = 0; i < NXP; i++) {
-                double v = a.pxp[k * NXP + i];
-                MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
-                xn[i] = v;
-            }
+            plant_next<NXP, NU>(P, x, u, a.pxp + k * NXP, a.t0 + k * a.h, a.h, xn);
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = xn[i];
         }
     }
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             double delta = delta_est;
             MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, fabs(xs[i] - xs_prev[i]));
             MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
-            const bool warm = a.ws_valid[bq] != 0 && delta <= kWsDelta;
+            const bool warm = a.ws_valid[bq] != 0 && delta <= kWsDelta && !P.no_warm;
             double *qd = sh.q + lane * Cfg::QN;
             MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = q.z0[i]; qd[NS + i] = q.zr[i]; qd[2 * NS + i] = q.c[i]; qd[3 * NS + i] = q.zlo_m[i]; qd[4 * NS + i] = q.zhi_m[i]; }
             MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = q.ur[i]; qd[5 * NS + NU + i] = q.us[i]; }
@@ -538,12 +575,7 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
             if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.U + (size_t)((size_t)k * NU + i) * Bs)[bq] = u[i]; }
             if (a.st_dyn) { (a.st_dyn + (size_t)k * Bs)[bq] = st_dyn; (a.it_dyn + (size_t)k * Bs)[bq] = it_dyn; }
             double xn[NXP];
-            MPC_UNROLL for (int i = 0; i < NXP; i++) {
-                double v = a.pxp[k * NXP + i];
-                MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
-                xn[i] = v;
-            }
+            plant_next<NXP, NU>(P, x, u, a.pxp + k * NXP, a.t0 + k * a.h, a.h, xn);
             MPC_UNROLL for (int i = 0; i < NXP; i++) (a.x + (size_t)(i) * Bs)[bq] = xn[i];
             MPC_UNROLL for (int i = 0; i < NX; i++) (a.xhat + (size_t)(i) * Bs)[bq] = xh[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) (a.u + (size_t)(i) * Bs)[bq] = u[i];
@@ -726,7 +758,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             // ---- OCP data (MPC_code.py:733-761) and the warm-start test -> LDS ------------------------------
             OcpInst<NS, NU> qi;
             build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, qi);
-            const bool warm = wsv[lane] != 0 && delta <= kWsDelta;
+            const bool warm = wsv[lane] != 0 && delta <= kWsDelta && !P.no_warm;
             double *qd = q + lane * Cfg::QN;
             MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
             MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = qi.ur[i]; qd[5 * NS + NU + i] = qi.us[i]; }
@@ -780,11 +812,10 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             }
             if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) (a.U + (size_t)((size_t)k * NU + i) * Bs)[bq] = u[i]; }
             if (a.st_dyn) { (a.st_dyn + (size_t)k * Bs)[bq] = st_dyn; (a.it_dyn + (size_t)k * Bs)[bq] = it_dyn; }
-            MPC_UNROLL for (int i = 0; i < NXP; i++) {
-                double v = a.pxp[k * NXP + i];
-                MPC_UNROLL for (int j = 0; j < NXP; j++) v += P.Ap[i][j] * x[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bp[i][j] * u[j];
-                kp[KC::K_X + i] = v;
+            {
+                double xn[NXP];
+                plant_next<NXP, NU>(P, x, u, a.pxp + k * NXP, a.t0 + k * a.h, a.h, xn);
+                MPC_UNROLL for (int i = 0; i < NXP; i++) kp[KC::K_X + i] = xn[i];
             }
             MPC_UNROLL for (int i = 0; i < NX; i++) kp[KC::K_XH + i] = xh[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) kp[KC::K_U + i] = u[i];
@@ -852,7 +883,7 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
         MPC_UNROLL for (int i = 0; i < NX; i++) delta = dmax(delta, dmax(fabs(xh[i] - w.prev[i * Bs + b]), fabs(xs[i] - w.prev[(NX + ND + i) * Bs + b])));
         MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - w.prev[(NX + i) * Bs + b]));
         MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - w.prev[(2 * NX + ND + i) * Bs + b]));
-        const bool warm = w.warm_on && w.valid[b] != 0 && delta <= kWsDelta;
+        const bool warm = w.warm_on && w.valid[b] != 0 && delta <= kWsDelta && !P.no_warm;
         double *qd = q + lane * Cfg::QN;
         MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
         MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = qi.ur[i]; qd[5 * NS + NU + i] = qi.us[i]; }
@@ -1062,6 +1093,7 @@ struct mpc_handle {
     int steps_per_launch = 50;  // closed-loop steps per kernel launch (a launch starts with cold scalar / instruction caches)
     int loop_kernel_opt = 0;    // option "loop_kernel": 0 = choose by batch size, 1 = instance per lane, 2 = horizon-parallel
     int ws_mode = -1;           // which loop kernel's layout the workspace holds (-1 = none: next OCPs start cold)
+    double h_sample = 1.0;      // sampling interval (mpc_lin_desc.h_sample): the time a user plant integrates over
     // per-call scratch (solve API)
     DevBuf scratch, ws;
     // loop state
@@ -1326,8 +1358,19 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
         delete h;
         return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d general_output_rows=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, (int)stage_has_uprev(d), ng, mpc_build_info());
     }
+#ifdef MPC_NL_PLANT_HEADER
+    if (!d->nl_plant) { delete h; return fail(-5, "this library simulates a user plant (User_fxp_Cont): the descriptor has nl_plant = 0"); }
+#else
+    if (d->nl_plant) { delete h; return fail(-5, "no kernel compiled for a user plant (nl_plant = 1): build the library with the plant's generated header (capi.Solver does)"); }
+#endif
     int rc = build_problem(d, h->hp);
     if (rc != 0) { delete h; return rc; }
+    h->h_sample = d->h_sample > 0.0 ? d->h_sample : 1.0;
+    {      // |A^32| > 1e4: the open-loop simulation every start rests on amplifies the shift's small mismatch by that much over the horizon
+        double nrm = 0.0;
+        for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));
+        h->hp.no_warm = nrm > 1e4 ? 1 : 0;
+    }
     h->device = d->device;
     hipError_t e = hipSetDevice(h->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1368,6 +1411,9 @@ extern "C" const char *mpc_build_info(void)
         MPC_DIM_LIST(MPC_INFO_DIM)
 #undef MPC_INFO_DIM
         s.pop_back();
+#ifdef MPC_NL_PLANT_HEADER
+        s += ";nlplant";
+#endif
     }
     return s.c_str();
 }
@@ -1819,6 +1865,11 @@ extern "C" int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double
 static int loop_mode(const mpc_handle *h)
 {
     if (h->loop_kernel_opt != 0) return h->loop_kernel_opt;
+    {      // violently unstable open loop: the kernels whose recursions are scans with A^(2^e) lose digits there (see ocp_uses_wave)
+        double nrm = 0.0;
+        for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));
+        if (nrm > 1e4) return 1;
+    }
     if (h->L.loop_wv && h->hp.N <= 64) return 3;
     if (!h->L.loop_tp || h->hp.N > 64) return 1;
     return h->B <= h->L.tp_max_batch ? 2 : 1;
@@ -1860,6 +1911,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         a.ws_valid = (int32_t *)h->st_flag.p; a.kf_valid = a.ws_valid + Bs; a.Kg = (double *)h->st_Kg.p; a.Pn = (double *)h->st_Pn.p;
         a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs; a.N = P.N;
+        a.h = h->h_sample; a.t0 = k * h->h_sample;
         if (mode == 3) { if (h->L.loop_wv(h->dp, a, h->stream)) return fail(-9, "cannot configure the wave-autonomous kernel (LDS %zu bytes)", h->L.wv_lds); }
         else if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);

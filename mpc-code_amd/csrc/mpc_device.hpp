@@ -47,7 +47,8 @@ enum : int { kSolved = 0, kMaxIter = 1, kInfeasible = 2 };
 // is a scalar load, whatever the kernel has stored to global memory in between
 struct DevProblem {
     int nx, nu, ny, nd, nxp, N, du_form, duss_form, y_bounded, estimator, max_iter, has_dsat;
-    int term_cons; double term_tol, term_gcap, term_floor;      // terminal equality x_N = xs (Control_Calc.py:197-198): Pf carries the weight that enforces it, the residual above term_tol means unreachable
+    int term_cons; double term_tol, term_gcap, term_floor;
+    int no_warm;      // violently unstable open loop: a shifted warm start re-simulated from the new state is worse than a cold start (mpc_amd.hip:mpc_lin_create)      // terminal equality x_N = xs (Control_Calc.py:197-198): Pf carries the weight that enforces it, the residual above term_tol means unreachable
     int in_is_du, zr_us;      // stage input is v = u - u_prev (bounds on it exist); reference of the u_prev states is us (cost on u - us)
     // stage form (z = x, or [x; u_prev] when du_form)
     double A[kMaxN][kMaxN], B[kMaxN][kMaxM], Q[kMaxN][kMaxN], M[kMaxN][kMaxM], R[kMaxM][kMaxM], Pf[kMaxN][kMaxN];

@@ -44,8 +44,9 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
     s = capi.Solver(p, device=device) if own else solver
     try:
         sched = p.schedules(nsteps)
-        if fused and not p.plant_is_linear:
-            raise ValueError("a non-linear plant (User_fxp_Cont) is simulated on the host: call run_closed_loop(..., fused=False)")
+        if fused and not p.plant_is_linear and not getattr(s, "fused_plant", False):
+            raise ValueError("this solver's library has no compiled plant function (User_fxp_Cont): the plant is simulated on the host, "
+                             "call run_closed_loop(..., fused=False)")
         if fused and p.has_model_params:
             raise ValueError("time-varying model parameters (def_px / def_py) go through the call-by-call mode: run_closed_loop(..., fused=False)")
         if fused:

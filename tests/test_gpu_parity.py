@@ -449,8 +449,6 @@ def test_nonlinear_plant_example_through_the_three_calls(nlplant, oracle_c, solv
     t, tc = s.target_solve(np.array([299.963, 0.1]), np.array([0.5, 0.659]), np.zeros(3), d, up), oc.target_solve(np.array([299.963, 0.1]), np.array([0.5, 0.659]), np.zeros(3), d, up)
     assert np.array_equal(t["status"], tc["status"]) and np.abs(t["xs"] - tc["xs"]).max() < 1e-8 and np.abs(t["us"] - tc["us"]).max() < 1e-8
     x0 = p.x0_p + rng.normal(size=(12, 3)) * [2e-4, 0.02, 2e-4]
-    with pytest.raises(ValueError):
-        run_closed_loop(p, x0, x0, 4, solver=s, fused=True)           # the fused kernel has no non-linear plant
     gl = run_closed_loop(p, x0, x0, 8, solver=s, fused=False)
     nl = rn.closed_loop_batch(p, 8, x0, x0, warm_start=False)
     assert np.array_equal(gl["STATUS_DYN"], nl["STATUS_DYN"]) and (gl["STATUS_DYN"] == 0).all()
@@ -708,3 +706,36 @@ def test_model_parameters_over_the_horizon(pkg, solver_factory):
     assert np.array_equal(r["STATUS_DYN"], np.stack([c["STATUS_DYN"] for c in cl], axis=1))
     with pytest.raises(ValueError, match="def_px"):
         run_closed_loop(p, x0, x0, 4, solver=s, fused=True)
+
+
+def test_fused_closed_loop_with_the_user_plant(nlplant, xp_nlplant):
+    """Ex_LMPC_nlplant / Ex_LMPCxp_nlplant: linear controller, the Ex-file's own plant function as the process.  The function is
+    traced and compiled into the problem's own library (capi.Solver, nlcodegen.emit_plant_header; mpc_amd.hip:plant_next integrates it
+    with Mx RK4 steps), so the whole loop runs in one kernel; it must equal the call-by-call mode with the plant on the host, which
+    tests above pin to the oracle.  Both models are open-loop unstable (|A^32| > 1e4): the library then picks the instance-per-lane
+    kernel and cold starts, and differences between two runs grow about threefold per step, hence 12 steps."""
+    from mpc_code_amd import capi
+    from mpc_code_amd.driver import run_closed_loop
+    rng = np.random.default_rng(3)
+    for p, tol_other in ((nlplant, 2e-3), (xp_nlplant, 1e-4)):
+        B, K = 48, 12
+        x0p = p.x0_p + rng.normal(size=(B, p.nxp)) * [2e-4, 0.02, 2e-4]
+        x0m = np.hstack([x0p, np.zeros((B, p.nx - p.nxp))]) if p.nx > p.nxp else x0p
+        s = capi.Solver(p)
+        assert s.fused_plant and s.build_info().endswith(";nlplant") and s.get_option("loop_kernel") == 1
+        ref = run_closed_loop(p, x0p, x0m, K, solver=s, fused=False)
+        r = run_closed_loop(p, x0p, x0m, K, solver=s, fused=True)
+        assert np.array_equal(r["STATUS_DYN"], ref["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], ref["STATUS_SS"])
+        for k in ("U", "Xp", "X_HAT", "XS", "D_HAT"):
+            assert np.abs(r[k] - ref[k]).max() < 1e-4, k
+        assert np.abs(r["Yp"] - ref["Yp"]).max() < 1e-4
+        for lk in (2, 3):          # the other kernels run it too (looser: their recursions are scans with powers of an unstable A)
+            s.set_option("loop_kernel", lk)
+            r2 = run_closed_loop(p, x0p, x0m, K, solver=s, fused=True)
+            assert np.array_equal(r2["STATUS_DYN"], ref["STATUS_DYN"]) and np.abs(r2["U"] - ref["U"]).max() < tol_other, lk
+        s.close()
+    s = capi.Solver(nlplant, lib_path=capi.LIB_PATH)            # the default library has no plant function: the plant stays on the host
+    assert not s.fused_plant
+    with pytest.raises(ValueError, match="no compiled plant"):
+        run_closed_loop(nlplant, nlplant.x0_p[None], nlplant.x0_m[None], 3, solver=s, fused=True)
+    s.close()
