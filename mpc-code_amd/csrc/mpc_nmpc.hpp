@@ -19,8 +19,10 @@
 namespace mpc {
 
 // x(t + h): MX RK4 steps of dx/dt = f(x, u, d, t)
+// Each integrator comes twice: *_inl (always inlined: the wave-autonomous kernel parks its iterates in the accumulation registers,
+// and a call would spill all of them around it) and a real function of the same name for the instance-per-lane kernel (code size).
 template <class M>
-__device__ __noinline__ void rk4_model(const double *x0, const double *u, const double *d, double t, double h, double *xn)
+__device__ __forceinline__ void rk4_model_inl(const double *x0, const double *u, const double *d, double t, double h, double *xn)
 {
     constexpr int NX = M::NX;
     if (M::DISCRETE) { M::f(x0, u, d, t, xn); return; }      // the user's map is the step (Utilities.py:186-198)
@@ -43,7 +45,10 @@ __device__ __noinline__ void rk4_model(const double *x0, const double *u, const 
 }
 
 template <class M>
-__device__ __noinline__ void rk4_plant(const double *x0, const double *u, double t, double h, double *xn)
+__device__ __noinline__ void rk4_model(const double *x0, const double *u, const double *d, double t, double h, double *xn) { rk4_model_inl<M>(x0, u, d, t, h, xn); }
+
+template <class M>
+__device__ __forceinline__ void rk4_plant_inl(const double *x0, const double *u, double t, double h, double *xn)
 {
     constexpr int NX = M::NXP;
     if (M::PLANT_DISCRETE) { M::fp(x0, u, t, xn); return; }
@@ -65,11 +70,14 @@ __device__ __noinline__ void rk4_plant(const double *x0, const double *u, double
     MPC_UNROLL for (int i = 0; i < NX; i++) xn[i] = x[i];
 }
 
+template <class M>
+__device__ __noinline__ void rk4_plant(const double *x0, const double *u, double t, double h, double *xn) { rk4_plant_inl<M>(x0, u, t, h, xn); }
+
 // The same with forward sensitivities: S = d x(t+h) / d [x0 | u | d], propagated through every Runge-Kutta stage
 // (dK_i = f_x(X_i) dX_i + [0 | f_u | f_d](X_i)).  Out: xn, A = S[:, :NX], B = S[:, NX:NX+NU], G = S[:, NX+NU:].
 template <class M>
-__device__ __noinline__ void rk4_model_sens(const double *x0, const double *u, const double *d, double t, double h,
-                                            double *xn, double (*A)[M::NX], double (*B)[M::NU], double (*G)[M::ND > 0 ? M::ND : 1])
+__device__ __forceinline__ void rk4_model_sens_inl(const double *x0, const double *u, const double *d, double t, double h,
+                                                   double *xn, double (*A)[M::NX], double (*B)[M::NU], double (*G)[M::ND > 0 ? M::ND : 1])
 {
     constexpr int NX = M::NX, NU = M::NU, ND = M::ND, NDD = ND > 0 ? ND : 1, NP = NX + NU + ND;
     if (M::DISCRETE) { M::f_jac(x0, u, d, t, xn, A, B, G); return; }
@@ -108,10 +116,17 @@ __device__ __noinline__ void rk4_model_sens(const double *x0, const double *u, c
     }
 }
 
+template <class M>
+__device__ __noinline__ void rk4_model_sens(const double *x0, const double *u, const double *d, double t, double h,
+                                            double *xn, double (*A)[M::NX], double (*B)[M::NU], double (*G)[M::ND > 0 ? M::ND : 1])
+{
+    rk4_model_sens_inl<M>(x0, u, d, t, h, xn, A, B, G);
+}
+
 // Extended Kalman filter, Estimator.py:313-386: gain and correction with the output Jacobian at the prior, then the prior of the
 // next step through the Jacobian of [Fx_model(x, u, d); d] at the corrected estimate.
-template <class M>
-__device__ void ekf_lane(const DevProblem &P, double (&xi)[M::NX + M::ND], double (&Pk)[M::NX + M::ND][M::NX + M::ND], const double (&y)[M::NY],
+template <class M, bool INL = false>
+__device__ __forceinline__ void ekf_lane(const DevProblem &P, double (&xi)[M::NX + M::ND], double (&Pk)[M::NX + M::ND][M::NX + M::ND], const double (&y)[M::NY],
                          const double *u, double t, double h)
 {
     constexpr int NX = M::NX, ND = M::ND, NE = NX + ND, NY = M::NY, NU = M::NU, NDD = ND > 0 ? ND : 1;
@@ -130,7 +145,7 @@ __device__ void ekf_lane(const DevProblem &P, double (&xi)[M::NX + M::ND], doubl
     MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) { double a = Pk[i][j]; MPC_UNROLL for (int l = 0; l < NY; l++) a -= K[i][l] * CP[l][j]; Pc[i][j] = a; } }
     MPC_UNROLL for (int i = 0; i < NE; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) a += K[i][l] * (y[l] - yhat[l]); xi[i] += a; }
     double xn[NX], A[NX][NX], B[NX][NU], G[NX][NDD], Aa[NE][NE], T[NE][NE];
-    rk4_model_sens<M>(xi, u, xi + NX, t, h, xn, A, B, G);
+    if (INL) rk4_model_sens_inl<M>(xi, u, xi + NX, t, h, xn, A, B, G); else rk4_model_sens<M>(xi, u, xi + NX, t, h, xn, A, B, G);
     MPC_UNROLL for (int i = 0; i < NE; i++) {
         MPC_UNROLL for (int j = 0; j < NE; j++) {
             double v = (i == j) ? 1.0 : 0.0;

@@ -42,6 +42,10 @@ struct WvCfg {
     __host__ __device__ static constexpr int ld(int N) { return (N + 1) | 1; }
     static constexpr int GUARD = 8;                                    // cells in front of T: look-ahead reads of the backward loops, stores of idle lanes
     __host__ __device__ static constexpr int t_doubles(int N) { return GUARD + ROWS * NI * ld(N); }
+    // time-varying stage data (wv_solve<.., LTV>: one SQP iteration of the non-linear path): per (instance, block) the matrices
+    // A_k (NS x NS), B_k (NS x NU), the affine term c_k, and the point they were linearised at (u_k, z_{k+1}), as rows behind the others
+    static constexpr int RL_A = ROWS, RL_B = RL_A + NS * NS, RL_C = RL_B + NS * NU, RL_P = RL_C + NS, ROWS_LTV = RL_P + NU + NS;
+    __host__ __device__ static constexpr int t_doubles_ltv(int N) { return GUARD + ROWS_LTV * NI * ld(N); }
     static constexpr int QN = 5 * NS + 2 * NU + 1;                     // z0 zr c zlo zhi | ur us | ws_delta
     static constexpr int ROWS_WS = NU + 2 * NC;                        // warm start kept in HBM between launches: u | l_lo | l_hi
     static constexpr int OUT = NU + NS + 1;                            // first input / next state of the final iterate, terminal miss
@@ -88,7 +92,7 @@ struct WvIterA {
 
 struct WvInst { double mu, mu_sum, sm, inv_ncon, gscale, res_s, res_p; int stall, iters, status; bool on, warm, keep_u; };
 
-enum : int { kWvOk0 = 1, kWvWarm = 2, kWvValid = 4, kWvKeepU = 8 };      // KeepU: warm start whose inputs are a caller's guess for THIS problem (not to be shifted)
+enum : int { kWvOk0 = 1, kWvWarm = 2, kWvValid = 4, kWvKeepU = 8, kWvNoShift = 16 };      // NoShift: warm start from the iterate as it is (an SQP iteration of the same step)      // KeepU: warm start whose inputs are a caller's guess for THIS problem (not to be shifted)
 
 // sums / maxima over the 16 lanes of a DPP row (= one instance of the target problem's constraint rows); result in every lane
 __device__ __forceinline__ double row16_sum(double v)
@@ -111,10 +115,14 @@ __device__ __forceinline__ double row16_max(double v)
 // Solves the four OCPs of this wave.  T: transposing buffer; q: instance data [4][QN] (z0 zr c zlo zhi | ur us | delta) and
 // iflag[4] (kWv*) written by the caller; X: the resident iterates - on entry the previous step's final iterate (used when
 // kWvWarm), on return this step's.  S[j].status / iters: verdicts.
-template <int NS, int NU, bool HASM, int NC, bool MASKED, int NI, class PT>
+// LTV: the stage matrices and affine terms come per (instance, block) from the rows RL_A / RL_B / RL_C of T (written by the caller:
+// the QP of one SQP iteration, x+ = A_k x + B_k u + c_k) instead of P.A / P.B / q's c.  The recursions that are scans with powers of
+// a constant A (initial simulation, costates of the stationarity test) then run as sequential sweeps over the lanes.
+template <int NS, int NU, bool HASM, int NC, bool MASKED, int NI, class PT, bool LTV = false>
 __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q, const int *iflag,
                                          WvIterA<NS, NU, NC> (&X)[NI], WvInst (&S)[NI], int max_iter)
 {
+    static_assert(!LTV || (NS <= 4 && !HASM), "time-varying stage matrices: one 4 x 4 tile per state matrix, no cross term");
     using Cfg = WvCfg<NS, NU, NC, NI>;
     using Iter = WvIter<NS, NU, NC>;
     constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK;
@@ -188,16 +196,34 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + (NU + i < NC ? hb[NU + i < NC ? NU + i : 0] : 0.0);
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = blk_on ? gz[i] : 0.0;
-        MPC_UNROLL for (int e = 0; e < 6; e++) {
-            const int d = 1 << e;
-            if (d < N) {
-                double t[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = __shfl_down(pi[i], d, 64); t[i] = (k + d < N) ? v : 0.0; }
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.Apow[e][l][i] * t[l]; pi[i] = a; }
-            }
-        }
         double rs_p = 0.0;
-        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.B[l][i] * pi[l]; rs_p = dmax(rs_p, fabs(a)); }
+        if (LTV) {
+            // pi_{k+1} = gz_{k+1} + A_{k+1}' pi_{k+2} (lane k holds block k = (u_k, z_{k+1}): its costate passes through the NEXT block's A):
+            // a sweep from the last lane down, each lane taking its successor's finished value
+            double An[NS][NS];
+            const int kn = k + 1 < N ? k + 1 : (N > 0 ? N - 1 : 0);
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int l = 0; l < NS; l++) An[i][l] = T[((Cfg::RL_A + i * NS + l) * NI + j) * LD + kn]; }
+            for (int s = N - 2; s >= 0; s--) {
+                double t[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = __shfl_down(pi[i], 1, 64);
+                if (k == s) { MPC_UNROLL for (int i = 0; i < NS; i++) { double a = gz[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += An[l][i] * t[l]; pi[i] = a; } }
+            }
+            MPC_UNROLL for (int i = 0; i < NU; i++) {
+                double a = gu[i];
+                MPC_UNROLL for (int l = 0; l < NS; l++) a += (blk_on ? tk(Cfg::RL_B + l * NU + i, j) : 0.0) * pi[l];
+                rs_p = dmax(rs_p, fabs(a));
+            }
+        } else {
+            MPC_UNROLL for (int e = 0; e < 6; e++) {
+                const int d = 1 << e;
+                if (d < N) {
+                    double t[NS];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = __shfl_down(pi[i], d, 64); t[i] = (k + d < N) ? v : 0.0; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.Apow[e][l][i] * t[l]; pi[i] = a; }
+                }
+            }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.B[l][i] * pi[l]; rs_p = dmax(rs_p, fabs(a)); }
+        }
         Sj.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
         const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
         const double res_s = wave_max(blk_on ? rs_p : 0.0);
@@ -238,7 +264,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] = a_get(X[j].u[i]);
                 MPC_UNROLL for (int i = 0; i < NC; i++) { Xj.ll[i] = a_get(X[j].ll[i]); Xj.lh[i] = a_get(X[j].lh[i]); }
             }
-            const bool rep = k >= N - 1;       // shift by one stage, the last block repeats
+            const bool rep = k >= N - 1 || (myflag & kWvNoShift) != 0;       // shift by one stage, the last block repeats (NoShift: every block stays)
             double ll0[NC], lh0[NC];
             MPC_UNROLL for (int i = 0; i < NU; i++) {
                 const double ulo = Pl.ulo[i], uhi = Pl.uhi[i];
@@ -268,7 +294,22 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             }
             // states of the initial point by forward simulation z_{k+1} = A z_k + B u_k + c: a linear recursion with a constant
             // matrix, taken as a scan over the lanes with A^(2^e) (lane k ends up with z_{k+1})
-            {
+            if (LTV) {      // z_{k+1} = A_k z_k + B_k u_k + c_k with this lane's own matrices: a sweep from lane 0 up
+                double Ak[NS][NS], bk[NS], xk[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) {
+                    double a = blk_on ? tk(Cfg::RL_C + i, j) : 0.0;
+                    MPC_UNROLL for (int l = 0; l < NU; l++) a += (blk_on ? tk(Cfg::RL_B + i * NU + l, j) : 0.0) * Xj.u[l];
+                    bk[i] = a;
+                    MPC_UNROLL for (int l = 0; l < NS; l++) Ak[i][l] = blk_on ? tk(Cfg::RL_A + i * NS + l, j) : 0.0;
+                }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * qd[l]; xk[i] = k == 0 ? a : 0.0; }
+                for (int s = 1; s < N; s++) {
+                    double t[NS];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = __shfl_up(xk[i], 1, 64);
+                    if (k == s) { MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * t[l]; xk[i] = a; } }
+                }
+                MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = xk[i];
+            } else {
                 double xk[NS];
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
                     double a = qd[2 * NS + i];
@@ -325,6 +366,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         double *Tt, *trash;
         double Ar[SB][SB], Atr[SB][SB], Br[SB], Btr[SB];      // A, A', B, B' as tiles: Ar[i][j](r, c) = A[4i + r][4j + c], Btr[j](r, c) = B[4j + c][r]
         double *p_hu, *p_hz[SB], *p_kf, *p_k[SB], *p_kt[SB], *p_li;
+        const double *p_a, *p_at, *p_b, *p_bt;      // LTV: this lane's element of A_k, A_k', B_k, B_k' as a function of the block (rows of T)
     };
     auto tile_ctx = [&](const PT &Pl) {
         int lo = threadIdx.x;
@@ -353,6 +395,10 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             c.p_kt[i] = trow((ri < NS && tc < NU) ? RA + tc * NS + ri : RZ);
         }
         c.p_hu = trow(tr < NU ? RG + tr : RZ); c.p_kf = trow(tr < NU ? RK + tr : RZ);
+        if (LTV) {
+            c.p_a = trow((tr < NS && tc < NS) ? Cfg::RL_A + tr * NS + tc : RZ); c.p_at = trow((tr < NS && tc < NS) ? Cfg::RL_A + tc * NS + tr : RZ);
+            c.p_b = trow((tr < NS && tc < NU) ? Cfg::RL_B + tr * NU + tc : RZ); c.p_bt = trow((tr < NU && tc < NS) ? Cfg::RL_B + tc * NU + tr : RZ);
+        }
         // -Lambda^-1 (symmetric, rows / columns < NU) as a tile
         const int li_i = tr > tc ? tr : tc, li_j = tr > tc ? tc : tr;
         c.p_li = trow((tr < NU && tc < NU) ? RA + NKF + li_i * (li_i + 1) / 2 + li_j : RZ);
@@ -416,31 +462,40 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int j = 0; j < SB; j++) { const int cj = 4 * j + tc; Pm[i][j] = (ri < NS && cj < NS) ? Pl.Pf[ri < NS ? ri : 0][cj < NS ? cj : 0] : 0.0; }
             PC[i] = 0.0;
         }
-        constexpr int NF = 2 * SB + 4;      // sigma_z[SB] sigma_u s0 s1 hu hz[SB]
+        constexpr int NF = 2 * SB + 4 + (LTV ? 3 : 0);      // sigma_z[SB] sigma_u s0 s1 hu hz[SB] (a b bt)
         double f[PD][NF];
+        const double *q_a = LTV ? c.p_a + (N - 1) : nullptr, *q_b = LTV ? c.p_b + (N - 1) : nullptr, *q_bt = LTV ? c.p_bt + (N - 1) : nullptr;
         auto fetch = [&](int d, int off) {
             MPC_UNROLL for (int i = 0; i < SB; i++) { f[d][i] = q_sz[i][off]; f[d][SB + 4 + i] = q_hz[i][off]; }
             f[d][SB] = q_su[off]; f[d][SB + 1] = q_s0[off]; f[d][SB + 2] = NU > 1 ? q_s1[off] : 0.0; f[d][SB + 3] = q_hu[off];
+            if (LTV) { f[d][NF - 3] = q_a[off]; f[d][NF - 2] = q_b[off]; f[d][NF - 1] = q_bt[off]; }
         };
         MPC_UNROLL for (int d = 0; d < PD; d++) fetch(d, -d);
         auto block = [&](int d, bool more) {
             double sz[SB], HZ[SB];
             MPC_UNROLL for (int i = 0; i < SB; i++) { sz[i] = f[d][i]; HZ[i] = f[d][SB + 4 + i]; }
             const double su = f[d][SB], s0 = f[d][SB + 1], s1 = f[d][SB + 2], HU = f[d][SB + 3];
+            // this block's matrices as tiles: the constants, or (LTV, one tile) the block's own from the table
+            double Arl[SB][SB], Brl[SB], Btrl[SB], BE0l[SB], BE1l[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { Brl[i] = c.Br[i]; Btrl[i] = c.Btr[i]; BE0l[i] = BE0[i]; BE1l[i] = BE1[i]; MPC_UNROLL for (int jj = 0; jj < SB; jj++) Arl[i][jj] = c.Ar[i][jj]; }
+            if (LTV) {
+                Arl[0][0] = f[d][NF - 3]; Brl[0] = f[d][NF - 2]; Btrl[0] = f[d][NF - 1];
+                BE0l[0] = dpp_move<0x00, 0xF>(Brl[0], Brl[0]); BE1l[0] = NU > 1 ? dpp_move<0x55, 0xF>(Brl[0], Brl[0]) : 0.0;      // columns 0 / 1 of B over the quad
+            }
             if (more) fetch(d, -PD - d);
             MPC_UNROLL for (int i = 0; i < SB; i++) Pm[i][i] += sz[i];
             // P A, P B, B'P (P symmetric: P' = P)
             double PA[SB][SB], PB[SB], BtP[SB];
             MPC_UNROLL for (int i = 0; i < SB; i++) {
                 double pb = 0.0, bp = 0.0;
-                MPC_UNROLL for (int l = 0; l < SB; l++) { pb = mm(Pm[l][i], c.Br[l], pb); bp = mm(c.Br[l], Pm[l][i], bp); }
+                MPC_UNROLL for (int l = 0; l < SB; l++) { pb = mm(Pm[l][i], Brl[l], pb); bp = mm(Brl[l], Pm[l][i], bp); }
                 PB[i] = pb; BtP[i] = bp;
-                MPC_UNROLL for (int j = 0; j < SB; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < SB; l++) a = mm(Pm[l][i], c.Ar[l][j], a); PA[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j < SB; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < SB; l++) a = mm(Pm[l][i], Arl[l][j], a); PA[i][j] = a; }
             }
             double X0 = RE0 + s0, X1 = RE1 + s1;
-            MPC_UNROLL for (int l = 0; l < SB; l++) { X0 = mm(BE0[l], PB[l], X0); if (NU > 1) X1 = mm(BE1[l], PB[l], X1); }
+            MPC_UNROLL for (int l = 0; l < SB; l++) { X0 = mm(BE0l[l], PB[l], X0); if (NU > 1) X1 = mm(BE1l[l], PB[l], X1); }
             double Psi[SB];
-            MPC_UNROLL for (int j = 0; j < SB; j++) { double a = Mtr[j]; MPC_UNROLL for (int l = 0; l < SB; l++) a = mm(c.Br[l], PA[l][j], a); Psi[j] = a; }      // M' + B'PA
+            MPC_UNROLL for (int j = 0; j < SB; j++) { double a = Mtr[j]; MPC_UNROLL for (int l = 0; l < SB; l++) a = mm(Brl[l], PA[l][j], a); Psi[j] = a; }      // M' + B'PA
             const double Rs = Rr + su;
             // every lane gets the numbers Lambda is made of (columns via the quad)
             const double a = dpp_move<0x00, 0xF>(X0, X0);
@@ -461,7 +516,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             const double mL = adjm * rdet, mLi = adjk * rdet;
             // right-hand side of the predictor for this block (off the chain of the matrix recursion)
             double PV[SB], psv = HU;
-            MPC_UNROLL for (int i = 0; i < SB; i++) { PV[i] = HZ[i] + PC[i]; psv = mm(c.Br[i], PV[i], psv); }      // hu + B'(hz + p+)
+            MPC_UNROLL for (int i = 0; i < SB; i++) { PV[i] = HZ[i] + PC[i]; psv = mm(Brl[i], PV[i], psv); }      // hu + B'(hz + p+)
             const double KFF = mm(mLi, psv, 0.0);                           // -Lambda^-1 psi, in every column
             q_st[0][-d] = sel_k0 ? Kk[0] : (st_l ? mL : KFF);
             MPC_UNROLL for (int j = 1; j < SB; j++) q_st[j][-d] = Kk[j];
@@ -471,7 +526,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int j = 0; j < SB; j++) RK_[j] = mm(Rs, Kk[j], 0.0);                                // R~ K
             MPC_UNROLL for (int i = 0; i < SB; i++) {
                 MPC_UNROLL for (int j = 0; j < SB; j++) {
-                    Acl[i][j] = mm(c.Btr[i], Kk[j], c.Ar[i][j]);            // A + B K
+                    Acl[i][j] = mm(Btrl[i], Kk[j], Arl[i][j]);              // A + B K
                     Tm[i][j] = mm(BtP[i], Kk[j], PA[i][j]);                 // P Acl = PA + PB K
                     if (HASM) MK[i][j] = mm(Mtr[i], Kk[j], 0.0);            // M K
                 }
@@ -492,6 +547,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int d = 0; d < PD; d++) block(d, true);
             MPC_UNROLL for (int i = 0; i < SB; i++) { q_sz[i] -= PD; q_hz[i] -= PD; q_st[i] -= stp[i]; }
             q_su -= PD; q_s0 -= PD; q_s1 -= PD; q_hu -= PD; q_sf -= stpf;
+            if (LTV) { q_a -= PD; q_b -= PD; q_bt -= PD; }
         }
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
@@ -509,23 +565,28 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         const int stp = st_any ? PD : 0;
         double PC[SB];
         MPC_UNROLL for (int i = 0; i < SB; i++) PC[i] = 0.0;
-        constexpr int NF = 2 * SB + 2;      // hu li hz[SB] k[SB]
+        constexpr int NF = 2 * SB + 2 + (LTV ? 3 : 0);      // hu li hz[SB] k[SB] (a b bt)
         double f[PD][NF];
+        const double *q_a = LTV ? c.p_a + (N - 1) : nullptr, *q_b = LTV ? c.p_b + (N - 1) : nullptr, *q_bt = LTV ? c.p_bt + (N - 1) : nullptr;
         auto fetch = [&](int d, int off) {
             f[d][0] = q_hu[off]; f[d][1] = q_li[off];
             MPC_UNROLL for (int i = 0; i < SB; i++) { f[d][2 + i] = q_hz[i][off]; f[d][2 + SB + i] = q_k[i][off]; }
+            if (LTV) { f[d][NF - 3] = q_a[off]; f[d][NF - 2] = q_b[off]; f[d][NF - 1] = q_bt[off]; }
         };
         MPC_UNROLL for (int d = 0; d < PD; d++) fetch(d, -d);
         auto block = [&](int d, bool more) {
             const double HU = f[d][0], mLi = f[d][1];
             double HZ[SB], Kk[SB];
             MPC_UNROLL for (int i = 0; i < SB; i++) { HZ[i] = f[d][2 + i]; Kk[i] = f[d][2 + SB + i]; }
+            double Arl[SB][SB], Brl[SB], Btrl[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { Brl[i] = c.Br[i]; Btrl[i] = c.Btr[i]; MPC_UNROLL for (int jj = 0; jj < SB; jj++) Arl[i][jj] = c.Ar[i][jj]; }
+            if (LTV) { Arl[0][0] = f[d][NF - 3]; Brl[0] = f[d][NF - 2]; Btrl[0] = f[d][NF - 1]; }
             if (more) fetch(d, -PD - d);
             double psv = HU;
-            MPC_UNROLL for (int i = 0; i < SB; i++) psv = mm(c.Br[i], HZ[i] + PC[i], psv);
+            MPC_UNROLL for (int i = 0; i < SB; i++) psv = mm(Brl[i], HZ[i] + PC[i], psv);
             q_st[-d] = mm(mLi, psv, 0.0);
             double Acl[SB][SB], PCn[SB];
-            MPC_UNROLL for (int i = 0; i < SB; i++) { MPC_UNROLL for (int j = 0; j < SB; j++) Acl[i][j] = mm(c.Btr[i], Kk[j], c.Ar[i][j]); }
+            MPC_UNROLL for (int i = 0; i < SB; i++) { MPC_UNROLL for (int j = 0; j < SB; j++) Acl[i][j] = mm(Btrl[i], Kk[j], Arl[i][j]); }
             MPC_UNROLL for (int i = 0; i < SB; i++) {
                 double cst = mm(Kk[i], HU, 0.0), dyn = 0.0;
                 MPC_UNROLL for (int l = 0; l < SB; l++) { cst = mm(Acl[l][i], HZ[l], cst); dyn = mm(Acl[l][i], PC[l], dyn); }
@@ -538,6 +599,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int d = 0; d < PD; d++) block(d, true);
             MPC_UNROLL for (int i = 0; i < SB; i++) { q_hz[i] -= PD; q_k[i] -= PD; }
             q_hu -= PD; q_li -= PD; q_st -= stp;
+            if (LTV) { q_a -= PD; q_b -= PD; q_bt -= PD; }
         }
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
@@ -563,24 +625,29 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         MPC_UNROLL for (int i = 0; i < SB; i++) { q_k[i] = c.p_k[i]; q_kt[i] = c.p_kt[i]; }
         double DZ[SB];
         MPC_UNROLL for (int i = 0; i < SB; i++) DZ[i] = 0.0;
-        constexpr int NF = 2 * SB + 1;      // kff k[SB] kt[SB]
+        constexpr int NF = 2 * SB + 1 + (LTV ? 2 : 0);      // kff k[SB] kt[SB] (at bt)
         double f[PD][NF];
+        const double *q_at = LTV ? c.p_at : nullptr, *q_bt = LTV ? c.p_bt : nullptr;
         auto fetch = [&](int d, int off) {
             f[d][0] = q_kf[off];
             MPC_UNROLL for (int i = 0; i < SB; i++) { f[d][1 + i] = q_k[i][off]; f[d][1 + SB + i] = q_kt[i][off]; }
+            if (LTV) { f[d][NF - 2] = q_at[off]; f[d][NF - 1] = q_bt[off]; }
         };
         MPC_UNROLL for (int d = 0; d < PD; d++) fetch(d, d);
         auto block = [&](int d, bool more) {
             const double KFF = f[d][0];
             double Kk[SB], KkT[SB];
             MPC_UNROLL for (int i = 0; i < SB; i++) { Kk[i] = f[d][1 + i]; KkT[i] = f[d][1 + SB + i]; }
+            double Atrl[SB][SB], Btrl[SB];
+            MPC_UNROLL for (int i = 0; i < SB; i++) { Btrl[i] = c.Btr[i]; MPC_UNROLL for (int jj = 0; jj < SB; jj++) Atrl[i][jj] = c.Atr[i][jj]; }
+            if (LTV) { Atrl[0][0] = f[d][NF - 2]; Btrl[0] = f[d][NF - 1]; }
             if (more) fetch(d, PD + d);
             double DU = KFF;
             MPC_UNROLL for (int j = 0; j < SB; j++) DU = mm(KkT[j], DZ[j], DU);                      // K dz + kff
             double DZn[SB];
             MPC_UNROLL for (int i = 0; i < SB; i++) {
-                double a = mm(c.Btr[i], KFF, 0.0);                                               // B kff
-                MPC_UNROLL for (int j = 0; j < SB; j++) a = mm(mm(Kk[j], c.Btr[i], c.Atr[j][i]), DZ[j], a);      // (A + B K)'[j][i]' dz_j = Acl[i][j] dz_j
+                double a = mm(Btrl[i], KFF, 0.0);                                                // B kff
+                MPC_UNROLL for (int j = 0; j < SB; j++) a = mm(mm(Kk[j], Btrl[i], Atrl[j][i]), DZ[j], a);        // (A + B K)'[j][i]' dz_j = Acl[i][j] dz_j
                 DZn[i] = a;
             }
             q_st[0][d] = st_u ? DU : DZn[0];
@@ -592,6 +659,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int d = 0; d < PD; d++) block(d, true);
             MPC_UNROLL for (int i = 0; i < SB; i++) { q_k[i] += PD; q_kt[i] += PD; q_st[i] += stp[i]; }
             q_kf += PD;
+            if (LTV) { q_at += PD; q_bt += PD; }
         }
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };

@@ -16,7 +16,7 @@ from . import nlcodegen
 from .capi import MpcAmdError
 
 NMPC_EXPORTS = ("nmpc_create", "nmpc_destroy", "nmpc_last_error", "nmpc_build_info", "nmpc_alloc", "nmpc_set_state", "nmpc_set_schedule",
-                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms")
+                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_get_kernel")
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)
@@ -46,6 +46,8 @@ def load_nmpc_library(path: str) -> ct.CDLL:
     lib.nmpc_set_schedule.argtypes = [vp, ct.c_int32, _dp, _dp, _dp, _dp]
     lib.nmpc_run.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
     lib.nmpc_sync.argtypes = [vp]
+    lib.nmpc_set_kernel.argtypes = [vp, ct.c_int32]
+    lib.nmpc_get_kernel.argtypes = [vp]
     lib.nmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
     lib.nmpc_last_kernel_ms.argtypes = [vp]; lib.nmpc_last_kernel_ms.restype = ct.c_float
     _libs[path] = lib
@@ -136,6 +138,13 @@ class NmpcSolver:
 
     def sync(self):
         self._chk(self.lib.nmpc_sync(self.h), "nmpc_sync")
+
+    def set_kernel(self, kernel: int):
+        """0 auto, 1 one instance per lane, 3 wave-autonomous (model state <= 4, nu <= 2, N <= 64)."""
+        self._chk(self.lib.nmpc_set_kernel(self.h, int(kernel)), "nmpc_set_kernel")
+
+    def get_kernel(self) -> int:
+        return int(self.lib.nmpc_get_kernel(self.h))
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.nmpc_last_kernel_ms(self.h))

@@ -176,14 +176,18 @@ def solver(nl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 3])
 @pytest.mark.parametrize("mode,max_sqp", [("rti", 1), ("sqp", 50)])
-def test_gpu_closed_loop_equals_the_golden_vectors(nl, gold, solver, mode, max_sqp):
+def test_gpu_closed_loop_equals_the_golden_vectors(nl, gold, solver, mode, max_sqp, kernel):
     """Real-time iteration over 40 steps (feed-flow change at step 25 included) and converged SQP over 8 steps.
     Tolerance: 1e-9 relative to 1 + |value| per step would be the solver tolerance; errors carry through the closed
     loop, so 2e-7 over the whole run (measured: 3e-9 / 2e-10)."""
     from mpc_code_amd import nmpc
     x0 = gold[mode + "_x0"]; ns = gold[mode + "_U"].shape[0]
+    solver.set_kernel(kernel)          # 1: one instance per lane; 3: wave-autonomous (lane = stage, QP on the matrix cores)
+    assert solver.get_kernel() == kernel
     r = nmpc.run_nmpc_closed_loop(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=max_sqp, sqp_tol=1e-9)
+    solver.set_kernel(0)
     assert np.array_equal(r["STATUS_DYN"], gold[mode + "_STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], gold[mode + "_STATUS_SS"])
     for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "Yp"):
         g = gold[f"{mode}_{k}"]
@@ -212,6 +216,14 @@ def test_gpu_full_size_batch_properties(nl, gold, solver):
     r2 = nmpc.run_nmpc_closed_loop(nl, x0[perm], x0[perm], nsteps=ns, solver=solver, max_sqp=1)
     for k in ("U", "X_HAT", "Xp", "D_HAT"):
         assert np.array_equal(r2[k], r[k][:, perm]), k
+    # the two kernels on a batch of 4096 (the wave-autonomous one is the default there): the same closed loops
+    assert solver.get_kernel() == 1
+    solver.set_kernel(3)
+    r3 = nmpc.run_nmpc_closed_loop(nl, x0[:4096], x0[:4096], nsteps=ns, solver=solver, max_sqp=1)
+    solver.set_kernel(0)
+    assert np.array_equal(r3["STATUS_DYN"], r["STATUS_DYN"][:, :4096])
+    for k in ("U", "X_HAT", "Xp", "D_HAT", "XS"):
+        assert np.max(np.abs(r3[k] - r[k][:, :4096]) / (1 + np.abs(r3[k]))) < 1e-7, k
     # the controlled loop contracts: 30 steps on, the level of every instance follows the same response to the feed-flow step
     # at t = 5, whatever its start in the box
     assert np.ptp(r["Xp"][-1, :, 2]) < 1e-3 and np.ptp(x0[:, 2]) > 0.02
@@ -224,12 +236,15 @@ def test_gpu_launch_chunks_continue_the_same_loop(nl, solver):
     rng = np.random.default_rng(3)
     x0 = np.tile(nl.x0_p, (B, 1)) + rng.uniform(-1, 1, size=(B, 3)) * [0.02, 2.0, 0.02]
     sched = nl.schedules(10)
-    solver.alloc(B, 10); solver.set_state(x0, x0); solver.set_schedule(sched)
-    solver.run(0, 10, 1, 1e-9); solver.sync()
-    a = solver.get_log("U").copy()
-    solver.alloc(B, 10); solver.set_state(x0, x0); solver.set_schedule(sched)
-    solver.run(0, 5, 1, 1e-9); solver.run(5, 5, 1, 1e-9); solver.sync()
-    assert np.array_equal(solver.get_log("U"), a)
+    for kernel in (1, 3):
+        solver.set_kernel(kernel)
+        solver.alloc(B, 10); solver.set_state(x0, x0); solver.set_schedule(sched)
+        solver.run(0, 10, 1, 1e-9); solver.sync()
+        a = solver.get_log("U").copy()
+        solver.alloc(B, 10); solver.set_state(x0, x0); solver.set_schedule(sched)
+        solver.run(0, 5, 1, 1e-9); solver.run(5, 5, 1, 1e-9); solver.sync()
+        assert np.array_equal(solver.get_log("U"), a), kernel
+    solver.set_kernel(0)
 
 
 @pytest.mark.gpu

@@ -20,7 +20,9 @@ for ex, gold, big in (("cstr_nmpc.py", "nmpc_cstr.npz", 16384), ("quadtank_nmpc_
         pg = p
     print(ex, s.build_info())
     gp = os.path.join(ROOT, "tests", "golden", gold)
-    if os.path.exists(gp):
+    for kern in ((3, 1) if "cstr" in ex else (1,)):
+      s.set_kernel(kern); print("=== kernel", kern, "in force", s.get_kernel())
+      if os.path.exists(gp):
         g = np.load(gp)
         for mode, ms in (("rti", 1), ("sqp", 50)):
             x0 = g[mode + "_x0"]; ns = g[mode + "_U"].shape[0]
@@ -31,12 +33,12 @@ for ex, gold, big in (("cstr_nmpc.py", "nmpc_cstr.npz", 16384), ("quadtank_nmpc_
             print(mode, "status dyn", r["STATUS_DYN"].T.tolist()[0], "golden", g[mode + "_STATUS_DYN"].T.tolist()[0])
             print(mode, "status ss", r["STATUS_SS"].T.tolist()[0], "sqp_dyn", r["SQP_DYN"].T.tolist()[0], "golden", g[mode + "_SQP_DYN"].T.tolist()[0])
             print(mode, "iters_dyn", r["ITERS_DYN"].T.tolist()[0], "sqp_ss", r["SQP_SS"].T.tolist()[0], "golden", g[mode + "_SQP_SS"].T.tolist()[0])
-    for B, ns, ms in ((big, 20, 1),):
+      for B, ns, ms in ((big, 20, 1), (big // 4, 20, 1)):
         rng = np.random.default_rng(1)
         x0 = p.x0_p * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, p.nxp)))
         r = nmpc.run_nmpc_closed_loop(p, x0, x0, nsteps=ns, solver=s, max_sqp=ms)
         ms_k = r["TIME_DYN"].sum() * 1e3
-        print(f"B={B} steps={ns} max_sqp={ms}: kernel {ms_k:.1f} ms  {B * ns / ms_k * 1e3 / 1e6:.3f} M NMPC steps/s  status dyn",
+        print(f"kernel {kern} B={B} steps={ns} max_sqp={ms}: kernel {ms_k:.1f} ms  {B * ns / ms_k * 1e3 / 1e6:.3f} M NMPC steps/s  status dyn",
               dict(zip(*[a.tolist() for a in np.unique(r['STATUS_DYN'], return_counts=True)])), "ss", dict(zip(*[a.tolist() for a in np.unique(r['STATUS_SS'], return_counts=True)])),
               "mean ipm it", r["ITERS_DYN"].mean(), "finite", bool(np.isfinite(r["U"]).all()))
     s.close()
