@@ -212,6 +212,14 @@ def test_gpu_full_size_batch_properties(nl, gold, solver):
     assert np.all(r["XS"] >= nl.xmin_ss - 1e-7) and np.all(r["XS"] <= nl.xmax_ss + 1e-7)
     g = gold["rti_U"][:ns, 0]
     assert np.max(np.abs(r["U"][:, 0] - g) / (1 + np.abs(g))) < 2e-7
+    # three instances drawn from the batch, re-run by the oracle (NumPy restatement, finite-difference Jacobians, dense QPs) from
+    # their own initial states: the batch's trajectories are the oracle's
+    import nmpc_oracle as no
+    for b in rng.choice(B, 3, replace=False):
+        o = no.closed_loop(nl, 6, x0_p=x0[b], x0_m=x0[b], max_sqp=1)
+        for k in ("U", "X_HAT", "XS", "Xp", "D_HAT"):
+            assert np.max(np.abs(r[k][:6, b] - o[k]) / (1 + np.abs(o[k]))) < 1e-6, (int(b), k)
+        assert np.array_equal(r["STATUS_DYN"][:6, b], o["STATUS_DYN"])
     perm = rng.permutation(B)
     r2 = nmpc.run_nmpc_closed_loop(nl, x0[perm], x0[perm], nsteps=ns, solver=solver, max_sqp=1)
     for k in ("U", "X_HAT", "Xp", "D_HAT"):
