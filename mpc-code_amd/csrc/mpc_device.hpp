@@ -400,7 +400,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 const double lhi = warm ? dmax(lprev[i].y, ws_mu * iv.y) : kMu0 * iv.y;
                 lv.x = fl ? llo : 0.0; lv.y = fh ? lhi : 0.0;
                 pz.x = 0.0; pz.y = 0.0;
-                b[(L::S + i) * 64] = sv; b[(L::L + i) * 64] = lv; b[(L::IS + i) * 64] = iv; b[(L::P + i) * 64] = pz;
+                b[(L::S + i) * 64] = sv; b[(L::L + i) * 64] = lv; b[(L::P + i) * 64] = pz;
             }
             st_field<NU>(b, L::U, uk); st_field<NS>(b, L::Z, z);
             st_field<NU>(b, L::DU, zero_u); st_field<NS>(b, L::DZ, zero_z);
@@ -430,7 +430,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; }
             ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z);
             if (upd) {
-                MPC_UNROLL for (int i = 0; i < NC; i++) { d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.p[i] = b[(L::P + i) * 64]; }
                 ld_field<NU>(b, L::DU, d.du); ld_field<NS>(b, L::DZ, d.dz);
             }
         };
@@ -456,7 +456,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                     const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + cur.p[i].y : 0.0;
                     const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + cur.p[i].x : 0.0;
                     const double dsh = fh ? -rh - dv : 0.0, dsl = fl ? rl + dv : 0.0;
-                    const double dlh = fh ? (-rch - lh * dsh) * cur.is[i].y : 0.0, dll = fl ? (-rcl - ll * dsl) * cur.is[i].x : 0.0;
+                    const double dlh = fh ? (-rch - lh * dsh) * frcp(sh) : 0.0, dll = fl ? (-rcl - ll * dsl) * frcp(sl) : 0.0;      // 1/s recomputed: one field less to stream
                     sl += alpha * dsl; sh += alpha * dsh; ll += alpha * dll; lh += alpha * dlh; v += alpha * dv;
                     if (i < NU) ublk[i < NU ? i : 0] = v; else zblk[i >= NU ? i - NU : 0] = v;
                 }
@@ -465,7 +465,6 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                 if (upd) {
                     v2d t; t.x = sl; t.y = sh; b[(L::S + i) * 64] = t;
                     t.x = ll; t.y = lh; b[(L::L + i) * 64] = t;
-                    t.x = isl; t.y = ish; b[(L::IS + i) * 64] = t;
                 }
                 mu_sum += sl * ll + sh * lh;
                 sig[i] = ll * isl + lh * ish;
@@ -600,7 +599,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             struct F1Blk { v2d s[NC], l[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f1 = [&](int k, F1Blk &d) {
                 const BlkPtr b = ws.blk(k);
-                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
             };
             F1Blk c1;
@@ -623,8 +622,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
                     const double v = i < NU ? c1.u[i < NU ? i : 0] : c1.z[i >= NU ? i - NU : 0];
                     const double dv = i < NU ? ddu[i < NU ? i : 0] : dz[i >= NU ? i - NU : 0];
-                    const double sl = c1.s[i].x, sh = c1.s[i].y, ll = c1.l[i].x, lh = c1.l[i].y, isl = c1.is[i].x, ish = c1.is[i].y;
-                    c1.s[i] = nb[(L::S + i) * 64]; c1.l[i] = nb[(L::L + i) * 64]; c1.is[i] = nb[(L::IS + i) * 64];
+                    const double sl = c1.s[i].x, sh = c1.s[i].y, ll = c1.l[i].x, lh = c1.l[i].y, isl = frcp(sl), ish = frcp(sh);
+                    c1.s[i] = nb[(L::S + i) * 64]; c1.l[i] = nb[(L::L + i) * 64];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
                     const double dsh = fh ? -rh - dv : 0.0, dsl = fl ? rl + dv : 0.0;
                     // rc = s*l:  dl = -l - l*ds/s,  -dl/l = 1 + ds/s
@@ -653,7 +652,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             struct B2Blk { v2d s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], K[NU * NS], li[NU * (NU + 1) / 2]; };
             auto load_b2 = [&](int k, B2Blk &d) {
                 const BlkPtr b = ws.blk(k);
-                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU * NS>(b, L::K, d.K); ld_field<NU * (NU + 1) / 2>(b, L::LI, d.li);
             };
             B2Blk c2;
@@ -673,8 +672,8 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
                     const double v = i < NU ? c2.u[i < NU ? i : 0] : c2.z[i >= NU ? i - NU : 0];
                     const double sl = c2.s[i].x, sh = c2.s[i].y, ll = c2.l[i].x, lh = c2.l[i].y;
-                    const double plo = c2.p[i].x, phi = c2.p[i].y, isl = c2.is[i].x, ish = c2.is[i].y;
-                    c2.s[i] = nb[(L::S + i) * 64]; c2.l[i] = nb[(L::L + i) * 64]; c2.p[i] = nb[(L::P + i) * 64]; c2.is[i] = nb[(L::IS + i) * 64];
+                    const double plo = c2.p[i].x, phi = c2.p[i].y, isl = frcp(sl), ish = frcp(sh);
+                    c2.s[i] = nb[(L::S + i) * 64]; c2.l[i] = nb[(L::L + i) * 64]; c2.p[i] = nb[(L::P + i) * 64];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
                     const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + phi : 0.0;
                     const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + plo : 0.0;
@@ -737,7 +736,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             struct F2Blk { v2d s[NC], l[NC], p[NC], is[NC]; double u[NU], z[NS], kff[NU], K[NU * NS]; };
             auto load_f2 = [&](int k, F2Blk &d) {
                 const BlkPtr b = ws.blk(k);
-                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; d.is[i] = b[(L::IS + i) * 64]; }
+                MPC_UNROLL for (int i = 0; i < NC; i++) { d.s[i] = b[(L::S + i) * 64]; d.l[i] = b[(L::L + i) * 64]; d.p[i] = b[(L::P + i) * 64]; }
                 ld_field<NU>(b, L::U, d.u); ld_field<NS>(b, L::Z, d.z); ld_field<NU>(b, L::KFF, d.kff); ld_field<NU * NS>(b, L::K, d.K);
             };
             F2Blk c3;
@@ -761,9 +760,9 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                     MPC_BOUNDS(k, i, lo, hi, fl, fh)
                     const double v = i < NU ? c3.u[i < NU ? i : 0] : c3.z[i >= NU ? i - NU : 0];
                     const double dv = i < NU ? ddu[i < NU ? i : 0] : dz[i >= NU ? i - NU : 0];
-                    const double sl = c3.s[i].x, sh = c3.s[i].y, ll = c3.l[i].x, lh = c3.l[i].y, isl = c3.is[i].x, ish = c3.is[i].y;
+                    const double sl = c3.s[i].x, sh = c3.s[i].y, ll = c3.l[i].x, lh = c3.l[i].y, isl = frcp(sl), ish = frcp(sh);
                     const double plo = c3.p[i].x, phi = c3.p[i].y;
-                    c3.s[i] = nb[(L::S + i) * 64]; c3.l[i] = nb[(L::L + i) * 64]; c3.p[i] = nb[(L::P + i) * 64]; c3.is[i] = nb[(L::IS + i) * 64];
+                    c3.s[i] = nb[(L::S + i) * 64]; c3.l[i] = nb[(L::L + i) * 64]; c3.p[i] = nb[(L::P + i) * 64];
                     const double rh = fh ? v + sh - hi : 0.0, rl = fl ? v - sl - lo : 0.0;
                     const double rch = fh ? sh * lh - dmax(sm, lh * kSFloor) + phi : 0.0;
                     const double rcl = fl ? sl * ll - dmax(sm, ll * kSFloor) + plo : 0.0;
