@@ -43,8 +43,8 @@ struct WvCfg {
     static constexpr int GUARD = 8;                                    // cells in front of T: look-ahead reads of the backward loops, stores of idle lanes
     __host__ __device__ static constexpr int t_doubles(int N) { return GUARD + ROWS * NI * ld(N); }
     // time-varying stage data (wv_solve<.., LTV>: one SQP iteration of the non-linear path): per (instance, block) the matrices
-    // A_k (NS x NS), B_k (NS x NU), the affine term c_k, and the point they were linearised at (u_k, z_{k+1}), as rows behind the others
-    static constexpr int RL_A = ROWS, RL_B = RL_A + NS * NS, RL_C = RL_B + NS * NU, RL_P = RL_C + NS, ROWS_LTV = RL_P + NU + NS;
+    // A_k (NS x NS), B_k (NS x NU) and the affine term c_k as rows behind the others (35 rows for ns = 3, nu = 2: four workgroups per CU at N = 30)
+    static constexpr int RL_A = ROWS, RL_B = RL_A + NS * NS, RL_C = RL_B + NS * NU, ROWS_LTV = RL_C + NS;
     __host__ __device__ static constexpr int t_doubles_ltv(int N) { return GUARD + ROWS_LTV * NI * ld(N); }
     static constexpr int QN = 5 * NS + 2 * NU + 1;                     // z0 zr c zlo zhi | ur us | ws_delta
     static constexpr int ROWS_WS = NU + 2 * NC;                        // warm start kept in HBM between launches: u | l_lo | l_hi

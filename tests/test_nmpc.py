@@ -225,7 +225,7 @@ def test_gpu_full_size_batch_properties(nl, gold, solver):
     for k in ("U", "X_HAT", "Xp", "D_HAT"):
         assert np.array_equal(r2[k], r[k][:, perm]), k
     # the two kernels on a batch of 4096 (the wave-autonomous one is the default there): the same closed loops
-    assert solver.get_kernel() == 1
+    assert solver.get_kernel() == 1                    # 16384 instances: the lane kernel (with helper waves for the linearisation)
     solver.set_kernel(3)
     r3 = nmpc.run_nmpc_closed_loop(nl, x0[:4096], x0[:4096], nsteps=ns, solver=solver, max_sqp=1)
     solver.set_kernel(0)
