@@ -152,7 +152,7 @@ def main_nmpc(args):
                       "batch_per_gpu": B, "horizon": p.N, "steps_per_launch": K, "max_sqp": args.max_sqp, "repeats": len(times),
                       "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "nmpc_loop_kernel (one instance per lane)", "launches": 1, "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
+                        "kernel": "nmpc_loop_kernel (one instance per lane; helper waves share the stage linearisations up to one workgroup per CU; the wave-autonomous kernel for batches up to 10240)", "launches": 1, "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
                         "note": "algorithmic bytes: resident state in and out + the shifted trajectory in and out + set points.  Measured traffic is two "
                                 "orders above them: this kernel is the instance-per-lane design, its Riccati workspace (20 KB per instance) and the "
                                 "linearisation slab (7 KB) stream through HBM in every sweep - about 2.5 TB/s over a launch, next to the dependent fp64 "
