@@ -63,9 +63,10 @@ int nmpc_set_schedule(nmpc_handle *h, int32_t nsteps, const double *ysp /* [nste
  * trajectory moves less than sqp_tol */
 int nmpc_run(nmpc_handle *h, int32_t k0, int32_t nsteps, int32_t max_sqp, double sqp_tol);
 int nmpc_sync(nmpc_handle *h);
-/* which closed-loop kernel nmpc_run launches: 0 = auto (the wave-autonomous one when the model fits: state <= 4, nu <= 2, N <= 64, no
- * input-move form), 1 = one instance per lane, 3 = wave-autonomous (one wave owns four instances, lane = stage, QP on the matrix cores);
- * nmpc_get_kernel returns the one in force */
+/* which closed-loop kernel nmpc_run launches: 1 = one instance per lane (any model), 3 = wave-autonomous (one wave owns four instances
+ * for a launch, lane = stage, QP on the matrix cores), 4 = split pipeline (per step one lane-style launch for estimator / target /
+ * plant and one wave-style launch for linearisation + QP); 3 and 4 need model state <= 4, nu <= 2, N <= 64 and no input-move form.
+ * 0 = auto: 4 up to 24576 instances when the model fits, else 1.  nmpc_get_kernel returns the one in force */
 int nmpc_set_kernel(nmpc_handle *h, int32_t kernel);
 int nmpc_get_kernel(nmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT"; [nsteps][B] int32: "STATUS_DYN","STATUS_SS","ITERS_DYN"

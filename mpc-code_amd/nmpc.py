@@ -140,7 +140,7 @@ class NmpcSolver:
         self._chk(self.lib.nmpc_sync(self.h), "nmpc_sync")
 
     def set_kernel(self, kernel: int):
-        """0 auto, 1 one instance per lane, 3 wave-autonomous (model state <= 4, nu <= 2, N <= 64)."""
+        """0 auto, 1 one instance per lane, 3 wave-autonomous, 4 split pipeline (the last two: model state <= 4, nu <= 2, N <= 64)."""
         self._chk(self.lib.nmpc_set_kernel(self.h, int(kernel)), "nmpc_set_kernel")
 
     def get_kernel(self) -> int:
