@@ -73,6 +73,10 @@ __device__ __forceinline__ double dpp_move(double old, double v)
     r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], a.i[1], CTRL, ROW_MASK, 0xF, false);
     return r.d;
 }
+// the neighbour lane's value over the whole wave: wave_shr:1 (lane i gets lane i - 1, lane 0 keeps `old`) and wave_shl:1 (lane i
+// gets lane i + 1, lane 63 keeps `old`) - ALU latency, where __shfl_up / __shfl_down go through the LDS crossbar (tools/calib/dpp_wave_shift.hip)
+__device__ __forceinline__ double wave_up1(double old, double v) { return dpp_move<0x138, 0xF>(old, v); }
+__device__ __forceinline__ double wave_dn1(double old, double v) { return dpp_move<0x130, 0xF>(old, v); }
 __device__ __forceinline__ double lane63(double v)
 {
     union { double d; int i[2]; } x; x.d = v;

@@ -196,22 +196,30 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + (NU + i < NC ? hb[NU + i < NC ? NU + i : 0] : 0.0);
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = blk_on ? gz[i] : 0.0;
+        Sj.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
+        const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
+        const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         double rs_p = 0.0;
         if (LTV) {
             // pi_{k+1} = gz_{k+1} + A_{k+1}' pi_{k+2} (lane k holds block k = (u_k, z_{k+1}): its costate passes through the NEXT block's A):
-            // a sweep from the last lane down, each lane taking its successor's finished value
-            double An[NS][NS];
-            const int kn = k + 1 < N ? k + 1 : (N > 0 ? N - 1 : 0);
-            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int l = 0; l < NS; l++) An[i][l] = T[((Cfg::RL_A + i * NS + l) * NI + j) * LD + kn]; }
-            for (int s = N - 2; s >= 0; s--) {
-                double t[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = __shfl_down(pi[i], 1, 64);
-                if (k == s) { MPC_UNROLL for (int i = 0; i < NS; i++) { double a = gz[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += An[l][i] * t[l]; pi[i] = a; } }
-            }
-            MPC_UNROLL for (int i = 0; i < NU; i++) {
-                double a = gu[i];
-                MPC_UNROLL for (int l = 0; l < NS; l++) a += (blk_on ? tk(Cfg::RL_B + l * NU + i, j) : 0.0) * pi[l];
-                rs_p = dmax(rs_p, fabs(a));
+            // a sweep from the last lane down.  Every lane below the last block recomputes from its successor in every round - lanes whose
+            // successor is final only reproduce their value - so the rounds carry no lane mask.  The costates serve the stationarity
+            // test alone: they are taken when it can decide (complementarity and feasibility in tolerance) and for the scale at it = 0.
+            if (it == 0 || ok_cp) {
+                double An[NS][NS];
+                const int kn = k + 1 < N ? k + 1 : (N > 0 ? N - 1 : 0);
+                const bool upd = k + 1 < N;
+                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int l = 0; l < NS; l++) An[i][l] = upd ? T[((Cfg::RL_A + i * NS + l) * NI + j) * LD + kn] : 0.0; }
+                for (int s = N - 2; s >= 0; s--) {
+                    double t[NS];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_dn1(0.0, pi[i]);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; if (upd) { a = gz[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += An[l][i] * t[l]; } pi[i] = a; }
+                }
+                MPC_UNROLL for (int i = 0; i < NU; i++) {
+                    double a = gu[i];
+                    MPC_UNROLL for (int l = 0; l < NS; l++) a += (blk_on ? tk(Cfg::RL_B + l * NU + i, j) : 0.0) * pi[l];
+                    rs_p = dmax(rs_p, fabs(a));
+                }
             }
         } else {
             MPC_UNROLL for (int e = 0; e < 6; e++) {
@@ -224,12 +232,9 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             }
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.B[l][i] * pi[l]; rs_p = dmax(rs_p, fabs(a)); }
         }
-        Sj.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
-        const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
-        const double res_s = wave_max(blk_on ? rs_p : 0.0);
+        const double res_s = (!LTV || it == 0 || ok_cp) ? wave_max(blk_on ? rs_p : 0.0) : Sj.res_s;
         Sj.mu = Sj.mu_sum * Sj.inv_ncon; Sj.res_s = res_s; Sj.res_p = res_p;
         if (it == 0) Sj.gscale = dmax(1.0, P.term_cons ? dmin(res_s, P.term_gcap) : res_s);      // mpc_device.hpp:rpdip_lane
-        const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         Sj.stall = ok_cp ? Sj.stall + 1 : 0;
         int verdict = -1;
         if (ok_cp && (res_s <= kTolStat * Sj.gscale + P.term_floor || (Sj.stall > kStallMax && res_s <= kTolStatAcc * Sj.gscale + P.term_floor))) verdict = kSolved;
@@ -303,10 +308,11 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     MPC_UNROLL for (int l = 0; l < NS; l++) Ak[i][l] = blk_on ? tk(Cfg::RL_A + i * NS + l, j) : 0.0;
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * qd[l]; xk[i] = k == 0 ? a : 0.0; }
+                const bool upd = k >= 1 && blk_on;      // (every lane above 0 recomputes from its predecessor in every round: no per-round mask)
                 for (int s = 1; s < N; s++) {
                     double t[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = __shfl_up(xk[i], 1, 64);
-                    if (k == s) { MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * t[l]; xk[i] = a; } }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_up1(0.0, xk[i]);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = xk[i]; if (upd) { a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * t[l]; } xk[i] = a; }
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = xk[i];
             } else {
