@@ -124,9 +124,13 @@ def main_nmpc(args):
     ns = max(K, W, 1)
     s.alloc(B, ns); s.set_schedule(p.schedules(ns))
     s.set_state(x0, x0)
+    kern = s.get_kernel()
+    split = kern == 4
+    if split:
+        s.time_kernels(True)                     # every wave-style launch bracketed by its own HIP events on the library's stream
     if W > 0:
         s.run(0, W, args.max_sqp); s.sync()
-    times, kms, spent = [], [], 0.0
+    times, kms, wms, wn, spent = [], [], [], 0, 0.0
     while True:
         s.set_state(x0, x0)                      # untimed: t = 0 again
         s.sync()
@@ -134,6 +138,8 @@ def main_nmpc(args):
         s.run(0, K, args.max_sqp); s.sync()
         dt = time.perf_counter() - t0
         times.append(dt); kms.append(s.last_kernel_ms()); spent += dt
+        if split:
+            ms, nl = s.wave_kernel_ms(); wms.append(ms / max(nl, 1)); wn = nl
         if (args.repeats > 0 and len(times) >= args.repeats) or (args.repeats == 0 and (spent >= args.min_seconds or len(times) >= 2000)):
             break
     dt = float(np.median(times))
@@ -141,22 +147,40 @@ def main_nmpc(args):
     ne = p.nx + p.nd
     state = p.nxp + p.nx + p.nd + ne * ne + p.nu + p.nx + p.nu
     ab = (2 * state + 2 * p.nw + p.ny + p.nu) * 8              # state in + out, shifted trajectory in + out, set points
-    per_launch_s = float(np.mean(kms)) * 1e-3
-    achieved = ab * B * K / per_launch_s / 1e9
-    traffic, traffic_src = measured_traffic("nmpc_loop_kernel", B * K, os.path.join(ROOT, "profiles", "r02_nmpc_pmc_summary.json"))
+    summary = os.path.join(ROOT, "profiles", "r02_nmpc_pmc_summary.json")
+    if split:
+        # the dominant kernel of the split pipeline: one launch = linearisation + QP of one step of every instance
+        per_launch_s = float(np.mean(wms)) * 1e-3
+        units = B
+        kname = "nmpc_loop_kernel_wv<true>"
+        kdesc = ("nmpc_loop_kernel_wv<true> (split pipeline, the wave-style launch of a step: one wave owns four instances, lane = stage - two "
+                 "instances side by side for N <= 32 -, RK4 sensitivities into LDS, QP on the matrix cores; %.0f %% of the device time of a "
+                 "run, the lane-style launch nmpc_step_lane_kernel - estimator, target, plant - is the rest)" % (100.0 * np.mean(wms) * wn / np.mean(kms)))
+        note = ("algorithmic bytes: resident state in and out + the shifted trajectory in and out + set points, per instance-step; one launch of "
+                "this kernel advances every instance by one step.  The kernel is bound by dependent fp64 chains (RK4 sensitivities, Riccati "
+                "recursions on one wave per SIMD), not by HBM: its measured traffic is the trajectories / multipliers (warm start rows) it loads "
+                "and stores per launch and the exchange buffers")
+    else:
+        per_launch_s = float(np.mean(kms)) * 1e-3
+        units = B * K
+        kname = "nmpc_loop_kernel"
+        kdesc = "nmpc_loop_kernel (one instance per lane, all steps in one launch; helper waves share the stage linearisations up to one workgroup per CU)"
+        note = ("algorithmic bytes: resident state in and out + the shifted trajectory in and out + set points.  Measured traffic is two "
+                "orders above them: this kernel is the instance-per-lane design, its Riccati workspace (20 KB per instance) and the "
+                "linearisation slab (7 KB) stream through HBM in every sweep")
+    achieved = ab * units / per_launch_s / 1e9
+    traffic, traffic_src = measured_traffic(kname, units, summary)
     out = {"metric": "closed-loop NMPC steps/sec over batch, Ex_NMPC N=30 (BASELINE configs[3])", "value": B * K / dt, "unit": "steps/s", "n_gpus": 1,
            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": "Ex_NMPC (nx=3,nu=2,ny=2,nd=2, RK4 Mx=10, EKF), N=30, batch=%d, x0=[0.874317,325,0.6528]*(1+0.02*U(-1,1)^3) seed %d, closed loop "
                                   "from t=0: EKF + target SQP + %s + plant per step" % (B, SEED, "one real-time SQP iteration" if args.max_sqp == 1 else "SQP (<= %d iterations)" % args.max_sqp),
-                      "batch_per_gpu": B, "horizon": p.N, "steps_per_launch": K, "max_sqp": args.max_sqp, "repeats": len(times),
-                      "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
+                      "batch_per_gpu": B, "horizon": p.N, "steps_per_run": K, "kernel": kern, "max_sqp": args.max_sqp, "repeats": len(times),
+                      "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3},
+                      "device_ms_per_run": float(np.mean(kms))},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "nmpc_loop_kernel (one instance per lane; helper waves share the stage linearisations up to one workgroup per CU; the wave-autonomous kernel for batches up to 10240)", "launches": 1, "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
-                        "note": "algorithmic bytes: resident state in and out + the shifted trajectory in and out + set points.  Measured traffic is two "
-                                "orders above them: this kernel is the instance-per-lane design, its Riccati workspace (20 KB per instance) and the "
-                                "linearisation slab (7 KB) stream through HBM in every sweep - about 2.5 TB/s over a launch, next to the dependent fp64 "
-                                "chains of the RK4 sensitivities; the on-chip (wave-autonomous) solver of the linear path is the next step (DESIGN.md section 8)"},
+                        "kernel": kdesc, "launches": (wn if split else 1) * len(times), "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
+                        "instance_steps_per_launch": units, "note": note},
            "solver": {"frac_solved": float((st == 0).mean()), "frac_maxiter": float((st == 1).mean()), "frac_infeasible_hold": float((st == 2).mean()),
                       "mean_sqp": float(sqp.mean()), "mean_ipm_iters_last_qp": float(it.mean())}}
     if not args.no_cpu_baseline:

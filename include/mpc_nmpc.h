@@ -72,7 +72,12 @@ int nmpc_get_kernel(nmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT"; [nsteps][B] int32: "STATUS_DYN","STATUS_SS","ITERS_DYN"
  * (interior-point iterations of the last QP),"SQP_DYN","SQP_SS" */
 int nmpc_get_log(nmpc_handle *h, const char *name, void *out);
-float nmpc_last_kernel_ms(nmpc_handle *h);
+float nmpc_last_kernel_ms(nmpc_handle *h);      /* device time of the last nmpc_run (all its launches), HIP events on the library's stream */
+/* split pipeline (kernel 4): with nmpc_time_kernels(h, 1) every wave-style launch (linearisation + QP, the dominant kernel) of the
+ * following runs is bracketed by its own pair of HIP events; nmpc_wave_kernel_ms returns their sum and count for the last run
+ * (0 launches when another kernel ran or timing is off) */
+int nmpc_time_kernels(nmpc_handle *h, int32_t on);
+int nmpc_wave_kernel_ms(nmpc_handle *h, float *total_ms, int32_t *launches);
 
 #ifdef __cplusplus
 }

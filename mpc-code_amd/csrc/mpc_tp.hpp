@@ -103,6 +103,35 @@ __device__ __forceinline__ double wave_max(double v)
     v = dmax(v, dpp_move<0x143, 0xC>(v, v));
     return lane63(v);
 }
+// the same over each half of the wave (lanes 0-31 | 32-63), every lane getting its half's result: the first five steps of the tree
+// above, so a half whose partner holds zeros (resp. the neutral element) gives the bits of the whole-wave result.  Safe under an exec
+// mask that switches whole halves off (the steps stay inside a half, v_readlane ignores exec).
+__device__ __forceinline__ double lane_of(double v, int l)
+{
+    union { double d; int i[2]; } x; x.d = v;
+    x.i[0] = __builtin_amdgcn_readlane(x.i[0], l); x.i[1] = __builtin_amdgcn_readlane(x.i[1], l);
+    return x.d;
+}
+__device__ __forceinline__ double half_sum(double v)
+{
+    v += dpp_move<0xB1, 0xF>(0.0, v);
+    v += dpp_move<0x4E, 0xF>(0.0, v);
+    v += dpp_move<0x141, 0xF>(0.0, v);
+    v += dpp_move<0x140, 0xF>(0.0, v);
+    v += dpp_move<0x142, 0xA>(0.0, v);
+    const double lo = lane_of(v, 31), hi = lane_of(v, 63);
+    return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ double half_max(double v)
+{
+    v = dmax(v, dpp_move<0xB1, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x4E, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x141, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x140, 0xF>(v, v));
+    v = dmax(v, dpp_move<0x142, 0xA>(v, v));
+    const double lo = lane_of(v, 31), hi = lane_of(v, 63);
+    return (threadIdx.x & 32) ? hi : lo;
+}
 __device__ __forceinline__ double uni(double v)       // a wave-uniform value into scalar registers
 {
     union { double d; int i[2]; } x; x.d = v;

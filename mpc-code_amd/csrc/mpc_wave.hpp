@@ -118,19 +118,30 @@ __device__ __forceinline__ double row16_max(double v)
 // LTV: the stage matrices and affine terms come per (instance, block) from the rows RL_A / RL_B / RL_C of T (written by the caller:
 // the QP of one SQP iteration, x+ = A_k x + B_k u + c_k) instead of P.A / P.B / q's c.  The recursions that are scans with powers of
 // a constant A (initial simulation, costates of the stationarity test) then run as sequential sweeps over the lanes.
-template <int NS, int NU, bool HASM, int NC, bool MASKED, int NI, class PT, bool LTV = false>
+// PAIR (horizons up to 32): the element-wise phases take two instances at once - lanes 0-31 the blocks of instance 2 j, lanes 32-63
+// those of instance 2 j + 1 - so X and S have NI / 2 entries, every "per instance" quantity of an entry is per lane (the same in the
+// lanes of a half: reductions run per half, branches on an instance's flags diverge by whole halves), and the caller reads verdicts
+// at a lane of the half.  The tile passes are the same; the sums are taken in the same tree order.
+template <int NS, int NU, bool HASM, int NC, bool MASKED, int NI, class PT, bool LTV = false, bool PAIR = false>
 __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q, const int *iflag,
-                                         WvIterA<NS, NU, NC> (&X)[NI], WvInst (&S)[NI], int max_iter)
+                                         WvIterA<NS, NU, NC> (&X)[PAIR ? NI / 2 : NI], WvInst (&S)[PAIR ? NI / 2 : NI], int max_iter)
 {
     static_assert(!LTV || (NS <= 4 && !HASM), "time-varying stage matrices: one 4 x 4 tile per state matrix, no cross term");
     using Cfg = WvCfg<NS, NU, NC, NI>;
     using Iter = WvIter<NS, NU, NC>;
     constexpr int NV = Cfg::NV, NKF = Cfg::NKF, NLI = Cfg::NLI, RA = Cfg::RA, RG = Cfg::RG, RK = Cfg::RK;
     static_assert(NS <= 8 && NU <= 2 && NI >= 1 && NI <= 4, "stage state <= 8 (2 x 2 tiles of 4 x 4), nu <= 2 (closed-form inverse of Lambda); at most four instances per product");
+    static_assert(!PAIR || NI % 2 == 0, "pairs of instances");
+    constexpr int NJ = PAIR ? NI / 2 : NI;      // register sets: instances, or pairs of instances
     const int lane = threadIdx.x, N = P.N, LD = Cfg::ld(N);
-    const int k = lane;
+    const int k = PAIR ? (lane & 31) : lane;
+    const int hsel = PAIR ? (lane >> 5) : 0;
+    auto ji = [&](int j) -> int { return PAIR ? 2 * j + hsel : j; };      // the instance this lane works on in register set j
     const bool blk_on = k < N, last = k == N - 1;
-    auto tk = [&](int row, int inst) -> double & { return T[(row * NI + inst) * LD + k]; };      // lane = block view
+    auto tk = [&](int row, int j) -> double & { return T[(row * NI + ji(j)) * LD + k]; };      // lane = block view
+    auto un = [](double v) -> double { return PAIR ? v : uni(v); };
+    auto rsum = [](double v) -> double { return PAIR ? half_sum(v) : wave_sum(v); };
+    auto rmax = [](double v) -> double { return PAIR ? half_max(v) : wave_max(v); };
     MPC_STAMP_INIT
 
     // the problem pointer made opaque: scalar loads of the constants stay inside the phase that asks for them (hoisted out of the
@@ -138,7 +149,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
     auto launder = [](const PT &Pin) -> const PT & { const PT *pp = &Pin; asm volatile("" : "+s"(pp)); return *pp; };
     struct Bnd { double lo[NC], hi[NC]; bool fl[NC], fh[NC]; };
     auto bounds = [&](const PT &Pl, int j, Bnd &Bd) {
-        const double *qd = q + j * Cfg::QN;
+        const double *qd = q + ji(j) * Cfg::QN;
         MPC_UNROLL for (int i = 0; i < NC; i++) {
             const double zlm = i >= NU ? qd[3 * NS + (i >= NU ? i - NU : 0)] : 0.0, zhm = i >= NU ? qd[4 * NS + (i >= NU ? i - NU : 0)] : 0.0;
             const double lm = i < NU ? Pl.ulo[i < NU ? i : 0] : zlm, hm = i < NU ? Pl.uhi[i < NU ? i : 0] : zhm;
@@ -150,7 +161,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
     };
     // cost gradient of the current point for this lane's block: gu (NU), gz (NS), with the bound multipliers
     auto gradient = [&](const PT &Pl, int j, const Iter &Xj, double (&gu)[NU], double (&gz)[NS]) {
-        const double *qd = q + j * Cfg::QN;
+        const double *qd = q + ji(j) * Cfg::QN;
         double dz1[NS], du[NU];
         MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = Xj.z[i] - qd[NS + i];
         MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = Xj.u[i] - qd[5 * NS + i];
@@ -196,8 +207,8 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int i = 0; i < NS; i++) tk(RG + NU + i, j) = gz[i] + (NU + i < NC ? hb[NU + i < NC ? NU + i : 0] : 0.0);
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = blk_on ? gz[i] : 0.0;
-        Sj.mu_sum = wave_sum(blk_on ? mu_p : 0.0);
-        const double res_p = wave_max(blk_on ? resp_p : 0.0), cres = wave_max(blk_on ? cres_p : 0.0), lmax = wave_max(blk_on ? lmax_p : 0.0);
+        Sj.mu_sum = rsum(blk_on ? mu_p : 0.0);
+        const double res_p = rmax(blk_on ? resp_p : 0.0), cres = rmax(blk_on ? cres_p : 0.0), lmax = rmax(blk_on ? lmax_p : 0.0);
         const bool ok_cp = (cres <= 1.0) && (res_p <= kTolFeas);
         double rs_p = 0.0;
         if (LTV) {
@@ -206,14 +217,14 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             // successor is final only reproduce their value - so the rounds carry no lane mask.  The costates serve the stationarity
             // test alone: they are taken when it can decide (complementarity and feasibility in tolerance) and for the scale at it = 0.
             if (it == 0 || ok_cp) {
-                double An[NS][NS];
+                double An[NS][NS], g0[NS];
                 const int kn = k + 1 < N ? k + 1 : (N > 0 ? N - 1 : 0);
-                const bool upd = k + 1 < N;
-                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int l = 0; l < NS; l++) An[i][l] = upd ? T[((Cfg::RL_A + i * NS + l) * NI + j) * LD + kn] : 0.0; }
+                const bool upd = k + 1 < N;      // (the other lanes: A = 0, their value stays gz resp. 0)
+                MPC_UNROLL for (int i = 0; i < NS; i++) { g0[i] = pi[i]; MPC_UNROLL for (int l = 0; l < NS; l++) { const double v = T[((Cfg::RL_A + i * NS + l) * NI + ji(j)) * LD + kn]; An[i][l] = upd ? v : 0.0; } }
                 for (int s = N - 2; s >= 0; s--) {
                     double t[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_dn1(0.0, pi[i]);
-                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; if (upd) { a = gz[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += An[l][i] * t[l]; } pi[i] = a; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_dn1(pi[i], pi[i]);      // (lane 63 reads itself: its A is 0)
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = g0[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += An[l][i] * t[l]; pi[i] = a; }
                 }
                 MPC_UNROLL for (int i = 0; i < NU; i++) {
                     double a = gu[i];
@@ -232,7 +243,8 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             }
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.B[l][i] * pi[l]; rs_p = dmax(rs_p, fabs(a)); }
         }
-        const double res_s = (!LTV || it == 0 || ok_cp) ? wave_max(blk_on ? rs_p : 0.0) : Sj.res_s;
+        double res_s = Sj.res_s;
+        if (!LTV || it == 0 || ok_cp) res_s = rmax(blk_on ? rs_p : 0.0);
         Sj.mu = Sj.mu_sum * Sj.inv_ncon; Sj.res_s = res_s; Sj.res_p = res_p;
         if (it == 0) Sj.gscale = dmax(1.0, P.term_cons ? dmin(res_s, P.term_gcap) : res_s);      // mpc_device.hpp:rpdip_lane
         Sj.stall = ok_cp ? Sj.stall + 1 : 0;
@@ -244,12 +256,12 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
     };
 
     // ---- instance constants and the initial point (cold: us pushed inside the box; warm: previous iterate shifted one stage)
-    MPC_UNROLL for (int j = 0; j < NI; j++) {
+    MPC_UNROLL for (int j = 0; j < NJ; j++) {
         WvInst &Sj = S[j];
         Iter Xj;
         const PT &Pl = P;
-        const double *qd = q + j * Cfg::QN;
-        const int myflag = __builtin_amdgcn_readfirstlane(iflag[j]);
+        const double *qd = q + ji(j) * Cfg::QN;
+        const int myflag = PAIR ? iflag[ji(j)] : __builtin_amdgcn_readfirstlane(iflag[j]);
         Sj.on = (myflag & kWvValid) && (myflag & kWvOk0);
         Sj.warm = (myflag & kWvWarm) != 0;
         Sj.mu = 0.0; Sj.mu_sum = 0.0; Sj.sm = 0.0; Sj.gscale = 1.0; Sj.stall = 0; Sj.iters = 0; Sj.res_s = 0.0; Sj.res_p = 0.0;
@@ -257,7 +269,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         Sj.status = ((myflag & kWvValid) && !(myflag & kWvOk0)) ? kInfeasible : kMaxIter;
         double ncon = 0.0;
         MPC_UNROLL for (int i = 0; i < NC; i++) {
-            const double zlm = i >= NU ? uni(qd[3 * NS + (i >= NU ? i - NU : 0)]) : 0.0, zhm = i >= NU ? uni(qd[4 * NS + (i >= NU ? i - NU : 0)]) : 0.0;
+            const double zlm = i >= NU ? un(qd[3 * NS + (i >= NU ? i - NU : 0)]) : 0.0, zhm = i >= NU ? un(qd[4 * NS + (i >= NU ? i - NU : 0)]) : 0.0;
             const double lm = i < NU ? Pl.ulo[i < NU ? i : 0] : zlm, hm = i < NU ? Pl.uhi[i < NU ? i : 0] : zhm;
             const double le = i < NU ? Pl.ulo[i < NU ? i : 0] : Pl.zlo_e[i >= NU ? i - NU : 0], he = i < NU ? Pl.uhi[i < NU ? i : 0] : Pl.zhi_e[i >= NU ? i - NU : 0];
             const bool flm = MASKED ? fin(lm) : true, fhm = MASKED ? fin(hm) : true, fle = MASKED ? fin(le) : true, fhe = MASKED ? fin(he) : true;
@@ -308,11 +320,15 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     MPC_UNROLL for (int l = 0; l < NS; l++) Ak[i][l] = blk_on ? tk(Cfg::RL_A + i * NS + l, j) : 0.0;
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * qd[l]; xk[i] = k == 0 ? a : 0.0; }
-                const bool upd = k >= 1 && blk_on;      // (every lane above 0 recomputes from its predecessor in every round: no per-round mask)
+                // every lane above 0 recomputes from its predecessor in every round (no per-round mask); lane 0 and the lanes beyond the
+                // horizon have A = 0 and keep their value
+                double x00[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) x00[i] = xk[i];
+                if (k == 0 || !blk_on) { MPC_UNROLL for (int i = 0; i < NS; i++) { bk[i] = x00[i]; MPC_UNROLL for (int l = 0; l < NS; l++) Ak[i][l] = 0.0; } }
                 for (int s = 1; s < N; s++) {
                     double t[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_up1(0.0, xk[i]);
-                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = xk[i]; if (upd) { a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * t[l]; } xk[i] = a; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_up1(xk[i], xk[i]);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * t[l]; xk[i] = a; }
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = xk[i];
             } else {
@@ -334,7 +350,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = xk[i];
             }
             Bnd Bd; bounds(Pl, j, Bd);
-            const double ws_delta = uni(qd[5 * NS + 2 * NU]);
+            const double ws_delta = un(qd[5 * NS + 2 * NU]);
             const double ws_smin = dmin(dmax(kWsKappa * ws_delta, kWsSMinLo), kWsSMinHi), ws_mu = kWsMuFactor * ws_smin * ws_smin;
             const double smin = Sj.warm ? ws_smin : kSMin;
             MPC_UNROLL for (int i = 0; i < NC; i++) {
@@ -670,10 +686,10 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         MPC_UNROLL for (int d = 0; d < PD - 1; d++) { if (d < rem) block(d, false); }
     };
 
-    AReg2 dvp[NI][NC];       // predictor direction of each instance's bounded variables, kept for the corrector's second-order terms
+    AReg2 dvp[NJ][NC];       // predictor direction of each instance's bounded variables, kept for the corrector's second-order terms
     for (int it = 0;; it++) {
         bool any_on = false;
-        MPC_UNROLL for (int j = 0; j < NI; j++) any_on = any_on || S[j].on;
+        MPC_UNROLL for (int j = 0; j < NJ; j++) any_on = any_on || (PAIR ? __any(S[j].on) != 0 : S[j].on);
         if (!any_on) break;      // wave-uniform: every instance has its verdict
         __syncthreads();
         pd_min = 1.0;
@@ -685,12 +701,12 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         MPC_TSTAMP(3);
         {
             const unsigned long long bad = __ballot(((lane >> 2) & 3) < NI && !(pd_min > 0.0));      // a Lambda lost definiteness: the instance stops as infeasible
-            MPC_UNROLL for (int j = 0; j < NI; j++) {
-                if (S[j].on && (bad & (0x000F000F000F000FULL << (4 * j)))) { S[j].on = false; S[j].status = kInfeasible; S[j].iters = it; }
+            MPC_UNROLL for (int j = 0; j < NJ; j++) {
+                if (S[j].on && (bad & (0x000F000F000F000FULL << (4 * ji(j))))) { S[j].on = false; S[j].status = kInfeasible; S[j].iters = it; }
             }
         }
         // ================= element-wise: predictor step length, centring, corrector rhs -> LDS ===========================
-        MPC_UNROLL for (int j = 0; j < NI; j++) {
+        MPC_UNROLL for (int j = 0; j < NJ; j++) {
             WvInst &Sj = S[j];
             if (Sj.on) {
                 Iter Xj; X[j].get(Xj);
@@ -712,7 +728,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     s2_p += dsl * dll + dsh * dlh;
                     pl[i] = dsl * dll; ph[i] = dsh * dlh;
                 }
-                const double m_aff = wave_max(blk_on ? maff_p : 1.0), s1 = wave_sum(blk_on ? s1_p : 0.0), s2 = wave_sum(blk_on ? s2_p : 0.0);
+                const double m_aff = rmax(blk_on ? maff_p : 1.0), s1 = rsum(blk_on ? s1_p : 0.0), s2 = rsum(blk_on ? s2_p : 0.0);
                 const double a_aff = frcp(m_aff);
                 const double mu_aff = (Sj.mu_sum + a_aff * s1 + a_aff * a_aff * s2) * Sj.inv_ncon;
                 const double rat = Sj.mu > 0.0 ? mu_aff * frcp(Sj.mu) : 0.0;
@@ -744,7 +760,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         __syncthreads();
         MPC_TSTAMP(3);
         // ================= element-wise: corrector step length, step; then the next iterate's residuals / gradients =====
-        MPC_UNROLL for (int j = 0; j < NI; j++) {
+        MPC_UNROLL for (int j = 0; j < NJ; j++) {
             WvInst &Sj = S[j];
             if (Sj.on) {
                 Iter Xj; X[j].get(Xj);
@@ -770,7 +786,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     if (Bd.fl[i]) mcc_p = dmax(mcc_p, -dll[i] * frcp_approx(Xj.ll[i]));
                     if (Bd.fh[i]) mcc_p = dmax(mcc_p, -dlh[i] * frcp_approx(Xj.lh[i]));
                 }
-                const double m_cc = wave_max(blk_on ? mcc_p : kTau);
+                const double m_cc = rmax(blk_on ? mcc_p : kTau);
                 const double alpha = m_cc <= kTau ? 1.0 : kTau * frcp(m_cc);
                 MPC_UNROLL for (int i = 0; i < NC; i++) { Xj.sl[i] += alpha * dsl[i]; Xj.sh[i] += alpha * dsh[i]; Xj.ll[i] += alpha * dll[i]; Xj.lh[i] += alpha * dlh[i]; }
                 MPC_UNROLL for (int i = 0; i < NU; i++) Xj.u[i] += alpha * dvzj[i];

@@ -16,7 +16,8 @@ from . import nlcodegen
 from .capi import MpcAmdError
 
 NMPC_EXPORTS = ("nmpc_create", "nmpc_destroy", "nmpc_last_error", "nmpc_build_info", "nmpc_alloc", "nmpc_set_state", "nmpc_set_schedule",
-                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_get_kernel")
+                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_get_kernel", "nmpc_time_kernels",
+                "nmpc_wave_kernel_ms")
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)
@@ -50,6 +51,8 @@ def load_nmpc_library(path: str) -> ct.CDLL:
     lib.nmpc_get_kernel.argtypes = [vp]
     lib.nmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
     lib.nmpc_last_kernel_ms.argtypes = [vp]; lib.nmpc_last_kernel_ms.restype = ct.c_float
+    lib.nmpc_time_kernels.argtypes = [vp, ct.c_int32]
+    lib.nmpc_wave_kernel_ms.argtypes = [vp, ct.POINTER(ct.c_float), _ip]
     _libs[path] = lib
     return lib
 
@@ -148,6 +151,17 @@ class NmpcSolver:
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.nmpc_last_kernel_ms(self.h))
+
+    def time_kernels(self, on: bool = True) -> None:
+        """Split pipeline: bracket every wave-style launch of the following runs with its own HIP events."""
+        self._chk(self.lib.nmpc_time_kernels(self.h, 1 if on else 0), "nmpc_time_kernels")
+
+    def wave_kernel_ms(self):
+        """(sum of the wave-style launches' durations in ms, their count) of the last run; (0, 0) unless time_kernels is on and the
+        split pipeline ran."""
+        ms, n = ct.c_float(0.0), ct.c_int32(0)
+        self._chk(self.lib.nmpc_wave_kernel_ms(self.h, ct.byref(ms), ct.byref(n)), "nmpc_wave_kernel_ms")
+        return float(ms.value), int(n.value)
 
     def get_log(self, name: str) -> np.ndarray:
         if name in self.LOGS:
