@@ -66,7 +66,8 @@ int nmpc_sync(nmpc_handle *h);
 /* which closed-loop kernel nmpc_run launches: 1 = one instance per lane (any model), 3 = wave-autonomous (one wave owns four instances
  * for a launch, lane = stage, QP on the matrix cores), 4 = split pipeline (per step one lane-style launch for estimator / target /
  * plant and one wave-style launch for linearisation + QP); 3 and 4 need model state <= 4, nu <= 2, N <= 64 and no input-move form.
- * 0 = auto: 4 up to 24576 instances when the model fits, else 1.  nmpc_get_kernel returns the one in force */
+ * 0 = auto when the model fits: 3 while one round of its waves holds the batch (16 instances per CU: 4096 on an MI355X), 4 beyond;
+ * else 1.  nmpc_get_kernel returns the one in force */
 int nmpc_set_kernel(nmpc_handle *h, int32_t kernel);
 int nmpc_get_kernel(nmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT"; [nsteps][B] int32: "STATUS_DYN","STATUS_SS","ITERS_DYN"

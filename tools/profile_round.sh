@@ -1,12 +1,28 @@
 #!/bin/bash
 # Round profile on the GPU box: bench line (the driver's command), rocprofv3 kernel trace of the same workload, PMC passes (each on
-# its own, bounded).   bash tools/profile_round.sh [round tag, default r02]     (writes under gpurun_out/prof/; copy into profiles/)
+# its own, bounded).   bash tools/profile_round.sh [round tag, default r02] [nmpc]     (writes under gpurun_out/prof/; copy into profiles/)
+# With "nmpc": the non-linear workload (bench.py --config nmpc), files <tag>_nmpc_*; its dominant kernel is the wave-style launch of the
+# split pipeline, one launch = one step of every instance.
 set -u
 export TMPDIR=/tmp
 TAG=${1:-r02}
 OUT=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out/prof
-rm -rf "$OUT"; mkdir -p "$OUT"
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+if [ "${2:-}" = "nmpc" ]; then
+    OUT=$OUT/nmpc; rm -rf "$OUT"; mkdir -p "$OUT"
+    timeout 600 python3 bench.py --config nmpc --steps 20 --warmup 2 > "$OUT/${TAG}_nmpc_bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -c 600 "$OUT/${TAG}_nmpc_bench.json"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --config nmpc --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
+    CMD="python3 bench.py --config nmpc --steps 20 --warmup 0 --repeats 2 --no-cpu-baseline"
+    for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+        tag=$(echo $pass | cut -d' ' -f1)
+        timeout 180 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$tag" -- $CMD > "$OUT/pmc_$tag.log" 2>&1; echo "pmc $tag rc=$?"
+    done
+    find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/${TAG}_nmpc_kernel_stats.csv"
+    python3 tools/pmc_summary.py nmpc_loop_kernel_wv "$OUT/${TAG}_nmpc_pmc_summary.json" 16384 "$CMD" "$OUT"/pmc_* > /dev/null 2>&1; head -c 1500 "$OUT/${TAG}_nmpc_pmc_summary.json"
+    head -5 "$OUT/${TAG}_nmpc_kernel_stats.csv"
+    exit 0
+fi
+rm -rf "$OUT"; mkdir -p "$OUT"
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -c 900 "$OUT/${TAG}_bench.json"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
 CMD="python3 bench.py --steps 20 --warmup 0 --repeats 4 --no-cpu-baseline"
