@@ -240,6 +240,37 @@ def test_gpu_full_size_batch_properties(nl, gold, solver):
 
 
 @pytest.mark.gpu
+def test_gpu_horizon_beyond_32_takes_the_unpaired_wave_kernels(pkg):
+    """N = 40: the wave-style kernels hold one instance per set of lanes (N <= 32: two side by side).  A ragged batch, real-time
+    iteration and SQP to the KKT point: the three kernels give the same closed loops, and the oracle's for one instance."""
+    from mpc_code_amd import nmpc
+    p40 = pkg.load_problem(pkg.example_path("cstr_nmpc.py"), overrides={"N": 40})
+    assert p40.N == 40
+    s = nmpc.NmpcSolver(p40)
+    B = 301
+    rng = np.random.default_rng(40)
+    x0 = np.tile(p40.x0_p, (B, 1)); x0[1:] *= 1.0 + 0.02 * rng.uniform(-1, 1, size=(B - 1, 3))
+    try:
+        for max_sqp, ns in ((1, 8), (30, 3)):
+            res = {}
+            for kern in (1, 3, 4):
+                s.set_kernel(kern)
+                res[kern] = nmpc.run_nmpc_closed_loop(p40, x0, x0, nsteps=ns, solver=s, max_sqp=max_sqp, sqp_tol=1e-9)
+            assert np.all(res[1]["STATUS_DYN"] == 0)
+            for kern in (3, 4):
+                assert np.array_equal(res[kern]["STATUS_DYN"], res[1]["STATUS_DYN"]) and np.array_equal(res[kern]["STATUS_SS"], res[1]["STATUS_SS"]), (max_sqp, kern)
+                for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+                    assert np.max(np.abs(res[kern][k] - res[1][k]) / (1 + np.abs(res[1][k]))) < 1e-7, (max_sqp, kern, k)
+            if max_sqp == 1:
+                import nmpc_oracle as no
+                o = no.closed_loop(p40, 3, x0_p=x0[5], x0_m=x0[5], max_sqp=1)
+                for k in ("U", "X_HAT", "XS", "Xp", "D_HAT"):
+                    assert np.max(np.abs(res[4][k][:3, 5] - o[k]) / (1 + np.abs(o[k]))) < 1e-6, k
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
 def test_gpu_launch_chunks_continue_the_same_loop(nl, solver):
     """Two launches of 5 steps continue the resident state exactly as one launch of 10."""
     B = 128

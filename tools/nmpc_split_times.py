@@ -21,4 +21,4 @@ for timed in (False, True, False):
         t0 = time.perf_counter(); s.run(0, K, 1); s.sync(); wall.append(time.perf_counter() - t0)
         dev.append(s.last_kernel_ms()); wv.append(s.wave_kernel_ms()[0])
     print(f"per-launch events {'on ' if timed else 'off'}: wall {np.median(wall)*1e3:.3f} ms, device {np.median(dev):.3f} ms, wave-style launches {np.median(wv):.3f} ms "
-          f"-> {B*K/np.median(wall)/1e6:.2f} M steps/s")
+          f"-> {B*K/np.median(wall)/1e6:.2f} M steps/s   (wall min {np.min(wall)*1e3:.2f} max {np.max(wall)*1e3:.2f})")
