@@ -223,7 +223,9 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 MPC_UNROLL for (int i = 0; i < NS; i++) { g0[i] = pi[i]; MPC_UNROLL for (int l = 0; l < NS; l++) { const double v = T[((Cfg::RL_A + i * NS + l) * NI + ji(j)) * LD + kn]; An[i][l] = upd ? v : 0.0; } }
                 for (int s = N - 2; s >= 0; s--) {
                     double t[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_dn1(pi[i], pi[i]);      // (lane 63 reads itself: its A is 0)
+                    // (lane 63 reads itself: its A is 0.  PAIR: the lanes without a successor block sit next to the other instance's
+                    // lanes - what arrives there is dropped, not multiplied by zero: a NaN of a diverged neighbour must not cross over)
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = wave_dn1(pi[i], pi[i]); t[i] = (PAIR && !upd) ? 0.0 : v; }
                     MPC_UNROLL for (int i = 0; i < NS; i++) { double a = g0[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += An[l][i] * t[l]; pi[i] = a; }
                 }
                 MPC_UNROLL for (int i = 0; i < NU; i++) {
@@ -327,7 +329,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 if (k == 0 || !blk_on) { MPC_UNROLL for (int i = 0; i < NS; i++) { bk[i] = x00[i]; MPC_UNROLL for (int l = 0; l < NS; l++) Ak[i][l] = 0.0; } }
                 for (int s = 1; s < N; s++) {
                     double t[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) t[i] = wave_up1(xk[i], xk[i]);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = wave_up1(xk[i], xk[i]); t[i] = (PAIR && (k == 0 || !blk_on)) ? 0.0 : v; }      // (PAIR: as in the costate sweep)
                     MPC_UNROLL for (int i = 0; i < NS; i++) { double a = bk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Ak[i][l] * t[l]; xk[i] = a; }
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) Xj.z[i] = xk[i];
