@@ -234,7 +234,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     rs_p = dmax(rs_p, fabs(a));
                 }
             }
-        } else {
+        } else if (it == 0 || ok_cp) {      // (the costates serve the stationarity test alone: taken when it can decide, and for the scale at it = 0)
             MPC_UNROLL for (int e = 0; e < 6; e++) {
                 const int d = 1 << e;
                 if (d < N) {
@@ -246,7 +246,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.B[l][i] * pi[l]; rs_p = dmax(rs_p, fabs(a)); }
         }
         double res_s = Sj.res_s;
-        if (!LTV || it == 0 || ok_cp) res_s = rmax(blk_on ? rs_p : 0.0);
+        if (it == 0 || ok_cp) res_s = rmax(blk_on ? rs_p : 0.0);
         Sj.mu = Sj.mu_sum * Sj.inv_ncon; Sj.res_s = res_s; Sj.res_p = res_p;
         if (it == 0) Sj.gscale = dmax(1.0, P.term_cons ? dmin(res_s, P.term_gcap) : res_s);      // mpc_device.hpp:rpdip_lane
         Sj.stall = ok_cp ? Sj.stall + 1 : 0;
