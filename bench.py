@@ -308,12 +308,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, x0, K)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dist:      # the gathered block of this rank must be what the kernel logged
         allU = solver.allgather_log("U", 0, K)
         assert np.array_equal(allU[rank], solver.loop_get_log("U")[:K]), "all-gather of U corrupted the data"
         comm.barrier()
     solver.close()
+    if rank == 0:
+        # the one JSON line is the last thing on stdout: whatever a native library left in C's stdio buffer goes out first
+        import ctypes
+        sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -2020,11 +2021,22 @@ int rccl_load()
         if (r_ != ncclSuccess) return fail(-12, "%s failed: %s (%s:%d)", #x, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+// RCCL writes its version banner to stdout when it initialises (NCCL_DEBUG=VERSION, as on the benchmark boxes): while one of its set-up
+// calls runs, file descriptor 1 points at stderr, so that a caller's stdout carries only what the caller prints (bench.py: one JSON line).
+namespace {
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
+    ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); close(saved); } }
+};
+}
+
 extern "C" int mpc_comm_unique_id(char *out128)
 {
     if (!out128) return fail(-1, "null argument");
     if (rccl_load()) return -12;
     ncclUniqueId id;
+    StdoutToStderr quiet;
     RCCL_TRY(g_rccl.GetUniqueId(&id));
     static_assert(sizeof(id) == MPC_COMM_ID_BYTES, "ncclUniqueId size");
     std::memcpy(out128, &id, sizeof(id));
@@ -2039,7 +2051,10 @@ extern "C" int mpc_comm_init(mpc_handle *h, int32_t rank, int32_t world, const c
     HIP_TRY(hipSetDevice(h->device));
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
-    RCCL_TRY(g_rccl.CommInitRank(&h->comm, world, id, rank));
+    {
+        StdoutToStderr quiet;
+        RCCL_TRY(g_rccl.CommInitRank(&h->comm, world, id, rank));
+    }
     h->rank = rank; h->world = world;
     return 0;
 }
