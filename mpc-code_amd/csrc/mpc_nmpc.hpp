@@ -75,11 +75,13 @@ __device__ __noinline__ void rk4_plant(const double *x0, const double *u, double
 
 // The same with forward sensitivities: S = d x(t+h) / d [x0 | u | d], propagated through every Runge-Kutta stage
 // (dK_i = f_x(X_i) dX_i + [0 | f_u | f_d](X_i)).  Out: xn, A = S[:, :NX], B = S[:, NX:NX+NU], G = S[:, NX+NU:].
-template <class M>
+// WITHG = false: the sensitivities with respect to the disturbance are not propagated (G is left untouched): target and OCP
+// linearise in (x, u) only.
+template <class M, bool WITHG = true>
 __device__ __forceinline__ void rk4_model_sens_inl(const double *x0, const double *u, const double *d, double t, double h,
                                                    double *xn, double (*A)[M::NX], double (*B)[M::NU], double (*G)[M::ND > 0 ? M::ND : 1])
 {
-    constexpr int NX = M::NX, NU = M::NU, ND = M::ND, NDD = ND > 0 ? ND : 1, NP = NX + NU + ND;
+    constexpr int NX = M::NX, NU = M::NU, ND = M::ND, NDD = ND > 0 ? ND : 1, NP = NX + NU + (WITHG ? ND : 0);
     if (M::DISCRETE) { M::f_jac(x0, u, d, t, xn, A, B, G); return; }
     const double dt = h / M::MX;
     double x[NX], S[NX][NP];
@@ -112,15 +114,15 @@ __device__ __forceinline__ void rk4_model_sens_inl(const double *x0, const doubl
         xn[i] = x[i];
         MPC_UNROLL for (int j = 0; j < NX; j++) A[i][j] = S[i][j];
         MPC_UNROLL for (int j = 0; j < NU; j++) B[i][j] = S[i][NX + j];
-        MPC_UNROLL for (int j = 0; j < ND; j++) G[i][j] = S[i][NX + NU + j];
+        if (WITHG) { MPC_UNROLL for (int j = 0; j < ND; j++) G[i][j] = S[i][NX + NU + (WITHG ? j : 0)]; }
     }
 }
 
-template <class M>
+template <class M, bool WITHG = true>
 __device__ __noinline__ void rk4_model_sens(const double *x0, const double *u, const double *d, double t, double h,
                                             double *xn, double (*A)[M::NX], double (*B)[M::NU], double (*G)[M::ND > 0 ? M::ND : 1])
 {
-    rk4_model_sens_inl<M>(x0, u, d, t, h, xn, A, B, G);
+    rk4_model_sens_inl<M, WITHG>(x0, u, d, t, h, xn, A, B, G);
 }
 
 // Extended Kalman filter, Estimator.py:313-386: gain and correction with the output Jacobian at the prior, then the prior of the
