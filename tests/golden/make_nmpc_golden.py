@@ -61,9 +61,32 @@ def quadtank():
           "status", out["sqp_STATUS_DYN"].ravel(), out["rti_STATUS_DYN"].ravel())
 
 
+def reactor():
+    """tests/golden/nmpc_reactor.npz: the two-state, one-input reactor (examples/reactor_nmpc.py, N = 25): real-time iteration over 30
+    steps (plant / model mismatch from t = 0, set-point change at step 21) for the shipped start and two perturbed ones (plant and model
+    start apart); 6 steps with every OCP iterated to its KKT point."""
+    p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_nmpc.py"))
+    rng = np.random.default_rng(20240613)
+    x0 = np.tile(p.x0_p, (3, 1)); x0[1:] += rng.uniform(-1, 1, size=(2, 2)) * 0.05
+    xm = x0.copy(); xm[2] += rng.uniform(-1, 1, 2) * 0.03
+    out = {}
+    t0 = time.time()
+    logs = [no.closed_loop(p, 30, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
+    out.update({"rti_" + k: np.stack([lg[k] for lg in logs], axis=1) for k in logs[0]}); out["rti_x0"] = x0; out["rti_xm"] = xm
+    print("reactor rti", time.time() - t0, flush=True)
+    logs = [no.closed_loop(p, 6, x0_p=a, x0_m=b, max_sqp=50, sqp_tol=1e-9, certify=True) for a, b in zip(x0[:2], xm[:2])]
+    out.update({"sqp_" + k: np.stack([lg[k] for lg in logs], axis=1) for k in logs[0]}); out["sqp_x0"] = x0[:2]; out["sqp_xm"] = xm[:2]
+    print("reactor sqp", time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(HERE, "nmpc_reactor.npz"), **out)
+    print("max KKT: defect", np.nanmax(out["sqp_KKT_DEFECT"]), "stationarity", np.nanmax(out["sqp_KKT_STAT"]), "violation", np.nanmax(out["sqp_KKT_VIOL"]),
+          "status", out["sqp_STATUS_DYN"].ravel(), np.bincount(out["rti_STATUS_DYN"].ravel()), "sqp iterations", out["sqp_SQP_DYN"].ravel())
+
+
 def main():
     if "quadtank" in sys.argv:
         return quadtank()
+    if "reactor" in sys.argv:
+        return reactor()
     p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "cstr_nmpc.py"))
     out = {}
     t0 = time.time()

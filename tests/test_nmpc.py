@@ -430,3 +430,87 @@ def test_gpu_discrete_example_shipped_schedule_properties(qt):
     assert (U >= qt.umin - 1e-6).all() and (U <= qt.umax + 1e-6).all() and (dU >= qt.Dumin - 1e-6).all() and (dU <= qt.Dumax + 1e-6).all()
     assert (r["Xp"][:, :, 2:] > -1e-9).all() and (r["Xp"][:, :, 2:] < 20.0).all()
     assert (r["Xp"][-1, :, 3] < r["Xp"][10, :, 3] - 0.5).all()          # tank 2 is being drained towards its new set point
+
+
+# ================================================================================================= two states, one input (examples/reactor_nmpc.py)
+RGOLD = os.path.join(ROOT, "tests", "golden", "nmpc_reactor.npz")
+
+
+@pytest.fixture(scope="module")
+def rx(pkg):
+    return pkg.load_problem(pkg.example_path("reactor_nmpc.py"))
+
+
+def test_reactor_example_is_classified_and_its_model_is_the_reference_reactor(pkg, rx):
+    """nx = 2, nu = 1: the smallest stage (the wave-style kernels take it: state <= 4, nu <= 2); continuous model, EKF, disturbances
+    inside the model.  With the disturbances at zero the model is the reactor of the reference's Ex_ENMPC.py (:42-49,64-65)."""
+    from mpc_code_amd import nlcodegen
+    assert (rx.nx, rx.nu, rx.ny, rx.nd, rx.nxp, rx.N, rx.h) == (2, 1, 2, 2, 2, 25, 2.0)
+    assert not rx.discrete and rx.offree == "nl" and rx.estimator == "ekf" and not rx.DUForm
+    assert "#define MPC_NL_WAVE_FITS 1" in nlcodegen.emit_model_header(rx)
+    from mpc_code_amd import symtrace as st
+    x, u = np.array([0.4, 0.55]), np.array([0.7])
+    want = [0.7 * (1.0 - 0.4) - 1.0 * 0.4, -0.7 * 0.55 + 1.0 * 0.4 - 0.05 * 0.55]
+    assert np.allclose([float(v) for v in st.evaluate(rx.f, rx._vals(x=x, u=u, d=np.zeros(2), t=0.0))], want, rtol=1e-14)
+    d = np.array([0.1, -0.05])      # the two disturbances: rate constant of the first reaction, dilution rate
+    want_d = [0.65 * (1.0 - 0.4) - 1.1 * 0.4, -0.65 * 0.55 + 1.1 * 0.4 - 0.05 * 0.55]
+    assert np.allclose([float(v) for v in st.evaluate(rx.f, rx._vals(x=x, u=u, d=d, t=0.0))], want_d, rtol=1e-14)
+    if os.path.isdir(REF):          # the same balances as the reference's file, traced from its own function
+        ref = pkg.load_exfile(os.path.join(REF, "Ex_ENMPC.py"))
+        fx = ref["User_fxm_Cont"](st.symvec("x", 2), st.symvec("u", 1), st.symvec("d", 2), st.Sym.var("t"), None)
+        vals = {"x[0]": 0.4, "x[1]": 0.55, "u[0]": 0.7, "d[0]": 0.0, "d[1]": 0.0, "t": 0.0}
+        assert np.allclose([float(v) for v in st.evaluate(list(fx), vals)], want, rtol=1e-14)
+
+
+def test_reactor_oracle_reproduces_its_golden_rows(rx):
+    import nmpc_oracle as no
+    g = np.load(RGOLD)
+    r = no.closed_loop(rx, 3, x0_p=g["rti_x0"][2], x0_m=g["rti_xm"][2], max_sqp=1)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        assert np.allclose(r[k], g["rti_" + k][:3, 2], rtol=1e-10, atol=1e-10), k
+    assert np.all(g["rti_STATUS_DYN"] == 0) and np.all(g["sqp_STATUS_DYN"] == 0)
+    assert np.nanmax(g["sqp_KKT_DEFECT"]) < 1e-10 and np.nanmax(g["sqp_KKT_STAT"]) < 1e-9 and np.nanmax(g["sqp_KKT_VIOL"]) < 1e-12
+    # offset-free: after the transient the product concentration sits on its set point although the plant's rate constant is not the model's
+    assert abs(g["rti_Xp"][20, 0, 1] - 0.56) < 1e-3 and abs(g["rti_Xp"][29, 0, 1] - 0.48) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 3, 4])
+@pytest.mark.parametrize("mode,max_sqp", [("rti", 1), ("sqp", 50)])
+def test_gpu_reactor_equals_the_golden_vectors(rx, mode, max_sqp, kernel):
+    """One input (the single-column forms of the solver's input block) on the time-varying tables, plant and model starting apart,
+    a set-point change inside the run: every kernel against the oracle's vectors."""
+    from mpc_code_amd import nmpc
+    g = np.load(RGOLD)
+    s = nmpc.NmpcSolver(rx)
+    try:
+        s.set_kernel(kernel)
+        ns = g[mode + "_U"].shape[0]
+        r = nmpc.run_nmpc_closed_loop(rx, g[mode + "_x0"], g[mode + "_xm"], nsteps=ns, solver=s, max_sqp=max_sqp, sqp_tol=1e-9)
+        assert np.array_equal(r["STATUS_DYN"], g[mode + "_STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], g[mode + "_STATUS_SS"])
+        for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+            gk = g[f"{mode}_{k}"]
+            assert np.max(np.abs(r[k] - gk) / (1.0 + np.abs(gk))) < 2e-7, k
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reactor_kernels_agree_on_a_ragged_batch(rx):
+    from mpc_code_amd import nmpc
+    B, ns = 1030, 24
+    rng = np.random.default_rng(8)
+    x0 = rx.x0_p + 0.05 * rng.uniform(-1, 1, size=(B, 2)); xm = x0 + 0.02 * rng.uniform(-1, 1, size=(B, 2))
+    s = nmpc.NmpcSolver(rx)
+    try:
+        res = {}
+        for kern in (1, 3, 4):
+            s.set_kernel(kern)
+            res[kern] = nmpc.run_nmpc_closed_loop(rx, x0, xm, nsteps=ns, solver=s, max_sqp=1)
+        assert np.all(res[1]["STATUS_DYN"] == 0) and np.all(res[1]["U"] >= rx.umin - 1e-9) and np.all(res[1]["U"] <= rx.umax + 1e-9)
+        for kern in (3, 4):
+            assert np.array_equal(res[kern]["STATUS_DYN"], res[1]["STATUS_DYN"])
+            for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+                assert np.max(np.abs(res[kern][k] - res[1][k]) / (1 + np.abs(res[1][k]))) < 1e-7, (kern, k)
+    finally:
+        s.close()
