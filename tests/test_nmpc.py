@@ -298,6 +298,25 @@ def test_gpu_kernels_agree_under_mismatch_holds_and_divergence(nl, solver, seed,
 
 
 @pytest.mark.gpu
+def test_gpu_held_steps_equal_the_oracle(nl, solver):
+    """A level below its lower output bound: the OCP is infeasible from the measured state, the previous input is held and the model
+    propagates the estimate (MPC_code.py:798-805) - every kernel against the oracle run of the same start, next to a healthy instance."""
+    from mpc_code_amd import nmpc
+    import nmpc_oracle as no
+    x0 = np.array([[0.874317, 325.0, 0.47], [0.9, 330.0, 0.51]])
+    o = [no.closed_loop(nl, 5, x0_p=x, x0_m=x, max_sqp=1) for x in x0]
+    assert np.all(o[0]["STATUS_DYN"] == 2) and np.all(o[1]["STATUS_DYN"] == 0)
+    for kern in (1, 3, 4):
+        solver.set_kernel(kern)
+        r = nmpc.run_nmpc_closed_loop(nl, x0, x0, nsteps=5, solver=solver, max_sqp=1)
+        for b in range(2):
+            assert np.array_equal(r["STATUS_DYN"][:, b], o[b]["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"][:, b], o[b]["STATUS_SS"]), (kern, b)
+            for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+                assert np.max(np.abs(r[k][:, b] - o[b][k]) / (1 + np.abs(o[b][k]))) < 1e-7, (kern, b, k)
+    solver.set_kernel(0)
+
+
+@pytest.mark.gpu
 def test_gpu_launch_chunks_continue_the_same_loop(nl, solver):
     """Two launches of 5 steps continue the resident state exactly as one launch of 10."""
     B = 128
