@@ -142,6 +142,31 @@ def test_fused_closed_loop_matches_c_restatement(which, B, nst, lk, cstr, wb, or
     assert_same_closed_loop(g, c, p, 1e-6)
 
 
+@pytest.mark.parametrize("which", ["cstr", "wb"])
+@pytest.mark.parametrize("lk", LOOP_KERNELS)
+def test_plant_and_model_starting_apart(lk, which, cstr, wb, oracle_c, solver_factory):
+    """x0_p != x0_m (MPC_code.py:442-476 take them from different Ex-file entries): the estimator has an innovation from the first
+    step on.  Every loop kernel against the C restatement; the restatement against the dense oracle on two instances."""
+    from mpc_code_amd.driver import run_closed_loop
+    import mpc_oracle as mo
+    p = cstr if which == "cstr" else wb
+    rng = np.random.default_rng(3)
+    B = 96
+    x0 = rng.uniform([-0.5, -8.0, -5.0], [0.5, 8.0, 5.0], size=(B, 3)) if which == "cstr" else 0.05 * rng.standard_normal((B, p.nx))
+    xm = x0 + rng.uniform(-1, 1, size=x0.shape) * ([0.05, 1.0, 0.5] if which == "cstr" else 0.02)
+    g = run_closed_loop(p, x0, xm, 12, solver=solver_factory(p, lk), fused=True)
+    c = oracle_c.OracleC(p).closed_loop(12, x0, xm)
+    assert np.array_equal(g["STATUS_DYN"], c["STATUS_DYN"]) and np.array_equal(g["STATUS_SS"], c["STATUS_SS"])
+    for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT"):
+        assert np.max(np.abs(g[k] - c[k])) < 1e-7, k
+    if lk == 3:
+        for b in (0, 1):
+            o = mo.closed_loop(p, 6, x0_p=x0[b], x0_m=xm[b])
+            assert np.array_equal(np.asarray(o["STATUS_DYN"]).ravel(), c["STATUS_DYN"][:6, b])
+            for k in ("U", "XS", "X_HAT", "D_HAT"):
+                assert np.max(np.abs(np.asarray(o[k]) - c[k][:6, b])) < 2e-6, (b, k)
+
+
 @pytest.mark.parametrize("lk", LOOP_KERNELS)
 def test_stepwise_calls_equal_fused_kernel(lk, cstr, solver_factory):
     """Calling the three solvers per step through the C-ABI (the literal drop-in for MPC_code.py:704,776 and
