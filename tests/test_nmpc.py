@@ -533,3 +533,30 @@ def test_gpu_reactor_kernels_agree_on_a_ragged_batch(rx):
                 assert np.max(np.abs(res[kern][k] - res[1][k]) / (1 + np.abs(res[1][k]))) < 1e-7, (kern, k)
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reactor_saturated_disturbance_and_sqp_limit_equal_the_oracle(pkg):
+    """The disturbance estimate clipped to [dmin, dmax] (MPC_code.py:655-668; the clipped value is the next step's prior) and SQP
+    stopped by its iteration limit (status 1, accepted like IPOPT's, :786): every kernel against oracle runs of the same starts."""
+    from mpc_code_amd import nmpc
+    import nmpc_oracle as no
+    p = pkg.load_problem(pkg.example_path("reactor_nmpc.py"), overrides={"dmin": -0.05 * np.ones((2, 1)), "dmax": 0.05 * np.ones((2, 1))})
+    x0 = np.array([[0.45, 0.50], [0.47, 0.53]]); xm = np.array([[0.45, 0.50], [0.44, 0.50]])
+    s = nmpc.NmpcSolver(p)
+    try:
+        for max_sqp, ns in ((1, 12), (3, 4)):
+            o = [no.closed_loop(p, ns, x0_p=a, x0_m=b, max_sqp=max_sqp, sqp_tol=1e-9) for a, b in zip(x0, xm)]
+            if max_sqp == 1:
+                assert o[0]["D_HAT"][-1, 0] == 0.05
+            else:
+                assert o[0]["STATUS_DYN"][0] == 1
+            for kern in (1, 3, 4):
+                s.set_kernel(kern)
+                r = nmpc.run_nmpc_closed_loop(p, x0, xm, nsteps=ns, solver=s, max_sqp=max_sqp, sqp_tol=1e-9)
+                for b in range(2):
+                    assert np.array_equal(r["STATUS_DYN"][:, b], o[b]["STATUS_DYN"]) and np.array_equal(r["SQP_DYN"][:, b], o[b]["SQP_DYN"]), (max_sqp, kern, b)
+                    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+                        assert np.max(np.abs(r[k][:, b] - o[b][k]) / (1 + np.abs(o[b][k]))) < 1e-7, (max_sqp, kern, b, k)
+    finally:
+        s.close()
