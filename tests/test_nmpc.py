@@ -560,3 +560,49 @@ def test_gpu_reactor_saturated_disturbance_and_sqp_limit_equal_the_oracle(pkg):
                         assert np.max(np.abs(r[k][:, b] - o[b][k]) / (1 + np.abs(o[b][k]))) < 1e-7, (max_sqp, kern, b, k)
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ex,N", [("reactor_nmpc.py", 2), ("reactor_nmpc.py", 32), ("reactor_nmpc.py", 33), ("reactor_nmpc.py", 64), ("cstr_nmpc.py", 32), ("cstr_nmpc.py", 3)])
+def test_gpu_edge_horizons_kernels_agree(pkg, ex, N):
+    """The shortest horizons, both sides of the paired / unpaired switch of the wave-style kernels (N = 32: the last block of one
+    instance sits in the lane next to the first block of its neighbour) and the longest they take."""
+    from mpc_code_amd import nmpc
+    p = pkg.load_problem(pkg.example_path(ex), overrides={"N": N})
+    s = nmpc.NmpcSolver(p)
+    B = 203
+    rng = np.random.default_rng(N)
+    x0 = p.x0_p * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, p.nx))); xm = x0 * (1.0 + 0.005 * rng.uniform(-1, 1, size=(B, p.nx)))
+    try:
+        res = {}
+        for kern in (1, 3, 4):
+            s.set_kernel(kern)
+            res[kern] = nmpc.run_nmpc_closed_loop(p, x0, xm, nsteps=6, solver=s, max_sqp=1)
+        ok = (res[1]["STATUS_DYN"] == 0).all(axis=0)
+        assert ok.sum() > B // 2
+        for kern in (3, 4):
+            assert np.array_equal(res[kern]["STATUS_DYN"], res[1]["STATUS_DYN"]) and np.array_equal(res[kern]["STATUS_SS"], res[1]["STATUS_SS"]), kern
+            for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+                assert np.max(np.abs(res[kern][k][:, ok] - res[1][k][:, ok]) / (1 + np.abs(res[1][k][:, ok]))) < 1e-8, (kern, k)
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_horizon_beyond_64_runs_on_the_lane_kernel_only(pkg):
+    from mpc_code_amd import nmpc
+    from mpc_code_amd.capi import MpcAmdError
+    p = pkg.load_problem(pkg.example_path("reactor_nmpc.py"), overrides={"N": 70})
+    s = nmpc.NmpcSolver(p)
+    try:
+        x0 = np.tile(p.x0_p, (5, 1))
+        s.alloc(5, 3); s.set_schedule(p.schedules(3)); s.set_state(x0, x0)
+        assert s.get_kernel() == 1
+        s.run(0, 3); s.sync()
+        assert np.all(s.get_log("STATUS_DYN")[:3] == 0)
+        for kern in (3, 4):
+            with pytest.raises(MpcAmdError, match="N <= 64"):
+                s.set_kernel(kern)
+        assert s.get_kernel() == 1
+    finally:
+        s.close()
