@@ -602,7 +602,15 @@ struct WvKernelCfg {
     // per-instance state kept in LDS across the steps of a launch
     static constexpr int K_X = 0, K_XH = NXP, K_DH = K_XH + NX, K_U = K_DH + NDD, K_XS = K_U + NU, K_US = K_XS + NX, K_P = K_US + NU,
                          K_TW = K_P + NE * NE, KEEP = K_TW + NTW;
-    static constexpr size_t lds_bytes(int N) { return sizeof(double) * (Cfg::lds_doubles(KEEP, N) + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 16; }
+    // The transposing buffer doubles as the exchange area of the 16-lanes-per-instance estimator (four instances x XCH doubles from its
+    // start): a very short horizon makes the buffer smaller than that (N = 2, CSTR: 192 against 216 doubles - the estimator overwrote the
+    // instance data behind it), so the region is the larger of the two.
+    static constexpr int t_region(int N)
+    {
+        const int t = Cfg::t_doubles(N), x = Cfg::GUARD + (Row16Tab<NX, NU, NY, ND>::fits ? 4 * Row16Tab<NX, NU, NY, ND>::XCH : 0);
+        return t > x ? t : x;
+    }
+    static constexpr size_t lds_bytes(int N) { return sizeof(double) * ((size_t)t_region(N) + NI * Cfg::QN + NI * Cfg::OUT + NI * KEEP + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 16; }
     static constexpr int ni() { return NI; }
 };
 
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
     extern __shared__ double wv_smem[];
     const DevProblem &P0 = *Pp;
     const int LD = Cfg::ld(P0.N);
-    double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::t_doubles(P0.N), *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
+    double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + KC::t_region(P0.N), *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
     int *const iflag = (int *)(keep + NI * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
     using RT = Row16Tab<NX, NU, NY, ND>;
     double *const tab = (double *)(wsv + 8);      // per-row constants of the 16-lanes-per-instance phases
@@ -673,6 +681,8 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             if (inst16 && a.DHAT && r16 >= NX && r16 < NE) (a.DHAT + (size_t)((size_t)k * ND + (r16 - NX)) * Bs)[bi] = xi_new;
             double delta = row16_max(r16 < NE ? fabs(xi_new - xi_old) : 0.0);      // warm-start test: estimate against its prediction
             __syncthreads();
+            // (the estimator's exchange area is the start of T: with a very short horizon it reaches the zero row of the tile view)
+            if (Cfg::RZ * NI * LD < 4 * RT::XCH) { for (int i = lane; i < NI * LD; i += 64) T[Cfg::RZ * NI * LD + i] = 0.0; }
             double dh[NDD], usv[NU];
             MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = kq[KC::K_DH + i];
             MPC_UNROLL for (int i = 0; i < NU; i++) usv[i] = kq[KC::K_US + i];

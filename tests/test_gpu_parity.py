@@ -143,6 +143,38 @@ def test_fused_closed_loop_matches_c_restatement(which, B, nst, lk, cstr, wb, or
 
 
 @pytest.mark.parametrize("which", ["cstr", "wb"])
+@pytest.mark.parametrize("N", [2, 3, 5, 64])
+def test_edge_horizons_match_c_restatement(N, which, pkg, oracle_c, solver_factory):
+    """The shortest horizons (N = 2: the transposing buffer of the wave kernel is smaller than the estimator's exchange area, which
+    once overwrote the instance data behind it) and the longest the on-chip kernels take; 65 goes to the lane kernel."""
+    from mpc_code_amd.driver import run_closed_loop
+    from mpc_code_amd.capi import MpcAmdError
+    p = pkg.load_problem(pkg.example_path("cstr_lmpc.py" if which == "cstr" else "wood_berry_lmpc.py"), overrides={"N": N})
+    rng = np.random.default_rng(N)
+    B = 70
+    x0 = rng.uniform([-0.5, -8.0, -5.0], [0.5, 8.0, 5.0], size=(B, 3)) if which == "cstr" else 0.05 * rng.standard_normal((B, p.nx))
+    c = oracle_c.OracleC(p).closed_loop(8, x0, x0)
+    for lk in (3, 2, 1, 0):
+        g = run_closed_loop(p, x0, x0, 8, solver=solver_factory(p, lk), fused=True)
+        assert np.array_equal(g["STATUS_DYN"], c["STATUS_DYN"]) and np.array_equal(g["STATUS_SS"], c["STATUS_SS"]), lk
+        for k in ("U", "XS", "US", "X_HAT", "Xp", "D_HAT"):
+            assert np.max(np.abs(g[k] - c[k])) < 1e-7, (lk, k)
+    if N == 64:
+        q = pkg.load_problem(pkg.example_path("cstr_lmpc.py" if which == "cstr" else "wood_berry_lmpc.py"), overrides={"N": 65})
+        from mpc_code_amd import capi
+        s = capi.Solver(q, device=0)
+        try:
+            for lk in (3, 2):
+                with pytest.raises(MpcAmdError, match="N <= 64|horizon"):
+                    s.set_option("loop_kernel", lk)
+        finally:
+            s.close()
+        g = run_closed_loop(q, x0, x0, 4, solver=solver_factory(q, 0), fused=True)
+        c = oracle_c.OracleC(q).closed_loop(4, x0, x0)
+        assert np.array_equal(g["STATUS_DYN"], c["STATUS_DYN"]) and np.max(np.abs(g["U"] - c["U"])) < 1e-7
+
+
+@pytest.mark.parametrize("which", ["cstr", "wb"])
 @pytest.mark.parametrize("lk", LOOP_KERNELS)
 def test_plant_and_model_starting_apart(lk, which, cstr, wb, oracle_c, solver_factory):
     """x0_p != x0_m (MPC_code.py:442-476 take them from different Ex-file entries): the estimator has an innovation from the first
