@@ -606,3 +606,23 @@ def test_gpu_horizon_beyond_64_runs_on_the_lane_kernel_only(pkg):
         assert s.get_kernel() == 1
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_discrete_example_plant_and_model_apart_equals_the_oracle(qt_mild):
+    """The quadruple tank (input-move form, Luenberger observer, lane kernel) with the model's levels started away from the plant's:
+    the first OCP's guess is the model state before the measurement update (MPC_code.py:740-756)."""
+    from mpc_code_amd import nmpc
+    import nmpc_oracle as no
+    rng = np.random.default_rng(4)
+    x0 = np.tile(qt_mild.x0_p, (2, 1)); xm = x0.copy(); xm[:, 2:] += rng.uniform(-1, 1, (2, 4)) * [0.5, 0.5, 0.2, 0.2]
+    s = nmpc.NmpcSolver(qt_mild)
+    try:
+        o = [no.closed_loop(qt_mild, 4, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
+        r = nmpc.run_nmpc_closed_loop(qt_mild, x0, xm, nsteps=4, solver=s, max_sqp=1)
+        for b in range(2):
+            assert np.array_equal(r["STATUS_DYN"][:, b], o[b]["STATUS_DYN"])
+            for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+                assert np.max(np.abs(r[k][:, b] - o[b][k]) / (1 + np.abs(o[b][k]))) < 1e-7, (b, k)
+    finally:
+        s.close()
