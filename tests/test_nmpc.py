@@ -626,3 +626,33 @@ def test_gpu_discrete_example_plant_and_model_apart_equals_the_oracle(qt_mild):
                 assert np.max(np.abs(r[k][:, b] - o[b][k]) / (1 + np.abs(o[b][k]))) < 1e-7, (b, k)
     finally:
         s.close()
+
+
+def _reactor_pxp(t):
+    return [np.array([0.002, -0.003])] if 4 <= t <= 12 else [np.zeros(2)]
+
+
+def _reactor_pyp(t):
+    return [np.array([0.0, 0.004])] if t >= 8 else [np.zeros(2)]
+
+
+@pytest.mark.gpu
+def test_gpu_reactor_plant_and_measurement_disturbance_schedules_equal_the_oracle(pkg):
+    """def_pxp / def_pyp (MPC_code.py:512-515: added to the plant's next state and to the measurement) on every kernel."""
+    from mpc_code_amd import nmpc
+    import nmpc_oracle as no
+    p = pkg.load_problem(pkg.example_path("reactor_nmpc.py"), overrides={"def_pxp": _reactor_pxp, "def_pyp": _reactor_pyp})
+    assert np.array_equal(p.schedules(4)["pxp"][2], [0.002, -0.003]) and np.array_equal(p.schedules(6)["pyp"][4], [0.0, 0.004])
+    x0 = np.array([[0.45, 0.50], [0.47, 0.52]]); xm = np.array([[0.45, 0.50], [0.46, 0.51]])
+    o = [no.closed_loop(p, 8, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
+    s = nmpc.NmpcSolver(p)
+    try:
+        for kern in (1, 3, 4):
+            s.set_kernel(kern)
+            r = nmpc.run_nmpc_closed_loop(p, x0, xm, nsteps=8, solver=s, max_sqp=1)
+            for b in range(2):
+                assert np.array_equal(r["STATUS_DYN"][:, b], o[b]["STATUS_DYN"])
+                for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "Yp"):
+                    assert np.max(np.abs(r[k][:, b] - o[b][k]) / (1 + np.abs(o[b][k]))) < 1e-7, (kern, b, k)
+    finally:
+        s.close()
