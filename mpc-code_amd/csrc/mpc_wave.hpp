@@ -177,8 +177,8 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
         }
         if (HASM) {     // cross terms of the Delta-u form: M (u_{k+1} - ur) into gz (k < N-1), M'(z_k - zr) into gu
             double un[NU], zp[NS];
-            MPC_UNROLL for (int i = 0; i < NU; i++) un[i] = __shfl_down(du[i], 1, 64);
-            MPC_UNROLL for (int i = 0; i < NS; i++) { const double t = __shfl_up(dz1[i], 1, 64); zp[i] = k > 0 ? t : qd[i] - qd[NS + i]; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) un[i] = wave_dn1(du[i], du[i]);      // (neighbour lanes on DPP wave shifts: no LDS round trip)
+            MPC_UNROLL for (int i = 0; i < NS; i++) { const double t = wave_up1(dz1[i], dz1[i]); zp[i] = k > 0 ? t : qd[i] - qd[NS + i]; }
             if (!last) { MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int l = 0; l < NU; l++) gz[i] += Pl.M[i][l] * un[l]; } }
             MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int l = 0; l < NS; l++) gu[i] += Pl.M[l][i] * zp[l]; }
         }
@@ -239,7 +239,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 const int d = 1 << e;
                 if (d < N) {
                     double t[NS];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = __shfl_down(pi[i], d, 64); t[i] = (k + d < N) ? v : 0.0; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = e == 0 ? wave_dn1(pi[i], pi[i]) : __shfl_down(pi[i], d, 64); t[i] = (k + d < N) ? v : 0.0; }
                     MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pi[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.Apow[e][l][i] * t[l]; pi[i] = a; }
                 }
             }
@@ -290,7 +290,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                 const bool f_lo = fin(ulo), f_hi = fin(uhi);
                 double v;
                 if (Sj.warm) {
-                    const double t = __shfl_down(Xj.u[i], 1, 64);
+                    const double t = wave_dn1(Xj.u[i], Xj.u[i]);
                     v = (rep || Sj.keep_u) ? Xj.u[i] : t;
                     if (f_lo) v = dmax(v, ulo);
                     if (f_hi) v = dmin(v, uhi);
@@ -307,7 +307,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
             }
             MPC_UNROLL for (int i = 0; i < NC; i++) {
                 if (Sj.warm) {
-                    const double tl = __shfl_down(Xj.ll[i], 1, 64), th = __shfl_down(Xj.lh[i], 1, 64);
+                    const double tl = wave_dn1(Xj.ll[i], Xj.ll[i]), th = wave_dn1(Xj.lh[i], Xj.lh[i]);
                     ll0[i] = rep ? Xj.ll[i] : tl; lh0[i] = rep ? Xj.lh[i] : th;
                 } else { ll0[i] = 0.0; lh0[i] = 0.0; }
             }
@@ -345,7 +345,7 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
                     const int d = 1 << e;
                     if (d < N) {
                         double t[NS];
-                        MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = __shfl_up(xk[i], d, 64); t[i] = k >= d ? v : 0.0; }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = e == 0 ? wave_up1(xk[i], xk[i]) : __shfl_up(xk[i], d, 64); t[i] = k >= d ? v : 0.0; }
                         MPC_UNROLL for (int i = 0; i < NS; i++) { double a = xk[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pl.Apow[e][i][l] * t[l]; xk[i] = a; }
                     }
                 }
