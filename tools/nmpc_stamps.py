@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: shader-clock ticks per phase of the non-linear kernels (library built with -DMPC_STAMPS):
-   tools/nmpc_stamps.py <lib> [kernel 1|3] [batch]"""
+   tools/nmpc_stamps.py <lib> [kernel 1|3|4] [batch]      (4: the wave-style launch of the split pipeline)"""
 import ctypes as ct, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ s = nmpc.NmpcSolver(p, lib_path=sys.argv[1]); s.set_kernel(kern)
 K = 12
 x0 = p.x0_p * (1.0 + 0.02 * np.random.default_rng(1).uniform(-1, 1, size=(B, 3)))
 s.alloc(B, K); s.set_schedule(p.schedules(K)); s.set_state(x0, x0)
-names = (["est+target", "init", "factor+rhs", "forward(x2)", "predictor ew", "rhs", "corrector ew + test", "linearise"] if kern == 3 else
+names = (["est+target", "init", "factor+rhs", "forward(x2)", "predictor ew", "rhs", "corrector ew + test", "linearise"] if kern in (3, 4) else
          ["init sweep", "B1", "F1", "B2", "F2", "est+target", "linearise", "-"])
 buf = np.zeros(64 * 8, np.uint64)
 s.lib.nmpc_debug_stamps(None, 0, 1)
