@@ -1,0 +1,614 @@
+"""ORACLE (test infrastructure, never shipped): economic NMPC with a moving-horizon estimator, restated with NumPy.
+
+PARITY UNPINNED against the reference's own solver: CasADi / IPOPT / IDAS cannot run here and the reference ships no vectors
+(SURVEY.md section 8c).  What this file pins instead is the *mathematics* of the reference's economic example
+(``Ex_ENMPC.py``; BASELINE configs[3] and [4]):
+
+* model / plant      ``defF_model`` / ``defF_p`` with ``StateFeedback`` and ``offree = "lin"``: ``Mx`` classical RK4 steps of the
+                     Ex-file's continuous functions per sampling interval, ``+ Bd d`` (``Utilities.py:157-183,174-177``), outputs
+                     ``y = x + Cd d`` (``:200-204``), plant output ``y = x_p`` (``:84-86``).
+* OCP                ``opt_dyn`` with ``ContForm`` (``Control_Calc.py:102-111,153-158``): multiple shooting where every interval
+                     integrates ``xdot = f(x,u,d,t,px) + px`` *together with the cost quadrature* of ``User_fobj_Cont(x,u,y,xs,us,ys)``
+                     (``y = Fy_model(x,u,d)``), terminal cost ``User_vfin(x_N, xs)`` (``:194-210``), bounds on ``x_1..x_N`` and ``u``
+                     (``:248-252``).  The reference integrates with SUNDIALS IDAS (adaptive BDF, CasADi's default tolerances
+                     reltol 1e-6 / abstol 1e-8); here - and in the product - the interval is ``quad_steps`` classical RK4 steps
+                     (default 20: within 1e-6 of the exact flow and quadrature on this example, ``test_enmpc_oracle.py``), so parity
+                     with the reference's NLP is *to integrator tolerance* by construction.
+* target             ``opt_ss`` with ``User_fssobj`` (``Target_Calc.py:20-161``): variables ``[xs, us, ys]``, fixed point of the
+                     discrete model, ``ys = Fy_model(xs, us, d)``, cold-started from ``(x0_m, u0)`` every step (``MPC_code.py:696-700``).
+* estimator          ``mhe`` (``Estimator.py:388-768``) on ``mhe_opt``'s NLP (``Utilities.py:825-990``): growing window for the
+                     first ``N_mhe`` steps (``MPC_code.py:591-598``), arrival cost ``1/2 (X_0 - x_bar)' P^-1 (X_0 - x_bar)``
+                     (``Utilities.py:944-945``), prior update by the smoothing recursion (``Estimator.py:652-665``) and
+                     ``x_bar`` = the second state of the optimal window (``:750-753``).  The smoothing *correction* of the cost
+                     (``Utilities.py:949-952``) is dead code in the reference: the solver object is built for the last time at
+                     ``ksim = N_mhe - 1`` (``MPC_code.py:591-598``), where ``ksim >= N_mhe`` is false - so it is not here either.
+* loop               ``MPC_code.py:485-827``.
+
+All three NLPs are solved by one dense primal-dual interior point method (``ipm_dense``: the outer algorithm of the reference's
+solver, exact Hessian of the Lagrangian, dense LU of the Newton system).  Derivatives are complex-step differences of
+the Ex-file's own functions (``exnum.py``; second derivatives: central differences of complex-step gradients) - nothing is
+shared with the product's tracer, generated code or Riccati solver.  ``kkt_nlp`` certifies a returned point against the NLP
+itself: the reference's IPOPT terminates on exactly these conditions.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import exnum
+
+STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2
+INF = float("inf")
+
+
+class EconProblem:
+    def __repr__(self):
+        return f"EconProblem({self.name!r}, nx={self.nx}, nu={self.nu}, ny={self.ny}, nd={self.nd}, N={self.N}, N_mhe={getattr(self, 'N_mhe', None)})"
+
+
+def _vec(v, n, fill):
+    if v is None:
+        return np.full(n, fill, dtype=np.float64)
+    return np.asarray(v, dtype=np.float64).reshape(n)
+
+
+def load_problem(path, overrides=None, quad_steps=20):
+    """The namespace of an economic example as numbers and plain Python functions (reference MPC_code.py:31-60,84-257,368-438)."""
+    ns = exnum.load(path, overrides)
+    p = EconProblem()
+    p.name = ns["__name__"]
+    p.nx, p.nu, p.ny, p.nd, p.nxp = (ns[k].size1() for k in ("x", "u", "y", "d", "xp"))
+    p.N, p.h, p.Nsim, p.Mx = int(ns["N"]), float(ns["h"]), int(ns["Nsim"]), int(ns.get("Mx", 10))
+    p.quad_steps = int(quad_steps)
+    assert ns.get("User_fxm_Cont") and ns.get("User_fobj_Cont") and ns.get("User_fssobj") and ns.get("User_fxp_Cont"), "an economic example with continuous model, plant and cost"
+    assert ns["StateFeedback"] is True and ns["offree"] == "lin"
+    p.fxm, p.fxp, p.fobj, p.fssobj, p.vfin = ns["User_fxm_Cont"], ns["User_fxp_Cont"], ns["User_fobj_Cont"], ns["User_fssobj"], ns.get("User_vfin")
+    p.Bd, p.Cd = np.asarray(ns["Bd"], dtype=float).reshape(p.nx, p.nd), np.asarray(ns["Cd"], dtype=float).reshape(p.ny, p.nd)
+    pick = lambda b, s, n, f: _vec(ns.get(b + s) if ns.get(b + s) is not None else ns.get(b), n, f)
+    p.umin, p.umax = pick("umin", "_dyn", p.nu, -INF), pick("umax", "_dyn", p.nu, INF)
+    p.xmin, p.xmax = pick("xmin", "_dyn", p.nx, -INF), pick("xmax", "_dyn", p.nx, INF)
+    p.umin_ss, p.umax_ss = pick("umin", "_ss", p.nu, -INF), pick("umax", "_ss", p.nu, INF)
+    p.xmin_ss, p.xmax_ss = pick("xmin", "_ss", p.nx, -INF), pick("xmax", "_ss", p.nx, INF)
+    p.ymin_ss, p.ymax_ss = pick("ymin", "_ss", p.ny, -INF), pick("ymax", "_ss", p.ny, INF)
+    assert ns.get("ymin") is None and ns.get("ymax") is None, "output rows in the OCP are not restated here"
+    p.dmin = None if ns.get("dmin") is None else _vec(ns["dmin"], p.nd, -INF)
+    p.dmax = None if ns.get("dmax") is None else _vec(ns["dmax"], p.nd, INF)
+    p.x0_p, p.x0_m, p.u0 = _vec(ns["x0_p"], p.nxp, 0.0), _vec(ns["x0_m"], p.nx, 0.0), _vec(ns["u0"], p.nu, 0.0)
+    p.max_iter = int(ns.get("Sol_itmax", 100))
+    p.mhe = bool(ns.get("mhe", False))
+    if p.mhe:
+        p.N_mhe, p.mhe_up = int(ns["N_mhe"]), ns.get("mhe_up", "smooth")
+        assert p.mhe_up == "smooth" and p.N_mhe >= 2, "only the smoothing update of the shipped example is restated"
+        p.n_w = ns["w"].size1()
+        p.fx_mhe, p.fobj_mhe = ns["User_fx_mhe_Cont"], ns["User_fobj_mhe"]
+        p.G_mhe = np.asarray(ns["G_mhe"], dtype=float) if ns.get("G_mhe") is not None else np.eye(p.nx + p.nd)      # MPC_code.py:387
+        p.P0 = np.asarray(ns["P0"], dtype=float)
+        p.x_bar = np.asarray(ns["x_bar"], dtype=float).reshape(p.nx + p.nd)
+        ne = p.nx + p.nd
+        p.xmin_mhe = np.concatenate([_vec(ns.get("xmin"), p.nx, -INF), _vec(ns.get("dmin"), p.nd, -INF)])      # MPC_code.py:397-402
+        p.xmax_mhe = np.concatenate([_vec(ns.get("xmax"), p.nx, INF), _vec(ns.get("dmax"), p.nd, INF)])
+        for k in ("wmin", "wmax", "vmin", "vmax"):
+            assert ns.get(k) is None, "noise bounds are not restated here"
+        assert p.G_mhe.shape == (ne, p.n_w)
+    return p
+
+
+# ---------------------------------------------------------------------------------------------------
+# the example's functions over P points at once (columns): real or complex
+# ---------------------------------------------------------------------------------------------------
+def _cols(v, P):
+    v = np.asarray(v)
+    return v if v.ndim == 2 else np.repeat(v.reshape(-1, 1), P, axis=1)
+
+
+def _rk4(rhs, Z, h, M):
+    dt = h / M
+    for _ in range(M):
+        k1 = rhs(Z); k2 = rhs(Z + 0.5 * dt * k1); k3 = rhs(Z + 0.5 * dt * k2); k4 = rhs(Z + dt * k3)
+        Z = Z + dt / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+    return Z
+
+
+def fy_model(p, X, D):
+    """Fy_model with StateFeedback: x + Cd d (+ py = 0), Utilities.py:200-204,243."""
+    return X + p.Cd @ D
+
+
+def fx_model(p, X, U, D, t=0.0):
+    """Fx_model(x,u,h,d,t,px): Mx RK4 steps of User_fxm_Cont, + Bd d (Utilities.py:160-177); columns are evaluation points."""
+    P = np.shape(X)[1]
+    zero = np.zeros((p.nx, 1))
+    with exnum.batched():
+        out = _rk4(lambda Z: np.asarray(p.fxm(Z, U, D, t, zero)) + 0 * Z, np.asarray(X), p.h, p.Mx)
+    return out + p.Bd @ _cols(D, P)
+
+
+def fx_plant(p, X, U, t=0.0):
+    """Fx_p: Mx RK4 steps of User_fxp_Cont(xp, t, u, pxp, pxmp) (Utilities.py:58-82)."""
+    zero = np.zeros((p.nxp, 1))
+    with exnum.batched():
+        return _rk4(lambda Z: np.asarray(p.fxp(Z, t, U, zero, zero)) + 0 * Z, np.asarray(X), p.h, p.Mx)
+
+
+def ocp_stage(p, X, U, D, Xs, Us, t=0.0):
+    """One shooting interval of the ContForm OCP: x(h) and the integral of the stage cost (Control_Calc.py:102-111,153-158), by
+    ``quad_steps`` RK4 steps of [f(x,u,d,t,px) + px; User_fobj_Cont(x, u, y, xs, us, ys)].  Note: no ``Bd d`` in these dynamics
+    (SURVEY App. C), unlike Fx_model."""
+    X = np.asarray(X); P = X.shape[1]
+    zero = np.zeros((p.nx, 1))
+    Ys = fy_model(p, _cols(Xs, P), _cols(D, P))
+
+    def rhs(Z):
+        x = Z[:p.nx]
+        with exnum.batched():
+            xd = np.asarray(p.fxm(x, U, D, t, zero)) + 0 * x
+            q = np.asarray(p.fobj(x, U, fy_model(p, x, _cols(D, P)), Xs, Us, Ys)) + 0 * x[0]
+        return np.vstack([xd, q[None]])
+    Z = _rk4(rhs, np.vstack([X, np.zeros((1, P), dtype=X.dtype)]), p.h, p.quad_steps)
+    return Z[:p.nx], Z[p.nx]
+
+
+def fx_mhe(p, Xi, U, W, t=0.0):
+    """Fx_mhe(csi,u,k,t,w,px) for offree = 'lin': [RK4 of User_fx_mhe_Cont(x,u,d,t,px,w) + Bd d; d] + G w (Utilities.py:749-821)."""
+    Xi = np.asarray(Xi); P = Xi.shape[1]
+    zero = np.zeros((p.nx, 1))
+    x, d = Xi[:p.nx], Xi[p.nx:]
+    with exnum.batched():
+        xn = _rk4(lambda Z: np.asarray(p.fx_mhe(Z, U, d, t, zero, W)) + 0 * Z, x, p.h, p.Mx)
+    return np.vstack([xn + p.Bd @ d, d]) + p.G_mhe @ _cols(W, P)
+
+
+def fy_es(p, Xi):
+    """Fy_es(csi,u,t,py) = Fy_model(x1,u,d1,t,py) (MPC_code.py:563-564)."""
+    return fy_model(p, Xi[:p.nx], Xi[p.nx:])
+
+
+# ---------------------------------------------------------------------------------------------------
+# derivatives: complex step (first), central differences of complex-step gradients (second)
+# ---------------------------------------------------------------------------------------------------
+CS = 1e-30
+
+
+def jac_cs(fun, z):
+    """fun: [n, P] -> [m, P] (columns = points); returns fun(z) [m] and d fun / d z [m, n] at the single point z."""
+    n = len(z)
+    Z = np.repeat(np.asarray(z, dtype=complex).reshape(n, 1), n + 1, axis=1)
+    Z[np.arange(n), np.arange(n)] += 1j * CS
+    out = np.asarray(fun(Z))
+    return out[:, n].real, out[:, :n].imag / CS
+
+
+def hess_fd(fun, z, rel=1e-5):
+    """Hessian of the scalar fun ([n, P] -> [P]) at z: central differences of complex-step gradients, symmetrised."""
+    n = len(z)
+    z = np.asarray(z, dtype=float)
+    dz = rel * np.maximum(1.0, np.abs(z))
+    cols = []
+    for j in range(n):
+        for sgn in (1.0, -1.0):
+            zz = z.copy(); zz[j] += sgn * dz[j]
+            Z = np.repeat(zz.astype(complex).reshape(n, 1), n, axis=1)
+            Z[np.arange(n), np.arange(n)] += 1j * CS
+            cols.append(Z)
+    G = np.asarray(fun(np.hstack(cols))).imag / CS      # [2 n * n]
+    G = G.reshape(n, 2, n)
+    H = (G[:, 0, :] - G[:, 1, :]) / (2.0 * dz[:, None])
+    return 0.5 * (H + H.T)
+
+
+# ---------------------------------------------------------------------------------------------------
+# dense primal-dual interior point method on  min f(w)  s.t.  g(w) = 0,  lo <= w <= hi
+# ---------------------------------------------------------------------------------------------------
+# The outer algorithm is the reference solver's (IPOPT with the options of MPC_code.py:262-263, i.e. its defaults [ext]): monotone
+# barrier parameter (mu_init 0.1, kappa_eps 10, kappa_mu 0.2, theta_mu 1.5), first guess pushed into the box (bound_push =
+# bound_frac 0.01), bound multipliers started at 1, fraction to the boundary tau = max(0.99, 1 - mu) with separate primal and dual
+# step lengths, multipliers kept within kappa_Sigma = 1e10 of mu / slack, exact Hessian of the Lagrangian shifted by delta I while
+# the reduced Hessian lacks positive curvature (inertia correction: delta = 1e-4, x100 / x8, restarted from a third of the last one),
+# scaled optimality error E_0 <= tol.  Not restated: the filter line search (every step is the full fraction-to-the-boundary
+# step), the least-squares start of the equality multipliers (they start at zero), the restoration phase, the "acceptable" stop.
+# The product runs the SAME outer algorithm with a Riccati factorisation of the same Newton system (csrc/mpc_enmpc.hpp).
+KAPPA_PUSH, MU_INIT, KAPPA_EPS, KAPPA_MU, THETA_MU, TAU_MIN, KAPPA_SIGMA, S_MAX = 1e-2, 0.1, 10.0, 0.2, 1.5, 0.99, 1e10, 100.0
+DELTA_FIRST, DELTA_MAX = 1e-4, 1e40
+
+
+def _null(E):
+    u, s, vt = np.linalg.svd(E)
+    r = int((s > 1e-12 * max(s.max(initial=0.0), 1.0)).sum())
+    return vt[r:].T
+
+
+def push_interior(w, lo, hi):
+    """IPOPT's projection of the first guess: at least min(kappa max(1, |bound|), kappa (hi - lo)) away from every finite bound."""
+    w = np.array(w, dtype=float)
+    fl, fh = np.isfinite(lo), np.isfinite(hi)
+    with np.errstate(invalid="ignore"):
+        gap = np.where(fl & fh, KAPPA_PUSH * (hi - lo), INF)
+        pl = np.minimum(KAPPA_PUSH * np.maximum(1.0, np.abs(lo)), gap)
+        ph = np.minimum(KAPPA_PUSH * np.maximum(1.0, np.abs(hi)), gap)
+        w = np.where(fl, np.maximum(w, lo + pl), w)
+        w = np.where(fh, np.minimum(w, hi - ph), w)
+    return w
+
+
+def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
+    """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n].  Variables with lo == hi are left to the
+    equality rows that fix them (the initial state of the OCP, MPC_code.py:734 + Control_Calc.py:126)."""
+    n = len(w0)
+    fixed = lo == hi
+    fl, fh = np.isfinite(lo) & ~fixed, np.isfinite(hi) & ~fixed
+    w = push_interior(w0, np.where(fl, lo, -INF), np.where(fh, hi, INF))
+    zl, zh = np.where(fl, 1.0, 0.0), np.where(fh, 1.0, 0.0)
+    nb = int(fl.sum() + fh.sum())
+    lam = None
+    mu, delta_last = MU_INIT, 0.0
+    status, it = STATUS_MAXITER, 0
+    for it in range(max_iter + 1):
+        if lam is None:
+            lam = np.zeros(len(evalf(w, np.zeros(0))[2]))
+        f, gf, c, J, H = evalf(w, lam)
+        m = len(c)
+        if not (np.all(np.isfinite(w)) and np.all(np.isfinite(gf)) and np.all(np.isfinite(c))):
+            status = STATUS_INFEASIBLE
+            break
+        sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
+        stat = gf + J.T @ lam - zl + zh
+        s_d = max(S_MAX, (np.abs(lam).sum() + zl.sum() + zh.sum()) / max(m + nb, 1)) / S_MAX
+        s_c = max(S_MAX, (zl.sum() + zh.sum()) / max(nb, 1)) / S_MAX
+
+        def err(mu_):
+            comp = max(np.abs(np.where(fl, sl * zl - mu_, 0.0)).max(), np.abs(np.where(fh, sh * zh - mu_, 0.0)).max())
+            return max(np.abs(stat).max() / s_d, np.abs(c).max(initial=0.0), comp / s_c)
+        if trace is not None:
+            trace.append(dict(it=it, f=f, E0=err(0.0), mu=mu, w=w.copy()))
+        if err(0.0) <= tol:
+            status = STATUS_SOLVED
+            break
+        if it == max_iter:
+            break
+        while mu > tol / 10.0 and err(mu) <= KAPPA_EPS * mu:
+            mu = max(tol / 10.0, min(KAPPA_MU * mu, mu ** THETA_MU))
+        tau = max(TAU_MIN, 1.0 - mu)
+        Sig = np.where(fl, zl / sl, 0.0) + np.where(fh, zh / sh, 0.0)
+        rhs_w = -(gf - np.where(fl, mu / sl, 0.0) + np.where(fh, mu / sh, 0.0))
+        Z = _null(J)
+        delta = 0.0
+        while True:
+            Hk = H + np.diag(Sig) + delta * np.eye(n)
+            if Z.shape[1] == 0 or np.linalg.eigvalsh(Z.T @ Hk @ Z).min() > 0.0:
+                break
+            delta = max(DELTA_FIRST, delta_last / 3.0) if delta == 0.0 else delta * (100.0 if delta_last == 0.0 else 8.0)
+            if delta > DELTA_MAX:
+                break
+        if delta > 0.0:
+            delta_last = delta
+        sol = np.linalg.solve(np.block([[Hk, J.T], [J, np.zeros((m, m))]]), np.concatenate([rhs_w, -c]))
+        dw, lam_new = sol[:n], sol[n:]
+        dzl = np.where(fl, mu / sl - zl - zl / sl * dw, 0.0)
+        dzh = np.where(fh, mu / sh - zh + zh / sh * dw, 0.0)
+
+        def maxstep(v, dv, mask):
+            neg = mask & (dv < 0)
+            return min(1.0, float(np.min(-tau * v[neg] / dv[neg]))) if neg.any() else 1.0
+        a_pr = min(maxstep(sl, dw, fl), maxstep(sh, -dw, fh))
+        a_du = min(maxstep(zl, dzl, fl), maxstep(zh, dzh, fh))
+        w = w + a_pr * dw
+        lam = lam + a_pr * (lam_new - lam)
+        zl, zh = zl + a_du * dzl, zh + a_du * dzh
+        sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
+        zl = np.where(fl, np.clip(zl, mu / (KAPPA_SIGMA * sl), KAPPA_SIGMA * mu / sl), 0.0)
+        zh = np.where(fh, np.clip(zh, mu / (KAPPA_SIGMA * sh), KAPPA_SIGMA * mu / sh), 0.0)
+    return dict(w=w, lam=lam, z_lo=zl, z_hi=zh, status=status, iters=it, mu=mu)
+
+
+def kkt_nlp(evalf, sol, lo, hi):
+    """Residuals of the NLP's own first-order conditions at sol: stationarity, constraint violation, complementarity, dual sign."""
+    w, lam, z_lo, z_hi = sol["w"], sol["lam"], sol["z_lo"], sol["z_hi"]
+    f, gf, g, J, _ = evalf(w, lam)
+    stat = gf + J.T @ lam + z_hi - z_lo
+    with np.errstate(invalid="ignore"):
+        comp = max(np.abs(np.where(np.isfinite(lo), z_lo * (w - lo), 0.0)).max(), np.abs(np.where(np.isfinite(hi), z_hi * (hi - w), 0.0)).max())
+    viol = float(np.maximum(np.maximum(lo - w, w - hi), 0.0).max())
+    return dict(stat=float(np.abs(stat).max()), eq=float(np.abs(g).max(initial=0.0)), viol=viol, comp=float(comp),
+                dual=float(max(np.maximum(-z_lo, 0).max(), np.maximum(-z_hi, 0).max())))
+
+
+# ---------------------------------------------------------------------------------------------------
+# OCP (opt_dyn with ContForm)
+# ---------------------------------------------------------------------------------------------------
+def ocp_eval(p, xhat, xs, us, d, t=0.0):
+    """evalf of the OCP in opt_dyn's own layout w = [x0,u0,x1,...,x_N] (Control_Calc.py:31-37); g = [x0 - X0; X_{k+1} - F_k ...]
+    (:126,156); f = sum of the interval quadratures + Vfin(X_N, xs) (:158,194-210)."""
+    n, m, N = p.nx, p.nu, p.N
+    nz = n + m
+    nw = nz * N + n
+
+    def evalf(w, lam):
+        X = np.array([w[nz * k: nz * k + n] for k in range(N + 1)]); U = np.array([w[nz * k + n: nz * (k + 1)] for k in range(N)])
+        Lm = lam.reshape(N + 1, n)[1:] if len(lam) else np.zeros((N, n))      # multipliers of X_{k+1} - F_k = 0
+        D = np.repeat(d.reshape(-1, 1), 1, axis=1)
+        # values and first derivatives of every interval: N * (nz + 1) points in one pass
+        Zb = np.hstack([np.concatenate([X[k], U[k]]).astype(complex).reshape(nz, 1).repeat(nz + 1, axis=1) for k in range(N)])
+        for k in range(N):
+            Zb[np.arange(nz), k * (nz + 1) + np.arange(nz)] += 1j * CS
+        Xn, q = ocp_stage(p, Zb[:n], Zb[n:], D, xs.reshape(-1, 1), us.reshape(-1, 1), t)
+        Xn = Xn.reshape(n, N, nz + 1); q = q.reshape(N, nz + 1)
+        F = Xn[:, :, nz].real.T; AB = np.transpose(Xn[:, :, :nz].imag / CS, (1, 0, 2)); ql = q[:, nz].real; gq = q[:, :nz].imag / CS
+        f = float(ql.sum())
+        gf = np.zeros(nw); g = np.zeros((N + 1) * n); J = np.zeros(((N + 1) * n, nw)); H = np.zeros((nw, nw))
+        g[:n] = xhat - X[0]; J[:n, :n] = -np.eye(n)
+        for k in range(N):
+            sl = slice(nz * k, nz * (k + 1))
+            gf[sl] += gq[k]
+            r = slice(n * (k + 1), n * (k + 2))
+            g[r] = X[k + 1] - F[k]
+            J[r, sl] = -AB[k]; J[r, nz * (k + 1): nz * (k + 1) + n] = np.eye(n)
+        if len(lam):
+            # Hessian of q_k - lam_{k+1}' F_k with respect to (x_k, u_k), every interval in one pass
+            def phi(Zall):      # [nz, N * P] -> [N * P]
+                Pk = Zall.shape[1] // N
+                Xn_, q_ = ocp_stage(p, Zall[:n], Zall[n:], D, xs.reshape(-1, 1), us.reshape(-1, 1), t)
+                lm = np.repeat(Lm, Pk, axis=0).T      # [n, N * Pk]
+                return q_ - (lm * Xn_).sum(axis=0)
+            # assemble the per-interval stencils side by side
+            zs = [np.concatenate([X[k], U[k]]) for k in range(N)]
+            dz = [1e-5 * np.maximum(1.0, np.abs(z)) for z in zs]
+            cols = []
+            for k in range(N):
+                blk = []
+                for j in range(nz):
+                    for sgn in (1.0, -1.0):
+                        zz = zs[k].copy(); zz[j] += sgn * dz[k][j]
+                        Zc = np.repeat(zz.astype(complex).reshape(nz, 1), nz, axis=1)
+                        Zc[np.arange(nz), np.arange(nz)] += 1j * CS
+                        blk.append(Zc)
+                cols.append(np.hstack(blk))
+            Gr = np.asarray(phi(np.hstack(cols))).imag / CS
+            Gr = Gr.reshape(N, nz, 2, nz)
+            for k in range(N):
+                Hk = (Gr[k, :, 0, :] - Gr[k, :, 1, :]) / (2.0 * dz[k][:, None])
+                H[nz * k: nz * (k + 1), nz * k: nz * (k + 1)] = 0.5 * (Hk + Hk.T)
+        # terminal cost
+        xN = X[N]
+        if p.vfin is not None:
+            vf = lambda Zc: np.array([p.vfin(Zc[:, i], xs) for i in range(Zc.shape[1])])
+            v, gv = jac_cs(lambda Zc: vf(Zc)[None], xN)
+            f += float(v[0]); gf[nz * N:] += gv[0]
+            if len(lam):
+                H[nz * N:, nz * N:] = hess_fd(vf, xN)
+        return f, gf, g, J, H
+    lo = np.full(nw, -INF); hi = np.full(nw, INF)
+    lo[:n] = hi[:n] = xhat                                   # MPC_code.py:734
+    for k in range(1, N + 1):                                # Control_Calc.py:248-252
+        lo[nz * k: nz * k + n], hi[nz * k: nz * k + n] = p.xmin, p.xmax
+        lo[nz * k - m: nz * k], hi[nz * k - m: nz * k] = p.umin, p.umax
+    return evalf, lo, hi
+
+
+def ocp_solve(p, xhat, xs, us, d, w_guess, max_iter=None, tol=1e-8, t=0.0):
+    max_iter = p.max_iter if max_iter is None else max_iter
+    evalf, lo, hi = ocp_eval(p, xhat, xs, us, d, t)
+    w0 = np.array(w_guess, dtype=float)
+    w0[:p.nx] = xhat
+    sol = ipm_dense(evalf, w0, lo, hi, tol=tol, max_iter=max_iter)
+    sol["evalf"], sol["lo"], sol["hi"] = evalf, lo, hi
+    return sol
+
+
+# ---------------------------------------------------------------------------------------------------
+# target (opt_ss with User_fssobj)
+# ---------------------------------------------------------------------------------------------------
+def target_eval(p, d, usp, ysp, xsp, t=0.0):
+    n, m, q = p.nx, p.nu, p.ny
+    nv = n + m + q
+
+    def cons(Wc):      # [nv, P] -> [n + q, P]: Fx_model(xs,us,h,d) - xs; Fy_model(xs,us,d) - ys   (Target_Calc.py:73-81; lambdaT = 0)
+        P = Wc.shape[1]
+        D = _cols(d, P)
+        return np.vstack([fx_model(p, Wc[:n], Wc[n:n + m], D, t) - Wc[:n], fy_model(p, Wc[:n], D) - Wc[n + m:]])
+
+    def cost(Wc):      # Fss_obj(dx, du, dy, xsp, usp, ysp) with QForm_ss False (Target_Calc.py:109-124)
+        return np.array([p.fssobj(Wc[:n, i], Wc[n:n + m, i], Wc[n + m:, i], xsp, usp, ysp) for i in range(Wc.shape[1])])
+
+    def evalf(w, lam):
+        g, J = jac_cs(cons, w)
+        f, gf = jac_cs(lambda Wc: cost(Wc)[None], w)
+        H = np.zeros((nv, nv))
+        if len(lam):
+            H = hess_fd(lambda Wc: cost(Wc) + (lam[:, None] * cons(Wc)).sum(axis=0), w)
+        return float(f[0]), gf[0], g, J, H
+    lo = np.concatenate([p.xmin_ss, p.umin_ss, p.ymin_ss]); hi = np.concatenate([p.xmax_ss, p.umax_ss, p.ymax_ss])
+    return evalf, lo, hi
+
+
+def target_solve(p, d, t=0.0, usp=None, ysp=None, xsp=None, max_iter=None, tol=1e-8):
+    max_iter = p.max_iter if max_iter is None else max_iter
+    usp = np.zeros(p.nu) if usp is None else usp; ysp = np.zeros(p.ny) if ysp is None else ysp; xsp = np.zeros(p.nx) if xsp is None else xsp
+    evalf, lo, hi = target_eval(p, d, usp, ysp, xsp, t)
+    y0 = fy_model(p, p.x0_m.reshape(-1, 1), d.reshape(-1, 1))[:, 0]
+    w0 = np.concatenate([p.x0_m, p.u0, y0])                 # MPC_code.py:696-700: cold start, every step
+    sol = ipm_dense(evalf, w0, lo, hi, tol=tol, max_iter=max_iter)
+    sol["evalf"], sol["lo"], sol["hi"] = evalf, lo, hi
+    sol["xs"], sol["us"], sol["ys"] = sol["w"][:p.nx], sol["w"][p.nx:p.nx + p.nu], sol["w"][p.nx + p.nu:]
+    return sol
+
+
+# ---------------------------------------------------------------------------------------------------
+# MHE (mhe_opt's NLP + mhe()'s bookkeeping)
+# ---------------------------------------------------------------------------------------------------
+def mhe_eval(p, N, Us, Ys, x_bar, Pinv, t=0.0):
+    """mhe_opt's NLP for a window of N stages in its own layout w = [x0,v0,w0,x1,...,x_N] (Utilities.py:831-846):
+    g = [Fy(X_k) + V_k - Y_k; Fx_mhe(X_k, U_k, W_k) - X_{k+1}] (k < N) (:909-926), f = sum F_obj_mhe(W_k, V_k) + arrival cost (:928-945)."""
+    ne, q, nw_ = p.nx + p.nd, p.ny, p.n_w
+    nb = ne + q + nw_
+    nopt = N * nb + ne
+    ng = N * (q + ne)
+
+    def evalf(w, lam):
+        f = 0.0; gf = np.zeros(nopt); g = np.zeros(ng); J = np.zeros((ng, nopt)); H = np.zeros((nopt, nopt))
+        Lm = lam.reshape(N, q + ne) if len(lam) else None
+        for k in range(N):
+            o0 = nb * k
+            X, V, W = w[o0:o0 + ne], w[o0 + ne:o0 + ne + q], w[o0 + ne + q:o0 + nb]
+            zk = np.concatenate([X, W])
+            Uk = Us[k].reshape(-1, 1)
+            Fv, Fj = jac_cs(lambda Zc: fx_mhe(p, Zc[:ne], Uk, Zc[ne:], t), zk)
+            yv, yj = jac_cs(lambda Zc: fy_es(p, Zc), X)
+            cv, cj = jac_cs(lambda Zc: np.array([p.fobj_mhe(Zc[:nw_, i], Zc[nw_:, i], t) for i in range(Zc.shape[1])])[None], np.concatenate([W, V]))
+            f += float(cv[0])
+            gf[o0 + ne + q:o0 + nb] += cj[0][:nw_]; gf[o0 + ne:o0 + ne + q] += cj[0][nw_:]
+            r0 = (q + ne) * k
+            g[r0:r0 + q] = yv + V - Ys[k]
+            J[r0:r0 + q, o0:o0 + ne] = yj; J[r0:r0 + q, o0 + ne:o0 + ne + q] = np.eye(q)
+            g[r0 + q:r0 + q + ne] = Fv - w[o0 + nb:o0 + nb + ne]
+            J[r0 + q:r0 + q + ne, o0:o0 + ne] = Fj[:, :ne]; J[r0 + q:r0 + q + ne, o0 + ne + q:o0 + nb] = Fj[:, ne:]
+            J[r0 + q:r0 + q + ne, o0 + nb:o0 + nb + ne] = -np.eye(ne)
+            if Lm is not None:
+                Hc = hess_fd(lambda Zc: np.array([p.fobj_mhe(Zc[:nw_, i], Zc[nw_:, i], t) for i in range(Zc.shape[1])]), np.concatenate([W, V]))
+                iw = np.arange(o0 + ne + q, o0 + nb); iv = np.arange(o0 + ne, o0 + ne + q)
+                idx = np.concatenate([iw, iv])
+                H[np.ix_(idx, idx)] += Hc
+                lf, ly = Lm[k, q:], Lm[k, :q]
+                Hd = hess_fd(lambda Zc: (lf[:, None] * fx_mhe(p, Zc[:ne], Uk, Zc[ne:], t)).sum(axis=0) + (ly[:, None] * fy_es(p, Zc[:ne])).sum(axis=0), zk)
+                idz = np.concatenate([np.arange(o0, o0 + ne), iw])
+                H[np.ix_(idz, idz)] += Hd
+        e0 = w[:ne] - x_bar
+        f += 0.5 * float(e0 @ Pinv @ e0); gf[:ne] += Pinv @ e0; H[:ne, :ne] += 0.5 * (Pinv + Pinv.T)
+        return f, gf, g, J, H
+    lo = np.full(nopt, -INF); hi = np.full(nopt, INF)
+    for k in range(N + 1):                                   # Utilities.py:956-966: the state boxes on every X_k
+        lo[nb * k: nb * k + ne], hi[nb * k: nb * k + ne] = p.xmin_mhe, p.xmax_mhe
+    return evalf, lo, hi
+
+
+class MheState:
+    """What mhe() carries from call to call (Estimator.py:388-768 arguments / MPC_code.py:405-438 initial values)."""
+
+    def __init__(self, p):
+        ne = p.nx + p.nd
+        self.U, self.Y, self.T = [], [], []
+        self.w_k, self.v_k = np.zeros(p.n_w), np.zeros(p.ny)
+        self.x_bar, self.P_k = p.x_bar.copy(), p.P0.copy()
+        self.bigA, self.bigP, self.bigPc = [], [], []
+        self.P_kal = p.P0.copy()
+        self.last = None
+
+
+def mhe_step(p, S, ksim, y_act, u_k, t_k=0.0, max_iter=None, tol=1e-10):
+    max_iter = p.max_iter if max_iter is None else max_iter      # ipopt.tol = 1e-10 for the estimator (MPC_code.py:383)
+    """One call of mhe() (Estimator.py:388-768) with ``mhe_up = 'smooth'``; returns the corrected estimate [x; d](k|k)."""
+    ne, q, nw_, m = p.nx + p.nd, p.ny, p.n_w, p.nu
+    nb = ne + q + nw_
+    N = min(ksim + 1, p.N_mhe)                               # MPC_code.py:591-593
+    # stacking (Estimator.py:474-501): the last input is doubled, the copy is the fictitious input of the prediction stage
+    if ksim < p.N_mhe:
+        S.U = S.U + ([u_k.copy()] if ksim == 0 else [u_k.copy(), u_k.copy()])
+        S.Y = S.Y + [y_act.copy()]; S.T = S.T + [t_k]
+    else:
+        S.U = S.U[1:] + [u_k.copy(), u_k.copy()]
+        S.Y = S.Y[1:] + [y_act.copy()]; S.T = S.T[1:] + [t_k]
+    assert len(S.U) == N and len(S.Y) == N
+    # first guess: x_bar propagated without noise (:503-512)
+    w0 = np.zeros(N * nb + ne)
+    xg = S.x_bar.copy()
+    for k in range(N):
+        w0[nb * k: nb * k + ne] = xg
+        xg = fx_mhe(p, xg.reshape(-1, 1), S.U[k].reshape(-1, 1), np.zeros((nw_, 1)), t_k)[:, 0]
+    w0[N * nb:] = xg
+    Pinv = np.linalg.inv(S.P_k)                              # :515-517
+    evalf, lo, hi = mhe_eval(p, N, S.U, S.Y, S.x_bar, Pinv, t_k)
+    sol = ipm_dense(evalf, w0, lo, hi, tol=tol, max_iter=max_iter)
+    sol["evalf"], sol["lo"], sol["hi"] = evalf, lo, hi
+    S.last = sol
+    w = sol["w"]
+    xkp1k = w[-ne:]; xhat_corr = w[-ne - nb:-nb]            # :532-534
+    S.v_k = w[-nb:-ne - nw_].copy()
+    if ksim != 0:
+        S.w_k = w[-ne - nw_:-ne].copy()                      # :536-538
+    # Kalman quantities for the smoothing update (:558-623)
+    Hk = np.linalg.inv(hess_fd(lambda Zc: np.array([p.fobj_mhe(Zc[:nw_, i], Zc[nw_:, i], t_k) for i in range(Zc.shape[1])]), np.concatenate([S.w_k, S.v_k])))
+    Q_k, R_k, S_k = Hk[:nw_, :nw_], Hk[-q:, -q:], Hk[:nw_, -q:]
+    _, C_k = jac_cs(lambda Zc: fy_es(p, Zc), xhat_corr)
+    _, Fj = jac_cs(lambda Zc: fx_mhe(p, Zc[:ne], u_k.reshape(-1, 1), Zc[ne:], t_k), np.concatenate([xhat_corr, S.w_k]))
+    A_k, G_k = Fj[:, :ne], Fj[:, ne:]
+    K_k = S.P_kal @ C_k.T @ np.linalg.inv(C_k @ S.P_kal @ C_k.T + R_k)
+    P_corr = S.P_kal - K_k @ C_k @ S.P_kal
+    Pi = S.P_kal
+    M_k = -K_k @ S_k.T
+    S.P_kal = A_k @ P_corr @ A_k.T + G_k @ Q_k @ G_k.T + A_k @ M_k @ G_k.T + G_k @ M_k @ A_k.T
+    S.bigA.append(A_k); S.bigP.append(Pi); S.bigPc.append(P_corr)
+    if ksim >= p.N_mhe - 1:                                  # :626-665: smoothed covariance of the window's second state
+        Nm = p.N_mhe
+        Pis = [None] * Nm
+        Pis[Nm - 1] = S.bigPc[Nm - 1]
+        for i in range(Nm - 2, -1, -1):
+            Pim = np.linalg.inv(S.bigP[i + 1])
+            Pis[i] = S.bigPc[i] + S.bigPc[i] @ S.bigA[i].T @ Pim @ (Pis[i + 1] - S.bigP[i + 1]) @ Pim @ S.bigA[i] @ S.bigPc[i]
+        S.P_k = Pis[1]
+        S.bigA, S.bigP, S.bigPc = S.bigA[1:], S.bigP[1:], S.bigPc[1:]
+        S.x_bar = w[nb:nb + ne].copy()                       # :750-753
+    S.U = [] if ksim == 0 else S.U[:-1]                      # :756-760
+    return xhat_corr.copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# closed loop (MPC_code.py:485-827)
+# ---------------------------------------------------------------------------------------------------
+def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
+    n, m, nd, N = p.nx, p.nu, p.nd, p.N
+    nz = n + m
+    x_k = (p.x0_p if x0_p is None else np.asarray(x0_p, dtype=float)).copy()
+    x0_m = (p.x0_m if x0_m is None else np.asarray(x0_m, dtype=float)).copy()
+    xhat = x0_m.copy(); dhat = np.zeros(nd); u_k = p.u0.copy()
+    S = MheState(p) if p.mhe else None
+    if S is not None and x0_m is not None:
+        S.x_bar[:n] = x0_m                                   # Ex-file: x_bar = [x0_m; 0]
+    xs_k, us_k = x0_m.copy(), u_k.copy()                     # MPC_code.py:682-684
+    w_opt = None; last_ok = True
+    log = {k: [] for k in ("U", "X_HAT", "D_HAT", "XS", "US", "Xp", "Yp", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "ITERS_MHE", "X_ES", "KKT_DYN", "KKT_SS", "KKT_MHE", "P_K")}
+    for ksim in range(nsteps):
+        t_k = ksim * p.h
+        log["Xp"].append(x_k.copy()); log["X_HAT"].append(xhat.copy())
+        y_k = x_k.copy()                                     # Fy_p with StateFeedback (Utilities.py:84-86)
+        log["Yp"].append(y_k.copy())
+        if p.mhe:
+            x_es = mhe_step(p, S, ksim, y_k, u_k, t_k)
+            log["ITERS_MHE"].append(S.last["iters"])
+            if certify:
+                log["KKT_MHE"].append(max(kkt_nlp(S.last["evalf"], S.last, S.last["lo"], S.last["hi"]).values()))
+            log["P_K"].append(S.P_k.copy())
+        else:
+            raise NotImplementedError("only the moving-horizon estimator of the shipped example is restated")
+        xhat, dhat = x_es[:n].copy(), x_es[n:].copy()
+        if p.dmin is not None:
+            dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)
+        log["X_ES"].append(x_es.copy()); log["D_HAT"].append(dhat.copy())
+        us_prev, xs_prev = us_k.copy(), xs_k.copy()
+        ts = target_solve(p, dhat, t_k)
+        if ts["status"] != STATUS_INFEASIBLE:
+            xs_k, us_k = ts["xs"].copy(), ts["us"].copy()
+        log["XS"].append(xs_k.copy()); log["US"].append(us_k.copy()); log["STATUS_SS"].append(ts["status"]); log["ITERS_SS"].append(ts["iters"])
+        if certify:
+            log["KKT_SS"].append(max(kkt_nlp(ts["evalf"], ts, ts["lo"], ts["hi"]).values()))
+        if w_opt is None:                                    # MPC_code.py:740-756
+            w_guess = np.zeros(nz * N + n)
+            for k in range(1, N + 1):
+                w_guess[k * nz - m:k * nz] = p.u0; w_guess[k * nz:k * nz + n] = x0_m
+            w_guess[:n] = x0_m
+        elif last_ok:
+            w_guess = np.concatenate([w_opt[nz:], us_prev, xs_prev])      # :764
+        sol = ocp_solve(p, xhat, xs_k, us_k, dhat, w_guess, t=t_k)
+        last_ok = sol["status"] != STATUS_INFEASIBLE
+        log["STATUS_DYN"].append(sol["status"]); log["ITERS_DYN"].append(sol["iters"])
+        if last_ok:
+            w_opt = sol["w"]
+            u_k = w_opt[n:nz].copy(); xhat = w_opt[nz:nz + n].copy()      # :798-799
+            if certify:
+                log["KKT_DYN"].append(max(kkt_nlp(sol["evalf"], sol, sol["lo"], sol["hi"]).values()))
+        else:
+            xhat = fx_model(p, xhat.reshape(-1, 1), u_k.reshape(-1, 1), dhat.reshape(-1, 1), t_k)[:, 0]      # :804-805
+            if certify:
+                log["KKT_DYN"].append(np.nan)
+        log["U"].append(u_k.copy())
+        if verbose:
+            print(f"step {ksim}: u {u_k}, xs {xs_k}, us {us_k}, iters {sol['iters']} / {ts['iters']} / {log['ITERS_MHE'][-1] if p.mhe else 0}, status {sol['status']}")
+        x_k = fx_plant(p, x_k.reshape(-1, 1), u_k.reshape(-1, 1), t_k)[:, 0]      # :813-816
+    return {k: np.array(v) for k, v in log.items() if len(v)}
