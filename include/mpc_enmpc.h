@@ -1,0 +1,70 @@
+/*
+ * mpc_enmpc.h - C-ABI of the economic MPC path (libmpc_enmpc_<model>.so): SURVEY.md section 8f ranks 2 and 3, BASELINE configs 4, 5.
+ *
+ * The library is built per model: the Ex-file's User_fxm_Cont / User_fxp_Cont / User_fobj_Cont / User_fssobj / User_vfin /
+ * User_fx_mhe_Cont / User_fobj_mhe are traced and emitted as device functions with their first and second derivatives
+ * (mpc-code_amd/econcodegen.py), the kernel of csrc/mpc_enmpc.hip is compiled against them for gfx950.  It replaces, for a batch
+ * of instances, the loop body of the reference for an economic example (MPC_code.py:485-827 with Ex_ENMPC.py):
+ *   defEstimator(..., 'mhe') -> mhe()          Estimator.py:388-768 on the NLP of mhe_opt, Utilities.py:825-990; MPC_code.py:583-641
+ *   solver_ss(...) on the NLP of opt_ss        Target_Calc.py:20-161 with User_fssobj; MPC_code.py:693-718
+ *   solver(...) on the NLP of opt_dyn          Control_Calc.py:20-260 with ContForm (:102-111,153-158); MPC_code.py:733-805
+ *   Fx_p / Fy_p                                Utilities.py:21-100; MPC_code.py:531-534,813-816
+ * All three NLPs are solved to their KKT points by a primal-dual interior point method (the outer algorithm of the reference's
+ * IPOPT); the shooting intervals of the OCP are integrated with quad_steps classical Runge-Kutta steps where
+ * the reference calls SUNDIALS IDAS.
+ * Conventions as mpc_amd.h: caller-owned contiguous float64 host arrays, one row per instance [B][dim]; status words 0 solved,
+ * 1 iteration limit (accepted, as the reference accepts it), 2 failed (non-finite iterate: the hold rule, MPC_code.py:804-805);
+ * 0 on success, negative code + enmpc_last_error() otherwise; no CPU path.
+ */
+#ifndef MPC_ENMPC_H
+#define MPC_ENMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct enmpc_handle enmpc_handle;
+
+typedef struct enmpc_desc {
+    int32_t nx, nu, ny, nd, nxp, nw; /* must equal the dimensions the library was generated for (nw: noise vector of the estimator) */
+    int32_t N;                       /* control horizon, 2..64 */
+    int32_t N_mhe;                   /* estimation horizon, 2..63 */
+    int32_t max_iter;                /* Sol_itmax: interior-point iterations per NLP */
+    int32_t quad_steps;              /* Runge-Kutta steps per shooting interval of the OCP (cost quadrature included) */
+    int32_t device;
+    double h;                        /* sampling interval */
+    double tol, tol_mhe;             /* optimality tolerances: IPOPT's default 1e-8, 1e-10 for the estimator (MPC_code.py:383) */
+    const double *umin, *umax, *xmin, *xmax;                                   /* OCP boxes; +-INFINITY = absent */
+    const double *umin_ss, *umax_ss, *xmin_ss, *xmax_ss, *ymin_ss, *ymax_ss;   /* target boxes */
+    const double *xmin_mhe, *xmax_mhe;                                         /* [nx+nd] boxes of the estimator's states (MPC_code.py:397-402) */
+    const double *dmin, *dmax;       /* saturation of dhat, or NULL */
+    const double *Bd, *Cd;           /* [nx][nd], [ny][nd] of offree = 'lin' */
+    const double *G_mhe;             /* [nx+nd][nw] */
+    const double *P0;                /* [nx+nd]^2 initial arrival weight and Kalman covariance (MPC_code.py:421-422,455-458) */
+    const double *x0_m, *u0;         /* the first guesses of target and OCP (MPC_code.py:696-700,740-756) */
+} enmpc_desc;
+
+int enmpc_create(const enmpc_desc *desc, enmpc_handle **out);
+void enmpc_destroy(enmpc_handle *h);
+const char *enmpc_last_error(void);
+const char *enmpc_build_info(void);      /* "gfx950;enmpc;dims=nx/nu/ny/nd/nxp/nw;mx=.." */
+
+/* resident closed loop */
+int enmpc_alloc(enmpc_handle *h, int32_t B, int32_t max_steps);
+/* plant state, model state, disturbance estimate, applied input, the estimator's prior mean x_bar [B][nx+nd]; resets the estimator
+ * (window, covariances = P0) and the OCP's warm start; the first target guess is (x0_m, u0) */
+int enmpc_set_state(enmpc_handle *h, const double *x_p, const double *xhat, const double *dhat, const double *u, const double *x_bar);
+/* steps [k0, k0+nsteps) of every instance in one launch; k0 must continue where the last run ended (0 after enmpc_set_state); asynchronous */
+int enmpc_run(enmpc_handle *h, int32_t k0, int32_t nsteps);
+int enmpc_sync(enmpc_handle *h);
+/* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT","X_ES" (the estimator's corrected [x; d]);
+ * [nsteps][B] int32: "STATUS_DYN","STATUS_SS","STATUS_MHE","ITERS_DYN","ITERS_SS","ITERS_MHE" (interior-point iterations) */
+int enmpc_get_log(enmpc_handle *h, const char *name, void *out);
+float enmpc_last_kernel_ms(enmpc_handle *h);      /* device time of the last enmpc_run, HIP events on the library's stream */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_ENMPC_H */

@@ -1,0 +1,165 @@
+"""ctypes binding of include/mpc_enmpc.h and the batched economic closed loop.
+
+``EnmpcSolver`` owns one per-model library (built by :mod:`econcodegen` from the traced Ex-file functions) and a handle on it;
+``run_enmpc_closed_loop`` is the loop body of the reference's ``MPC_code.py:485-827`` for an economic example with a moving-horizon
+estimator, for B instances that differ in their initial plant state - everything resident in HBM.  There is no CPU path: without a
+GPU ``EnmpcSolver`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import econcodegen
+from .capi import MpcAmdError
+
+ENMPC_EXPORTS = ("enmpc_create", "enmpc_destroy", "enmpc_last_error", "enmpc_build_info", "enmpc_alloc", "enmpc_set_state", "enmpc_run",
+                 "enmpc_sync", "enmpc_get_log", "enmpc_last_kernel_ms")
+
+_dp = ct.POINTER(ct.c_double)
+
+
+class _EDesc(ct.Structure):
+    _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "nw", "N", "N_mhe", "max_iter", "quad_steps", "device")]
+                + [(k, ct.c_double) for k in ("h", "tol", "tol_mhe")]
+                + [(k, _dp) for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe",
+                                      "dmin", "dmax", "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0")])
+
+
+_libs: Dict[str, ct.CDLL] = {}
+
+
+def load_enmpc_library(path: str) -> ct.CDLL:
+    if path in _libs:
+        return _libs[path]
+    lib = ct.CDLL(path)
+    vp = ct.c_void_p
+    lib.enmpc_create.argtypes = [ct.POINTER(_EDesc), ct.POINTER(vp)]; lib.enmpc_create.restype = ct.c_int
+    lib.enmpc_destroy.argtypes = [vp]; lib.enmpc_destroy.restype = None
+    lib.enmpc_last_error.restype = ct.c_char_p
+    lib.enmpc_build_info.restype = ct.c_char_p
+    lib.enmpc_alloc.argtypes = [vp, ct.c_int32, ct.c_int32]
+    lib.enmpc_set_state.argtypes = [vp] + [_dp] * 5
+    lib.enmpc_run.argtypes = [vp, ct.c_int32, ct.c_int32]
+    lib.enmpc_sync.argtypes = [vp]
+    lib.enmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
+    lib.enmpc_last_kernel_ms.argtypes = [vp]; lib.enmpc_last_kernel_ms.restype = ct.c_float
+    _libs[path] = lib
+    return lib
+
+
+def _c(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _rows(v, B, d):
+    a = np.asarray(v, dtype=np.float64)
+    return np.ascontiguousarray(np.broadcast_to(a.reshape(-1, d) if a.ndim > 1 else a, (B, d)))
+
+
+class EnmpcSolver:
+    """An economic problem (:class:`EconomicMPCProblem`) resident on one GPU."""
+
+    LOGS = {"U": "nu", "X_HAT": "nx", "XS": "nx", "US": "nu", "Xp": "nxp", "D_HAT": "nd", "X_ES": None}
+    ILOGS = ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")
+
+    def __init__(self, problem, device: int = 0, lib_path: Optional[str] = None, tol: float = 1e-8, tol_mhe: float = 1e-10):
+        self.p = p = problem
+        self.lib = load_enmpc_library(lib_path or econcodegen.build_enmpc_library(p))
+        self._keep = {}
+        d = _EDesc()
+        d.nx, d.nu, d.ny, d.nd, d.nxp, d.nw, d.N, d.N_mhe = p.nx, p.nu, p.ny, p.nd, p.nxp, p.n_w, p.N, p.N_mhe
+        d.max_iter, d.quad_steps, d.device, d.h, d.tol, d.tol_mhe = int(p.max_iter), int(p.quad_steps), int(device), float(p.h), float(tol), float(tol_mhe)
+        for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe", "dmin", "dmax",
+                  "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0"):
+            v = getattr(p, k, None)
+            if v is None:
+                setattr(d, k, None)
+            else:
+                a = _c(v)
+                self._keep[k] = a
+                setattr(d, k, a.ctypes.data_as(_dp))
+        self.h = ct.c_void_p()
+        rc = self.lib.enmpc_create(ct.byref(d), ct.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise MpcAmdError(f"enmpc_create failed ({rc}): {self.lib.enmpc_last_error().decode()}")
+        self.B = self.steps = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MpcAmdError(f"{what} failed ({rc}): {self.lib.enmpc_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.enmpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_info(self) -> str:
+        return self.lib.enmpc_build_info().decode()
+
+    def alloc(self, B: int, max_steps: int):
+        self._chk(self.lib.enmpc_alloc(self.h, int(B), int(max_steps)), "enmpc_alloc")
+        self.B, self.steps = int(B), 0
+
+    def set_state(self, x_p, xhat=None, dhat=None, u=None, x_bar=None):
+        p, B = self.p, self.B
+        xp = _rows(x_p, B, p.nxp)
+        xh = _rows(p.x0_m if xhat is None else xhat, B, p.nx)
+        dh = _rows(np.zeros(p.nd) if dhat is None else dhat, B, p.nd)
+        uu = _rows(p.u0 if u is None else u, B, p.nu)
+        xb = _rows(p.x_bar if x_bar is None else x_bar, B, p.nx + p.nd)
+        self._chk(self.lib.enmpc_set_state(self.h, *[a.ctypes.data_as(_dp) for a in (xp, xh, dh, uu, xb)]), "enmpc_set_state")
+        self.steps = 0
+
+    def run(self, k0: int, nsteps: int):
+        self._chk(self.lib.enmpc_run(self.h, int(k0), int(nsteps)), "enmpc_run")
+        self.steps = max(self.steps, k0 + nsteps)
+
+    def sync(self):
+        self._chk(self.lib.enmpc_sync(self.h), "enmpc_sync")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.enmpc_last_kernel_ms(self.h))
+
+    def get_log(self, name: str) -> np.ndarray:
+        p = self.p
+        if name in self.LOGS:
+            d = p.nx + p.nd if name == "X_ES" else getattr(p, self.LOGS[name])
+            out = np.empty((self.steps, self.B, d), dtype=np.float64)
+        elif name in self.ILOGS:
+            out = np.empty((self.steps, self.B), dtype=np.int32)
+        else:
+            raise KeyError(name)
+        self._chk(self.lib.enmpc_get_log(self.h, name.encode(), out.ctypes.data_as(ct.c_void_p)), "enmpc_get_log")
+        return out
+
+
+def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, steps_per_launch: int = 0, solver: Optional[EnmpcSolver] = None):
+    """The closed loop of the reference for B instances (rows of ``x0_p``); model state, input and the estimator's prior start from the
+    Ex-file's ``x0_m``, ``u0``, ``x_bar``.  Returns the reference's result arrays ``[nsteps, B, dim]`` plus status / iteration words."""
+    p = problem
+    nsteps = p.Nsim if nsteps is None else int(nsteps)
+    x0_p = np.atleast_2d(np.asarray(x0_p, dtype=np.float64))
+    s = solver or EnmpcSolver(p, device=device)
+    try:
+        s.alloc(len(x0_p), nsteps)
+        s.set_state(x0_p)
+        spl = steps_per_launch if steps_per_launch > 0 else nsteps
+        for k0 in range(0, nsteps, spl):
+            s.run(k0, min(spl, nsteps - k0))
+        s.sync()
+        out = {k: s.get_log(k) for k in list(s.LOGS) + list(s.ILOGS)}
+        out["kernel_ms"] = s.last_kernel_ms()
+        return out
+    finally:
+        if solver is None:
+            s.close()

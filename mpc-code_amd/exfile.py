@@ -143,12 +143,17 @@ def _make_standins() -> Dict[str, types.ModuleType]:
     for fn in ("exp", "log", "sqrt", "sin", "cos", "tan", "fabs", "tanh"):
         setattr(cas, fn, _elementwise(fn))
     cas.if_else = symtrace.if_else
+    cas.inv = np.linalg.inv      # numeric weights only (Ex_ENMPC.py:171: inv(Q) of a constant matrix)
     cas.__all__ = [k for k in vars(cas) if not k.startswith("_")]
     tools = types.ModuleType("casadi.tools")
     tools.__all__ = []
     cas.tools = tools
     util = types.ModuleType("Utilities")
-    util.__all__ = []
+
+    def xQx(x, Q):      # reference Utilities.py:247-265: the quadratic form x'Qx (the economic example's estimator cost uses it)
+        return symtrace_mtimes(x.T if hasattr(x, "T") else x, symtrace_mtimes(np.asarray(Q, dtype=np.float64), x))
+    util.xQx = xQx
+    util.__all__ = ["xQx"]
     past = types.ModuleType("past")
     putils = types.ModuleType("past.utils")
     putils.old_div = _old_div
