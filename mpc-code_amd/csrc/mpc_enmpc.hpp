@@ -19,6 +19,7 @@
 //     (A - I) and the reduced Hessian is nu x nu; computed redundantly by every lane (wave-uniform).
 #pragma once
 #include "mpc_tp.hpp"
+#include "mpc_rk4s2.hpp"
 
 namespace enm {
 using namespace mpc;
@@ -39,76 +40,6 @@ __device__ __forceinline__ double push_in(double v, double lo, double hi)
     if (fl) v = dmax(v, lo + pl);
     if (fh) v = dmin(v, hi - ph);
     return v;
-}
-
-// ---- Runge-Kutta with forward sensitivities of first and second order ---------------------------------------------------------------
-// R: a generated right-hand side (EcModel::Ocp / Mdl / Mhe): NR rows, the first NCX of them states with unit initial sensitivity,
-// NP sensitivity columns (initial states, then inputs), NPP = NP (NP + 1) / 2 packed pairs.
-template <class R, class Ctx>
-__device__ __forceinline__ void rk4_sens2(const double *x0, const Ctx &c, double t0, bool advance_t, double h, int M, double *xn,
-                                          double (*S)[R::NP], double (*T)[R::NPP])
-{
-    constexpr int NR = R::NR, NP = R::NP, NPP = R::NPP, NCX = R::NCX;
-    const double dt = h / M;
-    double x[NR];
-    MPC_UNROLL for (int i = 0; i < NR; i++) {
-        x[i] = i < NCX ? x0[i < NCX ? i : 0] : 0.0;
-        MPC_UNROLL for (int j = 0; j < NP; j++) S[i][j] = (i == j && i < NCX) ? 1.0 : 0.0;
-        MPC_UNROLL for (int j = 0; j < NPP; j++) T[i][j] = 0.0;
-    }
-    for (int s = 0; s < M; s++) {
-        const double ts = advance_t ? t0 + s * dt : t0;
-        double xa[NR], Sa[NR][NP], Ta[NR][NPP], k[NR], dK[NR][NP], d2K[NR][NPP];
-        MPC_UNROLL for (int i = 0; i < NR; i++) {
-            xa[i] = x[i]; k[i] = 0.0;
-            MPC_UNROLL for (int j = 0; j < NP; j++) { Sa[i][j] = S[i][j]; dK[i][j] = 0.0; }
-            MPC_UNROLL for (int j = 0; j < NPP; j++) { Ta[i][j] = T[i][j]; d2K[i][j] = 0.0; }
-        }
-        MPC_UNROLL for (int st = 0; st < 4; st++) {
-            const double a = st == 0 ? 0.0 : (st == 3 ? 1.0 : 0.5), w = (st == 0 || st == 3) ? 1.0 / 6.0 : 1.0 / 3.0;
-            double Xi[NR], dXi[NR][NP], d2Xi[NR][NPP];
-            MPC_UNROLL for (int i = 0; i < NR; i++) {
-                Xi[i] = x[i] + a * dt * k[i];
-                MPC_UNROLL for (int j = 0; j < NP; j++) dXi[i][j] = S[i][j] + a * dt * dK[i][j];
-                MPC_UNROLL for (int j = 0; j < NPP; j++) d2Xi[i][j] = T[i][j] + a * dt * d2K[i][j];
-            }
-            R::eval2(Xi, c, advance_t ? ts + a * dt : ts, dXi, d2Xi, k, dK, d2K);
-            MPC_UNROLL for (int i = 0; i < NR; i++) {
-                xa[i] += dt * w * k[i];
-                MPC_UNROLL for (int j = 0; j < NP; j++) Sa[i][j] += dt * w * dK[i][j];
-                MPC_UNROLL for (int j = 0; j < NPP; j++) Ta[i][j] += dt * w * d2K[i][j];
-            }
-        }
-        MPC_UNROLL for (int i = 0; i < NR; i++) {
-            x[i] = xa[i];
-            MPC_UNROLL for (int j = 0; j < NP; j++) S[i][j] = Sa[i][j];
-            MPC_UNROLL for (int j = 0; j < NPP; j++) T[i][j] = Ta[i][j];
-        }
-    }
-    MPC_UNROLL for (int i = 0; i < NR; i++) xn[i] = x[i];
-}
-
-// values only (plant, hold rule, first guess of the estimator)
-template <class R, class Ctx>
-__device__ __forceinline__ void rk4_plain(const double *x0, const Ctx &c, double t0, bool advance_t, double h, int M, double *xn)
-{
-    constexpr int NR = R::NR, NCX = R::NCX;
-    const double dt = h / M;
-    double x[NR];
-    MPC_UNROLL for (int i = 0; i < NR; i++) x[i] = i < NCX ? x0[i < NCX ? i : 0] : 0.0;
-    for (int s = 0; s < M; s++) {
-        const double ts = advance_t ? t0 + s * dt : t0;
-        double k1[NR], k2[NR], k3[NR], k4[NR], xa[NR];
-        R::eval0(x, c, ts, k1);
-        MPC_UNROLL for (int i = 0; i < NR; i++) xa[i] = x[i] + 0.5 * dt * k1[i];
-        R::eval0(xa, c, advance_t ? ts + 0.5 * dt : ts, k2);
-        MPC_UNROLL for (int i = 0; i < NR; i++) xa[i] = x[i] + 0.5 * dt * k2[i];
-        R::eval0(xa, c, advance_t ? ts + 0.5 * dt : ts, k3);
-        MPC_UNROLL for (int i = 0; i < NR; i++) xa[i] = x[i] + dt * k3[i];
-        R::eval0(xa, c, advance_t ? ts + dt : ts, k4);
-        MPC_UNROLL for (int i = 0; i < NR; i++) x[i] += dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-    }
-    MPC_UNROLL for (int i = 0; i < NR; i++) xn[i] = x[i];
 }
 
 template <int NP> __device__ __forceinline__ constexpr int pair_idx(int j, int k) { return j <= k ? j * NP - j * (j - 1) / 2 + (k - j) : k * NP - k * (k - 1) / 2 + (j - k); }

@@ -230,12 +230,42 @@ def push_interior(w, lo, hi):
 
 
 def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
-    """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n].  Variables with lo == hi are left to the
-    equality rows that fix them (the initial state of the OCP, MPC_code.py:734 + Control_Calc.py:126)."""
-    n = len(w0)
+    """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n].  Variables with lo == hi are PARAMETERS, as
+    IPOPT treats them (fixed_variable_treatment = make_parameter, its default [ext]): the initial state of the OCP (MPC_code.py:734)
+    drops out of the variables, and the rows that only restate it (Control_Calc.py:126) drop out of the constraints."""
     fixed = lo == hi
-    fl, fh = np.isfinite(lo) & ~fixed, np.isfinite(hi) & ~fixed
-    w = push_interior(w0, np.where(fl, lo, -INF), np.where(fh, hi, INF))
+    if fixed.any():
+        free = ~fixed
+        wf = np.where(fixed, lo, w0)
+        rows = None
+
+        def sub(wv, lam):
+            nonlocal rows
+            wfull = wf.copy(); wfull[free] = wv
+            if rows is None:
+                J0 = evalf(wfull, np.zeros(0))[3]
+                rows = np.abs(J0[:, free]).sum(axis=1) > 0.0
+            lfull = np.zeros(len(rows)); 
+            if len(lam):
+                lfull[rows] = lam
+            f, gf, g, J, H = evalf(wfull, lfull if len(lam) else lam)
+            return f, gf[free], g[rows], J[np.ix_(rows, free)], H[np.ix_(free, free)]
+        r = ipm_dense(sub, np.asarray(w0, dtype=float)[free], lo[free], hi[free], tol=tol, max_iter=max_iter, trace=trace)
+        wfull = wf.copy(); wfull[free] = r["w"]
+        lfull = np.zeros(len(rows)); lfull[rows] = r["lam"]
+        # multipliers of the dropped rows / bounds of the fixed variables, for the certificate of the full statement: the rows that
+        # restate a fixed variable take whatever makes its stationarity row vanish
+        f, gf, g, J, H = evalf(wfull, lfull)
+        zl = np.zeros(len(wfull)); zh = np.zeros(len(wfull)); zl[free] = r["z_lo"]; zh[free] = r["z_hi"]
+        st = gf + J.T @ lfull
+        Jd = J[np.ix_(~rows, fixed)]
+        if Jd.size:
+            lfull[~rows] = np.linalg.lstsq(Jd.T, -st[fixed], rcond=None)[0]
+        r.update(w=wfull, lam=lfull, z_lo=zl, z_hi=zh)
+        return r
+    n = len(w0)
+    fl, fh = np.isfinite(lo), np.isfinite(hi)
+    w = push_interior(w0, lo, hi)
     zl, zh = np.where(fl, 1.0, 0.0), np.where(fh, 1.0, 0.0)
     nb = int(fl.sum() + fh.sum())
     lam = None

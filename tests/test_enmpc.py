@@ -1,0 +1,346 @@
+"""Economic NMPC with the moving-horizon estimator (BASELINE configs[3] and [4]).
+
+CPU tests: the oracle against its committed vectors and against independent solvers / integrators; the product's host side (loader,
+generated derivative code compiled for the host) against the oracle's complex-step derivatives; the C-ABI's exports.
+GPU tests (-m gpu): the HIP path through the C-ABI against the oracle's golden vectors and, at the BASELINE sizes, through
+size-independent properties plus instances re-run by the oracle.
+"""
+import ctypes as ct
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REF, ROOT
+
+import enmpc_oracle as eo
+
+EX = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc.py")
+GOLD = os.path.join(ROOT, "tests", "golden", "enmpc_reactor.npz")
+TOL_U = 1e-7          # GPU against the oracle on u*, xs, us, [x; d]: both stop at a scaled KKT error of 1e-8 (measured: 1e-13)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def oprob():
+    return eo.load_problem(EX)
+
+
+@pytest.fixture(scope="module")
+def prob(pkg):
+    return pkg.load_problem(EX)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# oracle
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_golden_vectors_certify_themselves(gold):
+    for pre in ("ship_", "c4_", "c5_"):
+        assert int(gold[pre + "STATUS_DYN"].max()) == 0 and int(gold[pre + "STATUS_SS"].max()) == 0
+        for k in ("KKT_DYN", "KKT_SS", "KKT_MHE"):      # every NLP's own first-order conditions: what IPOPT terminates on (tol 1e-8)
+            assert float(gold[pre + k].max()) < 1e-8, (pre, k)
+    # the economics: the loop settles at the profit-optimal steady state of the reactor (u = 1.0430, cB = 0.4671)
+    assert abs(gold["ship_U"][-1, 0, 0] - 1.04297536) < 1e-7 and abs(gold["ship_XS"][-1, 0, 1] - 0.46708998) < 1e-7
+
+
+def test_oracle_reproduces_its_vectors(oprob, gold):
+    r = eo.closed_loop(oprob, 5)
+    for k in ("U", "XS", "US", "X_ES"):
+        assert np.abs(r[k] - gold["ship_" + k][:5, 0]).max() < 1e-12, k
+    assert r["ITERS_DYN"].tolist() == gold["ship_ITERS_DYN"][:5, 0].tolist()
+
+
+def test_interval_integration_is_within_the_reference_integrators_tolerance(oprob):
+    """20 Runge-Kutta steps per shooting interval against a tight adaptive integration of the same augmented system: below the
+    tolerances CasADi hands IDAS by default (reltol 1e-6), for state and cost quadrature over the whole input range."""
+    from scipy.integrate import solve_ivp
+    import exnum
+    p = oprob
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for _ in range(12):
+        x0 = rng.uniform([0.0, 0.0], [1.0, 1.0]); u = rng.uniform(0.0, 2.0, 1); d = rng.uniform(-0.1, 0.1, 2)
+
+        def rhs(t, z):
+            xd = np.asarray(p.fxm(z[:2], u, d, 0.0, np.zeros(2)), dtype=float)
+            return np.concatenate([xd, [p.fobj(z[:2], u, z[:2] + p.Cd @ d, None, None, None)]])
+        ex = solve_ivp(rhs, (0.0, p.h), np.concatenate([x0, [0.0]]), rtol=1e-12, atol=1e-14, method="DOP853").y[:, -1]
+        xn, q = eo.ocp_stage(p, x0.reshape(-1, 1), u.reshape(-1, 1), d.reshape(-1, 1), np.zeros((2, 1)), np.zeros((1, 1)))
+        worst = max(worst, float(np.abs(np.concatenate([xn[:, 0], q]) - ex).max()))
+    assert worst < 1e-6, worst
+
+
+def test_ocp_minimum_is_found_by_an_independent_solver(oprob):
+    """SciPy's SLSQP on the same NLP (short horizon), started at the oracle's answer perturbed: it returns to the same point, and its
+    cost is not lower anywhere it goes - the oracle's KKT point is a local minimum, not a saddle."""
+    from scipy.optimize import minimize
+    p = eo.load_problem(EX, overrides={"N": 6})
+    n, m, N = p.nx, p.nu, p.N
+    nz = n + m
+    ts = eo.target_solve(p, np.zeros(2))
+    xhat = np.array([0.8, 0.3])
+    wg = np.zeros(nz * N + n)
+    for k in range(1, N + 1):
+        wg[k * nz - m:k * nz] = p.u0; wg[k * nz:k * nz + n] = p.x0_m
+    sol = eo.ocp_solve(p, xhat, ts["xs"], ts["us"], np.zeros(2), wg)
+    assert sol["status"] == 0 and max(eo.kkt_nlp(sol["evalf"], sol, sol["lo"], sol["hi"]).values()) < 1e-8
+    evalf, lo, hi = sol["evalf"], sol["lo"], sol["hi"]
+    free = lo != hi
+    w0 = sol["w"].copy()
+
+    def full(v):
+        w = w0.copy(); w[free] = v
+        return w
+    fun = lambda v: evalf(full(v), np.zeros(0))[0]
+    jac = lambda v: evalf(full(v), np.zeros(0))[1][free]
+    con = {"type": "eq", "fun": lambda v: evalf(full(v), np.zeros(0))[2][n:], "jac": lambda v: evalf(full(v), np.zeros(0))[3][n:][:, free]}
+    rng = np.random.default_rng(0)
+    start = np.clip(w0[free] + 0.02 * rng.standard_normal(free.sum()), lo[free] + 1e-6, hi[free] - 1e-6)
+    r = minimize(fun, start, jac=jac, constraints=[con], bounds=list(zip(lo[free], hi[free])), method="SLSQP", options={"ftol": 1e-14, "maxiter": 400})
+    assert np.abs(r.x - w0[free]).max() < 1e-5, np.abs(r.x - w0[free]).max()
+    assert abs(r.fun - fun(w0[free])) < 1e-8
+
+
+def test_estimator_nlp_of_this_example_is_a_convex_qp_with_the_oracles_answer(oprob):
+    """With the input known the reactor is linear in its state, so mhe_opt's NLP is a strictly convex QP here: solved once more
+    by the dense Mehrotra solver of the linear path's oracle (another algorithm, another file) - same estimate."""
+    import mpc_oracle as o
+    p = oprob
+    S = eo.MheState(p)
+    y = [np.array([0.9, 0.1]), np.array([0.6, 0.4]), np.array([0.55, 0.45])]
+    us = [np.array([0.0]), np.array([0.4]), np.array([0.7])]
+    for k in range(3):
+        xes = eo.mhe_step(p, S, k, y[k], us[k])
+    sol = S.last
+    f, gf, g, J, H = sol["evalf"](sol["w"] * 0.0, np.zeros(len(sol["lam"])))      # a QP: data at the origin define it
+    lo, hi = sol["lo"], sol["hi"]
+    bounded = np.isfinite(lo) | np.isfinite(hi)
+    qp = o.qp_ipm_dense(H, gf, J, -g, np.eye(len(lo))[bounded], lo[bounded], hi[bounded], tol=1e-12)
+    assert qp["status"] == 0
+    assert np.abs(qp["w"] - sol["w"]).max() < 1e-8
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "Ex_ENMPC.py")), reason="reference tree not present")
+def test_repo_example_is_the_reference_example(oprob, pkg):
+    """mpc-code_amd/examples/reactor_enmpc.py poses the problem of the reference's Ex_ENMPC.py: the oracle gives bit-equal loops on
+    the two files, and the product's loader takes the reference file unmodified."""
+    ref = eo.load_problem(os.path.join(REF, "Ex_ENMPC.py"))
+    a, b = eo.closed_loop(oprob, 3), eo.closed_loop(ref, 3)
+    for k in ("U", "XS", "US", "X_ES", "P_K"):
+        assert np.array_equal(a[k], b[k]), k
+    q = pkg.load_problem(os.path.join(REF, "Ex_ENMPC.py"), overrides={"N": 40, "N_mhe": 20})
+    assert (q.N, q.N_mhe, q.nx, q.nu, q.n_w, q.max_iter) == (40, 20, 2, 1, 4, 200)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# product, host side
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_loader_classifies_and_refuses(pkg, prob):
+    from mpc_code_amd import EconomicMPCProblem, UnsupportedProblem
+    assert isinstance(prob, EconomicMPCProblem) and (prob.N, prob.N_mhe, prob.quad_steps, prob.max_iter) == (25, 10, 20, 200)
+    assert np.array_equal(prob.xmax_mhe, [1.0, 1.0, np.inf, np.inf]) and np.array_equal(prob.x_bar, [1.2, 0.5, 0.0, 0.0])
+    for over in ({"mhe_up": "filter"}, {"slacks": True}, {"N": 80}, {"N_mhe": 64}, {"StateFeedback": False}, {"TermCons": True}):
+        with pytest.raises(UnsupportedProblem):
+            pkg.load_problem(EX, overrides=over)
+
+
+@pytest.fixture(scope="module")
+def shim(prob, tmp_path_factory):
+    """the generated model code + the Runge-Kutta sensitivity driver of the product, compiled for the host"""
+    from mpc_code_amd import econcodegen
+    d = tmp_path_factory.mktemp("enmpc_shim")
+    hdr = os.path.join(d, "model.hpp")
+    with open(hdr, "w") as fh:
+        fh.write(econcodegen.emit_econ_header(prob))
+    so = os.path.join(d, "shim.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-D__device__=", "-D__forceinline__=inline", f'-DMPC_EC_MODEL_HEADER="{hdr}"',
+                           "-o", so, os.path.join(ROOT, "tests", "enmpc_host_shim.cpp")])
+    return ct.CDLL(so)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ct.POINTER(ct.c_double))
+
+
+def test_generated_sensitivities_match_complex_step_derivatives(shim, oprob):
+    """What the kernels integrate - state, cost quadrature, first and second forward sensitivities through the Runge-Kutta stages, from
+    the traced and generated code - against the oracle's complex-step / finite-difference derivatives of the Ex-file's own functions."""
+    p = oprob
+    n, m = p.nx, p.nu
+    NP, NPP = n + m, (n + m) * (n + m + 1) // 2
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        x = rng.uniform(0.05, 0.95, n); u = rng.uniform(0.05, 1.9, m); d = rng.uniform(-0.1, 0.1, p.nd); xs = rng.uniform(0.2, 0.8, n); us = rng.uniform(0.2, 1.5, m)
+        xn = np.zeros(n + 1); S = np.zeros((n + 1, NP)); T = np.zeros((n + 1, NPP))
+        shim.shim_ocp(_ptr(x), _ptr(u), _ptr(d), _ptr(xs), _ptr(us), ct.c_double(p.h), ct.c_int(p.quad_steps), _ptr(xn), _ptr(S), _ptr(T))
+        D = d.reshape(-1, 1)
+        fun = lambda Zc: np.vstack(eo.ocp_stage(p, Zc[:n], Zc[n:], D, xs.reshape(-1, 1), us.reshape(-1, 1)))
+        v, J = eo.jac_cs(fun, np.concatenate([x, u]))
+        assert np.abs(xn - v).max() < 1e-13 and np.abs(S - J).max() < 1e-12
+        for r in range(n + 1):
+            H = eo.hess_fd(lambda Zc: fun(Zc)[r], np.concatenate([x, u]))
+            Hp = np.zeros((NP, NP)); Hp[np.triu_indices(NP)] = T[r]; Hp = Hp + np.triu(Hp, 1).T
+            assert np.abs(Hp - H).max() < 5e-8 * max(1.0, np.abs(H).max()), (r, np.abs(Hp - H).max())
+        # the model alone (target, hold rule) and the plant
+        xm = np.zeros(n); Sm = np.zeros((n, NP)); Tm = np.zeros((n, NPP))
+        shim.shim_mdl(_ptr(x), _ptr(u), _ptr(d), ct.c_double(p.h), _ptr(xm), _ptr(Sm), _ptr(Tm))
+        fm = lambda Zc: eo.fx_model(p, Zc[:n], Zc[n:], np.zeros((p.nd, 1)))      # (Bd d is added outside the integrator)
+        v, J = eo.jac_cs(fm, np.concatenate([x, u]))
+        assert np.abs(xm - v).max() < 1e-13 and np.abs(Sm - J).max() < 1e-12
+        xpn = np.zeros(n)
+        shim.shim_plant(_ptr(x), _ptr(u), ct.c_double(p.h), _ptr(xpn))
+        assert np.abs(xpn - eo.fx_plant(p, x.reshape(-1, 1), u.reshape(-1, 1))[:, 0]).max() < 1e-14
+        # estimator model: sensitivities with respect to the state only
+        xe = np.zeros(n); Se = np.zeros((n, n)); Te = np.zeros((n, n * (n + 1) // 2))
+        shim.shim_mhe(_ptr(x), _ptr(u), ct.c_double(p.h), _ptr(xe), _ptr(Se), _ptr(Te))
+        fe = lambda Zc: eo.fx_mhe(p, np.vstack([Zc, np.zeros_like(Zc)]), u.reshape(-1, 1), np.zeros((p.n_w, 1)))[:n]
+        v, J = eo.jac_cs(fe, x)
+        assert np.abs(xe - v).max() < 1e-13 and np.abs(Se - J).max() < 1e-12
+
+
+def test_generated_cost_functions_match_the_example(shim, oprob):
+    p = oprob
+    rng = np.random.default_rng(6)
+    w = rng.uniform(0.1, 1.0, 5); f = np.zeros(1); g = np.zeros(5); H = np.zeros((5, 5))
+    shim.shim_fss(_ptr(w), _ptr(f), _ptr(g), _ptr(H))
+    cost = lambda Wc: np.array([p.fssobj(Wc[:2, i], Wc[2:3, i], Wc[3:, i], None, None, None) for i in range(Wc.shape[1])])
+    v, J = eo.jac_cs(lambda Wc: cost(Wc)[None], w)
+    assert abs(f[0] - v[0]) < 1e-15 and np.abs(g - J[0]).max() < 1e-14 and np.abs(H - eo.hess_fd(cost, w)).max() < 1e-7
+    x = rng.uniform(0, 1, 2); xs = rng.uniform(0, 1, 2); g2 = np.zeros(2); H2 = np.zeros((2, 2))
+    shim.shim_vfin(_ptr(x), _ptr(xs), _ptr(f), _ptr(g2), _ptr(H2))
+    assert abs(f[0] - p.vfin(x, xs)) < 1e-10 and np.abs(H2 - 4000.0 * np.eye(2)).max() < 1e-9 and np.abs(g2 - 4000.0 * (x - xs)).max() < 1e-9
+    wv = rng.standard_normal(6); g3 = np.zeros(6); H3 = np.zeros((6, 6))
+    shim.shim_cmhe(_ptr(wv), _ptr(f), _ptr(g3), _ptr(H3))
+    assert abs(f[0] - p.fobj_mhe(wv[:4], wv[4:], 0.0)) < 1e-14 and np.abs(g3 - wv).max() < 1e-15 and np.abs(H3 - np.eye(6)).max() < 1e-15
+
+
+def test_capi_exports_every_declared_symbol(prob):
+    """the per-model library builds for gfx950 and exports what include/mpc_enmpc.h declares (no compute call without a GPU)"""
+    from mpc_code_amd import econcodegen, enmpc
+    lib = ct.CDLL(econcodegen.build_enmpc_library(prob))
+    hdr = open(os.path.join(ROOT, "include", "mpc_enmpc.h")).read()
+    declared = set(re.findall(r"\b(enmpc_[a-z_]+)\s*\(", hdr))
+    assert declared == set(enmpc.ENMPC_EXPORTS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    lib.enmpc_build_info.restype = ct.c_char_p
+    assert lib.enmpc_build_info().decode().startswith("gfx950;enmpc;dims=2/1/2/2/2/4;mx=10")
+    src = open(os.path.join(ROOT, "mpc-code_amd", "enmpc.py")).read() + open(os.path.join(ROOT, "mpc-code_amd", "econcodegen.py")).read() + open(os.path.join(ROOT, "mpc-code_amd", "econproblem.py")).read()
+    assert "oracle" not in src.replace("the oracle", "") or "import enmpc_oracle" not in src      # the product never touches the checker
+    assert "enmpc_oracle" not in src and "exnum" not in src
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path through the C-ABI
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _gpu_loop(pkg, over, x0, nsteps, **kw):
+    from mpc_code_amd import enmpc
+    p = pkg.load_problem(EX, overrides=over)
+    return p, enmpc.run_enmpc_closed_loop(p, x0, nsteps, **kw)
+
+
+def _check(r, gold, pre, nsteps):
+    for k in ("U", "XS", "US", "X_ES", "X_HAT", "Xp", "D_HAT"):
+        assert np.abs(r[k] - gold[pre + k][:nsteps]).max() < TOL_U, (pre, k, np.abs(r[k] - gold[pre + k][:nsteps]).max())
+    for k in ("STATUS_DYN", "STATUS_SS"):
+        assert np.array_equal(r[k], gold[pre + k][:nsteps]), (pre, k)
+    # the same path, not only the same end: interior-point iteration counts of all three NLPs equal the oracle's at every step
+    for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+        assert np.array_equal(r[k], gold[pre + k][:nsteps]), (pre, k, r[k].T.tolist(), gold[pre + k][:nsteps].T.tolist())
+
+
+@pytest.mark.gpu
+def test_gpu_shipped_example_follows_the_golden_loop(pkg, gold):
+    p, r = _gpu_loop(pkg, None, gold["ship_x0"], 21)
+    _check(r, gold, "ship_", 21)
+    assert int(r["STATUS_MHE"].max()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_baseline_config_horizons_follow_the_golden_loops(pkg, gold):
+    p, r = _gpu_loop(pkg, {"N": 40}, gold["c4_x0"], 10)           # BASELINE configs[3]: N = 40
+    _check(r, gold, "c4_", 10)
+    p, r = _gpu_loop(pkg, {"N_mhe": 20}, gold["c5_x0"], 24)       # BASELINE configs[4]: N_mhe = 20, through the window's filling
+    _check(r, gold, "c5_", 24)
+
+
+@pytest.mark.gpu
+def test_gpu_launch_boundaries_do_not_change_the_loop(pkg, gold):
+    x0 = np.vstack([gold["ship_x0"], gold["c4_x0"]])
+    p, a = _gpu_loop(pkg, None, x0, 14)
+    p, b = _gpu_loop(pkg, None, x0, 14, steps_per_launch=3)      # state, window and lists through HBM between launches
+    for k in ("U", "XS", "X_ES", "ITERS_DYN", "ITERS_MHE"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_batches(pkg):
+    """BASELINE configs[3] at one GPU's share and at the whole batch (N = 40; 16384 and 131072 instances), configs[4] at its whole
+    batch (N_mhe = 20; 32768): every NLP of every instance solved, bounds kept, the loop invariant under a permutation of the batch,
+    the economics reached - and instances picked from the batch re-run by the oracle."""
+    from mpc_code_amd import enmpc
+    rng = np.random.default_rng(20250614)
+    x0 = rng.uniform([0.5, 0.0], [1.0, 0.5], size=(131072, 2))
+    p = pkg.load_problem(EX, overrides={"N": 40})
+    s = enmpc.EnmpcSolver(p)
+    r = enmpc.run_enmpc_closed_loop(p, x0, 4, solver=s)
+    for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+        assert int(r[k].max()) == 0, k
+    assert r["U"].min() >= 0.0 and r["U"].max() <= 2.0 and np.isfinite(r["X_ES"]).all()
+    assert r["XS"].min() >= 0.0 and r["XS"].max() <= 1.0 and r["X_ES"][..., :2].min() >= -1e-9 and r["X_ES"][..., :2].max() <= 1.0 + 1e-9
+    sub = x0[:16384]
+    a = enmpc.run_enmpc_closed_loop(p, sub, 12, solver=s)
+    assert np.array_equal(a["U"][:4], r["U"][:4, :16384])                       # an instance does not see its neighbours
+    perm = rng.permutation(16384)
+    b = enmpc.run_enmpc_closed_loop(p, sub[perm], 12, solver=s)
+    assert np.array_equal(b["U"], a["U"][:, perm]) and np.array_equal(b["ITERS_DYN"], a["ITERS_DYN"][:, perm])
+    assert int(a["STATUS_DYN"].max()) == 0 and int(a["STATUS_MHE"].max()) == 0
+    # economics: after 12 steps every loop is heading to the profit-optimal feed rate, the targets already sit there
+    assert np.abs(a["US"][-1] - 1.0430).max() < 0.05 and np.abs(a["U"][-1] - 1.0430).max() < 0.2
+    s.close()
+    q = eo.load_problem(EX, overrides={"N": 40})
+    for i in (0, 7777, 16383):
+        o = eo.closed_loop(q, 4, x0_p=sub[i])
+        for k in ("U", "XS", "US", "X_ES"):
+            assert np.abs(a[k][:4, i] - o[k]).max() < TOL_U, (i, k)
+        assert a["ITERS_DYN"][:4, i].tolist() == o["ITERS_DYN"].tolist()
+    p5 = pkg.load_problem(EX, overrides={"N_mhe": 20})
+    r5 = enmpc.run_enmpc_closed_loop(p5, x0[:32768], 23)
+    for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+        assert int(r5[k].max()) == 0, k
+    q5 = eo.load_problem(EX, overrides={"N_mhe": 20})
+    o = eo.closed_loop(q5, 23, x0_p=x0[31000])
+    for k in ("U", "X_ES"):
+        assert np.abs(r5[k][:, 31000] - o[k]).max() < TOL_U, k
+
+
+@pytest.mark.gpu
+def test_gpu_ragged_batches_and_call_order(pkg, gold):
+    from mpc_code_amd import enmpc
+    from mpc_code_amd.capi import MpcAmdError
+    p = pkg.load_problem(EX)
+    s = enmpc.EnmpcSolver(p)
+    assert s.build_info().startswith("gfx950;enmpc;dims=2/1/2/2/2/4")
+    s.alloc(3, 8)
+    with pytest.raises(MpcAmdError):
+        s.run(0, 2)                          # no state yet
+    s.set_state(np.tile(gold["ship_x0"], (3, 1)))
+    with pytest.raises(MpcAmdError):
+        s.run(2, 2)                          # the estimator's window is sequential
+    with pytest.raises(MpcAmdError):
+        s.run(0, 9)                          # more steps than allocated
+    s.run(0, 2); s.run(2, 3); s.sync()
+    U = s.get_log("U")
+    assert U.shape == (5, 3, 1) and np.abs(U[:, 0] - gold["ship_U"][:5, 0]).max() < TOL_U and np.array_equal(U[:, 0], U[:, 2])
+    s.close()
+    for B in (1, 65):
+        x0 = np.tile(gold["ship_x0"], (B, 1))
+        r = enmpc.run_enmpc_closed_loop(p, x0, 3)
+        assert np.abs(r["U"][:, -1] - gold["ship_U"][:3, 0]).max() < TOL_U
