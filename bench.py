@@ -109,6 +109,178 @@ def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
                        f"same warm start, gcc -O3 -march=native -fopenmp built on this host; the reference's own CasADi/IPOPT path is not installable here")
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it (WORLD_SIZE unset): start N copies of this command, one per
+    GPU, with RANK / LOCAL_RANK / WORLD_SIZE and an explicit rendezvous file for the RCCL id (mpc-code_amd/shard.py), wait for them and
+    leave with the worst exit code - this process never touches the GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the
+    ranks already exist: then --gpus must agree with it, a line that says n_gpus != --gpus is never printed."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+        return
+    if args.gpus <= 1:
+        return
+    import subprocess
+    import tempfile
+    fd, rdzv = tempfile.mkstemp(prefix="mpc_amd_rccl_", suffix=".id"); os.close(fd); os.unlink(rdzv)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MPC_AMD_RDZV_FILE=rdzv, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    try:
+        os.unlink(rdzv)
+    except OSError:
+        pass
+    sys.exit(rc)
+
+
+def dry_run(args):
+    """The launch path without a GPU: the ranks meet through the same file rendezvous that carries the RCCL id
+    (shard.exchange_unique_id), every rank leaves a marker, rank 0 reports the ranks it saw."""
+    from mpc_code_amd import shard
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    uid = bytes(range(128))
+    if world > 1:
+        got = shard.exchange_unique_id((lambda: uid) if rank == 0 else None, rank, world, timeout=60.0)
+        assert got == uid
+        base = shard.rendezvous_path()
+        open(f"{base}.rank{rank}", "w").write(os.environ.get("LOCAL_RANK", ""))
+        if rank == 0:
+            t0 = time.time()
+            while not all(os.path.exists(f"{base}.rank{r}") for r in range(world)):
+                if time.time() - t0 > 60.0:
+                    sys.exit("dry run: not every rank arrived")
+                time.sleep(0.01)
+            seen = sorted(int(open(f"{base}.rank{r}").read()) for r in range(world))
+            for r in range(world):
+                os.unlink(f"{base}.rank{r}")
+            os.unlink(base)
+    else:
+        seen = [0]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "local_ranks_seen": seen}), flush=True)
+
+
+ENMPC_CONFIGS = {
+    "enmpc": dict(over={"N": 40}, batch=16384, metric="closed-loop economic NMPC steps/sec over batch, Ex_ENMPC N=40 (BASELINE configs[3])",
+                  what="BASELINE configs[3]: N = 40 (ships 25), N_mhe = 10; 131072 instances over 8 GPUs = 16384 per GPU"),
+    "mhe": dict(over={"N_mhe": 20}, batch=4096, metric="closed-loop MHE + economic NMPC steps/sec over batch, Ex_ENMPC N_mhe=20 (BASELINE configs[4])",
+                what="BASELINE configs[4]: N_mhe = 20 (ships 10), N = 25; 32768 instances over 8 GPUs = 4096 per GPU"),
+}
+FP64_PEAK_TFLOPS = 78.6      # MI355X vector fp64, public spec [ext] (SURVEY.md section 8d)
+
+
+def enmpc_alg(p, it_dyn, it_ss, it_mhe, nw_mean):
+    """Algorithmic bytes and flops per instance-step of the economic loop: bytes = the state a step carries in
+    and out (plant / model state, targets, the estimator's prior, window and covariance lists, the OCP's primal warm start
+    MPC_code.py:764); flops = interior-point iterations x stages x Runge-Kutta stage evaluations x the operations of the generated
+    second-order sensitivity code + the Riccati recursions, from the iteration counts of the run."""
+    ne = p.nx + p.nd
+    state = p.nxp + p.nx + p.nd + p.nu + p.nx + p.nu + ne + 2 * ne * ne + p.n_w + p.ny
+    carried = state + p.nw + p.N_mhe * (p.ny + p.nu) + p.N_mhe * 3 * ne * ne
+    nbytes = 8 * 2 * carried
+    npo, npm = p.nx + p.nu, p.nx
+    rk = lambda rows, cols: 4 * (2 * rows * (1 + cols + cols * (cols + 1) // 2) * 3 + 12 * rows * cols)      # accumulate K, dK, d2K + sparse chain rule, per RK step
+    f_ocp = it_dyn * p.N * (p.quad_steps * rk(p.nx + 1, npo) + 2 * (7 * p.nx ** 3 // 3 + 4 * p.nx ** 2 * p.nu + 2 * p.nx * p.nu ** 2) + 60 * (p.nx + p.nu))
+    f_ss = it_ss * (p.Mx * rk(p.nx, npo) + 2 * (p.nx + p.nu + p.ny) ** 3)
+    f_mhe = it_mhe * nw_mean * (p.Mx * rk(p.nx, npm) + 2 * (7 * ne ** 3 // 3 + 4 * ne * ne * p.n_w + 2 * ne * p.n_w ** 2 + p.n_w ** 3 // 3) + 60 * (ne + p.n_w))
+    return nbytes, float(f_ocp + f_ss + f_mhe)
+
+
+def main_enmpc(args):
+    """BASELINE configs[3] / [4]: the economic example Ex_ENMPC.py (continuous-time cost quadrature, moving-horizon estimator), every NLP
+    of every step solved to its KKT point; instances sharded over the GPUs, one process each (weak scaling), the controls all-gathered
+    through RCCL (the communicator of libmpc_amd.so) inside the timed region."""
+    cfg = ENMPC_CONFIGS[args.config]
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    import mpc_code_amd as m
+    from mpc_code_amd import capi, enmpc, shard
+    K, W = args.steps, args.warmup
+    B = args.batch if args.batch != B_PER_GPU else cfg["batch"]
+    p = m.load_problem(m.example_path("reactor_enmpc.py"), overrides=cfg["over"])
+    s = enmpc.EnmpcSolver(p, device=local_rank)      # raises without the GPU: no CPU fallback
+    comm = csolver = None
+    if world > 1 or args.force_dist:                 # the job's communicator: RCCL inside libmpc_amd.so, on this rank's GPU
+        csolver = capi.Solver(m.load_problem(m.example_path("cstr_lmpc.py")), device=local_rank)
+        comm = shard.RcclComm(csolver, rank, world)
+    rng = np.random.default_rng(SEED)
+    x0 = rng.uniform([0.5, 0.0], [1.0, 0.5], size=(B * world, 2))[rank * B:(rank + 1) * B]
+    ns = max(K, W, 1)
+    s.alloc(B, ns)
+    if W > 0:
+        s.set_state(x0); s.run(0, W); s.sync()
+    times, kms, spent = [], [], 0.0
+    while True:
+        s.set_state(x0)                              # untimed: t = 0 again (cold OCP, empty estimation window)
+        s.sync()
+        if comm is not None:
+            comm.barrier()
+        t0 = time.perf_counter()
+        s.run(0, K); s.sync()
+        if comm is not None:
+            allU = comm.allgather(s.get_log("U")[:K])      # every rank's controls on every rank (RCCL all-gather)
+            comm.barrier()
+        dt = time.perf_counter() - t0
+        if comm is not None:
+            dt = comm.max(dt)
+        times.append(dt); kms.append(s.last_kernel_ms()); spent += dt
+        if (args.repeats > 0 and len(times) >= args.repeats) or (args.repeats == 0 and (spent >= args.min_seconds or len(times) >= 2000)):
+            break
+    dt = float(np.median(times))
+    if comm is not None:
+        assert np.array_equal(allU[rank], s.get_log("U")[:K]), "all-gather of U corrupted the data"
+    if rank == 0:
+        st = {k: s.get_log(k)[:K] for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")}
+        nw_mean = float(np.mean([min(k + 1, p.N_mhe) for k in range(K)]))
+        ab, fl = enmpc_alg(p, float(st["ITERS_DYN"].mean()), float(st["ITERS_SS"].mean()), float(st["ITERS_MHE"].mean()), nw_mean)
+        per_launch_s = float(np.mean(kms)) * 1e-3
+        achieved = ab * B * K / per_launch_s / 1e9
+        tflops = fl * B * K / per_launch_s / 1e12
+        traffic, traffic_src = measured_traffic("enmpc_loop_kernel", B * K, os.path.join(ROOT, "profiles", "r03_enmpc_pmc_summary.json"))
+        out = {"metric": cfg["metric"], "value": B * world * K / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "Ex_ENMPC (isothermal reactor, nx=2,nu=1,ny=2,nd=2; continuous-time economic cost integrated over every shooting interval, "
+                                      "moving-horizon estimator with smoothing update), %s, x0_p~U([0.5,1]x[0,0.5]) seed %d, x0_m=[1.2,0.5], closed loop from t=0: MHE NLP + "
+                                      "target NLP + OCP NLP (each to its KKT point, tol 1e-8 / 1e-10) + plant per step" % (cfg["what"], SEED),
+                          "batch_per_gpu": B, "horizon": p.N, "mhe_horizon": p.N_mhe, "quad_steps": p.quad_steps, "steps_per_launch": K, "repeats": len(times),
+                          "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U inside the timed region" % world,
+                          "rccl_ranks": (csolver.comm_rank()[1] if csolver is not None else 1),
+                          "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            "kernel": "enmpc_loop_kernel (one wave = one instance, lane = stage; all K steps in one launch)", "launches": len(times), "avg_launch_ms": per_launch_s * 1e3,
+                            "alg_bytes_per_step": ab, "instance_steps_per_launch": B * K,
+                            "fp64": {"achieved_tflops": tflops, "peak_tflops": FP64_PEAK_TFLOPS, "frac": tflops / FP64_PEAK_TFLOPS, "alg_flops_per_step": fl},
+                            "note": "the path is bound by fp64 vector issue and dependent-instruction latency (Runge-Kutta sensitivities, Riccati recursion over the lanes), "
+                                    "not by HBM: a launch reads and writes the carried state once and keeps it in registers for its K steps; 'fp64' prices the "
+                                    "algorithmic flops of the run's iteration counts against the vector fp64 peak"},
+               "solver": {"frac_solved_dyn": float((st["STATUS_DYN"] == 0).mean()), "frac_solved_ss": float((st["STATUS_SS"] == 0).mean()), "frac_solved_mhe": float((st["STATUS_MHE"] == 0).mean()),
+                          "mean_iters_dyn": float(st["ITERS_DYN"].mean()), "mean_iters_ss": float(st["ITERS_SS"].mean()), "mean_iters_mhe": float(st["ITERS_MHE"].mean())}}
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import enmpc_oracle as eo
+            q = eo.load_problem(m.example_path("reactor_enmpc.py"), overrides=cfg["over"])
+            t0 = time.perf_counter(); nst = 0; ni = 0
+            while time.perf_counter() - t0 < 12.0:
+                eo.closed_loop(q, 6, x0_p=x0[ni]); nst += 6; ni += 1
+            cpu = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": nst / cpu, "unit": "steps/s", "cores": 1, "kind": "port",
+                                   "sample": "%d instance(s) x 6 closed-loop steps from t=0 of the same workload, %.1f s on one core: oracle/enmpc_oracle.py, a NumPy restatement "
+                                             "(dense interior point, complex-step derivatives) - the checker, not a tuned CPU implementation; the reference's CasADi/IPOPT/IDAS "
+                                             "path is not installable here" % (ni, cpu)}
+        import ctypes
+        sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+    s.close()
+    if csolver is not None:
+        csolver.close()
+
+
 def main_nmpc(args):
     """BASELINE configs[3]: the non-linear CSTR of Ex_NMPC.py with N = 30, EKF, batch 16384 (SURVEY.md 8d cfg 3), one GPU."""
     if int(os.environ.get("WORLD_SIZE", "1")) != 1:
@@ -210,12 +382,19 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="GPU time to spend in timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="create the RCCL communicator even for one rank: exercises the N>1 code path on a 1-GPU box")
-    ap.add_argument("--config", default="lmpc", choices=["lmpc", "nmpc"], help="lmpc: the metric workload (BASELINE configs[1]); nmpc: configs[3], "
-                    "Ex_NMPC N=30, batch 16384, one real-time SQP iteration per step (SURVEY.md 8f rank 1), one GPU")
+    ap.add_argument("--config", default="lmpc", choices=["lmpc", "nmpc", "enmpc", "mhe"], help="lmpc: the metric workload (BASELINE configs[1]); nmpc: "
+                    "configs[2], Ex_NMPC N=30, batch 16384, one real-time SQP iteration per step, one GPU; enmpc: configs[3], Ex_ENMPC N=40, batch "
+                    "16384 per GPU (131072 over 8); mhe: configs[4], Ex_ENMPC with N_mhe=20, batch 4096 per GPU (32768 over 8)")
     ap.add_argument("--max-sqp", type=int, default=1, help="nmpc: SQP iterations per OCP (1 = real-time iteration)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: every rank goes through the rendezvous only and rank 0 prints who was there (launcher test)")
     args = ap.parse_args()
+    launch_ranks(args)                # --gpus N without a launcher: N child processes, one per GPU (before anything here touches the GPU)
+    if args.dry_run:
+        return dry_run(args)
     if args.config == "nmpc":
         return main_nmpc(args)
+    if args.config in ("enmpc", "mhe"):
+        return main_enmpc(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -294,6 +473,7 @@ def main():
                                    "closed loop from t=0: Kalman filter + target QP + OCP (Riccati-PDIP) + plant per step" % (B, SEED),
                        "batch_per_gpu": B, "horizon": prob.N, "steps_per_launch": K / max(n_launch, 1), "loop_kernel": KERNEL_NAMES[loop_kernel],
                        "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U (mpc_allgather_log) inside the timed region" % world,
+                       "rccl_ranks": (solver.comm_rank()[1] if use_dist else 1),
                        "repeats": len(times), "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

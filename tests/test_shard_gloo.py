@@ -98,3 +98,22 @@ def test_shard_bounds_cover_the_batch():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launcher_starts_one_rank_per_gpu_and_refuses_a_mismatch():
+    """``bench.py --gpus N`` without a launcher starts N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE, an explicit rendezvous file), and
+    under a launcher it refuses a WORLD_SIZE that disagrees with --gpus: a line whose n_gpus differs from --gpus is never printed.
+    ``--dry-run`` takes the ranks through the same file rendezvous that carries the RCCL id, without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPC_AMD_RDZV_FILE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"dry_run": True, "n_gpus": 4, "gpus_arg": 4, "local_ranks_seen": [0, 1, 2, 3]}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="8", RANK="0"), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=8" in r.stderr and r.stdout.strip() == ""
+    # without a GPU a real run fails loudly in every rank and the launcher passes the failure on (no CPU fallback, no line)
+    from conftest import gpu_available
+    if not gpu_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and '"metric"' not in r.stdout
