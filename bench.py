@@ -180,15 +180,16 @@ def enmpc_alg(p, it_dyn, it_ss, it_mhe, nw_mean):
     MPC_code.py:764); flops = interior-point iterations x stages x Runge-Kutta stage evaluations x the operations of the generated
     second-order sensitivity code + the Riccati recursions, from the iteration counts of the run."""
     ne = p.nx + p.nd
-    state = p.nxp + p.nx + p.nd + p.nu + p.nx + p.nu + ne + 2 * ne * ne + p.n_w + p.ny
-    carried = state + p.nw + p.N_mhe * (p.ny + p.nu) + p.N_mhe * 3 * ne * ne
-    nbytes = 8 * 2 * carried
+    st_mhe = p.nxp + p.nx + p.nd + p.nu + ne + 2 * ne * ne + p.n_w + p.ny + p.N_mhe * (p.ny + p.nu) + p.N_mhe * 3 * ne * ne      # + window, covariance lists
+    st_tgt = p.nd + 2 * (p.nx + p.nu)
+    st_ocp = p.nxp + p.nx + p.nd + p.nu + 2 * (p.nx + p.nu) + p.nw                                                            # + primal warm start
     npo, npm = p.nx + p.nu, p.nx
     rk = lambda rows, cols: 4 * (2 * rows * (1 + cols + cols * (cols + 1) // 2) * 3 + 12 * rows * cols)      # accumulate K, dK, d2K + sparse chain rule, per RK step
     f_ocp = it_dyn * p.N * (p.quad_steps * rk(p.nx + 1, npo) + 2 * (7 * p.nx ** 3 // 3 + 4 * p.nx ** 2 * p.nu + 2 * p.nx * p.nu ** 2) + 60 * (p.nx + p.nu))
     f_ss = it_ss * (p.Mx * rk(p.nx, npo) + 2 * (p.nx + p.nu + p.ny) ** 3)
     f_mhe = it_mhe * nw_mean * (p.Mx * rk(p.nx, npm) + 2 * (7 * ne ** 3 // 3 + 4 * ne * ne * p.n_w + 2 * ne * p.n_w ** 2 + p.n_w ** 3 // 3) + 60 * (ne + p.n_w))
-    return nbytes, float(f_ocp + f_ss + f_mhe)
+    b = [16 * st_mhe, 16 * st_tgt, 16 * st_ocp]      # in and out, 8 bytes each
+    return [(b[0], float(f_mhe)), (b[1], float(f_ss)), (b[2], float(f_ocp)), (sum(b), float(f_ocp + f_ss + f_mhe))]      # estimator, target, OCP kernels; all in one
 
 
 def main_enmpc(args):
@@ -211,9 +212,12 @@ def main_enmpc(args):
     x0 = rng.uniform([0.5, 0.0], [1.0, 0.5], size=(B * world, 2))[rank * B:(rank + 1) * B]
     ns = max(K, W, 1)
     s.alloc(B, ns)
+    kern = s.get_kernel()
+    if kern == 2:
+        s.time_kernels(True)                         # every launch of the split pipeline between HIP events on the library's stream
     if W > 0:
         s.set_state(x0); s.run(0, W); s.sync()
-    times, kms, spent = [], [], 0.0
+    times, kms, pms, spent = [], [], [], 0.0
     while True:
         s.set_state(x0)                              # untimed: t = 0 again (cold OCP, empty estimation window)
         s.sync()
@@ -228,6 +232,8 @@ def main_enmpc(args):
         if comm is not None:
             dt = comm.max(dt)
         times.append(dt); kms.append(s.last_kernel_ms()); spent += dt
+        if kern == 2:
+            pms.append(s.phase_ms()[0])
         if (args.repeats > 0 and len(times) >= args.repeats) or (args.repeats == 0 and (spent >= args.min_seconds or len(times) >= 2000)):
             break
     dt = float(np.median(times))
@@ -236,26 +242,38 @@ def main_enmpc(args):
     if rank == 0:
         st = {k: s.get_log(k)[:K] for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")}
         nw_mean = float(np.mean([min(k + 1, p.N_mhe) for k in range(K)]))
-        ab, fl = enmpc_alg(p, float(st["ITERS_DYN"].mean()), float(st["ITERS_SS"].mean()), float(st["ITERS_MHE"].mean()), nw_mean)
-        per_launch_s = float(np.mean(kms)) * 1e-3
-        achieved = ab * B * K / per_launch_s / 1e9
-        tflops = fl * B * K / per_launch_s / 1e12
-        traffic, traffic_src = measured_traffic("enmpc_loop_kernel", B * K, os.path.join(ROOT, "profiles", "r03_enmpc_pmc_summary.json"))
+        parts = enmpc_alg(p, float(st["ITERS_DYN"].mean()), float(st["ITERS_SS"].mean()), float(st["ITERS_MHE"].mean()), nw_mean)
+        if kern == 2:      # the dominant kernel of the split pipeline: one launch = one phase of one step of every instance
+            share = np.mean(pms, axis=0)
+            j = int(np.argmax(share))
+            kname = ("enmpc_mhe_kernel", "enmpc_target_kernel", "enmpc_ocp_kernel")[j]
+            kdesc = ("%s (split pipeline: per step one launch for the estimator, one for the target - lane = instance - and one for OCP + plant; estimator and OCP with one "
+                     "wave per instance, lane = stage, Riccati recursion over the lanes; device time by phase: estimator %.0f %%, target %.0f %%, OCP + plant %.0f %%)"
+                     % (kname, *(100.0 * share / share.sum())))
+            ab, fl = parts[j]
+            per_launch_s, units, launches = float(share[j]) / K * 1e-3, B, K * len(times)
+        else:
+            kname, kdesc = "enmpc_loop_kernel", "enmpc_loop_kernel (one wave = one instance, lane = stage; every phase of all K steps in one launch)"
+            ab, fl = parts[3]
+            per_launch_s, units, launches = float(np.mean(kms)) * 1e-3, B * K, len(times)
+        achieved = ab * units / per_launch_s / 1e9
+        tflops = fl * units / per_launch_s / 1e12
+        traffic, traffic_src = measured_traffic(kname, units, os.path.join(ROOT, "profiles", "r03_%s_pmc_summary.json" % args.config))
         out = {"metric": cfg["metric"], "value": B * world * K / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "Ex_ENMPC (isothermal reactor, nx=2,nu=1,ny=2,nd=2; continuous-time economic cost integrated over every shooting interval, "
                                       "moving-horizon estimator with smoothing update), %s, x0_p~U([0.5,1]x[0,0.5]) seed %d, x0_m=[1.2,0.5], closed loop from t=0: MHE NLP + "
                                       "target NLP + OCP NLP (each to its KKT point, tol 1e-8 / 1e-10) + plant per step" % (cfg["what"], SEED),
-                          "batch_per_gpu": B, "horizon": p.N, "mhe_horizon": p.N_mhe, "quad_steps": p.quad_steps, "steps_per_launch": K, "repeats": len(times),
+                          "batch_per_gpu": B, "horizon": p.N, "mhe_horizon": p.N_mhe, "quad_steps": p.quad_steps, "steps_per_run": K, "kernel": kern, "repeats": len(times),
                           "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U inside the timed region" % world,
                           "rccl_ranks": (csolver.comm_rank()[1] if csolver is not None else 1),
                           "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                            "kernel": "enmpc_loop_kernel (one wave = one instance, lane = stage; all K steps in one launch)", "launches": len(times), "avg_launch_ms": per_launch_s * 1e3,
-                            "alg_bytes_per_step": ab, "instance_steps_per_launch": B * K,
+                            "kernel": kdesc, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
+                            "alg_bytes_per_step": ab, "instance_steps_per_launch": units, "device_ms_per_run": float(np.mean(kms)),
                             "fp64": {"achieved_tflops": tflops, "peak_tflops": FP64_PEAK_TFLOPS, "frac": tflops / FP64_PEAK_TFLOPS, "alg_flops_per_step": fl},
                             "note": "the path is bound by fp64 vector issue and dependent-instruction latency (Runge-Kutta sensitivities, Riccati recursion over the lanes), "
-                                    "not by HBM: a launch reads and writes the carried state once and keeps it in registers for its K steps; 'fp64' prices the "
+                                    "not by HBM: 'achieved' prices the state the priced kernel carries in and out per instance-step (DESIGN.md section 10), 'fp64' the "
                                     "algorithmic flops of the run's iteration counts against the vector fp64 peak"},
                "solver": {"frac_solved_dyn": float((st["STATUS_DYN"] == 0).mean()), "frac_solved_ss": float((st["STATUS_SS"] == 0).mean()), "frac_solved_mhe": float((st["STATUS_MHE"] == 0).mean()),
                           "mean_iters_dyn": float(st["ITERS_DYN"].mean()), "mean_iters_ss": float(st["ITERS_SS"].mean()), "mean_iters_mhe": float(st["ITERS_MHE"].mean())}}

@@ -59,10 +59,21 @@ int enmpc_set_state(enmpc_handle *h, const double *x_p, const double *xhat, cons
 /* steps [k0, k0+nsteps) of every instance in one launch; k0 must continue where the last run ended (0 after enmpc_set_state); asynchronous */
 int enmpc_run(enmpc_handle *h, int32_t k0, int32_t nsteps);
 int enmpc_sync(enmpc_handle *h);
+/* which kernels enmpc_run launches: 1 = one launch for all steps (one wave per instance, lane = stage of the horizon, every phase in it:
+ * the instance's state stays in registers); 2 = split pipeline, per step one launch for the estimator (wave = instance), one for the target
+ * (lane = instance: the target problem is serial per instance) and one for OCP + plant (wave = instance); 0 = auto: 1 while one round of
+ * waves holds the batch (four instances per CU: 1024 on an MI355X), 2 beyond.  Same results either way.  enmpc_get_kernel: the one in force */
+int enmpc_set_kernel(enmpc_handle *h, int32_t kernel);
+int enmpc_get_kernel(enmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT","X_ES" (the estimator's corrected [x; d]);
  * [nsteps][B] int32: "STATUS_DYN","STATUS_SS","STATUS_MHE","ITERS_DYN","ITERS_SS","ITERS_MHE" (interior-point iterations) */
 int enmpc_get_log(enmpc_handle *h, const char *name, void *out);
 float enmpc_last_kernel_ms(enmpc_handle *h);      /* device time of the last enmpc_run, HIP events on the library's stream */
+/* split pipeline (kernel 2): with enmpc_time_kernels(h, 1) every launch of the following runs is bracketed by HIP events on the library's
+ * stream; enmpc_phase_ms returns, for the last run, the summed device time of the estimator, target and OCP + plant kernels (ms3[0..2]) and
+ * the number of launches of each (= its steps; 0 when kernel 1 ran or timing is off) */
+int enmpc_time_kernels(enmpc_handle *h, int32_t on);
+int enmpc_phase_ms(enmpc_handle *h, float *ms3, int32_t *launches);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ from . import econcodegen
 from .capi import MpcAmdError
 
 ENMPC_EXPORTS = ("enmpc_create", "enmpc_destroy", "enmpc_last_error", "enmpc_build_info", "enmpc_alloc", "enmpc_set_state", "enmpc_run",
-                 "enmpc_sync", "enmpc_get_log", "enmpc_last_kernel_ms")
+                 "enmpc_sync", "enmpc_get_log", "enmpc_last_kernel_ms", "enmpc_set_kernel", "enmpc_get_kernel", "enmpc_time_kernels",
+                 "enmpc_phase_ms")
 
 _dp = ct.POINTER(ct.c_double)
 
@@ -46,6 +47,10 @@ def load_enmpc_library(path: str) -> ct.CDLL:
     lib.enmpc_sync.argtypes = [vp]
     lib.enmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
     lib.enmpc_last_kernel_ms.argtypes = [vp]; lib.enmpc_last_kernel_ms.restype = ct.c_float
+    lib.enmpc_set_kernel.argtypes = [vp, ct.c_int32]
+    lib.enmpc_get_kernel.argtypes = [vp]
+    lib.enmpc_time_kernels.argtypes = [vp, ct.c_int32]
+    lib.enmpc_phase_ms.argtypes = [vp, ct.POINTER(ct.c_float), ct.POINTER(ct.c_int32)]
     _libs[path] = lib
     return lib
 
@@ -127,6 +132,22 @@ class EnmpcSolver:
     def sync(self):
         self._chk(self.lib.enmpc_sync(self.h), "enmpc_sync")
 
+    def set_kernel(self, kernel: int):
+        """0 auto, 1 one launch for all steps, 2 split pipeline (one launch per phase and step)"""
+        self._chk(self.lib.enmpc_set_kernel(self.h, int(kernel)), "enmpc_set_kernel")
+
+    def get_kernel(self) -> int:
+        return int(self.lib.enmpc_get_kernel(self.h))
+
+    def time_kernels(self, on: bool = True):
+        self._chk(self.lib.enmpc_time_kernels(self.h, int(bool(on))), "enmpc_time_kernels")
+
+    def phase_ms(self):
+        """(estimator, target, OCP + plant) device milliseconds of the last run and the launches of each (split pipeline, timing on)"""
+        ms, n = (ct.c_float * 3)(), ct.c_int32(0)
+        self._chk(self.lib.enmpc_phase_ms(self.h, ms, ct.byref(n)), "enmpc_phase_ms")
+        return [float(v) for v in ms], int(n.value)
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.enmpc_last_kernel_ms(self.h))
 
@@ -143,7 +164,8 @@ class EnmpcSolver:
         return out
 
 
-def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, steps_per_launch: int = 0, solver: Optional[EnmpcSolver] = None):
+def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, steps_per_launch: int = 0, solver: Optional[EnmpcSolver] = None,
+                          kernel: Optional[int] = None):
     """The closed loop of the reference for B instances (rows of ``x0_p``); model state, input and the estimator's prior start from the
     Ex-file's ``x0_m``, ``u0``, ``x_bar``.  Returns the reference's result arrays ``[nsteps, B, dim]`` plus status / iteration words."""
     p = problem
@@ -152,6 +174,8 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
     s = solver or EnmpcSolver(p, device=device)
     try:
         s.alloc(len(x0_p), nsteps)
+        if kernel is not None:
+            s.set_kernel(kernel)
         s.set_state(x0_p)
         spl = steps_per_launch if steps_per_launch > 0 else nsteps
         for k0 in range(0, nsteps, spl):

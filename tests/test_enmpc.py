@@ -257,27 +257,32 @@ def _check(r, gold, pre, nsteps):
 
 
 @pytest.mark.gpu
-def test_gpu_shipped_example_follows_the_golden_loop(pkg, gold):
-    p, r = _gpu_loop(pkg, None, gold["ship_x0"], 21)
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_gpu_shipped_example_follows_the_golden_loop(pkg, gold, kernel):
+    p, r = _gpu_loop(pkg, None, gold["ship_x0"], 21, kernel=kernel)
     _check(r, gold, "ship_", 21)
     assert int(r["STATUS_MHE"].max()) == 0
 
 
 @pytest.mark.gpu
-def test_gpu_baseline_config_horizons_follow_the_golden_loops(pkg, gold):
-    p, r = _gpu_loop(pkg, {"N": 40}, gold["c4_x0"], 10)           # BASELINE configs[3]: N = 40
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_gpu_baseline_config_horizons_follow_the_golden_loops(pkg, gold, kernel):
+    p, r = _gpu_loop(pkg, {"N": 40}, gold["c4_x0"], 10, kernel=kernel)           # BASELINE configs[3]: N = 40
     _check(r, gold, "c4_", 10)
-    p, r = _gpu_loop(pkg, {"N_mhe": 20}, gold["c5_x0"], 24)       # BASELINE configs[4]: N_mhe = 20, through the window's filling
+    p, r = _gpu_loop(pkg, {"N_mhe": 20}, gold["c5_x0"], 24, kernel=kernel)       # BASELINE configs[4]: N_mhe = 20, through the window's filling
     _check(r, gold, "c5_", 24)
 
 
 @pytest.mark.gpu
-def test_gpu_launch_boundaries_do_not_change_the_loop(pkg, gold):
+def test_gpu_launch_boundaries_and_launch_styles_do_not_change_the_loop(pkg, gold):
     x0 = np.vstack([gold["ship_x0"], gold["c4_x0"]])
-    p, a = _gpu_loop(pkg, None, x0, 14)
-    p, b = _gpu_loop(pkg, None, x0, 14, steps_per_launch=3)      # state, window and lists through HBM between launches
-    for k in ("U", "XS", "X_ES", "ITERS_DYN", "ITERS_MHE"):
-        assert np.array_equal(a[k], b[k]), k
+    p, a = _gpu_loop(pkg, None, x0, 14, kernel=1)                # one launch for all steps: the state stays in registers
+    p, b = _gpu_loop(pkg, None, x0, 14, steps_per_launch=3, kernel=1)      # state, window and lists through HBM between launches
+    p, c = _gpu_loop(pkg, None, x0, 14, kernel=2)                # split pipeline: a launch per phase and step, target with lane = instance
+    for k in ("U", "XS", "US", "X_ES", "X_HAT", "Xp", "D_HAT", "ITERS_DYN", "ITERS_SS", "ITERS_MHE", "STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    for k in ("U", "XS", "X_ES"):
+        assert np.abs(c[k][:, 0] - gold["ship_" + k][:14, 0]).max() < TOL_U, k
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box: bench line (the driver's command), rocprofv3 kernel trace of the same workload, PMC passes (each on
-# its own, bounded).   bash tools/profile_round.sh [round tag, default r02] [nmpc]     (writes under gpurun_out/prof/; copy into profiles/)
+# its own, bounded).   bash tools/profile_round.sh [round tag, default r02] [nmpc|enmpc|mhe]     (writes under gpurun_out/prof/; copy into profiles/)
 # With "nmpc": the non-linear workload (bench.py --config nmpc), files <tag>_nmpc_*; its dominant kernel is the wave-style launch of the
 # split pipeline, one launch = one step of every instance.
 set -u
@@ -20,6 +20,22 @@ if [ "${2:-}" = "nmpc" ]; then
     find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/${TAG}_nmpc_kernel_stats.csv"
     python3 tools/pmc_summary.py nmpc_loop_kernel_wv "$OUT/${TAG}_nmpc_pmc_summary.json" 16384 "$CMD" "$OUT"/pmc_* > /dev/null 2>&1; head -c 1500 "$OUT/${TAG}_nmpc_pmc_summary.json"
     head -5 "$OUT/${TAG}_nmpc_kernel_stats.csv"
+    exit 0
+fi
+if [ "${2:-}" = "enmpc" ] || [ "${2:-}" = "mhe" ]; then      # the economic workloads (bench.py --config enmpc | mhe), files <tag>_<config>_*
+    CFG=$2; OUT=$OUT/$CFG; rm -rf "$OUT"; mkdir -p "$OUT"
+    timeout 600 python3 bench.py --config $CFG --steps 20 --warmup 2 > "$OUT/${TAG}_${CFG}_bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -c 600 "$OUT/${TAG}_${CFG}_bench.json"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --config $CFG --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
+    CMD="python3 bench.py --config $CFG --steps 20 --warmup 0 --repeats 2 --no-cpu-baseline"
+    for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"; do
+        tag=$(echo $pass | cut -d' ' -f1)
+        timeout 180 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$tag" -- $CMD > "$OUT/pmc_$tag.log" 2>&1; echo "pmc $tag rc=$?"
+    done
+    find "$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/${TAG}_${CFG}_kernel_stats.csv"
+    B=16384; [ "$CFG" = "mhe" ] && B=4096
+    KERN=$(python3 -c "import json,sys; print(json.load(open('$OUT/${TAG}_${CFG}_bench.json'))['roofline']['kernel'].split()[0])")
+    python3 tools/pmc_summary.py $KERN "$OUT/${TAG}_${CFG}_pmc_summary.json" $B "$CMD" "$OUT"/pmc_* > /dev/null 2>&1; head -c 1200 "$OUT/${TAG}_${CFG}_pmc_summary.json"
+    head -6 "$OUT/${TAG}_${CFG}_kernel_stats.csv"
     exit 0
 fi
 rm -rf "$OUT"; mkdir -p "$OUT"
