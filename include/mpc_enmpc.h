@@ -62,7 +62,9 @@ int enmpc_sync(enmpc_handle *h);
 /* which kernels enmpc_run launches: 1 = one launch for all steps (one wave per instance, lane = stage of the horizon, every phase in it:
  * the instance's state stays in registers); 2 = split pipeline, per step one launch for the estimator (wave = instance), one for the target
  * (lane = instance: the target problem is serial per instance) and one for OCP + plant (wave = instance); 0 = auto: 1 while one round of
- * waves holds the batch (four instances per CU: 1024 on an MI355X), 2 beyond.  Same results either way.  enmpc_get_kernel: the one in force */
+ * waves holds the batch (four instances per CU: 1024 on an MI355X), 2 beyond.  In the split pipeline a wave holds 64 / SEG instances side
+ * by side where a horizon fits SEG = 16 or 32 lanes (and the batch has waves to spare); kernel = 16 / 32 / 64 forces the split pipeline with
+ * that SEG.  Same results either way.  enmpc_get_kernel: 1 or 2, the launch style in force */
 int enmpc_set_kernel(enmpc_handle *h, int32_t kernel);
 int enmpc_get_kernel(enmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT","X_ES" (the estimator's corrected [x; d]);

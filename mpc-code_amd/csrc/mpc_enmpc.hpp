@@ -51,10 +51,48 @@ struct StageLin {
     double F[NS], A[NS][NS], B[NS][NU], lx[NS], lu[NU], Q[NS][NS], M[NS][NU], R[NU][NU];
 };
 
-template <int N_> __device__ __forceinline__ void bcast_vec(const double (&v)[N_], int l, double (&o)[N_]) { MPC_UNROLL for (int i = 0; i < N_; i++) o[i] = lane_of(v[i], l); }
-template <int N_> __device__ __forceinline__ void bcast_sym(const double (&v)[N_][N_], int l, double (&o)[N_][N_])
+// ---- segments of a wave: SEG = 64 (one instance per wave), 32 or 16 lanes per instance (two or four instances side by side when the
+// horizon leaves the lanes idle).  k = lane & (SEG - 1) is the stage; everything "uniform" is uniform within a segment. -------------------
+template <int SEG>
+struct Seg {
+    static_assert(SEG == 64 || SEG == 32 || SEG == 16, "segments of 64, 32 or 16 lanes");
+    __device__ static __forceinline__ int stage(int lane) { return lane & (SEG - 1); }
+    // the neighbour stage's value inside the segment: stage 0 (resp. the last) keeps `old`
+    __device__ static __forceinline__ double up1(double old, double v, int k) { const double s = wave_up1(old, v); return (SEG < 64 && k == 0) ? old : s; }
+    __device__ static __forceinline__ double dn1(double old, double v, int k) { const double s = wave_dn1(old, v); return (SEG < 64 && k == SEG - 1) ? old : s; }
+    // stage kk's value to every lane of its segment (kk wave-uniform)
+    __device__ static __forceinline__ double bcast(double v, int kk, int lane)
+    {
+        if (SEG == 64) return lane_of(v, kk);
+        return __shfl(v, (lane & ~(SEG - 1)) + kk);
+    }
+    __device__ static __forceinline__ double max(double v)
+    {
+        if (SEG == 64) return wave_max(v);
+        if (SEG == 32) return half_max(v);
+        v = dmax(v, dpp_move<0xB1, 0xF>(v, v)); v = dmax(v, dpp_move<0x4E, 0xF>(v, v)); v = dmax(v, dpp_move<0x141, 0xF>(v, v)); v = dmax(v, dpp_move<0x140, 0xF>(v, v));
+        return v;
+    }
+    __device__ static __forceinline__ double min(double v) { return -max(-v); }
+    __device__ static __forceinline__ double sum(double v)
+    {
+        if (SEG == 64) return wave_sum(v);
+        if (SEG == 32) return half_sum(v);
+        v += dpp_move<0xB1, 0xF>(0.0, v); v += dpp_move<0x4E, 0xF>(0.0, v); v += dpp_move<0x141, 0xF>(0.0, v); v += dpp_move<0x140, 0xF>(0.0, v);
+        return v;
+    }
+    __device__ static __forceinline__ bool any(bool p, int lane)
+    {
+        if (SEG == 64) return __any(p ? 1 : 0) != 0;
+        const unsigned long long m = __ballot(p ? 1 : 0), segmask = SEG == 32 ? 0xFFFFFFFFull : 0xFFFFull;
+        return ((m >> (lane & ~(SEG - 1))) & segmask) != 0ull;
+    }
+};
+
+template <int SEG, int N_> __device__ __forceinline__ void bcast_vec(const double (&v)[N_], int kk, int lane, double (&o)[N_]) { MPC_UNROLL for (int i = 0; i < N_; i++) o[i] = Seg<SEG>::bcast(v[i], kk, lane); }
+template <int SEG, int N_> __device__ __forceinline__ void bcast_sym(const double (&v)[N_][N_], int kk, int lane, double (&o)[N_][N_])
 {
-    MPC_UNROLL for (int i = 0; i < N_; i++) { MPC_UNROLL for (int j = i; j < N_; j++) { const double a = lane_of(v[i][j], l); o[i][j] = a; o[j][i] = a; } }
+    MPC_UNROLL for (int i = 0; i < N_; i++) { MPC_UNROLL for (int j = i; j < N_; j++) { const double a = Seg<SEG>::bcast(v[i][j], kk, lane); o[i][j] = a; o[j][i] = a; } }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -66,13 +104,15 @@ template <int N_> __device__ __forceinline__ void bcast_sym(const double (&v)[N_
 // lin(xk, u, pi, L): this lane's stage linearised; term(xn, gv, Hv): terminal cost at this lane's x_{k+1} (used from lane N-1).
 // u / xn come in as the first guess (pushed into the box here) and leave as the final iterate.  Returns the status.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NS, int NU, bool FREE0, class LinF, class TermF>
-__device__ __forceinline__ int ipm_stage(const int N, const int lane, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
+template <int NS, int NU, bool FREE0, int SEG, class LinF, class TermF>
+__device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
                                          double (&pi)[NS], const double (&ulo)[NU], const double (&uhi)[NU], const double (&xlo)[NS],
                                          const double (&xhi)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
                                          const int max_iter, LinF lin, TermF term, int &iters)
 {
-    const bool on = lane < N;
+    using SG = Seg<SEG>;
+    const int k = SG::stage(lane);
+    const bool on = k < N;
     bool flu[NU], fhu[NU], flx[NS], fhx[NS];
     double zlu[NU], zhu[NU], zlx[NS], zhx[NS], zl0[NS], zh0[NS];
     int nbl = 0;      // finite bounds per stage
@@ -81,14 +121,18 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
     MPC_UNROLL for (int i = 0; i < NS; i++) { flx[i] = fin(xlo[i]); fhx[i] = fin(xhi[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); xn[i] = push_in(xn[i], xlo[i], xhi[i]); pi[i] = 0.0; }
     MPC_UNROLL for (int i = 0; i < NS; i++) { zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0; if (FREE0) x0v[i] = push_in(x0v[i], xlo[i], xhi[i]); }
     const double nb = (double)(N * (nbl + nbx) + (FREE0 ? nbx : 0)), meq = (double)(N * NS);
+    // everything below that looks wave-uniform is uniform per SEGMENT (= per instance): mu, the shifts, status, the iteration count.  A
+    // segment that has finished (done) keeps computing with its frozen iterate while its wave neighbours go on; `live` = false marks a
+    // segment without an instance (ragged batch)
     double mu = kMuInit, delta_last = 0.0;
     int status = kStMaxIter;
+    bool done = !live;
     iters = 0;
     for (int it = 0;; it++) {
-        iters = it;
+        if (!done) iters = it;
         // ---- linearise this lane's stage at (x_k, u_k); x_k is the neighbour's x_{k+1} ------------------------------------------------
         double xk[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = wave_up1(FREE0 ? x0v[i] : x0fix[i], xn[i]);
+        MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
         StageLin<NS, NU> L;
         lin(xk, u, pi, L);
         double gv[NS], Hv[NS][NS];
@@ -100,7 +144,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
             MPC_UNROLL for (int j = 0; j < NS; j++) a += L.A[j][i] * pi[j];
             gxA[i] = a;
         }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = wave_dn1(0.0, gxA[i]); gnext[i] = lane == N - 1 ? gv[i] : sh; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, gxA[i], k); gnext[i] = k == N - 1 ? gv[i] : sh; }
         double slu[NU], shu[NU], slx[NS], shx[NS], sl0[NS], sh0[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) { slu[i] = flu[i] ? u[i] - ulo[i] : 1.0; shu[i] = fhu[i] ? uhi[i] - u[i] : 1.0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) { slx[i] = flx[i] ? xn[i] - xlo[i] : 1.0; shx[i] = fhx[i] ? xhi[i] - xn[i] : 1.0; sl0[i] = (FREE0 && flx[i]) ? x0v[i] - xlo[i] : 1.0; sh0[i] = (FREE0 && fhx[i]) ? xhi[i] - x0v[i] : 1.0; }
@@ -122,26 +166,35 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
             if (flx[i]) { cmax = dmax(cmax, slx[i] * zlx[i]); cmin = dmin(cmin, slx[i] * zlx[i]); }
             if (fhx[i]) { cmax = dmax(cmax, shx[i] * zhx[i]); cmin = dmin(cmin, shx[i] * zhx[i]); }
         }
-        e_st = wave_max(on ? e_st : 0.0); e_c = wave_max(on ? e_c : 0.0); s_pi = wave_sum(on ? s_pi : 0.0); s_z = wave_sum(on ? s_z : 0.0);
-        cmax = wave_max(on ? cmax : -INFINITY); cmin = wave_min(on ? cmin : INFINITY);
-        double g0[NS];      // gradient with respect to the free initial state: stage 0's part + arrival cost
+        e_st = SG::max(on ? e_st : 0.0); e_c = SG::max(on ? e_c : 0.0); s_pi = SG::sum(on ? s_pi : 0.0); s_z = SG::sum(on ? s_z : 0.0);
+        cmax = SG::max(on ? cmax : -INFINITY); cmin = SG::min(on ? cmin : INFINITY);
+        double g0[NS], ga0[NS];      // gradient with respect to the free initial state: stage 0's part + arrival cost
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                double a = lane_of(gxA[i], 0);
+                const double ga = SG::bcast(gxA[i], 0, lane);
+                double a = ga;
                 MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0v[j] - xbar[j]);
-                g0[i] = a;
+                g0[i] = a; ga0[i] = ga;
                 e_st = dmax(e_st, fabs(a - zl0[i] + zh0[i])); s_z += zl0[i] + zh0[i];
                 finite = finite && finite_all(a) && finite_all(x0v[i]);
                 if (flx[i]) { cmax = dmax(cmax, sl0[i] * zl0[i]); cmin = dmin(cmin, sl0[i] * zl0[i]); }
                 if (fhx[i]) { cmax = dmax(cmax, sh0[i] * zh0[i]); cmin = dmin(cmin, sh0[i] * zh0[i]); }
             }
         }
-        if (__any((on && !finite) ? 1 : 0)) { status = kStFailed; break; }
+        const bool nonfinite = SG::any(on && !finite, lane);
         const double s_d = dmax(kSMax, (s_pi + s_z) / dmax(meq + nb, 1.0)) / kSMax, s_c = dmax(kSMax, s_z / dmax(nb, 1.0)) / kSMax;
         auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), nb > 0.0 ? dmax(cmax - m_, m_ - cmin) / s_c : 0.0); };
-        if (err(0.0) <= tol) { status = kStSolved; break; }
-        if (it >= max_iter) break;
-        while (mu > tol / 10.0 && err(mu) <= kKappaEps * mu) mu = dmax(tol / 10.0, dmin(kKappaMu * mu, mu * sqrt(mu)));
+        if (!done) {
+            if (nonfinite) { status = kStFailed; done = true; }
+            else if (err(0.0) <= tol) { status = kStSolved; done = true; }
+            else if (it >= max_iter) done = true;
+        }
+        if (__all(done ? 1 : 0)) break;
+        for (;;) {      // (per segment) while (mu > tol / 10 && E_mu <= kappa_eps mu) mu = ...
+            const bool dec = !done && mu > tol / 10.0 && err(mu) <= kKappaEps * mu;
+            if (!__any(dec ? 1 : 0)) break;
+            if (dec) mu = dmax(tol / 10.0, dmin(kKappaMu * mu, mu * sqrt(mu)));
+        }
         const double tau = dmax(kTauMin, 1.0 - mu);
         // ---- barrier terms; those of x_k come from the neighbour that holds x_k --------------------------------------------------------
         double Su[NU], bu[NU], Sx[NS], bx[NS], Sxk[NS], bxk[NS], S0[NS], b0[NS];
@@ -152,7 +205,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             const double il = flx[i] ? 1.0 / slx[i] : 0.0, ih = fhx[i] ? 1.0 / shx[i] : 0.0;
             Sx[i] = zlx[i] * il + zhx[i] * ih; bx[i] = -mu * il + mu * ih;
-            Sxk[i] = wave_up1(0.0, Sx[i]); bxk[i] = wave_up1(0.0, bx[i]);
+            Sxk[i] = SG::up1(0.0, Sx[i], k); bxk[i] = SG::up1(0.0, bx[i], k);
             const double jl = (FREE0 && flx[i]) ? 1.0 / sl0[i] : 0.0, jh = (FREE0 && fhx[i]) ? 1.0 / sh0[i] : 0.0;
             S0[i] = zl0[i] * jl + zh0[i] * jh; b0[i] = -mu * jl + mu * jh;
         }
@@ -163,7 +216,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
         for (;;) {
             double Pt[NS][NS], pt[NS], Pn[NS][NS], pn[NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) { pt[i] = gv[i] + bx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) Pt[i][j] = Hv[i][j] + (i == j ? Sx[i] + delta : 0.0); }
-            bcast_sym<NS>(Pt, N - 1, Pn); bcast_vec<NS>(pt, N - 1, pn);
+            bcast_sym<SEG, NS>(Pt, N - 1, lane, Pn); bcast_vec<SEG, NS>(pt, N - 1, lane, pn);
             bool bad = false;
             for (int kk = N - 1; kk >= 0; kk--) {
                 double PA[NS][NS], PB[NS][NU], pc[NS];
@@ -204,25 +257,28 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
                     pk[i] = a;
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Pk[i][j] + Pk[j][i]); Pk[i][j] = a; Pk[j][i] = a; } }
-                if (lane == kk) {
+                if (k == kk) {
                     MPC_UNROLL for (int i = 0; i < NU; i++) { kff[i] = kl[i]; MPC_UNROLL for (int j = 0; j < NS; j++) K[i][j] = Kl[i][j]; }
                     MPC_UNROLL for (int i = 0; i < NS; i++) { pnx[i] = pn[i]; MPC_UNROLL for (int j = 0; j < NS; j++) Pnx[i][j] = Pn[i][j]; }
                     if (!ok) bad = true;
                 }
-                bcast_sym<NS>(Pk, kk, Pn); bcast_vec<NS>(pk, kk, pn);
+                bcast_sym<SEG, NS>(Pk, kk, lane, Pn); bcast_vec<SEG, NS>(pk, kk, lane, pn);
             }
             if (FREE0) {      // the initial state: value function of stage 0 + arrival cost + its own barrier
                 double P0[NS][NS], p0[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) { p0[i] = pn[i] + (g0[i] - lane_of(gxA[i], 0)) + b0[i]; MPC_UNROLL for (int j = 0; j < NS; j++) P0[i][j] = Pn[i][j] + 0.5 * (Pinv[i][j] + Pinv[j][i]) + (i == j ? S0[i] : 0.0); }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { p0[i] = pn[i] + (g0[i] - ga0[i]) + b0[i]; MPC_UNROLL for (int j = 0; j < NS; j++) P0[i][j] = Pn[i][j] + 0.5 * (Pinv[i][j] + Pinv[j][i]) + (i == j ? S0[i] : 0.0); }
                 if (!sym_inverse<NS>(P0)) bad = true;
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a -= P0[i][j] * p0[j]; dx0[i] = a; }
             } else { MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = 0.0; }
-            if (!__any(bad ? 1 : 0)) break;
-            delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
-            if (delta > kDeltaMax) { failed = true; break; }
+            const bool retry = SG::any(bad, lane) && !done && !failed;      // this segment lacks curvature: a larger shift, all over again
+            if (retry) {
+                delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
+                if (delta > kDeltaMax) failed = true;
+            }
+            if (!__any((retry && !failed) ? 1 : 0)) break;      // (segments that were fine recompute the same numbers with their own shift)
         }
-        if (failed) { status = kStFailed; break; }
-        if (delta > 0.0) delta_last = delta;
+        if (!done && failed) { status = kStFailed; done = true; }
+        if (!done && delta > 0.0) delta_last = delta;
         // ---- Newton direction: forward over the lanes ---------------------------------------------------------------------------------
         double du[NU], dxn[NS], dx[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) { dx[i] = dx0[i]; dxn[i] = 0.0; }
@@ -236,8 +292,8 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
                 MPC_UNROLL for (int j = 0; j < NU; j++) a += L.B[i][j] * dul[j];
                 dxl[i] = a;
             }
-            if (lane == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dul[i]; MPC_UNROLL for (int i = 0; i < NS; i++) dxn[i] = dxl[i]; }
-            bcast_vec<NS>(dxl, kk, dx);
+            if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dul[i]; MPC_UNROLL for (int i = 0; i < NS; i++) dxn[i] = dxl[i]; }
+            bcast_vec<SEG, NS>(dxl, kk, lane, dx);
         }
         double pin[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pnx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Pnx[i][j] * dxn[j]; pin[i] = a; }
@@ -257,7 +313,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
             if (flx[i]) { apr = ratio(apr, slx[i], dxn[i]); adu = ratio(adu, zlx[i], dzlx[i]); }
             if (fhx[i]) { apr = ratio(apr, shx[i], -dxn[i]); adu = ratio(adu, zhx[i], dzhx[i]); }
         }
-        apr = wave_min(on ? apr : 1.0); adu = wave_min(on ? adu : 1.0);
+        apr = SG::min(on ? apr : 1.0); adu = SG::min(on ? adu : 1.0);
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 dzl0[i] = flx[i] ? mu / sl0[i] - zl0[i] - zl0[i] / sl0[i] * dx0[i] : 0.0;
@@ -268,6 +324,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
         }
         // ---- step; multipliers kept within kappa_Sigma of mu / slack --------------------------------------------------------------------
         auto clampz = [&](double z, double s) { return dmin(dmax(z, mu / (kKappaSigma * s)), kKappaSigma * mu / s); };
+        if (!done) {      // (a finished segment keeps its iterate)
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             u[i] += apr * du[i];
             zlu[i] += adu * dzlu[i]; zhu[i] += adu * dzhu[i];
@@ -285,6 +342,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const doub
                 if (flx[i]) zl0[i] = clampz(zl0[i], x0v[i] - xlo[i]);
                 if (fhx[i]) zh0[i] = clampz(zh0[i], xhi[i] - x0v[i]);
             }
+        }
         }
     }
     return status;

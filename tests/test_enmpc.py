@@ -283,6 +283,21 @@ def test_gpu_launch_boundaries_and_launch_styles_do_not_change_the_loop(pkg, gol
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
     for k in ("U", "XS", "X_ES"):
         assert np.abs(c[k][:, 0] - gold["ship_" + k][:14, 0]).max() < TOL_U, k
+    # two and four instances side by side in a wave (segments of 32 / 16 lanes): N = 25, N_mhe = 10 take 32 / 16, and a ragged batch
+    # leaves segments without an instance
+    xr = np.vstack([x0, x0[::-1], x0[:3]])
+    p, a = _gpu_loop(pkg, None, xr, 14, kernel=64)
+    for seg in (32, 16):
+        p, b = _gpu_loop(pkg, None, xr, 14, kernel=seg)
+        for k in ("U", "XS", "US", "X_ES", "X_HAT", "Xp", "D_HAT"):
+            assert np.abs(a[k] - b[k]).max() < 1e-12, (seg, k, np.abs(a[k] - b[k]).max())
+        for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE", "STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+            assert np.array_equal(a[k], b[k]), (seg, k)
+    p, b = _gpu_loop(pkg, {"N": 12, "N_mhe": 5}, xr, 9, kernel=16)      # both horizons in 16 lanes: four OCPs per wave too
+    p, a = _gpu_loop(pkg, {"N": 12, "N_mhe": 5}, xr, 9, kernel=1)
+    for k in ("U", "X_ES", "XS"):
+        assert np.abs(a[k] - b[k]).max() < 1e-12, k
+    assert np.array_equal(a["ITERS_DYN"], b["ITERS_DYN"]) and np.array_equal(a["ITERS_MHE"], b["ITERS_MHE"])
 
 
 @pytest.mark.gpu
