@@ -5,7 +5,7 @@
 //
 // The three NLPs of a closed-loop step (reference MPC_code.py:485-827 with Ex_ENMPC.py) are solved by one primal-dual interior point
 // method whose outer algorithm is the reference solver's (IPOPT at the defaults MPC_code.py:262-263 leaves it at [ext]; restated and
-// documented in oracle/enmpc_oracle.py:ipm_dense, the checker): monotone barrier parameter, start pushed into the box, fraction to the
+// documented in DESIGN.md section 10; the checker restates it with dense linear algebra): monotone barrier parameter, start pushed into the box, fraction to the
 // boundary, exact Hessian of the Lagrangian with inertia correction, scaled optimality error.  What is particular here:
 //   * OCP (opt_dyn with ContForm, Control_Calc.py:20-260): every lane integrates ITS shooting interval - state, cost quadrature and
 //     their first and second forward sensitivities with respect to (x_k, u_k) through the Runge-Kutta stages (generated code,
@@ -24,7 +24,7 @@
 namespace enm {
 using namespace mpc;
 
-// ---- the outer algorithm's constants (oracle/enmpc_oracle.py carries the same) ----------------------------------------------------
+// ---- the outer algorithm's constants (the checker carries the same) ----------------------------------------------------
 constexpr double kPush = 1e-2, kMuInit = 0.1, kKappaEps = 10.0, kKappaMu = 0.2, kTauMin = 0.99, kKappaSigma = 1e10, kSMax = 100.0,
                  kDeltaFirst = 1e-4, kDeltaMax = 1e40;
 enum : int { kStSolved = 0, kStMaxIter = 1, kStFailed = 2 };

@@ -156,13 +156,22 @@ def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMP
     """Classify a non-linear Ex-file namespace (reference MPC_code.py:84-257 probes) and trace its functions."""
     has = lambda k: k in ns and ns[k] is not None and not k.startswith("__")
     for bad in ("User_fobj_Cont", "User_fobj_Dis", "User_fobj_Coll", "User_fssobj",
-                "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "def_px", "def_py", "def_pxmp", "def_pymp", "A"):
+                "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "def_px", "def_py", "def_pxmp", "def_pymp", "A", "G_wn"):
         if has(bad):
             raise UnsupportedProblem(f"'{bad}' is outside the non-linear path built so far")
+    if has("R_wn"):
+        # the reference adds UNSEEDED Gaussian noise to every measurement (MPC_code.py:538-541): a run is not reproducible even there.
+        # The batched loop is deterministic and runs noise-free - said out loud, not silently (Ex_NMPC.py ships R_wn)
+        import warnings
+        warnings.warn("R_wn: the measurement noise of the example (unseeded in the reference, MPC_code.py:538-541) is not simulated; the loop runs noise-free", UserWarning, stacklevel=3)
     for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks", "TermCons", "mhe", "ContForm",
-                 "DUFormEcon", "kal", "kalss"):
+                 "DUFormEcon", "kal", "kalss", "estimating"):
         if ns.get(flag, False) is True:
             raise UnsupportedProblem(f"flag {flag}=True is outside the non-linear path built so far")
+    if ns.get("LinPar", True) is not True:
+        raise UnsupportedProblem("LinPar = False is outside the non-linear path built so far")
+    if (ns.get("dmin") is None) != (ns.get("dmax") is None):
+        raise UnsupportedProblem("dmin and dmax have to come together (the estimate is clipped to both, MPC_code.py:657-664)")
     discrete = has("User_fxm_Dis")
     plant_discrete = has("User_fxp_Dis")
     for req in ("User_fxm_Dis" if discrete else "User_fxm_Cont", "User_fym", "User_fxp_Dis" if plant_discrete else "User_fxp_Cont", "User_fyp",
@@ -195,11 +204,14 @@ def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMP
     hp = _trace(ns["User_fyp"], (col(vxp), col(vu), vt, zero(ny), zero(ny)))         # Utilities.py:94
     if len(f) != nx or len(hy) != ny or len(fp) != nxp or len(hp) != ny:
         raise UnsupportedProblem("a user function returns a vector of the wrong length")
+    hy_user = list(hy)      # the user's map alone: with offree = 'lin' the + Cd d below is carried per instance by the kernels' output rows
     Bd = Cd = None
     if offree == "lin":        # Fx_model = F(x,u,d,t) + Bd d, Fy_model = h(x,u,d,t) + Cd d (Utilities.py:189-193,231-233)
         Bd, Cd = _mat(ns["Bd"], nx, nd, "Bd"), _mat(ns["Cd"], ny, nd, "Cd")
         f = [f[i] + sum((float(Bd[i, j]) * vd[j] for j in range(nd)), st.Sym.const(0.0)) for i in range(nx)]
         hy = [hy[i] + sum((float(Cd[i, j]) * vd[j] for j in range(nd)), st.Sym.const(0.0)) for i in range(ny)]
+    if any(not e.is_const(0.0) for row in st.jacobian(hy, vu) for e in row):
+        raise UnsupportedProblem("User_fym depends on u: the target and the OCP linearise the output map in x only")
     ycols = []
     hx = st.jacobian(hy, vx)
     for i in range(ny):      # bounded outputs have to be single states with unit gain (then their bounds are boxes on states)
@@ -214,6 +226,12 @@ def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMP
     y_lo, y_hi = pick("ymin", "_dyn", ny, -INF), pick("ymax", "_dyn", ny, INF)
     if any(c < 0 and (np.isfinite(y_lo[i]) or np.isfinite(y_hi[i])) for i, c in enumerate(ycols)):
         raise UnsupportedProblem("a bounded output is not a single state")
+    for i, c in enumerate(ycols):      # a bounded row has to BE the state (its box is put on the state): nothing of d or a constant beside it
+        if c >= 0 and (np.isfinite(y_lo[i]) or np.isfinite(y_hi[i])):
+            others = [st.diff(hy_user[i], v) for j, v in enumerate(vx) if j != c] + [st.diff(hy_user[i], v) for v in vd]
+            at0 = float(np.asarray(st.evaluate([hy_user[i]], {**{f"x[{j}]": 0.0 for j in range(nx)}, **{f"u[{j}]": 0.0 for j in range(nu)}, **{f"d[{j}]": 0.0 for j in range(nd)}, "t": 0.0})[0]))
+            if any(not e.is_const(0.0) for e in others) or at0 != 0.0:
+                raise UnsupportedProblem(f"bounded output {i} is state {c} plus something else (d, a constant): its bounds are not a box on the state")
     if has("R"):
         R, DUForm = _mat(ns["R"], nu, nu, "R"), False
     elif has("S"):

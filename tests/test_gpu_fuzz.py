@@ -74,6 +74,6 @@ def test_random_problem_closed_loop_against_the_c_restatement(seed, nx, nu, ny, 
     ref = oracle_c.OracleC(p).closed_loop(K, x0, x0)
     for lk in (1, 2, 3):
         r = run_closed_loop(p, x0, x0, K, solver=solver_factory(p, lk))
-        same = (r["STATUS_DYN"] == ref["STATUS_DYN"]).all(axis=0) & (r["STATUS_SS"] == ref["STATUS_SS"]).all(axis=0)
-        assert same.mean() > 0.97, (seed, lk, same.mean())
-        assert np.abs(r["U"] - ref["U"])[:, same].max() < 1e-6, (seed, lk)
+        # every status word of every instance-step equal (tools/flip_report.py: no label differs on any of these problems), then values
+        assert np.array_equal(r["STATUS_DYN"], ref["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], ref["STATUS_SS"]), (seed, lk)
+        assert np.abs(r["U"] - ref["U"]).max() < 1e-6, (seed, lk)
