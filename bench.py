@@ -376,10 +376,11 @@ def main_nmpc(args):
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import nmpc_oracle as no
+        op = no.load_problem(m.example_path("cstr_nmpc.py"))      # the checker's own reading of the example
         t0 = time.perf_counter(); nst = 0
         while time.perf_counter() - t0 < 10.0 and nst < K:
             nst += 4
-            no.closed_loop(p, 4, x0_p=x0[nst // 4 - 1], x0_m=x0[nst // 4 - 1], max_sqp=args.max_sqp)
+            no.closed_loop(op, 4, x0_p=x0[nst // 4 - 1], x0_m=x0[nst // 4 - 1], max_sqp=args.max_sqp)
         cpu = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": nst / cpu, "unit": "steps/s", "cores": 1, "kind": "port",
                                "sample": "%d instance(s) x 4 closed-loop steps of the same workload, %.1f s: oracle/nmpc_oracle.py, a NumPy restatement (dense QPs) - "

@@ -31,8 +31,78 @@ DEFAULTS = dict(
 )
 
 
+class NumMat:
+    """A small dense matrix of NUMBERS with the part of ``casadi.SX``'s surface the examples use inside their functions: ``SX(n, m)``
+    zeros, element and slice reads (a slice is a COPY, as in CasADi), element and slice assignment - an argument clamped in place
+    stays clamped for the rest of the function, as in CasADi -, ``.T``, ``size1()``, arithmetic, ``mtimes``.  A column indexed with
+    one integer gives the number itself."""
+    __array_priority__ = 1000
+
+    def __init__(self, a):
+        a = np.array(a)
+        self.a = a.reshape(-1, 1) if a.ndim < 2 else a
+
+    zeros = classmethod(lambda cls, n, m=1: cls(np.zeros((int(n), int(m)))))
+    col = classmethod(lambda cls, items: cls(np.asarray(items).reshape(-1, 1)))
+    shape = property(lambda self: self.a.shape)
+    T = property(lambda self: NumMat(self.a.T.copy()))
+    size1 = lambda self: self.a.shape[0]
+    size2 = lambda self: self.a.shape[1]
+    __len__ = lambda self: self.a.shape[0]
+
+    def __iter__(self):
+        return iter(self.a.ravel()) if self.a.shape[1] == 1 else iter(NumMat(r[None].copy()) for r in self.a)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)) and self.a.shape[1] == 1:
+            return self.a[idx, 0]
+        r = self.a[idx]
+        return NumMat(np.array(r)) if isinstance(r, np.ndarray) else r
+
+    def __setitem__(self, idx, v):
+        v = v.a if isinstance(v, NumMat) else np.asarray(v)
+        if v.dtype.kind == "c" and self.a.dtype.kind != "c":
+            self.a = self.a.astype(complex)
+        if isinstance(idx, (int, np.integer)) and self.a.shape[1] == 1:
+            self.a[idx, 0] = v.ravel()[0] if v.ndim else v
+        else:
+            tgt = self.a[idx]
+            self.a[idx] = v.reshape(tgt.shape) if (v.ndim and isinstance(tgt, np.ndarray) and v.size == tgt.size) else v
+
+    @staticmethod
+    def _arr(o):
+        if isinstance(o, NumMat):
+            return o.a
+        o = np.asarray(o)
+        return o.reshape(-1, 1) if o.ndim == 1 else o
+
+    def _bin(self, o, f):
+        return NumMat(f(self.a, NumMat._arr(o)))
+    __add__ = lambda self, o: self._bin(o, lambda a, b: a + b)
+    __radd__ = lambda self, o: self._bin(o, lambda a, b: b + a)
+    __sub__ = lambda self, o: self._bin(o, lambda a, b: a - b)
+    __rsub__ = lambda self, o: self._bin(o, lambda a, b: b - a)
+    __mul__ = lambda self, o: self._bin(o, lambda a, b: a * b)
+    __rmul__ = lambda self, o: self._bin(o, lambda a, b: b * a)
+    __truediv__ = lambda self, o: self._bin(o, lambda a, b: a / b)
+    __rtruediv__ = lambda self, o: self._bin(o, lambda a, b: b / a)
+    __pow__ = lambda self, o: self._bin(o, lambda a, b: a ** b)
+    __neg__ = lambda self: NumMat(-self.a)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.a if dtype is None else self.a.astype(dtype)
+
+
 class Shape:
-    """``SX.sym(name, n[, m])``: only the shape is ever read at module level (``d.size1()``)."""
+    """``SX.sym(name, n[, m])``: only the shape is ever read at module level (``d.size1()``).  ``SX(n, m)`` inside a user function is a
+    zero matrix to be filled in (Ex_NMPC_dis.py:72,113), ``SX(1.)`` a number."""
+
+    def __new__(cls, name=None, n=1, m=1):
+        if isinstance(name, (int, np.integer)):
+            return NumMat.zeros(name, n)
+        if isinstance(name, float):
+            return name
+        return super().__new__(cls)
 
     def __init__(self, name, n=1, m=1):
         self.name, self.n, self.m = name, int(n), int(m)
@@ -61,7 +131,7 @@ class batched:
 
 def vertcat(*parts):
     if not BATCH:
-        return np.concatenate([np.atleast_1d(np.asarray(a)) for a in parts])
+        return np.concatenate([np.ravel(np.asarray(a)) for a in parts])
     rows = []
     for a in parts:
         a = np.asarray(a)
@@ -76,7 +146,7 @@ def mtimes(*ms):
     out = ms[0]
     for b in ms[1:]:
         out = out * b if (np.ndim(out) == 0 or np.ndim(b) == 0) else np.asarray(out) @ np.asarray(b)
-    return out
+    return out.ravel()[0] if isinstance(out, np.ndarray) and out.shape == (1, 1) else out
 
 
 def xQx(x, Q):

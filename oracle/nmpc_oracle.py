@@ -5,7 +5,8 @@ PARITY UNPINNED against the reference's own solver: CasADi/IPOPT cannot run here
 
 * model / plant      ``defF_model`` / ``defF_p``: ``Mx`` classical RK4 steps of the Ex-file's continuous functions per sampling
                      interval, time carried as a state (``Utilities.py:157-183``, ``:58-82``; ``casadi.simpleRK``).  The
-                     Ex-file's own Python functions are called on NumPy arrays - no tracer, no generated code;
+                     Ex-file is executed by the oracle's own loader (``load_problem`` -> ``exnum.py``) and its Python functions are
+                     called on NumPy arrays - nothing of the product's loader, stand-ins, tracer or generated code;
 * Jacobians          central finite differences of that discrete map (independent of the product's symbolic ones);
 * estimator          ``ekf`` (``Estimator.py:313-386``) on ``[x; d]`` with ``d+ = d`` (``MPC_code.py:546-561``);
 * target             the NLP of ``opt_ss`` (``Target_Calc.py:20-161``) for a non-linear model, by Newton-type SQP: every iteration
@@ -24,10 +25,85 @@ from __future__ import annotations
 
 import numpy as np
 
+import exnum
 import mpc_oracle as o
-from mpc_code_amd import symtrace as st
 
 STATUS_SOLVED, STATUS_MAXITER, STATUS_INFEASIBLE = 0, 1, 2
+INF = float("inf")
+
+
+# ---------------------------------------------------------------------------------------------------
+# the problem, read from the Ex-file by the oracle's own loader (exnum.py): nothing of the product's loader, tracer or stand-ins
+# ---------------------------------------------------------------------------------------------------
+class NlProblem:
+    def __repr__(self):
+        return f"oracle NlProblem({self.name!r}, nx={self.nx}, nu={self.nu}, ny={self.ny}, nd={self.nd}, N={self.N}, discrete={self.discrete})"
+
+    def schedules(self, nsteps, k0=0):
+        ysp = np.zeros((nsteps, self.ny)); usp = np.zeros((nsteps, self.nu)); xsp = np.zeros((nsteps, self.nx))
+        pxp = np.zeros((nsteps, self.nxp)); pyp = np.zeros((nsteps, self.ny))
+        for i in range(nsteps):
+            t = (k0 + i) * self.h
+            if self.defSP is not None:
+                a, b, c = self.defSP(t)
+                ysp[i], usp[i], xsp[i] = np.ravel(a), np.ravel(b), np.ravel(c)
+            if self.def_pxp is not None:
+                pxp[i] = np.ravel(self.def_pxp(t)[0])      # MPC_code.py:512-515
+            if self.def_pyp is not None:
+                pyp[i] = np.ravel(self.def_pyp(t)[0])
+        return dict(ysp=ysp, usp=usp, xsp=xsp, pxp=pxp, pyp=pyp)
+
+
+def _vec(v, n, fill):
+    return np.full(n, fill, dtype=np.float64) if v is None else np.asarray(v, dtype=np.float64).reshape(n)
+
+
+def load_problem(path, overrides=None):
+    """The namespace of a non-linear tracking example as numbers and plain Python functions (reference MPC_code.py:31-60,84-257 probes;
+    defaults Default_Values.py:16-131)."""
+    ns = exnum.load(path, overrides)
+    has = lambda k: ns.get(k) is not None
+    p = NlProblem()
+    p.name = ns["__name__"]
+    p.nx, p.nu, p.ny, p.nd, p.nxp = (ns[k].size1() for k in ("x", "u", "y", "d", "xp"))
+    p.N, p.h, p.Nsim, p.Mx = int(ns["N"]), float(ns["h"]), int(ns["Nsim"]), int(ns.get("Mx", 10))
+    p.discrete, p.plant_discrete = has("User_fxm_Dis"), has("User_fxp_Dis")
+    p.funcs = {k: ns[k] for k in ("User_fxm_Cont", "User_fxm_Dis", "User_fym", "User_fxp_Cont", "User_fxp_Dis", "User_fyp", "User_vfin") if has(k)}
+    p.offree = ns.get("offree", "no")
+    assert p.offree in ("nl", "lin")
+    p.Bd = np.asarray(ns["Bd"], dtype=float).reshape(p.nx, p.nd) if p.offree == "lin" else None
+    p.Cd = np.asarray(ns["Cd"], dtype=float).reshape(p.ny, p.nd) if p.offree == "lin" else None
+    p.Q = np.asarray(ns["Q"], dtype=float).reshape(p.nx, p.nx)
+    p.DUForm = not has("R")                                   # S instead of R: cost on input moves (MPC_code.py:237-239)
+    p.R = np.asarray(ns["S"] if p.DUForm else ns["R"], dtype=float).reshape(p.nu, p.nu)
+    p.Qss = np.asarray(ns["Qss"], dtype=float).reshape(p.ny, p.ny)
+    p.DUssForm = (not has("Rss")) and has("Sss")              # :216-218
+    p.Rss = np.asarray(ns["Sss"] if p.DUssForm else (ns["Rss"] if has("Rss") else np.zeros((p.nu, p.nu))), dtype=float).reshape(p.nu, p.nu)
+    pick = lambda b, sfx, n, f: _vec(ns.get(b + sfx) if ns.get(b + sfx) is not None else ns.get(b), n, f)
+    for b, n in (("u", p.nu), ("x", p.nx), ("y", p.ny)):
+        setattr(p, b + "min", pick(b + "min", "_dyn", n, -INF)); setattr(p, b + "max", pick(b + "max", "_dyn", n, INF))
+        setattr(p, b + "min_ss", pick(b + "min", "_ss", n, -INF)); setattr(p, b + "max_ss", pick(b + "max", "_ss", n, INF))
+    p.dmin = None if not has("dmin") else _vec(ns["dmin"], p.nd, -INF)
+    p.dmax = None if not has("dmax") else _vec(ns["dmax"], p.nd, INF)
+    p.Dumin = _vec(ns.get("Dumin"), p.nu, -INF) if (has("Dumin") or has("Dumax")) else None
+    p.Dumax = _vec(ns.get("Dumax"), p.nu, INF) if (has("Dumin") or has("Dumax")) else None
+    p.estimator = "ekf" if ns.get("ekf", False) else "lue"
+    ne = p.nx + p.nd
+    p.Q_kf = np.asarray(ns["Q_kf"], dtype=float).reshape(ne, ne) if p.estimator == "ekf" else None
+    p.R_kf = np.asarray(ns["R_kf"], dtype=float).reshape(p.ny, p.ny) if p.estimator == "ekf" else None
+    p.K = np.asarray(ns["K"], dtype=float).reshape(ne, p.ny) if p.estimator == "lue" else None
+    p.P0 = np.asarray(ns["P0"], dtype=float).reshape(ne, ne) if has("P0") else np.zeros((ne, ne))
+    p.x0_p, p.x0_m, p.u0 = _vec(ns["x0_p"], p.nxp, 0.0), _vec(ns["x0_m"], p.nx, 0.0), _vec(ns["u0"], p.nu, 0.0)
+    p.dhat0 = _vec(ns.get("dhat0"), p.nd, 0.0)
+    p.max_iter = int(ns.get("Sol_itmax", 100))
+    p.defSP, p.def_pxp, p.def_pyp = ns.get("defSP"), ns.get("def_pxp"), ns.get("def_pyp")
+    p.Pf = np.zeros((p.nx, p.nx))
+    if has("User_vfin"):      # Vfin(dx, xs), a quadratic form of dx = X[N] - xs (Control_Calc.py:193-210): its Hessian by central differences (exact for a quadratic)
+        vf = lambda dx: float(np.real(np.ravel(ns["User_vfin"](_sm(dx), _sm(np.ones(p.nx))))[0]))
+        e = np.eye(p.nx)
+        H = np.array([[(vf(e[i] + e[j]) - vf(e[i] - e[j]) - vf(e[j] - e[i]) + vf(-e[i] - e[j])) / 4.0 for j in range(p.nx)] for i in range(p.nx)])
+        p.Pf = 0.5 * (H + H.T)
+    return p
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -38,8 +114,8 @@ def _col(v, n):
 
 
 def _sm(v):
-    """The container the Ex-file functions index, slice and assign into (numbers inside: no tracing here)."""
-    return st.SymMat.col([float(a) for a in np.ravel(v)])
+    """The container the Ex-file functions index, slice and assign into (numbers inside)."""
+    return exnum.NumMat.col([float(a) for a in np.ravel(v)])
 
 
 def _rk4(f, x, t, h, Mx):

@@ -2,7 +2,8 @@
 """Generate tests/golden/nmpc_cstr.npz (run in the build container; about ten minutes).
 
 The non-linear path's reference run needs CasADi + IPOPT, which are not installable here, and the reference ships no
-vectors for it: PARITY UNPINNED against a reference run.  The fixture comes from oracle/nmpc_oracle.py - SQP whose QPs are
+vectors for it: PARITY UNPINNED against a reference run.  The fixture comes from oracle/nmpc_oracle.py (which reads the example with its own
+loader, oracle/exnum.py: nothing of the product is imported here) - SQP whose QPs are
 solved by the dense interior point + exact active-set polish of oracle/mpc_oracle.py - and is self-certifying for the
 converged mode: every OCP row carries the residuals of the NLP's own KKT conditions (dynamics defect of the RK4 model,
 stationarity with multipliers fitted on the active set, bound violation), the conditions IPOPT terminates on.
@@ -21,7 +22,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import mpc_code_amd as m          # noqa: E402
 import nmpc_oracle as no          # noqa: E402
 
 
@@ -43,7 +43,7 @@ def quadtank():
     every OCP iterated to its KKT point."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from nmpc_cases import quadtank_mild_setpoints
-    p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "quadtank_nmpc_dis.py"), overrides={"defSP": quadtank_mild_setpoints})
+    p = no.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "quadtank_nmpc_dis.py"), overrides={"defSP": quadtank_mild_setpoints})
     rng = np.random.default_rng(20240612)
     x0 = np.tile(p.x0_p, (2, 1)); x0[1, 2:] += rng.uniform(-1, 1, 4) * [1.0, 1.0, 0.3, 0.3]
     out = {}
@@ -65,7 +65,7 @@ def reactor():
     """tests/golden/nmpc_reactor.npz: the two-state, one-input reactor (examples/reactor_nmpc.py, N = 25): real-time iteration over 30
     steps (plant / model mismatch from t = 0, set-point change at step 21) for the shipped start and two perturbed ones (plant and model
     start apart); 6 steps with every OCP iterated to its KKT point."""
-    p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_nmpc.py"))
+    p = no.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_nmpc.py"))
     rng = np.random.default_rng(20240613)
     x0 = np.tile(p.x0_p, (3, 1)); x0[1:] += rng.uniform(-1, 1, size=(2, 2)) * 0.05
     xm = x0.copy(); xm[2] += rng.uniform(-1, 1, 2) * 0.03
@@ -87,7 +87,7 @@ def main():
         return quadtank()
     if "reactor" in sys.argv:
         return reactor()
-    p = m.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "cstr_nmpc.py"))
+    p = no.load_problem(os.path.join(ROOT, "mpc-code_amd", "examples", "cstr_nmpc.py"))
     out = {}
     t0 = time.time()
     x0 = starts(p, 3)

@@ -62,6 +62,15 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dp, f)
 
 
+def test_oracle_never_imports_the_product():
+    """The checker reads the examples with its own loader (oracle/exnum.py) and differentiates their functions numerically: no import of the
+    product's package - loader, stand-ins, tracer, generated code - anywhere under oracle/."""
+    for f in os.listdir(os.path.join(ROOT, "oracle")):
+        if f.endswith((".py", ".c")):
+            src = open(os.path.join(ROOT, "oracle", f), errors="ignore").read()
+            assert not re.search(r"^\s*(from|import)\s+(mpc_code_amd|symtrace|exfile|nlcodegen|econcodegen)", src, re.M), f
+
+
 def test_product_and_bench_do_not_use_pytorch():
     """north_star: host side is Python + ctypes, no PyTorch; the collective is RCCL inside the library."""
     files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]

@@ -26,6 +26,21 @@ def gold():
     return np.load(GOLD)
 
 
+def oracle_problem(name, overrides=None):
+    """The checker's own reading of an example (oracle/nmpc_oracle.py:load_problem -> oracle/exnum.py): the oracle never sees the product's
+    loader, stand-ins or tracer."""
+    import warnings
+    import nmpc_oracle as no
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return no.load_problem(name if os.path.isabs(name) else os.path.join(ROOT, "mpc-code_amd", "examples", name), overrides)
+
+
+@pytest.fixture(scope="module")
+def onl():
+    return oracle_problem("cstr_nmpc.py")
+
+
 def sample(p, n=6, seed=0):
     rng = np.random.default_rng(seed)
     x = p.x0_m + rng.normal(size=(n, p.nx)) * [0.02, 3.0, 0.02]
@@ -84,7 +99,7 @@ def test_if_else_is_traced_as_a_select(nl):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
-def test_same_problem_as_the_reference_example(pkg, nl):
+def test_same_problem_as_the_reference_example(pkg, nl, onl):
     """The reference's Ex_NMPC.py loads unmodified and defines the same problem as examples/cstr_nmpc.py."""
     ref = pkg.load_problem(os.path.join(REF, "Ex_NMPC.py"), overrides={"N": 30})
     for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "dmin", "dmax", "Q_kf", "R_kf", "P0", "x0_p", "x0_m",
@@ -94,9 +109,12 @@ def test_same_problem_as_the_reference_example(pkg, nl):
     import nmpc_oracle as no
     x, u, d = sample(nl, 4, seed=2)
     for i in range(4):
-        assert np.allclose(no.model_fx(ref, x[i], u[i], d[i]), no.model_fx(nl, x[i], u[i], d[i]), rtol=1e-13, atol=0)
+        oref = oracle_problem(os.path.join(REF, "Ex_NMPC.py"), {"N": 30})
+        assert np.allclose(no.model_fx(oref, x[i], u[i], d[i]), no.model_fx(onl, x[i], u[i], d[i]), rtol=1e-13, atol=0)
         for t in (0.0, 7.0, 30.0):
-            assert np.allclose(no.plant_fx(ref, x[i], u[i], t), no.plant_fx(nl, x[i], u[i], t), rtol=1e-13, atol=0)
+            assert np.allclose(no.plant_fx(oref, x[i], u[i], t), no.plant_fx(onl, x[i], u[i], t), rtol=1e-13, atol=0)
+    for k in ("Q", "R", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax", "dmin", "dmax", "Q_kf", "R_kf", "P0", "x0_p", "x0_m", "u0", "dhat0"):
+        assert np.array_equal(getattr(onl, k), getattr(nl, k)), k      # two independent loaders, one problem
 
 
 def test_unsupported_nonlinear_features_are_refused(pkg, tmp_path):
@@ -110,14 +128,14 @@ def test_unsupported_nonlinear_features_are_refused(pkg, tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------- oracle (CPU)
-def test_oracle_reproduces_its_golden_rows(nl, gold):
+def test_oracle_reproduces_its_golden_rows(nl, onl, gold):
     import nmpc_oracle as no
-    r = no.closed_loop(nl, 3, x0_p=gold["rti_x0"][1], x0_m=gold["rti_x0"][1], max_sqp=1)
+    r = no.closed_loop(onl, 3, x0_p=gold["rti_x0"][1], x0_m=gold["rti_x0"][1], max_sqp=1)
     for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
         assert np.allclose(r[k], gold["rti_" + k][:3, 1], rtol=1e-10, atol=1e-10), k
 
 
-def test_golden_converged_rows_satisfy_the_nlp_kkt_conditions(nl, gold):
+def test_golden_converged_rows_satisfy_the_nlp_kkt_conditions(nl, onl, gold):
     """Re-verify the certificate without trusting any solver: dynamics defect, stationarity and bounds of the NLP
     (Control_Calc.py:20-260) at the stored trajectories."""
     import nmpc_oracle as no
@@ -125,7 +143,7 @@ def test_golden_converged_rows_satisfy_the_nlp_kkt_conditions(nl, gold):
     assert gold["sqp_KKT_DEFECT"].max() < 1e-10 and gold["sqp_KKT_STAT"].max() < 1e-8 and gold["sqp_KKT_VIOL"].max() < 1e-10
     k, b = 0, 1
     w = gold["sqp_W"][k, b]
-    c = no.kkt_nlp(nl, w, w[:nl.nx], gold["sqp_XS"][k, b], gold["sqp_US"][k, b], gold["sqp_D_HAT"][k, b], 0.0)
+    c = no.kkt_nlp(onl, w, w[:nl.nx], gold["sqp_XS"][k, b], gold["sqp_US"][k, b], gold["sqp_D_HAT"][k, b], 0.0)
     assert c["defect"] < 1e-10 and c["stationarity"] < 1e-8 and c["bound_violation"] < 1e-10
 
 
@@ -197,7 +215,7 @@ def test_gpu_closed_loop_equals_the_golden_vectors(nl, gold, solver, mode, max_s
 
 
 @pytest.mark.gpu
-def test_gpu_full_size_batch_properties(nl, gold, solver):
+def test_gpu_full_size_batch_properties(nl, onl, gold, solver):
     """BASELINE configs[3]: B = 16384, N = 30.  Instance 0 is the golden instance; the rest start in the box of SURVEY.md 8d cfg 3.
     Properties: every status solved, inputs and predicted states within their bounds, results independent of the position in
     the batch (bit for bit), the golden instance reproduced."""
@@ -216,7 +234,7 @@ def test_gpu_full_size_batch_properties(nl, gold, solver):
     # their own initial states: the batch's trajectories are the oracle's
     import nmpc_oracle as no
     for b in rng.choice(B, 3, replace=False):
-        o = no.closed_loop(nl, 6, x0_p=x0[b], x0_m=x0[b], max_sqp=1)
+        o = no.closed_loop(onl, 6, x0_p=x0[b], x0_m=x0[b], max_sqp=1)
         for k in ("U", "X_HAT", "XS", "Xp", "D_HAT"):
             assert np.max(np.abs(r[k][:6, b] - o[k]) / (1 + np.abs(o[k]))) < 1e-6, (int(b), k)
         assert np.array_equal(r["STATUS_DYN"][:6, b], o["STATUS_DYN"])
@@ -263,7 +281,7 @@ def test_gpu_horizon_beyond_32_takes_the_unpaired_wave_kernels(pkg):
                     assert np.max(np.abs(res[kern][k] - res[1][k]) / (1 + np.abs(res[1][k]))) < 1e-7, (max_sqp, kern, k)
             if max_sqp == 1:
                 import nmpc_oracle as no
-                o = no.closed_loop(p40, 3, x0_p=x0[5], x0_m=x0[5], max_sqp=1)
+                o = no.closed_loop(oracle_problem("cstr_nmpc.py", {"N": 40}), 3, x0_p=x0[5], x0_m=x0[5], max_sqp=1)
                 for k in ("U", "X_HAT", "XS", "Xp", "D_HAT"):
                     assert np.max(np.abs(res[4][k][:3, 5] - o[k]) / (1 + np.abs(o[k]))) < 1e-6, k
     finally:
@@ -298,13 +316,13 @@ def test_gpu_kernels_agree_under_mismatch_holds_and_divergence(nl, solver, seed,
 
 
 @pytest.mark.gpu
-def test_gpu_held_steps_equal_the_oracle(nl, solver):
+def test_gpu_held_steps_equal_the_oracle(nl, onl, solver):
     """A level below its lower output bound: the OCP is infeasible from the measured state, the previous input is held and the model
     propagates the estimate (MPC_code.py:798-805) - every kernel against the oracle run of the same start, next to a healthy instance."""
     from mpc_code_amd import nmpc
     import nmpc_oracle as no
     x0 = np.array([[0.874317, 325.0, 0.47], [0.9, 330.0, 0.51]])
-    o = [no.closed_loop(nl, 5, x0_p=x, x0_m=x, max_sqp=1) for x in x0]
+    o = [no.closed_loop(onl, 5, x0_p=x, x0_m=x, max_sqp=1) for x in x0]
     assert np.all(o[0]["STATUS_DYN"] == 2) and np.all(o[1]["STATUS_DYN"] == 0)
     for kern in (1, 3, 4):
         solver.set_kernel(kern)
@@ -378,14 +396,15 @@ def test_traced_discrete_model_equals_the_user_function(qt):
     numbers; the shipped start is a steady state of the sampled map; levels outside [0, 20] are clamped as the reference clamps them."""
     import nmpc_oracle as no
     from mpc_code_amd import symtrace as st
+    oqt = oracle_problem("quadtank_nmpc_dis.py")
     rng = np.random.default_rng(0)
     for x in [qt.x0_m + rng.normal(size=6) * [3, 3, 2, 2, 0.5, 0.5] for _ in range(3)] + [np.array([50, 50, 25.0, -1.0, 0.2, 19.99])]:
         u = qt.u0 + rng.normal(size=2) * 5; d = rng.normal(size=2) * 0.1
         tr = np.array([float(v) for v in st.evaluate(qt.f, qt._vals(x=x, u=u, d=d, t=0.0))])
-        assert np.allclose(tr, no.model_fx(qt, x, u, d), rtol=1e-14, atol=1e-14)
-    assert np.abs(no.model_fx(qt, qt.x0_m, qt.u0, np.zeros(2)) - qt.x0_m).max() < 1e-5
+        assert np.allclose(tr, no.model_fx(oqt, x, u, d), rtol=1e-14, atol=1e-14)
+    assert np.abs(no.model_fx(oqt, qt.x0_m, qt.u0, np.zeros(2)) - qt.x0_m).max() < 1e-5
     J = np.array([[float(st.evaluate([e], qt._vals(x=qt.x0_m, u=qt.u0, d=np.zeros(2), t=0.0))[0]) for e in row] for row in qt.f_x])
-    A, B, G, _ = no.linearize(qt, qt.x0_m, qt.u0, np.zeros(2))
+    A, B, G, _ = no.linearize(oqt, qt.x0_m, qt.u0, np.zeros(2))
     assert np.allclose(J, A, rtol=1e-6, atol=1e-8) and np.allclose(J[:2], 0.0) and np.allclose(G, qt.Bd)
 
 
@@ -399,8 +418,9 @@ def test_same_problem_as_the_reference_discrete_example(pkg, qt):
     rng = np.random.default_rng(1)
     for x in [qt.x0_m + rng.normal(size=6) * [3, 3, 2, 2, 0.5, 0.5] for _ in range(3)] + [np.array([50, 50, 25.0, -1.0, 0.2, 19.99]), np.array([50, 50, 19.9, 0.01, 22, 0.0])]:
         u = qt.u0 + rng.normal(size=2) * 5
-        assert np.allclose(no.model_fx(ref, x, u, np.zeros(2)), no.model_fx(qt, x, u, np.zeros(2)), rtol=1e-13, atol=1e-13)       # clamping included
-        assert np.allclose(no.plant_fx(ref, x, u, 100.0), no.plant_fx(qt, x, u, 100.0), rtol=1e-13, atol=1e-13)
+        oref, oqt = oracle_problem(os.path.join(REF, "Ex_NMPC_dis.py"), {"N": 20}), oracle_problem("quadtank_nmpc_dis.py")
+        assert np.allclose(no.model_fx(oref, x, u, np.zeros(2)), no.model_fx(oqt, x, u, np.zeros(2)), rtol=1e-13, atol=1e-13)       # clamping included
+        assert np.allclose(no.plant_fx(oref, x, u, 100.0), no.plant_fx(oqt, x, u, 100.0), rtol=1e-13, atol=1e-13)
     for t in (10, 60, 1500, 2500, 3500, 4500, 6000):
         assert all(np.array_equal(a_, b_) for a_, b_ in zip(ref.defSP(t), qt.defSP(t))) and np.array_equal(ref.def_pxp(t)[0], qt.def_pxp(t)[0])
 
@@ -408,7 +428,8 @@ def test_same_problem_as_the_reference_discrete_example(pkg, qt):
 def test_discrete_oracle_reproduces_its_golden_rows(qt_mild):
     import nmpc_oracle as no
     g = np.load(QGOLD)
-    r = no.closed_loop(qt_mild, 2, x0_p=g["rti_x0"][1], x0_m=g["rti_x0"][1], max_sqp=1)
+    from nmpc_cases import quadtank_mild_setpoints
+    r = no.closed_loop(oracle_problem("quadtank_nmpc_dis.py", {"defSP": quadtank_mild_setpoints}), 2, x0_p=g["rti_x0"][1], x0_m=g["rti_x0"][1], max_sqp=1)
     for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
         assert np.allclose(r[k], g["rti_" + k][:2, 1], rtol=1e-10, atol=1e-10), k
     assert np.all(g["sqp_STATUS_DYN"] == 0) and np.nanmax(g["sqp_KKT_DEFECT"]) < 1e-8 and np.nanmax(g["sqp_KKT_STAT"]) < 1e-7 and np.nanmax(g["sqp_KKT_VIOL"]) < 1e-9
@@ -484,7 +505,7 @@ def test_reactor_example_is_classified_and_its_model_is_the_reference_reactor(pk
 def test_reactor_oracle_reproduces_its_golden_rows(rx):
     import nmpc_oracle as no
     g = np.load(RGOLD)
-    r = no.closed_loop(rx, 3, x0_p=g["rti_x0"][2], x0_m=g["rti_xm"][2], max_sqp=1)
+    r = no.closed_loop(oracle_problem("reactor_nmpc.py"), 3, x0_p=g["rti_x0"][2], x0_m=g["rti_xm"][2], max_sqp=1)
     for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
         assert np.allclose(r[k], g["rti_" + k][:3, 2], rtol=1e-10, atol=1e-10), k
     assert np.all(g["rti_STATUS_DYN"] == 0) and np.all(g["sqp_STATUS_DYN"] == 0)
@@ -546,7 +567,8 @@ def test_gpu_reactor_saturated_disturbance_and_sqp_limit_equal_the_oracle(pkg):
     s = nmpc.NmpcSolver(p)
     try:
         for max_sqp, ns in ((1, 12), (3, 4)):
-            o = [no.closed_loop(p, ns, x0_p=a, x0_m=b, max_sqp=max_sqp, sqp_tol=1e-9) for a, b in zip(x0, xm)]
+            op = oracle_problem("reactor_nmpc.py", {"dmin": -0.05 * np.ones((2, 1)), "dmax": 0.05 * np.ones((2, 1))})
+            o = [no.closed_loop(op, ns, x0_p=a, x0_m=b, max_sqp=max_sqp, sqp_tol=1e-9) for a, b in zip(x0, xm)]
             if max_sqp == 1:
                 assert o[0]["D_HAT"][-1, 0] == 0.05
             else:
@@ -618,7 +640,9 @@ def test_gpu_discrete_example_plant_and_model_apart_equals_the_oracle(qt_mild):
     x0 = np.tile(qt_mild.x0_p, (2, 1)); xm = x0.copy(); xm[:, 2:] += rng.uniform(-1, 1, (2, 4)) * [0.5, 0.5, 0.2, 0.2]
     s = nmpc.NmpcSolver(qt_mild)
     try:
-        o = [no.closed_loop(qt_mild, 4, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
+        from nmpc_cases import quadtank_mild_setpoints
+        oqm = oracle_problem("quadtank_nmpc_dis.py", {"defSP": quadtank_mild_setpoints})
+        o = [no.closed_loop(oqm, 4, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
         r = nmpc.run_nmpc_closed_loop(qt_mild, x0, xm, nsteps=4, solver=s, max_sqp=1)
         for b in range(2):
             assert np.array_equal(r["STATUS_DYN"][:, b], o[b]["STATUS_DYN"])
@@ -644,7 +668,8 @@ def test_gpu_reactor_plant_and_measurement_disturbance_schedules_equal_the_oracl
     p = pkg.load_problem(pkg.example_path("reactor_nmpc.py"), overrides={"def_pxp": _reactor_pxp, "def_pyp": _reactor_pyp})
     assert np.array_equal(p.schedules(4)["pxp"][2], [0.002, -0.003]) and np.array_equal(p.schedules(6)["pyp"][4], [0.0, 0.004])
     x0 = np.array([[0.45, 0.50], [0.47, 0.52]]); xm = np.array([[0.45, 0.50], [0.46, 0.51]])
-    o = [no.closed_loop(p, 8, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
+    op = oracle_problem("reactor_nmpc.py", {"def_pxp": _reactor_pxp, "def_pyp": _reactor_pyp})
+    o = [no.closed_loop(op, 8, x0_p=a, x0_m=b, max_sqp=1) for a, b in zip(x0, xm)]
     s = nmpc.NmpcSolver(p)
     try:
         for kern in (1, 3, 4):
