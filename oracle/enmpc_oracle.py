@@ -55,6 +55,7 @@ def load_problem(path, overrides=None, quad_steps=20):
     """The namespace of an economic example as numbers and plain Python functions (reference MPC_code.py:31-60,84-257,368-438)."""
     ns = exnum.load(path, overrides)
     p = EconProblem()
+    p.ns = ns
     p.name = ns["__name__"]
     p.nx, p.nu, p.ny, p.nd, p.nxp = (ns[k].size1() for k in ("x", "u", "y", "d", "xp"))
     p.N, p.h, p.Nsim, p.Mx = int(ns["N"]), float(ns["h"]), int(ns["Nsim"]), int(ns.get("Mx", 10))

@@ -57,6 +57,18 @@ def test_oracle_reproduces_its_vectors(oprob, gold):
     assert r["ITERS_DYN"].tolist() == gold["ship_ITERS_DYN"][:5, 0].tolist()
 
 
+def test_c_restatement_follows_the_golden_loops(gold):
+    """oracle/enmpc_oracle.c - hand-written functions, complex-step derivatives, null-space (QR + Cholesky) Newton steps - against the vectors of
+    the NumPy oracle (dense LU): the same loops to rounding and the same interior-point iteration counts, at the shipped and both BASELINE sizes."""
+    import enmpc_oracle_c as ec
+    for pre, over, ns in (("ship_", None, 21), ("c4_", {"N": 40}, 10), ("c5_", {"N_mhe": 20}, 24)):
+        r = ec.OracleEC(eo.load_problem(EX, overrides=over)).closed_loop(ns, gold[pre + "x0"])
+        for k in ("U", "XS", "US", "X_ES", "Xp"):
+            assert np.abs(r[k] - gold[pre + k][:ns]).max() < 1e-11, (pre, k, np.abs(r[k] - gold[pre + k][:ns]).max())
+        for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE", "STATUS_DYN", "STATUS_SS"):
+            assert np.array_equal(r[k], gold[pre + k][:ns]), (pre, k)
+
+
 def test_interval_integration_is_within_the_reference_integrators_tolerance(oprob):
     """20 Runge-Kutta steps per shooting interval against a tight adaptive integration of the same augmented system: below the
     tolerances CasADi hands IDAS by default (reltol 1e-6), for state and cost quadrature over the whole input range."""
@@ -331,6 +343,14 @@ def test_gpu_full_size_batches(pkg):
         for k in ("U", "XS", "US", "X_ES"):
             assert np.abs(a[k][:4, i] - o[k]).max() < TOL_U, (i, k)
         assert a["ITERS_DYN"][:4, i].tolist() == o["ITERS_DYN"].tolist()
+    # EVERY instance of the per-GPU share, every step, against the C restatement on the host cores: values, status words and the
+    # interior-point iteration counts of all three NLPs
+    import enmpc_oracle_c as ec
+    c = ec.OracleEC(q).closed_loop(12, sub)
+    for k in ("U", "XS", "US", "X_ES", "Xp"):
+        assert np.abs(a[k] - c[k]).max() < TOL_U, (k, np.abs(a[k] - c[k]).max())
+    for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+        assert np.array_equal(a[k], c[k]), (k, int((a[k] != c[k]).sum()))
     p5 = pkg.load_problem(EX, overrides={"N_mhe": 20})
     r5 = enmpc.run_enmpc_closed_loop(p5, x0[:32768], 23)
     for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
@@ -339,6 +359,11 @@ def test_gpu_full_size_batches(pkg):
     o = eo.closed_loop(q5, 23, x0_p=x0[31000])
     for k in ("U", "X_ES"):
         assert np.abs(r5[k][:, 31000] - o[k]).max() < TOL_U, k
+    c5 = ec.OracleEC(q5).closed_loop(23, x0[:4096])      # configs[4]'s per-GPU share through the filling of the window, every instance
+    for k in ("U", "XS", "X_ES"):
+        assert np.abs(r5[k][:, :4096] - c5[k]).max() < TOL_U, k
+    for k in ("STATUS_DYN", "STATUS_MHE", "ITERS_DYN", "ITERS_MHE"):
+        assert np.array_equal(r5[k][:, :4096], c5[k]), k
 
 
 @pytest.mark.gpu
