@@ -79,7 +79,23 @@ static void rk4(const EProb *P, const cplx *x0, cplx u, const double *d, int ste
 }
 
 /* ---- dense helpers ------------------------------------------------------------------------------------------------------------------ */
-static double *vec(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
+/* Work space: one arena per thread, used as a stack (mark / release).  (malloc per solve would put a third-of-a-megabyte block through
+ * mmap / munmap every time: with hundreds of threads the kernel's address-space lock becomes the benchmark.) */
+#define ARENA_DOUBLES (6u << 20)
+static __thread double *arena = NULL;
+static __thread size_t arena_top = 0;
+static double *vec(size_t n)
+{
+    if (!arena) arena = (double *)malloc(sizeof(double) * ARENA_DOUBLES);
+    if (n == 0) n = 1;
+    if (!arena || arena_top + n > ARENA_DOUBLES) abort();
+    double *p = arena + arena_top;
+    arena_top += n;
+    memset(p, 0, sizeof(double) * n);
+    return p;
+}
+static size_t arena_mark(void) { return arena_top; }
+static void arena_release(size_t mark) { arena_top = mark; }
 
 /* Householder QR of A' (n x m, m <= n; Jt[i*m+j] = J[j][i]) in place; v's below the diagonal, beta in tau, R on and above */
 static int qr_factor(int n, int m, double *A, double *tau)
@@ -171,6 +187,7 @@ static double push_in(double v, double lo, double hi)
 /* n variables (none fixed: the caller has removed parameters), m equalities */
 static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, const double *lo, const double *hi, double tol, int max_iter, int *iters, double *lam_out)
 {
+    const size_t mark_ = arena_mark();
     double *zl = vec(n), *zh = vec(n), *lam = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m),
            *sl = vec(n), *sh = vec(n), *Sig = vec(n), *gt = vec(n), *dw = vec(n), *lamn = vec(m), *py = vec(n), *tmp = vec(n), *Hr = vec((size_t)(n - m) * (n - m)), *rz = vec(n), *HZ = vec((size_t)n * (n - m)), *Zc = vec(n);
     int nb = 0, status = ST_MAXITER, it = 0;
@@ -261,7 +278,7 @@ static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, cons
     }
     *iters = it;
     if (lam_out) memcpy(lam_out, lam, sizeof(double) * m);
-    free(zl); free(zh); free(lam); free(gf); free(g); free(J); free(H); free(Jt); free(tau); free(sl); free(sh); free(Sig); free(gt); free(dw); free(lamn); free(py); free(tmp); free(Hr); free(rz); free(HZ); free(Zc);
+    arena_release(mark_);
     return status;
 }
 
@@ -346,11 +363,12 @@ static void ocp_evalf(void *vctx, const double *w, const double *lam, int want_h
 static int ocp_solve(const EProb *P, const double *xhat, const double *xs, const double *us, const double *d, double *w /* guess in, optimum out */, int *iters)
 {
     const int N = P->N, n = NZ * N, m = NX * N;
+    const size_t mark_ = arena_mark();
     double *lo = vec(n), *hi = vec(n);
     for (int k = 0; k < N; k++) { lo[NZ * k] = P->umin[0]; hi[NZ * k] = P->umax[0]; for (int r = 0; r < NX; r++) { lo[NZ * k + 1 + r] = P->xmin[r]; hi[NZ * k + 1 + r] = P->xmax[r]; } }
     OcpCtx c = {P, xhat, xs, us, d};
     const int st = ipm_nullspace(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, iters, NULL);
-    free(lo); free(hi);
+    arena_release(mark_);
     return st;
 }
 
@@ -487,6 +505,7 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
     S->Y[NY * (N - 1)] = y[0]; S->Y[NY * (N - 1) + 1] = y[1];
     S->U[N - 1] = u; if (N >= 2) S->U[N - 2] = u;
     const int n = N * NB + NE;
+    const size_t mark_ = arena_mark();
     double *w = vec(n), *lo = vec(n), *hi = vec(n);
     cplx xc[NE], wz[NW] = {0, 0, 0, 0}, xo[NE];
     for (int i = 0; i < NE; i++) xc[i] = S->xbar[i];
@@ -540,7 +559,7 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
         for (int i = 0; i + 1 < Nm; i++) { memcpy(S->bA[i], S->bA[i + 1], sizeof(Ak)); memcpy(S->bP[i], S->bP[i + 1], sizeof(Ak)); memcpy(S->bPc[i], S->bPc[i + 1], sizeof(Ak)); }
         for (int i = 0; i < NE; i++) S->xbar[i] = w[NB + i];
     }
-    free(w); free(lo); free(hi);
+    arena_release(mark_);
     return st;
 }
 
@@ -558,7 +577,8 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
         MheState *S = (MheState *)calloc(1, sizeof(MheState));
         double x[NX] = {x0_p[NX * b], x0_p[NX * b + 1]}, xh[NX] = {P->x0m[0], P->x0m[1]}, dh[ND] = {0, 0}, u = P->u0[0], xs[NX] = {P->x0m[0], P->x0m[1]}, us = P->u0[0];
         for (int i = 0; i < NE; i++) { S->xbar[i] = x_bar0 ? x_bar0[NE * b + i] : (i < NX ? P->x0m[i] : 0.0); for (int j = 0; j < NE; j++) S->Pk[i * NE + j] = S->Pkal[i * NE + j] = P->P0[i][j]; }
-        double *wopt = vec(NZ * N), *wg = vec(NZ * N);
+        const size_t mark_b = arena_mark();
+        double *wopt = vec(NZ * N), *wg = vec(NZ * N), *wtry = vec(NZ * N);
         int have_w = 0, last_ok = 1;
         for (int k = 0; k < nsteps; k++) {
             const size_t o = (size_t)k * B + b;
@@ -575,13 +595,11 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
             if (ss != ST_FAILED) { xs[0] = v[0]; xs[1] = v[1]; us = v[2]; }
             if (!have_w) for (int kk = 0; kk < N; kk++) { wg[NZ * kk] = P->u0[0]; wg[NZ * kk + 1] = P->x0m[0]; wg[NZ * kk + 2] = P->x0m[1]; }
             else if (last_ok) { memcpy(wg, wopt + NZ, sizeof(double) * NZ * (N - 1)); wg[NZ * (N - 1)] = us_prev; wg[NZ * (N - 1) + 1] = xs_prev[0]; wg[NZ * (N - 1) + 2] = xs_prev[1]; }
-            double *wtry = vec(NZ * N);
             memcpy(wtry, wg, sizeof(double) * NZ * N);
             const int sd = ocp_solve(P, xh, xs, &us, dh, wtry, &itd);
             last_ok = sd != ST_FAILED; have_w = 1;
             if (last_ok) { memcpy(wopt, wtry, sizeof(double) * NZ * N); u = wopt[0]; xh[0] = wopt[1]; xh[1] = wopt[2]; }
             else { cplx xc[2] = {xh[0], xh[1]}, xo[NX + 1]; cplx zz[3] = {xc[0], xc[1], u}; model_map(P, zz, dh, xo); xh[0] = creal(xo[0]); xh[1] = creal(xo[1]); }
-            free(wtry);
             if (U) U[o] = u;
             if (XS) { XS[o * NX] = xs[0]; XS[o * NX + 1] = xs[1]; }
             if (US) US[o] = us;
@@ -591,7 +609,7 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
             rk4(P, xc, u, NULL, P->Mx, 0, xo, NULL);      /* plant: the same balances (Ex_ENMPC.py:42-49) */
             x[0] = creal(xo[0]); x[1] = creal(xo[1]);
         }
-        free(wopt); free(wg); free(S);
+        arena_release(mark_b); free(S);
     }
     return 0;
 }
