@@ -135,6 +135,21 @@ def test_oracle_reproduces_its_golden_rows(nl, onl, gold):
         assert np.allclose(r[k], gold["rti_" + k][:3, 1], rtol=1e-10, atol=1e-10), k
 
 
+def test_c_restatement_follows_the_golden_loops(onl, gold):
+    """oracle/nmpc_oracle.c (hand-written CSTR, complex-step Jacobians, QPs by the null-space interior point method) against the vectors of
+    the NumPy oracle (finite-difference Jacobians, dense Mehrotra + exact active-set polish): real-time iteration over 40 steps through the
+    feed-flow change, and SQP iterated to the KKT point."""
+    import nmpc_oracle_c as nc
+    o = nc.OracleNC(onl)
+    r = o.closed_loop(40, gold["rti_x0"], max_sqp=1)
+    assert np.array_equal(r["STATUS_DYN"], gold["rti_STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], gold["rti_STATUS_SS"])
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        assert np.max(np.abs(r[k] - gold["rti_" + k]) / (1 + np.abs(gold["rti_" + k]))) < 1e-8, k
+    ns = gold["sqp_U"].shape[0]
+    r = o.closed_loop(ns, gold["rti_x0"][:gold["sqp_U"].shape[1]], max_sqp=50)
+    assert np.max(np.abs(r["U"] - gold["sqp_U"]) / (1 + np.abs(gold["sqp_U"]))) < 1e-8 and int(r["STATUS_DYN"].max()) == 0
+
+
 def test_golden_converged_rows_satisfy_the_nlp_kkt_conditions(nl, onl, gold):
     """Re-verify the certificate without trusting any solver: dynamics defect, stationarity and bounds of the NLP
     (Control_Calc.py:20-260) at the stored trajectories."""
@@ -238,6 +253,15 @@ def test_gpu_full_size_batch_properties(nl, onl, gold, solver):
         for k in ("U", "X_HAT", "XS", "Xp", "D_HAT"):
             assert np.max(np.abs(r[k][:6, b] - o[k]) / (1 + np.abs(o[k]))) < 1e-6, (int(b), k)
         assert np.array_equal(r["STATUS_DYN"][:6, b], o["STATUS_DYN"])
+    # a whole slice of the batch - 2048 instances, all 30 steps, the feed-flow step at t = 5 included - against the C restatement on the host
+    # cores (hand-written CSTR, complex-step Jacobians, null-space QP solves): values of every instance-step and every status word
+    import nmpc_oracle_c as nc
+    cb = 2048
+    c = nc.OracleNC(onl).closed_loop(ns, x0[:cb], max_sqp=1, nthreads=64)
+    assert np.array_equal(r["STATUS_DYN"][:, :cb], c["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"][:, :cb], c["STATUS_SS"])
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        e = np.max(np.abs(r[k][:, :cb] - c[k]) / (1 + np.abs(c[k])))
+        assert e < 1e-6, (k, e)
     perm = rng.permutation(B)
     r2 = nmpc.run_nmpc_closed_loop(nl, x0[perm], x0[perm], nsteps=ns, solver=solver, max_sqp=1)
     for k in ("U", "X_HAT", "Xp", "D_HAT"):
