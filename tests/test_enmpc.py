@@ -353,13 +353,14 @@ def test_gpu_full_size_batches(pkg):
         towards the same point.  Measured on 196 608 instance-steps (tools/enmpc_fullsize_check.py): OCP 0, target 9, estimator 143."""
         d = np.abs(gk.astype(int) - ck.astype(int))
         assert (d != 0).mean() < 2e-3 and d.max() <= 4, (what, int((d != 0).sum()), int(d.max()))
-    c = ec.OracleEC(q).closed_loop(8, sub, nthreads=64)
+    nc_ = 5      # (the cold step and four warm ones: 82 k instance-steps, about a minute of the box's host cores; 12 steps: tools/enmpc_fullsize_check.py)
+    c = ec.OracleEC(q).closed_loop(nc_, sub, nthreads=64)
     for k in ("U", "XS", "US", "X_ES", "Xp"):
-        assert np.abs(a[k][:8] - c[k]).max() < TOL_U, (k, np.abs(a[k][:8] - c[k]).max())
+        assert np.abs(a[k][:nc_] - c[k]).max() < TOL_U, (k, np.abs(a[k][:nc_] - c[k]).max())
     for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
-        assert np.array_equal(a[k][:8], c[k]), (k, int((a[k][:8] != c[k]).sum()))
+        assert np.array_equal(a[k][:nc_], c[k]), (k, int((a[k][:nc_] != c[k]).sum()))
     for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
-        same_path(a[k][:8], c[k], k)
+        same_path(a[k][:nc_], c[k], k)
     p5 = pkg.load_problem(EX, overrides={"N_mhe": 20})
     r5 = enmpc.run_enmpc_closed_loop(p5, x0[:32768], 23)
     for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
@@ -368,13 +369,13 @@ def test_gpu_full_size_batches(pkg):
     o = eo.closed_loop(q5, 23, x0_p=x0[31000])
     for k in ("U", "X_ES"):
         assert np.abs(r5[k][:, 31000] - o[k]).max() < TOL_U, k
-    c5 = ec.OracleEC(q5).closed_loop(23, x0[:4096], nthreads=64)      # configs[4]'s per-GPU share through the filling of the window, every instance
+    c5 = ec.OracleEC(q5).closed_loop(23, x0[:2048], nthreads=64)      # half of configs[4]'s per-GPU share through the filling of the window, every step
     for k in ("U", "XS", "X_ES"):
-        assert np.abs(r5[k][:, :4096] - c5[k]).max() < TOL_U, k
+        assert np.abs(r5[k][:, :2048] - c5[k]).max() < TOL_U, k
     for k in ("STATUS_DYN", "STATUS_MHE"):
-        assert np.array_equal(r5[k][:, :4096], c5[k]), k
+        assert np.array_equal(r5[k][:, :2048], c5[k]), k
     for k in ("ITERS_DYN", "ITERS_MHE"):
-        same_path(r5[k][:, :4096], c5[k], k)
+        same_path(r5[k][:, :2048], c5[k], k)
 
 
 @pytest.mark.gpu
