@@ -104,7 +104,7 @@ def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     nbn = int(min(len(x0), max(64, max_seconds * rate1 * nthr * 0.5 / nsteps)))
     # the fastest thread count, not the largest: all hardware threads, one per physical core (SMT off), a quarter - each a bounded sample
     tried = {}
-    for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4)}, reverse=True):
+    for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
         tried[th] = run(nbn, th, target_seconds / 2.0)      # explicit: orc_closed_loop's thread count is sticky (omp_set_num_threads)
     best = max(tried, key=lambda th: tried[th][0])
     vn, rn, sn = tried[best]
@@ -291,7 +291,7 @@ def main_enmpc(args):
             nthr = oc.max_threads()
             t0 = time.perf_counter(); oc.closed_loop(K, x0[:2], nthreads=1, logs=False); r1 = 2 * K / (time.perf_counter() - t0)      # one core, to size the samples
             tried = {}
-            for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4)}, reverse=True):
+            for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
                 nb = int(min(B, max(th, 5.0 * r1 * th / K)))       # about 5 s per thread count
                 t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
             best = max(tried, key=lambda th: tried[th][0])
@@ -396,7 +396,7 @@ def main_nmpc(args):
         nthr = oc.max_threads()
         t0 = time.perf_counter(); oc.closed_loop(K, x0[:2], max_sqp=args.max_sqp, nthreads=1, logs=False); r1 = 2 * K / (time.perf_counter() - t0)
         tried = {}
-        for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4)}, reverse=True):
+        for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
             nb = int(min(B, max(th, 5.0 * r1 * th / K)))
             t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], max_sqp=args.max_sqp, nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
         best = max(tried, key=lambda th: tried[th][0])
