@@ -193,7 +193,15 @@ def enmpc_alg(p, it_dyn, it_ss, it_mhe, nw_mean):
     rk = lambda rows, cols: 4 * (2 * rows * (1 + cols + cols * (cols + 1) // 2) * 3 + 12 * rows * cols)      # accumulate K, dK, d2K + sparse chain rule, per RK step
     f_ocp = it_dyn * p.N * (p.quad_steps * rk(p.nx + 1, npo) + 2 * (7 * p.nx ** 3 // 3 + 4 * p.nx ** 2 * p.nu + 2 * p.nx * p.nu ** 2) + 60 * (p.nx + p.nu))
     f_ss = it_ss * (p.Mx * rk(p.nx, npo) + 2 * (p.nx + p.nu + p.ny) ** 3)
-    f_mhe = it_mhe * nw_mean * (p.Mx * rk(p.nx, npm) + 2 * (7 * ne ** 3 // 3 + 4 * ne * ne * p.n_w + 2 * ne * p.n_w ** 2 + p.n_w ** 3 // 3) + 60 * (ne + p.n_w))
+    # the estimator's stage matrices A = [[Phi_x, Bd], [0, I]], B = G_mhe have their zeros and ones compiled in (csrc/mpc_enmpc.hip MheStage):
+    # a general entry costs a multiply-add (2), a one an add (1), a zero nothing
+    wgt = lambda m_: float(np.sum(np.where(m_ == 0.0, 0, np.where(m_ == 1.0, 1, 2))))
+    wA = 2.0 * p.nx * p.nx + wgt(np.asarray(p.Bd).reshape(p.nx, -1)) + p.nd
+    wB = wgt(np.asarray(p.G_mhe))
+    nw_ = p.n_w
+    ric_mhe = (ne * (wA + wB) + 2 * ne * ne) + (nw_ * wB + ne * wB + wB) + (ne * wA + wA) + nw_ ** 3 + (2 * nw_ * nw_ * ne + 2 * nw_ * nw_) \
+        + (2 * ne * ne * nw_ + 2 * ne * nw_) + (wA + wB) + (wA + wB + 2 * nw_ * ne)      # PA PB pc | Quu Qux qu | Qxx qx | inverse | gains | P p | gradients | forward
+    f_mhe = it_mhe * nw_mean * (p.Mx * rk(p.nx, npm) + ric_mhe + 60 * (ne + p.n_w))
     b = [16 * st_mhe, 16 * st_tgt, 16 * st_ocp]      # in and out, 8 bytes each
     return [(b[0], float(f_mhe)), (b[1], float(f_ss)), (b[2], float(f_ocp)), (sum(b), float(f_ocp + f_ss + f_mhe))]      # estimator, target, OCP kernels; all in one
 

@@ -104,7 +104,16 @@ template <int SEG, int N_> __device__ __forceinline__ void bcast_sym(const doubl
 // lin(xk, u, pi, L): this lane's stage linearised; term(xn, gv, Hv): terminal cost at this lane's x_{k+1} (used from lane N-1).
 // u / xn come in as the first guess (pushed into the box here) and leave as the final iterate.  Returns the status.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NS, int NU, bool FREE0, int SEG, class LinF, class TermF>
+// ST: what is known at compile time about the stage matrices - a_kind(i, j) / b_kind(i, j) = 0 (the entry of A / B is zero), 1 (it is one), 2 (general: read
+// L.A[i][j] / L.B[i][j]).  With the loops unrolled the products with zeros and ones disappear and the entries that are never read are never held.
+struct DenseStage {
+    __device__ static constexpr int a_kind(int, int) { return 2; }
+    __device__ static constexpr int b_kind(int, int) { return 2; }
+};
+#define EC_A(acc, x, i_, j_) do { if (ST::a_kind(i_, j_) == 1) acc += (x); else if (ST::a_kind(i_, j_) == 2) acc += L.A[i_][j_] * (x); } while (0)
+#define EC_B(acc, x, i_, j_) do { if (ST::b_kind(i_, j_) == 1) acc += (x); else if (ST::b_kind(i_, j_) == 2) acc += L.B[i_][j_] * (x); } while (0)
+
+template <int NS, int NU, bool FREE0, int SEG, class ST, class LinF, class TermF>
 __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
                                          double (&pi)[NS], const double (&ulo)[NU], const double (&uhi)[NU], const double (&xlo)[NS],
                                          const double (&xhi)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
@@ -141,7 +150,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             c[i] = xn[i] - L.F[i];
             double a = L.lx[i];
-            MPC_UNROLL for (int j = 0; j < NS; j++) a += L.A[j][i] * pi[j];
+            MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, pi[j], j, i);
             gxA[i] = a;
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, gxA[i], k); gnext[i] = k == N - 1 ? gv[i] : sh; }
@@ -153,7 +162,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         bool finite = true;
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             double r = L.lu[i] - zlu[i] + zhu[i];
-            MPC_UNROLL for (int j = 0; j < NS; j++) r += L.B[j][i] * pi[j];
+            MPC_UNROLL for (int j = 0; j < NS; j++) EC_B(r, pi[j], j, i);
             e_st = dmax(e_st, fabs(r)); s_z += zlu[i] + zhu[i];
             finite = finite && finite_all(r) && finite_all(u[i]);
             if (flu[i]) { cmax = dmax(cmax, slu[i] * zlu[i]); cmin = dmin(cmin, slu[i] * zlu[i]); }
@@ -211,6 +220,10 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         // ---- Riccati factorisation over the lanes, repeated with a larger shift while a stage lacks positive curvature ----------------
         double K[NU][NS], kff[NU], Pnx[NS][NS], pnx[NS], dx0[NS];
+        // (lanes beyond the horizon never receive theirs: zero, not indeterminate - an indeterminate value lets the optimiser pick what suits it,
+        // and with B = I known at compile time it picked something that broke the lanes inside the horizon, SEG = 64, round 3)
+        MPC_UNROLL for (int i = 0; i < NU; i++) { kff[i] = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) K[i][j] = 0.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { pnx[i] = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) Pnx[i][j] = 0.0; }
         double delta = 0.0;
         bool failed = false;
         for (;;) {
@@ -221,24 +234,24 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             for (int kk = N - 1; kk >= 0; kk--) {
                 double PA[NS][NS], PB[NS][NU], pc[NS];
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pn[i][l] * L.A[l][j]; PA[i][j] = a; }
-                    MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Pn[i][l] * L.B[l][j]; PB[i][j] = a; }
+                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, Pn[i][l], l, j); PA[i][j] = a; }
+                    MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, Pn[i][l], l, j); PB[i][j] = a; }
                     double a = pn[i];
                     MPC_UNROLL for (int l = 0; l < NS; l++) a -= Pn[i][l] * c[l];
                     pc[i] = a;
                 }
                 double Quu[NU][NU], Qux[NU][NS], Qxx[NS][NS], qu[NU], qx[NS];
                 MPC_UNROLL for (int i = 0; i < NU; i++) {
-                    MPC_UNROLL for (int j = 0; j < NU; j++) { double a = L.R[i][j] + (i == j ? Su[i] + delta : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += L.B[l][i] * PB[l][j]; Quu[i][j] = a; }
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = L.M[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += L.B[l][i] * PA[l][j]; Qux[i][j] = a; }
+                    MPC_UNROLL for (int j = 0; j < NU; j++) { double a = L.R[i][j] + (i == j ? Su[i] + delta : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PB[l][j], l, i); Quu[i][j] = a; }
+                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = L.M[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PA[l][j], l, i); Qux[i][j] = a; }
                     double a = L.lu[i] + bu[i];
-                    MPC_UNROLL for (int l = 0; l < NS; l++) a += L.B[l][i] * pc[l];
+                    MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, pc[l], l, i);
                     qu[i] = a;
                 }
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = L.Q[i][j] + (i == j ? Sxk[i] + delta : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) a += L.A[l][i] * PA[l][j]; Qxx[i][j] = a; }
+                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = L.Q[i][j] + (i == j ? Sxk[i] + delta : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, PA[l][j], l, i); Qxx[i][j] = a; }
                     double a = L.lx[i] + bxk[i];
-                    MPC_UNROLL for (int l = 0; l < NS; l++) a += L.A[l][i] * pc[l];
+                    MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, pc[l], l, i);
                     qx[i] = a;
                 }
                 MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Quu[i][j] + Quu[j][i]); Quu[i][j] = a; Quu[j][i] = a; } }
@@ -288,8 +301,8 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += K[i][j] * dx[j]; dul[i] = a; }
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = -c[i];
-                MPC_UNROLL for (int j = 0; j < NS; j++) a += L.A[i][j] * dx[j];
-                MPC_UNROLL for (int j = 0; j < NU; j++) a += L.B[i][j] * dul[j];
+                MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, dx[j], i, j);
+                MPC_UNROLL for (int j = 0; j < NU; j++) EC_B(a, dul[j], i, j);
                 dxl[i] = a;
             }
             if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dul[i]; MPC_UNROLL for (int i = 0; i < NS; i++) dxn[i] = dxl[i]; }

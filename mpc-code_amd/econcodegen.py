@@ -159,11 +159,18 @@ def emit_econ_header(p) -> str:
     vmw.update({f"v[{i}]": f"wv[{nw + i}]" for i in range(ny)})
     vmw["t"] = "t"
     cmhe = emit_scalar("cmhe", p.c_mhe, vwv, vmw, "const double *wv, double t")
+    def cmat(name, a):      # a constant matrix as a constexpr function of its indices: zeros and ones are known to the compiler where the loops unroll
+        a = [[float(v) for v in row] for row in a]
+        terms = "".join(f"(i == {i} && j == {j}) ? {v!r} : " for i, row in enumerate(a) for j, v in enumerate(row) if v != 0.0)
+        return f"    __host__ __device__ static constexpr double {name}(int i, int j) {{ return {terms}0.0; }}\n"
+    consts = cmat("Bd", p.Bd) + cmat("Cd", p.Cd) + cmat("G", p.G_mhe)
     return f"""// GENERATED by mpc-code_amd/econcodegen.py from the traced functions of '{p.name}' - do not edit.
 #pragma once
 struct EcModel {{
     static constexpr int NX = {nx}, NU = {nu}, NY = {ny}, ND = {nd}, NXP = {nxp}, NW = {nw}, MX = {p.Mx};
-    struct Ctx {{ double u[NU], d[ND], xs[NX], us[NU]; }};      // what a right-hand side reads besides its state
+    // disturbance model and noise input of the example (offree = 'lin': Bd, Cd, Utilities.py:174-177,202-204; G_mhe, MPC_code.py:387): part of the problem
+    // definition, compiled in so that the estimator's recursions skip their zeros and ones; enmpc_create checks the descriptor against them
+{consts}    struct Ctx {{ double u[NU], d[ND], xs[NX], us[NU]; }};      // what a right-hand side reads besides its state
     // shooting interval of the ContForm OCP: [User_fxm_Cont + px; User_fobj_Cont]   (Control_Calc.py:102-111)
 {ocp}
     // the model alone: target's fixed-point equation, hold rule   (Utilities.py:157-183)

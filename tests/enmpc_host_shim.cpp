@@ -1,7 +1,7 @@
 // Test infrastructure: the product's GENERATED model code (mpc-code_amd/econcodegen.py) and its Runge-Kutta sensitivity driver
 // (mpc-code_amd/csrc/mpc_rk4s2.hpp) compiled for the HOST, so that tests/test_enmpc.py can compare the product's first and second
 // derivatives with the oracle's complex-step ones without a GPU.  Built by the test with
-//   g++ -O1 -std=c++17 -shared -fPIC -D__device__= -D__forceinline__=inline -DMPC_EC_MODEL_HEADER="..." tests/enmpc_host_shim.cpp
+//   g++ -O1 -std=c++17 -shared -fPIC -D__device__= -D__host__= -D__forceinline__=inline -DMPC_EC_MODEL_HEADER="..." tests/enmpc_host_shim.cpp
 #define MPC_UNROLL
 #include MPC_EC_MODEL_HEADER
 #include "../mpc-code_amd/csrc/mpc_rk4s2.hpp"

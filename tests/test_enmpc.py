@@ -172,7 +172,7 @@ def shim(prob, tmp_path_factory):
     with open(hdr, "w") as fh:
         fh.write(econcodegen.emit_econ_header(prob))
     so = os.path.join(d, "shim.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-D__device__=", "-D__forceinline__=inline", f'-DMPC_EC_MODEL_HEADER="{hdr}"',
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-D__device__=", "-D__host__=", "-D__forceinline__=inline", f'-DMPC_EC_MODEL_HEADER="{hdr}"',
                            "-o", so, os.path.join(ROOT, "tests", "enmpc_host_shim.cpp")])
     return ct.CDLL(so)
 
