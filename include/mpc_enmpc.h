@@ -34,6 +34,7 @@ typedef struct enmpc_desc {
     int32_t max_iter;                /* Sol_itmax: interior-point iterations per NLP */
     int32_t quad_steps;              /* Runge-Kutta steps per shooting interval of the OCP (cost quadrature included) */
     int32_t device;
+    int32_t mhe_update;              /* update of the arrival cost, mhe_up (Estimator.py:626-736): 0 = 'smooth', 1 = 'filter' */
     double h;                        /* sampling interval */
     double tol, tol_mhe;             /* optimality tolerances: IPOPT's default 1e-8, 1e-10 for the estimator (MPC_code.py:383) */
     const double *umin, *umax, *xmin, *xmax;                                   /* OCP boxes; +-INFINITY = absent */

@@ -63,7 +63,18 @@ struct Seg {
     // stage kk's value to every lane of its segment (kk wave-uniform)
     __device__ static __forceinline__ double bcast(double v, int kk, int lane)
     {
-        if (SEG == 64) return lane_of(v, kk);
+        if (SEG == 64) {
+            // v_readlane leaves the value in scalar registers; it is moved to vector registers at once.  Not a matter of taste: with the
+            // broadcasts of the recursions left in scalar registers (a few dozen doubles per stage, far more than the scalar file holds next
+            // to the problem constants) five of six builds of the estimator kernel computed garbage from the first step on - iteration
+            // counts like 314141150, not reproducible from run to run - whatever else changed (-O2, scheduler and spill options, the dense
+            // recursion); with the move, or with ds_bpermute broadcasts instead, all of them are right (round 3, tools/enmpc_bcast_matrix.py).
+            double r = lane_of(v, kk);
+#ifndef EC_BCAST_IN_SGPRS      // (the matrix's failing leg)
+            asm("" : "+v"(r));
+#endif
+            return r;
+        }
         return __shfl(v, (lane & ~(SEG - 1)) + kk);
     }
     __device__ static __forceinline__ double max(double v)

@@ -66,6 +66,7 @@ class EconomicMPCProblem:
     u0: np.ndarray = None
     max_iter: int = 100
     N_mhe: int = 0
+    mhe_up: str = "smooth"          # update of the arrival cost: 'smooth' | 'filter' (Estimator.py:626-736)
     n_w: int = 0
     G_mhe: np.ndarray = None
     P0: np.ndarray = None
@@ -128,8 +129,8 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         raise UnsupportedProblem("the economic path needs StateFeedback = True and offree = 'lin' (outputs y = x + Cd d)")
     if not ns.get("mhe", False):
         raise UnsupportedProblem("the economic path needs the moving-horizon estimator (mhe = True)")
-    if ns.get("mhe_up", "smooth") != "smooth":
-        raise UnsupportedProblem("only the smoothing update of the arrival cost (mhe_up = 'smooth') is built")
+    if ns.get("mhe_up", "smooth") not in ("smooth", "filter"):
+        raise UnsupportedProblem("mhe_up: 'smooth' or 'filter' (Estimator.py:626-736)")
     for req in ("N_mhe", "w", "User_fx_mhe_Cont", "User_fobj_mhe", "P0", "x_bar"):
         if not has(req):
             raise UnsupportedProblem(f"'{req}' missing for the moving-horizon estimator")
@@ -182,7 +183,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         ymin_ss=pick("ymin", "_ss", ny, -INF), ymax_ss=pick("ymax", "_ss", ny, INF),
         dmin=None if ns.get("dmin") is None else _vec(ns["dmin"], nd, -INF), dmax=None if ns.get("dmax") is None else _vec(ns["dmax"], nd, INF),
         x0_p=_vec(ns["x0_p"], nxp, 0.0), x0_m=_vec(ns["x0_m"], nx, 0.0), u0=_vec(ns["u0"], nu, 0.0), max_iter=int(ns.get("Sol_itmax", 100)),
-        N_mhe=N_mhe, n_w=n_w, G_mhe=G, P0=_mat(ns["P0"], nx + nd, nx + nd, "P0"), x_bar=np.asarray(ns["x_bar"], dtype=np.float64).reshape(nx + nd),
+        N_mhe=N_mhe, mhe_up=str(ns.get("mhe_up", "smooth")), n_w=n_w, G_mhe=G, P0=_mat(ns["P0"], nx + nd, nx + nd, "P0"), x_bar=np.asarray(ns["x_bar"], dtype=np.float64).reshape(nx + nd),
         xmin_mhe=np.concatenate([_vec(ns.get("xmin"), nx, -INF), _vec(ns.get("dmin"), nd, -INF)]),      # MPC_code.py:397-402
         xmax_mhe=np.concatenate([_vec(ns.get("xmax"), nx, INF), _vec(ns.get("dmax"), nd, INF)]),
         name=name or str(ns.get("__name__", "")),

@@ -23,7 +23,7 @@ _dp = ct.POINTER(ct.c_double)
 
 
 class _EDesc(ct.Structure):
-    _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "nw", "N", "N_mhe", "max_iter", "quad_steps", "device")]
+    _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "nw", "N", "N_mhe", "max_iter", "quad_steps", "device", "mhe_update")]
                 + [(k, ct.c_double) for k in ("h", "tol", "tol_mhe")]
                 + [(k, _dp) for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe",
                                       "dmin", "dmax", "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0")])
@@ -77,6 +77,7 @@ class EnmpcSolver:
         d = _EDesc()
         d.nx, d.nu, d.ny, d.nd, d.nxp, d.nw, d.N, d.N_mhe = p.nx, p.nu, p.ny, p.nd, p.nxp, p.n_w, p.N, p.N_mhe
         d.max_iter, d.quad_steps, d.device, d.h, d.tol, d.tol_mhe = int(p.max_iter), int(p.quad_steps), int(device), float(p.h), float(tol), float(tol_mhe)
+        d.mhe_update = {"smooth": 0, "filter": 1}[p.mhe_up]
         for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe", "dmin", "dmax",
                   "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0"):
             v = getattr(p, k, None)

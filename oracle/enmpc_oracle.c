@@ -31,7 +31,7 @@ enum { NX = 2, NU = 1, NY = 2, ND = 2, NE = 4, NW = 4, NZ = NX + NU, NV = NX + N
 #include "orc_dense.h"
 
 typedef struct {
-    int32_t N, N_mhe, Mx, quad, max_iter, has_dsat;
+    int32_t N, N_mhe, Mx, quad, max_iter, has_dsat, mhe_filter;      /* mhe_filter: mhe_up = 'filter' (else 'smooth') */
     double h, tol, tol_mhe;
     double par[7];               /* cA0, V, k1, k2, alfa, beta, terminal weight */
     double umin[NU], umax[NU], xmin[NX], xmax[NX], tlo[NV], thi[NV], elo[NE], ehi[NE], dmin[ND], dmax[ND];
@@ -279,10 +279,33 @@ static void mhe_evalf(void *vctx, const double *w, const double *lam, int want_h
 /* ---- what mhe() carries from call to call ------------------------------------------------------------------------------------------- */
 typedef struct {
     double U[64], Y[64 * NY], wk[NW], vk[NY], xbar[NE], Pk[NE * NE], Pkal[NE * NE], bA[64][NE * NE], bP[64][NE * NE], bPc[64][NE * NE];
+    double XL[64][NE], WL[64][NW];      /* the lists of x(k+1|k) and w_k the 'filter' update reads (:541-554; V is not needed: the cost's Hessian is constant) */
     int nU, nL;
 } MheState;
 
 static void mm4(const double *A, const double *B, double *C, int tb) { for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = 0.0; for (int l = 0; l < NE; l++) s += A[i * NE + l] * (tb ? B[j * NE + l] : B[l * NE + j]); C[i * NE + j] = s; } }
+
+/* P(k|k) and P(k+1|k) of an extended Kalman step on the covariance Pin, linearised at (x, u, w) - Estimator.py:557-623 and :629-649 are
+   this with different arguments; the Hessian of the estimator cost is the identity here, so Q_k = I, R_k = I, S_k = 0 (no cross terms) */
+static void ekf_cov(const EProb *P, const double *Pin, const double *x, double u, const double *wk, double *Ak, double *Pc, double *Pn)
+{
+    double Ca[NY * NE], K[NE * NY], Sm[NY * NY], Si[NY * NY], T1[NE * NE], T2[NE * NE];
+    cplx zc[NE + NW], oo[NE];
+    for (int j = 0; j < NE; j++) {
+        for (int i = 0; i < NE; i++) zc[i] = x[i];
+        for (int i = 0; i < NW; i++) zc[NE + i] = wk[i];
+        zc[j] += I * CS;
+        mhe_map(P, zc, u, zc + NE, oo);
+        for (int r = 0; r < NE; r++) Ak[r * NE + j] = cimag(oo[r]) / CS;
+    }
+    for (int r = 0; r < NY; r++) for (int i = 0; i < NE; i++) Ca[r * NE + i] = i < NX ? (r == i) : P->Cd[r][i - NX];
+    for (int r = 0; r < NY; r++) for (int q = 0; q < NY; q++) { double s = r == q ? 1.0 : 0.0; for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) s += Ca[r * NE + i] * Pin[i * NE + j] * Ca[q * NE + j]; Sm[r * NY + q] = s; }
+    inv_small(NY, Sm, Si);
+    for (int i = 0; i < NE; i++) for (int r = 0; r < NY; r++) { double s = 0.0; for (int j = 0; j < NE; j++) for (int q = 0; q < NY; q++) s += Pin[i * NE + j] * Ca[q * NE + j] * Si[q * NY + r]; K[i * NY + r] = s; }
+    for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = Pin[i * NE + j]; for (int r = 0; r < NY; r++) for (int l = 0; l < NE; l++) s -= K[i * NY + r] * Ca[r * NE + l] * Pin[l * NE + j]; Pc[i * NE + j] = s; }
+    mm4(Ak, Pc, T1, 0); mm4(T1, Ak, T2, 1);      /* A Pc A' */
+    for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = T2[i * NE + j]; for (int l = 0; l < NW; l++) s += P->G[i][l] * P->G[j][l]; Pn[i * NE + j] = s; }      /* + G Q G' */
+}
 
 static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, double u, double *xes, int *iters)
 {
@@ -312,25 +335,27 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
     for (int i = 0; i < NE; i++) xes[i] = Xl[i];
     for (int i = 0; i < NY; i++) S->vk[i] = Xl[NE + i];
     if (ksim != 0) for (int i = 0; i < NW; i++) S->wk[i] = Xl[NE + NY + i];
-    /* Kalman quantities (Estimator.py:558-623); the Hessian of the estimator cost is the identity here, so Q_k = I, R_k = I, S_k = 0 */
-    double Ak[NE * NE], Ca[NY * NE], K[NE * NY], Sm[NY * NY], Si[NY * NY], Pc[NE * NE], T1[NE * NE], T2[NE * NE];
-    cplx zc[NE + NW], oo[NE];
-    for (int j = 0; j < NE; j++) {
-        for (int i = 0; i < NE; i++) zc[i] = xes[i];
-        for (int i = 0; i < NW; i++) zc[NE + i] = S->wk[i];
-        zc[j] += I * CS;
-        mhe_map(P, zc, u, zc + NE, oo);
-        for (int r = 0; r < NE; r++) Ak[r * NE + j] = cimag(oo[r]) / CS;
-    }
-    for (int r = 0; r < NY; r++) for (int i = 0; i < NE; i++) Ca[r * NE + i] = i < NX ? (r == i) : P->Cd[r][i - NX];
-    for (int r = 0; r < NY; r++) for (int q = 0; q < NY; q++) { double s = r == q ? 1.0 : 0.0; for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) s += Ca[r * NE + i] * S->Pkal[i * NE + j] * Ca[q * NE + j]; Sm[r * NY + q] = s; }
-    inv_small(NY, Sm, Si);
-    for (int i = 0; i < NE; i++) for (int r = 0; r < NY; r++) { double s = 0.0; for (int j = 0; j < NE; j++) for (int q = 0; q < NY; q++) s += S->Pkal[i * NE + j] * Ca[q * NE + j] * Si[q * NY + r]; K[i * NY + r] = s; }
-    for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = S->Pkal[i * NE + j]; for (int r = 0; r < NY; r++) for (int l = 0; l < NE; l++) s -= K[i * NY + r] * Ca[r * NE + l] * S->Pkal[l * NE + j]; Pc[i * NE + j] = s; }
     const int idx = ksim < Nm - 1 ? ksim : Nm - 1;
+    {   /* the lists of one-step predictions and process noises (:541-554) */
+        const int il = ksim < Nm ? ksim : Nm - 1;
+        if (ksim >= Nm) for (int i = 0; i + 1 < Nm; i++) { memcpy(S->XL[i], S->XL[i + 1], sizeof(S->XL[0])); memcpy(S->WL[i], S->WL[i + 1], sizeof(S->WL[0])); }
+        for (int i = 0; i < NE; i++) S->XL[il][i] = w[NB * N + i];
+        for (int i = 0; i < NW; i++) S->WL[il][i] = S->wk[i];
+    }
+    double Ak[NE * NE], Pc[NE * NE], Pn[NE * NE], T1[NE * NE], T2[NE * NE];
+    if (P->mhe_filter) {      /* (:557-623 also run for 'filter' in the reference, into lists nothing reads afterwards: left out here) */
+        if (ksim >= Nm - 1) {      /* :627-649: one Kalman step on the prior weight at the window's first entries; :740-748 */
+            ekf_cov(P, S->Pk, S->XL[0], S->U[0], S->WL[0], Ak, Pc, Pn);
+            memcpy(S->Pk, Pn, sizeof(Pn));
+            for (int i = 0; i < NE; i++) S->xbar[i] = S->XL[0][i];
+        }
+        arena_release(mark_);
+        return st;
+    }
+    /* Kalman quantities (Estimator.py:558-623) */
+    ekf_cov(P, S->Pkal, xes, u, S->wk, Ak, Pc, Pn);
     memcpy(S->bA[idx], Ak, sizeof(Ak)); memcpy(S->bP[idx], S->Pkal, sizeof(Ak)); memcpy(S->bPc[idx], Pc, sizeof(Ak));
-    mm4(Ak, Pc, T1, 0); mm4(T1, Ak, T2, 1);      /* A Pc A' */
-    for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = T2[i * NE + j]; for (int l = 0; l < NW; l++) s += P->G[i][l] * P->G[j][l]; S->Pkal[i * NE + j] = s; }      /* + G Q G' (S_k = 0: no cross terms) */
+    memcpy(S->Pkal, Pn, sizeof(Pn));
     if (ksim >= Nm - 1) {      /* smoothing (:652-665) */
         double Pis[NE * NE], Pim[NE * NE], D[NE * NE], Gn[NE * NE];
         memcpy(Pis, S->bPc[Nm - 1], sizeof(Pis));

@@ -78,7 +78,7 @@ def load_problem(path, overrides=None, quad_steps=20):
     p.mhe = bool(ns.get("mhe", False))
     if p.mhe:
         p.N_mhe, p.mhe_up = int(ns["N_mhe"]), ns.get("mhe_up", "smooth")
-        assert p.mhe_up == "smooth" and p.N_mhe >= 2, "only the smoothing update of the shipped example is restated"
+        assert p.mhe_up in ("smooth", "filter") and p.N_mhe >= 2, "prior updates: 'smooth' (the shipped example) and 'filter'"
         p.n_w = ns["w"].size1()
         p.fx_mhe, p.fobj_mhe = ns["User_fx_mhe_Cont"], ns["User_fobj_mhe"]
         p.G_mhe = np.asarray(ns["G_mhe"], dtype=float) if ns.get("G_mhe") is not None else np.eye(p.nx + p.nd)      # MPC_code.py:387
@@ -520,12 +520,13 @@ class MheState:
         self.x_bar, self.P_k = p.x_bar.copy(), p.P0.copy()
         self.bigA, self.bigP, self.bigPc = [], [], []
         self.P_kal = p.P0.copy()
+        self.X, self.V, self.W = [], [], []                  # the lists of x(k+1|k), v_k, w_k the 'filter' update reads (:541-554)
         self.last = None
 
 
 def mhe_step(p, S, ksim, y_act, u_k, t_k=0.0, max_iter=None, tol=1e-10):
     max_iter = p.max_iter if max_iter is None else max_iter      # ipopt.tol = 1e-10 for the estimator (MPC_code.py:383)
-    """One call of mhe() (Estimator.py:388-768) with ``mhe_up = 'smooth'``; returns the corrected estimate [x; d](k|k)."""
+    """One call of mhe() (Estimator.py:388-768), ``mhe_up = 'smooth'`` or ``'filter'``; returns the corrected estimate [x; d](k|k)."""
     ne, q, nw_, m = p.nx + p.nd, p.ny, p.n_w, p.nu
     nb = ne + q + nw_
     N = min(ksim + 1, p.N_mhe)                               # MPC_code.py:591-593
@@ -554,17 +555,36 @@ def mhe_step(p, S, ksim, y_act, u_k, t_k=0.0, max_iter=None, tol=1e-10):
     S.v_k = w[-nb:-ne - nw_].copy()
     if ksim != 0:
         S.w_k = w[-ne - nw_:-ne].copy()                      # :536-538
+    # the lists of one-step predictions and noises (:541-554)
+    if ksim < p.N_mhe:
+        S.X, S.V, S.W = S.X + [xkp1k.copy()], S.V + [S.v_k.copy()], S.W + [S.w_k.copy()]
+    else:
+        S.X, S.V, S.W = S.X[1:] + [xkp1k.copy()], S.V[1:] + [S.v_k.copy()], S.W[1:] + [S.w_k.copy()]
+
+    def ekf_covariance(P_in, w_, v_, x_c, x_a, u_, t_):
+        """P(k|k) and P(k+1|k) of an extended Kalman step with correlated noises, weights from the estimator's cost (:557-623 and
+        :629-649 are this with different arguments): C at x_c, A and G at (x_a, u_, w_)."""
+        Hk = np.linalg.inv(hess_fd(lambda Zc: np.array([p.fobj_mhe(Zc[:nw_, i], Zc[nw_:, i], t_) for i in range(Zc.shape[1])]), np.concatenate([w_, v_])))
+        Q_k, R_k, S_k = Hk[:nw_, :nw_], Hk[-q:, -q:], Hk[:nw_, -q:]
+        _, C_k = jac_cs(lambda Zc: fy_es(p, Zc), x_c)
+        _, Fj = jac_cs(lambda Zc: fx_mhe(p, Zc[:ne], u_.reshape(-1, 1), Zc[ne:], t_), np.concatenate([x_a, w_]))
+        A_k, G_k = Fj[:, :ne], Fj[:, ne:]
+        K_k = P_in @ C_k.T @ np.linalg.inv(C_k @ P_in @ C_k.T + R_k)
+        P_corr = P_in - K_k @ C_k @ P_in
+        M_k = -K_k @ S_k.T
+        return A_k, P_corr, A_k @ P_corr @ A_k.T + G_k @ Q_k @ G_k.T + A_k @ M_k @ G_k.T + G_k @ M_k @ A_k.T
+
+    if p.mhe_up == "filter":
+        # (:557-623 also run for 'filter' in the reference, into lists nothing reads afterwards: left out here)
+        if ksim >= p.N_mhe - 1:                              # :627-649: one Kalman step on the prior weight, at the window's first entries
+            # (C is evaluated at Xmin[0] in the reference: Fy_es is linear in the state here, so the point does not matter)
+            _, _, S.P_k = ekf_covariance(S.P_k, S.W[0], S.V[0], S.X[0], S.X[0], S.U[0], S.T[0])
+            S.x_bar = S.X[0].copy()                          # :740-748
+        S.U = [] if ksim == 0 else S.U[:-1]
+        return xhat_corr.copy()
     # Kalman quantities for the smoothing update (:558-623)
-    Hk = np.linalg.inv(hess_fd(lambda Zc: np.array([p.fobj_mhe(Zc[:nw_, i], Zc[nw_:, i], t_k) for i in range(Zc.shape[1])]), np.concatenate([S.w_k, S.v_k])))
-    Q_k, R_k, S_k = Hk[:nw_, :nw_], Hk[-q:, -q:], Hk[:nw_, -q:]
-    _, C_k = jac_cs(lambda Zc: fy_es(p, Zc), xhat_corr)
-    _, Fj = jac_cs(lambda Zc: fx_mhe(p, Zc[:ne], u_k.reshape(-1, 1), Zc[ne:], t_k), np.concatenate([xhat_corr, S.w_k]))
-    A_k, G_k = Fj[:, :ne], Fj[:, ne:]
-    K_k = S.P_kal @ C_k.T @ np.linalg.inv(C_k @ S.P_kal @ C_k.T + R_k)
-    P_corr = S.P_kal - K_k @ C_k @ S.P_kal
     Pi = S.P_kal
-    M_k = -K_k @ S_k.T
-    S.P_kal = A_k @ P_corr @ A_k.T + G_k @ Q_k @ G_k.T + A_k @ M_k @ G_k.T + G_k @ M_k @ A_k.T
+    A_k, P_corr, S.P_kal = ekf_covariance(S.P_kal, S.w_k, S.v_k, xhat_corr, xhat_corr, u_k, t_k)
     S.bigA.append(A_k); S.bigP.append(Pi); S.bigPc.append(P_corr)
     if ksim >= p.N_mhe - 1:                                  # :626-665: smoothed covariance of the window's second state
         Nm = p.N_mhe

@@ -22,7 +22,7 @@ NX, NU, NY, ND, NE, NW, NV = 2, 1, 2, 2, 4, 4, 5
 
 
 class _EProb(ct.Structure):
-    _fields_ = ([(k, ct.c_int32) for k in ("N", "N_mhe", "Mx", "quad", "max_iter", "has_dsat")] + [(k, ct.c_double) for k in ("h", "tol", "tol_mhe")]
+    _fields_ = ([(k, ct.c_int32) for k in ("N", "N_mhe", "Mx", "quad", "max_iter", "has_dsat", "mhe_filter")] + [(k, ct.c_double) for k in ("h", "tol", "tol_mhe")]
                 + [("par", ct.c_double * 7), ("umin", ct.c_double * NU), ("umax", ct.c_double * NU), ("xmin", ct.c_double * NX), ("xmax", ct.c_double * NX),
                    ("tlo", ct.c_double * NV), ("thi", ct.c_double * NV), ("elo", ct.c_double * NE), ("ehi", ct.c_double * NE), ("dmin", ct.c_double * ND), ("dmax", ct.c_double * ND),
                    ("Bd", ct.c_double * (NX * ND)), ("Cd", ct.c_double * (NY * ND)), ("G", ct.c_double * (NE * NW)), ("P0", ct.c_double * (NE * NE)),
@@ -53,6 +53,7 @@ class OracleEC:
         self.lib = ct.CDLL(build(fast))
         s = _EProb()
         s.N, s.N_mhe, s.Mx, s.quad, s.max_iter, s.has_dsat = p.N, p.N_mhe, p.Mx, p.quad_steps, p.max_iter, int(p.dmin is not None)
+        s.mhe_filter = int(getattr(p, "mhe_up", "smooth") == "filter")
         s.h, s.tol, s.tol_mhe = p.h, 1e-8, 1e-10
         fill = lambda field, v: field.__setitem__(slice(0, len(field)), [float(a) for a in np.ravel(v)])
         fill(s.par, _params(p))

@@ -10,6 +10,7 @@ terminates on.
   ship_*   the example as shipped (N = 25, N_mhe = 10), 21 steps = its Nsim, the shipped start
   c4_*     BASELINE configs[3]: N = 40, 10 steps, 3 starts of the benchmark box x0_p ~ U([0.5, 1] x [0, 0.5])
   c5_*     BASELINE configs[4]: N_mhe = 20, 24 steps (the window fills at step 19: growing window, then the smoothing update), 2 starts
+  flt_*    the example with mhe_up = 'filter' (Estimator.py:627-649,740-748) and N_mhe = 6, 16 steps, 2 starts
 """
 import os
 import sys
@@ -49,7 +50,11 @@ def main():
     x5 = box(2, seed=7)
     out.update({"c5_" + k: v for k, v in run(p5, 24, x5).items()}); out["c5_x0"] = x5
     print("config 5", time.time() - t0)
-    for pre in ("ship_", "c4_", "c5_"):
+    pf = eo.load_problem(EX, overrides={"mhe_up": "filter", "N_mhe": 6})
+    xf = np.vstack([pf.x0_p[None], box(1, seed=11)])
+    out.update({"flt_" + k: v for k, v in run(pf, 16, xf).items()}); out["flt_x0"] = xf
+    print("filter update", time.time() - t0)
+    for pre in ("ship_", "c4_", "c5_", "flt_"):
         worst = max(float(out[pre + k].max()) for k in ("KKT_DYN", "KKT_SS", "KKT_MHE"))
         print(pre, "largest KKT residual", worst, "all solved", int(out[pre + "STATUS_DYN"].max()) == 0 and int(out[pre + "STATUS_SS"].max()) == 0)
     np.savez_compressed(os.path.join(HERE, "enmpc_reactor.npz"), **out)

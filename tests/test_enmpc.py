@@ -61,7 +61,7 @@ def test_c_restatement_follows_the_golden_loops(gold):
     """oracle/enmpc_oracle.c - hand-written functions, complex-step derivatives, null-space (QR + Cholesky) Newton steps - against the vectors of
     the NumPy oracle (dense LU): the same loops to rounding and the same interior-point iteration counts, at the shipped and both BASELINE sizes."""
     import enmpc_oracle_c as ec
-    for pre, over, ns in (("ship_", None, 21), ("c4_", {"N": 40}, 10), ("c5_", {"N_mhe": 20}, 24)):
+    for pre, over, ns in (("ship_", None, 21), ("c4_", {"N": 40}, 10), ("c5_", {"N_mhe": 20}, 24), ("flt_", {"mhe_up": "filter", "N_mhe": 6}, 16)):
         r = ec.OracleEC(eo.load_problem(EX, overrides=over)).closed_loop(ns, gold[pre + "x0"])
         for k in ("U", "XS", "US", "X_ES", "Xp"):
             assert np.abs(r[k] - gold[pre + k][:ns]).max() < 1e-11, (pre, k, np.abs(r[k] - gold[pre + k][:ns]).max())
@@ -158,7 +158,8 @@ def test_loader_classifies_and_refuses(pkg, prob):
     from mpc_code_amd import EconomicMPCProblem, UnsupportedProblem
     assert isinstance(prob, EconomicMPCProblem) and (prob.N, prob.N_mhe, prob.quad_steps, prob.max_iter) == (25, 10, 20, 200)
     assert np.array_equal(prob.xmax_mhe, [1.0, 1.0, np.inf, np.inf]) and np.array_equal(prob.x_bar, [1.2, 0.5, 0.0, 0.0])
-    for over in ({"mhe_up": "filter"}, {"slacks": True}, {"N": 80}, {"N_mhe": 64}, {"StateFeedback": False}, {"TermCons": True}):
+    assert pkg.load_problem(EX, overrides={"mhe_up": "filter"}).mhe_up == "filter" and prob.mhe_up == "smooth"
+    for over in ({"mhe_up": "window"}, {"slacks": True}, {"N": 80}, {"N_mhe": 64}, {"StateFeedback": False}, {"TermCons": True}):
         with pytest.raises(UnsupportedProblem):
             pkg.load_problem(EX, overrides=over)
 
@@ -286,6 +287,17 @@ def test_gpu_baseline_config_horizons_follow_the_golden_loops(pkg, gold, kernel)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 2, 64])
+def test_gpu_filter_update_of_the_arrival_cost_follows_the_golden_loop(pkg, gold, kernel):
+    """mhe_up = 'filter' (Estimator.py:627-649,740-748): the arrival weight takes one Kalman step at the first entries of the lists of
+    one-step predictions and noises, the prior mean becomes the list's first prediction - through the filling of the window and beyond."""
+    p, r = _gpu_loop(pkg, {"mhe_up": "filter", "N_mhe": 6}, gold["flt_x0"], 16, kernel=kernel)
+    _check(r, gold, "flt_", 16)
+    p, q = _gpu_loop(pkg, {"mhe_up": "filter", "N_mhe": 6}, gold["flt_x0"], 16, kernel=kernel, steps_per_launch=5)      # the lists through HBM between launches
+    assert np.array_equal(q["U"], r["U"]) and np.array_equal(q["X_ES"], r["X_ES"])
+
+
+@pytest.mark.gpu
 def test_gpu_launch_boundaries_and_launch_styles_do_not_change_the_loop(pkg, gold):
     x0 = np.vstack([gold["ship_x0"], gold["c4_x0"]])
     p, a = _gpu_loop(pkg, None, x0, 14, kernel=1)                # one launch for all steps: the state stays in registers
@@ -401,3 +413,27 @@ def test_gpu_ragged_batches_and_call_order(pkg, gold):
         x0 = np.tile(gold["ship_x0"], (B, 1))
         r = enmpc.run_enmpc_closed_loop(p, x0, 3)
         assert np.abs(r["U"][:, -1] - gold["ship_U"][:3, 0]).max() < TOL_U
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("over,nsteps", [({"N": 2, "N_mhe": 2}, 8), ({"N": 3, "N_mhe": 3}, 8), ({"N": 33, "N_mhe": 17}, 22), ({"N": 64, "N_mhe": 63}, 66),
+                                         ({"Sol_itmax": 4}, 6), ({"Sol_itmax": 1}, 4)])
+def test_gpu_edge_horizons_and_iteration_limits_follow_the_c_restatement(pkg, over, nsteps):
+    """Shortest and longest horizons a wavefront holds (one stage per lane: 2 <= N <= 64, 2 <= N_mhe <= 63), a window that crosses the
+    32-lane segment, and NLPs cut off at the iteration limit (accepted like the reference accepts every status but 'infeasible',
+    MPC_code.py:714,786): every launch style against the C restatement, every step, through the filling of the window."""
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc
+    x0 = np.random.default_rng(5).uniform([0.5, 0.0], [1.0, 0.5], size=(3 if nsteps > 50 else 6, 2))      # (the longest horizons: half a minute of host time per instance)
+    p = pkg.load_problem(EX, overrides=over)
+    c = ec.OracleEC(eo.load_problem(EX, overrides=over)).closed_loop(nsteps, x0, nthreads=6)
+    s = enmpc.EnmpcSolver(p)
+    for kernel in (1, 2):
+        r = enmpc.run_enmpc_closed_loop(p, x0, nsteps, solver=s, kernel=kernel)
+        for k in ("U", "XS", "US", "X_ES", "Xp"):
+            assert np.abs(r[k] - c[k]).max() < TOL_U, (kernel, k, np.abs(r[k] - c[k]).max())
+        for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+            assert np.array_equal(r[k], c[k]), (kernel, k, r[k].T.tolist(), c[k].T.tolist())
+    if "Sol_itmax" in over:
+        assert int(c["STATUS_DYN"].max()) == 1      # the cut-off shows
+    s.close()

@@ -68,7 +68,7 @@ def test_every_example_of_the_reference_loads_unmodified(pkg):
             kinds[os.path.basename(f)] = type(pkg.load_problem(f)).__name__
     assert kinds == {"Ex_ENMPC.py": "EconomicMPCProblem", "Ex_LMPC_CSTR.py": "LinearMPCProblem", "Ex_LMPC_WB.py": "LinearMPCProblem", "Ex_LMPC_nlplant.py": "LinearMPCProblem",
                      "Ex_LMPCxp_nlplant.py": "LinearMPCProblem", "Ex_NMPC.py": "NonlinearMPCProblem", "Ex_NMPC_dis.py": "NonlinearMPCProblem"}, kinds
-    for over in ({"slacks": True}, {"Collocation": True}, {"mhe_up": "filter"}):
+    for over in ({"slacks": True}, {"Collocation": True}, {"mhe_up": "other"}):
         with pytest.raises(pkg.UnsupportedProblem):
             pkg.load_problem(os.path.join(REF, "Ex_ENMPC.py"), overrides=over)
 

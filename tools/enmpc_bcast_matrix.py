@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic (round 3): where the broadcasts of the wave = instance recursions may live.  Builds the economic library with the v_readlane
+broadcasts left in scalar registers (-DEC_BCAST_IN_SGPRS) and with the move to vector registers the product uses, each under six build
+perturbations, and runs the shipped example on kernel 1 and on the forced 64-lane split pipeline against the golden loop ('.' right,
+'X' wrong, 'T' no answer within 25 s).   build here:  tools/enmpc_bcast_matrix.py build      run on the GPU box:  tools/enmpc_bcast_matrix.py
+Recorded: profiles/r03_enmpc_bcast_matrix.txt."""
+import os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mpc_code_amd as m
+from mpc_code_amd import enmpc, econcodegen
+g = np.load(os.path.join(ROOT, "tests", "golden", "enmpc_reactor.npz"))
+p = m.load_problem(m.example_path("reactor_enmpc.py"))
+PERT = {"plain": [], "O2": ["-O2"], "noagpr": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"], "nopost": ["-mllvm", "-enable-post-misched=0"], "dense": ["-DMPC_EC_DENSE_MHE"],
+        "nosink": ["-mllvm", "-disable-machine-sink"]}
+MODE = {"in-scalar-registers": ["-DEC_BCAST_IN_SGPRS"], "moved-to-vector-registers": []}
+libs = {(a, b): econcodegen.build_enmpc_library(p, extra_flags=MODE[a] + PERT[b]) for a in MODE for b in PERT}
+if sys.argv[1:] == ["build"]:
+    sys.exit(0)
+if len(sys.argv) == 3:      # child process: one library (a wrong kernel may never come back)
+    s = enmpc.EnmpcSolver(p, lib_path=libs[(sys.argv[1], sys.argv[2])])
+    res = ""
+    for kern in (1, 64):
+        r = enmpc.run_enmpc_closed_loop(p, g["ship_x0"], 12, solver=s, kernel=kern)
+        res += "." if np.abs(r["U"] - g["ship_U"][:12]).max() < 1e-9 and np.array_equal(r["ITERS_MHE"], g["ship_ITERS_MHE"][:12]) else "X"
+    print(res)
+    sys.exit(0)
+for a in MODE:
+    out = []
+    for b in PERT:
+        try:
+            o = subprocess.run([sys.executable, __file__, a, b], capture_output=True, text=True, timeout=25).stdout.strip().split("\n")[-1]
+        except subprocess.TimeoutExpired:
+            o = "T"
+        out.append(f"{b}:{o}")
+    print(f"{a:28s} (kernel 1, kernel 64)  " + "  ".join(out), flush=True)
