@@ -257,6 +257,7 @@ struct LoopArgs {
     int B, nsteps; size_t Bs;
     int N;                                           // horizon (host side: sizes the dynamic LDS of the wave-autonomous kernel)
     double t0, h;                                    // time of the launch's first step, sampling interval (a user plant integrates in time)
+    int wv_ni;                                       // wave-autonomous kernel: instances per wave (0 = by batch size; option "wave_instances")
 };
 
 // x_p(t + h) (MPC_code.py:813-816).  Linear plant: Ap x + Bp u + pxp (Utilities.py:45-49).  User plant: MX classical RK4 steps of
@@ -987,6 +988,20 @@ static constexpr int kTpMaxBatch = 16384;     // auto choice of the loop kernel 
 // bound modes: which variant of the OCP kernels a problem may use (cheapest first)
 enum { kBoundsAllFinite = 1, kBoundsInputsOnly = 2, kBoundsGeneric = 0 };
 
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED, int NI>
+static int launch_loop_wv(const DevProblem *p, LoopArgs a, hipStream_t s, int dev)
+{
+    using KC = WvKernelCfg<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
+    auto kern = loop_kernel_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
+    static bool attr_set[64] = {};      // per device: more than 64 KB of dynamic LDS has to be asked for
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KC::lds_bytes(64)) != hipSuccess) return -1;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.B + NI - 1) / NI), dim3(64), KC::lds_bytes(a.N), s, p, a);
+    return 0;
+}
+
 template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG, int NC, bool MASKED>
 static Launchers make_launchers_mode()
 {
@@ -1037,17 +1052,21 @@ static Launchers make_launchers_mode()
         constexpr size_t lds = KC::lds_bytes(64);      // the longest horizon; a launch asks for what its own horizon needs
         l.wv_lds = lds; l.wv_ws_per_inst = sizeof(double) * 64 * KC::Cfg::ROWS_WS;
         if (lds <= 160 * 1024) {
+            // Instances per wave by the size of the batch: a wave is alone on its SIMD (512 registers), so a batch of fewer than NI waves
+            // per SIMD leaves SIMDs empty while the others work through NI instances one after the other in the element-wise phases.
+            // Up to one instance per SIMD: NI = 1; up to two: NI = 2 (the matrix-core passes cost the same for 1, 2 or 4 tiles).  The
+            // arithmetic of an instance does not depend on its neighbours in the wave: same results bit for bit (tests/test_gpu_parity.py).
             l.loop_wv = [](const DevProblem *p, LoopArgs a, hipStream_t s) -> int {
-                auto kern = loop_kernel_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>;
-                static bool attr_set[64] = {};
-                int dev = 0;
+                int dev = 0, cus = 0;
                 if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-                if (!attr_set[dev]) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-                    attr_set[dev] = true;
-                }
-                hipLaunchKernelGGL(kern, dim3((a.B + NI - 1) / NI), dim3(64), KC::lds_bytes(a.N), s, p, a);
-                return 0;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1;
+                const int simds = 4 * cus;
+                int ni = a.wv_ni > 0 ? a.wv_ni : (a.B <= simds ? 1 : (a.B <= 2 * simds ? 2 : NI));
+                if (ni > NI) ni = NI;
+                if (ni == 3) ni = 2;
+                if (ni == 1) return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, 1>(p, a, s, dev);
+                if (ni == 2) return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, 2>(p, a, s, dev);
+                return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>(p, a, s, dev);
             };
             l.wv_ns = NSZ_;
             l.ocp_wv = [](const DevProblem *p, OcpWvArgs a, int N, hipStream_t s) -> int {
@@ -1103,6 +1122,7 @@ struct mpc_handle {
     bool timed = false; int n_launches = 0;
     int steps_per_launch = 50;  // closed-loop steps per kernel launch (a launch starts with cold scalar / instruction caches)
     int loop_kernel_opt = 0;    // option "loop_kernel": 0 = choose by batch size, 1 = instance per lane, 2 = horizon-parallel
+    int wv_ni_opt = 0;          // option "wave_instances": instances per wave of the wave-autonomous loop kernel (0 = by batch size, else 1, 2 or 4)
     int ws_mode = -1;           // which loop kernel's layout the workspace holds (-1 = none: next OCPs start cold)
     double h_sample = 1.0;      // sampling interval (mpc_lin_desc.h_sample): the time a user plant integrates over
     // per-call scratch (solve API)
@@ -1441,6 +1461,12 @@ extern "C" int mpc_set_option(mpc_handle *h, const char *name, double value)
         h->loop_kernel_opt = v;
         return 0;
     }
+    if (!std::strcmp(name, "wave_instances")) {
+        const int v = (int)value;
+        if (v != 0 && v != 1 && v != 2 && v != 4) return fail(-1, "wave_instances must be 0 (by batch size), 1, 2 or 4");
+        h->wv_ni_opt = v;
+        return 0;
+    }
     if (!std::strcmp(name, "ocp_warm_start")) { h->ocp_warm = value != 0.0; h->pc_B = 0; return 0; }
     if (!std::strcmp(name, "ocp_kernel")) {
         const int v = (int)value;
@@ -1460,6 +1486,7 @@ extern "C" int mpc_get_option(mpc_handle *h, const char *name, double *value)
     if (!h || !name || !value) return fail(-1, "null argument");
     if (!std::strcmp(name, "steps_per_launch")) { *value = h->steps_per_launch; return 0; }
     if (!std::strcmp(name, "loop_kernel")) { *value = loop_mode(h); return 0; }
+    if (!std::strcmp(name, "wave_instances")) { *value = h->wv_ni_opt; return 0; }
     if (!std::strcmp(name, "ocp_warm_start")) { *value = h->ocp_warm; return 0; }
     if (!std::strcmp(name, "ocp_kernel")) { *value = ocp_uses_wave(h) ? 3 : 1; return 0; }
     return fail(-1, "unknown option '%s'", name);
@@ -1922,7 +1949,7 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         a.ws_valid = (int32_t *)h->st_flag.p; a.kf_valid = a.ws_valid + Bs; a.Kg = (double *)h->st_Kg.p; a.Pn = (double *)h->st_Pn.p;
         a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs; a.N = P.N;
-        a.h = h->h_sample; a.t0 = k * h->h_sample;
+        a.h = h->h_sample; a.t0 = k * h->h_sample; a.wv_ni = h->wv_ni_opt;
         if (mode == 3) { if (h->L.loop_wv(h->dp, a, h->stream)) return fail(-9, "cannot configure the wave-autonomous kernel (LDS %zu bytes)", h->L.wv_lds); }
         else if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);

@@ -795,3 +795,25 @@ def test_fused_closed_loop_with_the_user_plant(nlplant, xp_nlplant):
     with pytest.raises(ValueError, match="no compiled plant"):
         run_closed_loop(nlplant, nlplant.x0_p[None], nlplant.x0_m[None], 3, solver=s, fused=True)
     s.close()
+
+
+def test_instances_per_wave_follow_the_batch_size_and_do_not_change_the_loop(cstr, wb, oracle_c, solver_factory):
+    """The wave-autonomous kernel takes one, two or four instances per wave by the size of the batch (a wave is alone on its SIMD, so
+    a small batch spreads over more SIMDs): an instance's arithmetic does not depend on its neighbours - the same closed loop bit for
+    bit whatever the packing, and the C restatement's loop; ragged batches leave instance slots of the last wave empty."""
+    from mpc_code_amd.driver import run_closed_loop
+    for p, B, K in ((cstr, 203, 12), (wb, 61, 14)):
+        x0 = bench_x0(B, 5) if p is cstr else np.zeros((B, p.nx)) + np.random.default_rng(3).normal(size=(B, p.nx)) * 0.05
+        runs = {}
+        for ni in (0, 1, 2, 4):
+            s = solver_factory(p, 3)
+            s.set_option("wave_instances", ni)
+            runs[ni] = run_closed_loop(p, x0, x0, K, solver=s)
+        for ni in (1, 2, 4):
+            for k in ("U", "XS", "US", "X_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"):
+                assert np.array_equal(runs[ni][k], runs[0][k]), (p.name, ni, k)
+        c = oracle_c.OracleC(p).closed_loop(K, x0, x0)
+        assert assert_same_closed_loop(runs[0], c, p, TOL_PORT, max_flipped=0.0) == 0
+    s = solver_factory(cstr, 3)
+    with pytest.raises(Exception):
+        s.set_option("wave_instances", 3)
