@@ -67,6 +67,11 @@ int enmpc_sync(enmpc_handle *h);
  * by side where a horizon fits SEG = 16 or 32 lanes (and the batch has waves to spare); kernel = 16 / 32 / 64 forces the split pipeline with
  * that SEG.  Same results either way.  enmpc_get_kernel: 1 or 2, the launch style in force */
 int enmpc_set_kernel(enmpc_handle *h, int32_t kernel);
+/* split pipeline: the batch in `groups` parts (multiples of 64 instances), each part's launches on a HIP stream of its own - the three launches of a
+ * step depend on each other, the parts do not, so one part's target launch (a few dozen waves) runs beside another part's estimator or OCP launch.
+ * 0 = by batch size (default), 1..8.  Results do not depend on it.  All streams are ordered after / before the handle's stream at the ends of
+ * enmpc_run; with enmpc_time_kernels on, one part. */
+int enmpc_set_groups(enmpc_handle *h, int32_t groups);
 int enmpc_get_kernel(enmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT","X_ES" (the estimator's corrected [x; d]);
  * [nsteps][B] int32: "STATUS_DYN","STATUS_SS","STATUS_MHE","ITERS_DYN","ITERS_SS","ITERS_MHE" (interior-point iterations) */

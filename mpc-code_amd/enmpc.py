@@ -17,7 +17,7 @@ from .capi import MpcAmdError
 
 ENMPC_EXPORTS = ("enmpc_create", "enmpc_destroy", "enmpc_last_error", "enmpc_build_info", "enmpc_alloc", "enmpc_set_state", "enmpc_run",
                  "enmpc_sync", "enmpc_get_log", "enmpc_last_kernel_ms", "enmpc_set_kernel", "enmpc_get_kernel", "enmpc_time_kernels",
-                 "enmpc_phase_ms")
+                 "enmpc_phase_ms", "enmpc_set_groups")
 
 _dp = ct.POINTER(ct.c_double)
 
@@ -48,6 +48,7 @@ def load_enmpc_library(path: str) -> ct.CDLL:
     lib.enmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
     lib.enmpc_last_kernel_ms.argtypes = [vp]; lib.enmpc_last_kernel_ms.restype = ct.c_float
     lib.enmpc_set_kernel.argtypes = [vp, ct.c_int32]
+    lib.enmpc_set_groups.argtypes = [vp, ct.c_int32]
     lib.enmpc_get_kernel.argtypes = [vp]
     lib.enmpc_time_kernels.argtypes = [vp, ct.c_int32]
     lib.enmpc_phase_ms.argtypes = [vp, ct.POINTER(ct.c_float), ct.POINTER(ct.c_int32)]
@@ -137,6 +138,10 @@ class EnmpcSolver:
         """0 auto, 1 one launch for all steps, 2 split pipeline (one launch per phase and step)"""
         self._chk(self.lib.enmpc_set_kernel(self.h, int(kernel)), "enmpc_set_kernel")
 
+    def set_groups(self, groups: int):
+        """split pipeline: groups of the batch, each on its own stream (0: by batch size)"""
+        self._chk(self.lib.enmpc_set_groups(self.h, int(groups)), "enmpc_set_groups")
+
     def get_kernel(self) -> int:
         return int(self.lib.enmpc_get_kernel(self.h))
 
@@ -166,7 +171,7 @@ class EnmpcSolver:
 
 
 def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, steps_per_launch: int = 0, solver: Optional[EnmpcSolver] = None,
-                          kernel: Optional[int] = None):
+                          kernel: Optional[int] = None, groups: Optional[int] = None):
     """The closed loop of the reference for B instances (rows of ``x0_p``); model state, input and the estimator's prior start from the
     Ex-file's ``x0_m``, ``u0``, ``x_bar``.  Returns the reference's result arrays ``[nsteps, B, dim]`` plus status / iteration words."""
     p = problem
@@ -177,6 +182,8 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
         s.alloc(len(x0_p), nsteps)
         if kernel is not None:
             s.set_kernel(kernel)
+        if groups is not None:
+            s.set_groups(groups)
         s.set_state(x0_p)
         spl = steps_per_launch if steps_per_launch > 0 else nsteps
         for k0 in range(0, nsteps, spl):

@@ -317,6 +317,13 @@ def test_gpu_launch_boundaries_and_launch_styles_do_not_change_the_loop(pkg, gol
             assert np.abs(a[k] - b[k]).max() < 1e-12, (seg, k, np.abs(a[k] - b[k]).max())
         for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE", "STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
             assert np.array_equal(a[k], b[k]), (seg, k)
+    # the split pipeline's groups of the batch on streams of their own: the same loop whatever their number (ragged last group included)
+    xg = np.tile(x0, (90, 1))[:347]
+    p, a = _gpu_loop(pkg, None, xg, 6, kernel=2, groups=1)
+    for G in (2, 3, 8):
+        p, b = _gpu_loop(pkg, None, xg, 6, kernel=2, groups=G)
+        for k in ("U", "XS", "X_ES", "Xp", "ITERS_DYN", "ITERS_MHE", "STATUS_DYN"):
+            assert np.array_equal(a[k], b[k]), (G, k)
     p, b = _gpu_loop(pkg, {"N": 12, "N_mhe": 5}, xr, 9, kernel=16)      # both horizons in 16 lanes: four OCPs per wave too
     p, a = _gpu_loop(pkg, {"N": 12, "N_mhe": 5}, xr, 9, kernel=1)
     for k in ("U", "X_ES", "XS"):
