@@ -142,6 +142,12 @@ int mpc_loop_get_state(mpc_handle *h, double *x_p, double *xhat, double *dhat, d
                        double *xs, double *us);
 int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double *ysp, const double *usp,
                           const double *xsp, const double *pxp, const double *pyp);
+/* Model parameters that vary over the horizon, for every step of the fused loop (def_px / def_py, MPC_code.py:492-497): px [nsteps][N][nx] with
+ * px[k][i] = def_px(t_k + i) - the reference's indexing: time plus stage index -, py [nsteps][N][ny] likewise; either may be NULL, both NULL switch
+ * them off.  Estimator, target, the stage-0 output test, the hold rule and the plant see px[k][0], py[k][0] (p_x_k, p_y_k: MPC_code.py:500-507).
+ * With a schedule set mpc_loop_run uses the instance-per-lane loop with per-block stage data, target and OCP cold at every step: the same numbers
+ * as the call-by-call sequence mpc_set_model_offsets / mpc_kf_update / mpc_target_solve / mpc_ocp_solve(px, py). */
+int mpc_loop_set_model_schedule(mpc_handle *h, int32_t nsteps, const double *px, const double *py);
 int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps);
 int mpc_loop_sync(mpc_handle *h);
 int mpc_loop_get_log(mpc_handle *h, const char *name, void *out);

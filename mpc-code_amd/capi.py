@@ -124,6 +124,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     lib.mpc_loop_set_state.argtypes = [ct.c_void_p] + [_dp] * 7
     lib.mpc_loop_get_state.argtypes = [ct.c_void_p] + [_dp] * 7
     lib.mpc_loop_set_schedule.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5
+    lib.mpc_loop_set_model_schedule.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 2
     lib.mpc_ocp_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 7 + [_dp, _dp, _dp, _ip, _ip, _dp]
     lib.mpc_target_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5 + [_dp, _dp, _dp, _ip, _ip]
     lib.mpc_kf_update.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp, _dp]
@@ -145,7 +146,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
 
 
 EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update", "mpc_set_model_offsets",
-           "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_run",
+           "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_set_model_schedule", "mpc_loop_run",
            "mpc_loop_sync", "mpc_loop_get_log", "mpc_closed_loop", "mpc_last_kernel_ms", "mpc_stream", "mpc_dev_ptr",
            "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_get_option", "mpc_build_info",
            "mpc_comm_unique_id", "mpc_comm_init", "mpc_comm_destroy", "mpc_comm_rank", "mpc_comm_allgather",
@@ -402,6 +403,16 @@ class Solver:
         self._chk(self.lib.mpc_loop_set_schedule(self.h, int(nsteps), _p(s["ysp"]), _p(s["usp"]), _p(s.get("xsp")),
                                                  _p(s.get("pxp")), _p(s.get("pyp"))), "mpc_loop_set_schedule")
         self._sched_n = int(nsteps)
+
+    def loop_set_model_schedule(self, px=None, py=None):
+        """``def_px`` / ``def_py`` for every step of the fused loop: ``px`` [nsteps, N, nx] with ``px[k, i] = def_px(t_k + i)``, ``py`` [nsteps, N, ny]
+        likewise (``MPC_code.py:492-497``); both ``None`` switch them off."""
+        p = self.p
+        pxa = None if px is None else np.ascontiguousarray(np.asarray(px, dtype=np.float64).reshape(-1, p.N, p.nx))
+        pya = None if py is None else np.ascontiguousarray(np.asarray(py, dtype=np.float64).reshape(-1, p.N, p.ny))
+        n = 0 if pxa is None and pya is None else len(pxa if pxa is not None else pya)
+        self._msched_keep = (pxa, pya)
+        self._chk(self.lib.mpc_loop_set_model_schedule(self.h, int(n), _p(pxa), _p(pya)), "mpc_loop_set_model_schedule")
 
     def loop_run(self, k0: int, nsteps: int):
         self._chk(self.lib.mpc_loop_run(self.h, int(k0), int(nsteps)), "mpc_loop_run")

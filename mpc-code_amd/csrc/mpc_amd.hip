@@ -258,6 +258,8 @@ struct LoopArgs {
     int N;                                           // horizon (host side: sizes the dynamic LDS of the wave-autonomous kernel)
     double t0, h;                                    // time of the launch's first step, sampling interval (a user plant integrates in time)
     int wv_ni;                                       // wave-autonomous kernel: instances per wave (0 = by batch size; option "wave_instances")
+    const double *px_h, *py_h;                       // def_px / def_py over the horizon, [step][N][nx] / [step][N][ny] offset to k0 (loop_kernel_pxy), or nullptr
+    double *lin;                                     // loop_kernel_pxy: slab of per-block stage data
 };
 
 // x_p(t + h) (MPC_code.py:813-816).  Linear plant: Ap x + Bp u + pxp (Utilities.py:45-49).  User plant: MX classical RK4 steps of
@@ -405,6 +407,157 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
     MPC_UNROLL for (int i = 0; i < NU; i++) { a.u[i * Bs + b] = u[i]; a.us[i * Bs + b] = us[i]; }
     a.ws_valid[b] = ws_valid ? 1 : 0;
+}
+
+// The closed loop with model parameters that vary over the horizon (def_px / def_py, MPC_code.py:492-510): at step k the OCP sees
+// px_i = def_px(t_k + i), py_i = def_py(t_k + i), i = 0..N-1 (the reference's indexing: time plus stage index), estimator, target, the
+// stage-0 output test and the hold rule see the first of them (p_x_k, p_y_k: MPC_code.py:500-502,524,693,770-772,804).  Instance per lane
+// like loop_kernel; the OCP is ocp_kernel_pxy's - per-block affine terms and boxes in a slab, rpdip_lane<.., LTV>, cold every step - so a
+// fused run equals the call-by-call one (three C-ABI calls per step with mpc_set_model_offsets) bit for bit.  One instantiation per
+// dimension set (all bounds maskable).
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG>
+__global__ __launch_bounds__(64) void loop_kernel_pxy(const DevProblem *__restrict__ Pp, LoopArgs a)
+{
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NB = NX + (DU ? NU : 0), NE = NX + ND, NC = NS + NU, NLTV = NS * (NS + NU + 1), NLIN = NLTV + 2 * NS;
+    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    const size_t Bs = a.Bs;
+    const int N = P.N;
+    double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
+    MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
+    StageConst<NS, NU> C;
+    load_stage_const<NS, NU, DU>(P, C);
+    constexpr int SL = BlkLayout<NS, NU, NC>::SLOTS;
+    Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (N + 2) + 1) * SL * 64), N, SL, lane};
+    double *const lin = a.lin + (size_t)blockIdx.x * N * NLIN * 64 + lane;
+    for (int k = 0; k < a.nsteps; k++) {
+        const double *pxh = a.px_h ? a.px_h + (size_t)k * N * NX : nullptr, *pyh = a.py_h ? a.py_h + (size_t)k * N * NY : nullptr;
+        double px0[NX], py0[NY];
+        MPC_UNROLL for (int i = 0; i < NX; i++) px0[i] = pxh ? pxh[i] : 0.0;
+        MPC_UNROLL for (int i = 0; i < NY; i++) py0[i] = pyh ? pyh[i] : 0.0;
+        if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
+        if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
+        // ---- measure and estimate (MPC_code.py:524-534, 577-668): yhat = Fy_model(xhat, dhat) + p_y_k ----
+        if (P.estimator != MPC_EST_NONE) {
+            double xi[NE], innov[NY];
+            MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
+            MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double yh = P.fyc[i] + py0[i], yy = a.pyp[k * NY + i];
+                MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+                MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
+                innov[i] = (yy + py0[i]) - yh;      // the plant's output carries p_ymp = p_y_k too (MPC_code.py:505-507,534)
+            }
+            if (P.estimator == MPC_EST_KALMAN) {
+                double Pk[NE][NE];
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
+                kalman_lane<NE, NY>(P, xi, Pk, innov);
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+            } else {
+                MPC_UNROLL for (int i = 0; i < NE; i++) { double s = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s += P.Kfix[i][l] * innov[l]; xi[i] += s; }
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
+            MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
+        }
+        if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) a.DHAT[((size_t)k * ND + i) * Bs + b] = dh[i]; }
+        // ---- target with p_x_k, p_y_k in its equalities (MPC_code.py:693-718), cold like the per-call entry point ----
+        double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
+        MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
+        MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
+        int it_ss;
+        const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, nullptr, 0, nullptr, pxh ? px0 : nullptr, pyh ? py0 : nullptr);
+        if (st_ss != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
+        }
+        if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XS[((size_t)k * NX + i) * Bs + b] = xs[i]; }
+        if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) a.US[((size_t)k * NU + i) * Bs + b] = us[i]; }
+        if (a.YS) {   // ys = Fy_model(xs, us, dhat, p_y_k), MPC_code.py:730
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double v = P.fyc[i] + py0[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Cm[i][j] * xs[j];
+                MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Cd[i][j] * dh[j];
+                a.YS[((size_t)k * NY + i) * Bs + b] = v;
+            }
+        }
+        // ---- OCP (MPC_code.py:733-805): per-block affine terms and boxes -> slab (as ocp_kernel_pxy) ----
+        OcpInst<NS, NU> q;
+        build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, q);
+        double e0[NY];      // output offsets without py
+        MPC_UNROLL for (int i = 0; i < NY; i++) { double e = P.fyc[i]; MPC_UNROLL for (int j = 0; j < ND; j++) e += P.Cd[i][j] * dh[j]; e0[i] = e; }
+        if (P.y_bounded && pyh) {      // the stage-0 row is a test of the given x_0 (Control_Calc.py:128-151), with py_0
+            q.ok0 = true;
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double y0 = e0[i] + py0[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) y0 += P.Cm[i][j] * xh[j];
+                const double rl = kBoundRelax * dmax(1.0, fabs(P.ymin[i])), rh = kBoundRelax * dmax(1.0, fabs(P.ymax[i]));
+                if (!(y0 >= P.ymin[i] - rl) || !(y0 <= P.ymax[i] + rh)) q.ok0 = false;
+            }
+        }
+        for (int kk = 0; kk < N; kk++) {
+            double *lb = lin + (size_t)kk * NLIN * 64;
+            double pxk[NX];
+            MPC_UNROLL for (int i = 0; i < NX; i++) pxk[i] = pxh ? pxh[(size_t)kk * NX + i] : 0.0;
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NS; j++) lb[(i * NS + j) * 64] = C.A[i][j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) lb[(NS * NS + i * NU + j) * 64] = C.B[i][j];
+                double c = q.c[i];
+                if (i < NX) c += pxk[i < NX ? i : 0];
+                if (i >= NB) { const int r = P.yg_row[i >= NB ? i - NB : 0]; MPC_UNROLL for (int j = 0; j < NX; j++) c += P.Cm[r][j] * pxk[j]; }
+                lb[(NS * NS + NS * NU + i) * 64] = c;
+            }
+            double lo[NS], hi[NS];
+            const bool end = kk == N - 1;
+            MPC_UNROLL for (int i = 0; i < NS; i++) { lo[i] = end ? P.zlo_e[i] : P.zlo_m[i]; hi[i] = end ? P.zhi_e[i] : P.zhi_m[i]; }
+            if (P.y_bounded && !end) {
+                MPC_UNROLL for (int i = 0; i < NY; i++) {
+                    const double e = e0[i] + (pyh ? pyh[(size_t)(kk + 1) * NY + i] : 0.0);
+                    const double sc = P.ymap_scale[i];
+                    const double aa = (P.ymin[i] - e) / sc, bb = (P.ymax[i] - e) / sc;
+                    const double l = sc > 0 ? aa : bb, hh = sc > 0 ? bb : aa;
+                    const int idx = P.ymap_idx[i];
+                    MPC_UNROLL for (int j = 0; j < NS; j++)
+                        if (j == idx) { lo[j] = dmax(lo[j], l); hi[j] = dmin(hi[j], hh); }
+                }
+            }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { lb[(NLTV + i) * 64] = lo[i]; lb[(NLTV + NS + i) * 64] = hi[i]; }
+        }
+        double u0[NU], z1[NS], res[3];
+        int it_dyn;
+        int st_dyn = rpdip_lane<NS, NU, DU, NC, true, true>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it_dyn, lin, 1, NLIN, NLTV);
+        if (P.term_cons && st_dyn != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st_dyn = kInfeasible;
+        if (st_dyn != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];          // :798
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
+        } else {                                                           // :804-805 hold u, propagate the model (with p_x_k)
+            double xn[NX];
+            MPC_UNROLL for (int i = 0; i < NX; i++) {
+                double v = P.fxc[i] + px0[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Am[i][j] * xh[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bm[i][j] * u[j];
+                MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Bd[i][j] * dh[j];
+                xn[i] = v;
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xn[i];
+        }
+        if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) a.U[((size_t)k * NU + i) * Bs + b] = u[i]; }
+        if (a.st_dyn) { a.st_dyn[(size_t)k * Bs + b] = st_dyn; a.st_ss[(size_t)k * Bs + b] = st_ss; a.it_dyn[(size_t)k * Bs + b] = it_dyn; a.it_ss[(size_t)k * Bs + b] = it_ss; }
+        {
+            double xn[NXP], pxpk[NXP];      // the plant's state equation carries p_xmp = p_x_k too (MPC_code.py:500-504,813-816)
+            MPC_UNROLL for (int i = 0; i < NXP; i++) pxpk[i] = a.pxp[k * NXP + i] + ((pxh && i < NX) ? px0[i < NX ? i : 0] : 0.0);
+            plant_next<NXP, NU>(P, x, u, pxpk, a.t0 + k * a.h, a.h, xn);
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = xn[i];
+        }
+    }
+    MPC_UNROLL for (int i = 0; i < NXP; i++) a.x[i * Bs + b] = x[i];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { a.xhat[i * Bs + b] = xh[i]; a.xs[i * Bs + b] = xs[i]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { a.u[i * Bs + b] = u[i]; a.us[i * Bs + b] = us[i]; }
+    a.ws_valid[b] = 0;      // (this kernel's workspace layout is not a warm start for the others)
 }
 
 // The closed loop with the horizon-parallel OCP solver (mpc_tp.hpp): a workgroup of NI waves owns NI instances.
@@ -969,6 +1122,7 @@ __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__
 struct Launchers {
     void (*ocp)(const DevProblem *, OcpArgs, hipStream_t);
     void (*ocp_pxy)(const DevProblem *, OcpPxyArgs, hipStream_t);      // time-varying px / py: one variant (all bounds maskable)
+    void (*loop_pxy)(const DevProblem *, LoopArgs, hipStream_t);       // the closed loop with def_px / def_py schedules (instance per lane)
     int pxy_ws_rows, pxy_nc, pxy_lin;                                  // its workspace rows / bounded variables / slab entries per block
     void (*target)(const DevProblem *, TargetArgs, hipStream_t);
     void (*kf)(const DevProblem *, KfArgs, hipStream_t);
@@ -1010,6 +1164,7 @@ static Launchers make_launchers_mode()
     {
         constexpr int NSZ = NX + (DU ? NU : 0) + NG;
         l.ocp_pxy = [](const DevProblem *p, OcpPxyArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel_pxy<NX, NU, NY, ND, DU, NG>), dim3((a.o.B + 63) / 64), dim3(64), 0, s, p, a); };
+        l.loop_pxy = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel_pxy<NX, NU, NY, ND, NXP, DU, NG>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
         l.pxy_ws_rows = 2 * BlkLayout<NSZ, NU, NSZ + NU>::SLOTS; l.pxy_nc = NSZ + NU; l.pxy_lin = NSZ * (NSZ + NU + 1) + 2 * NSZ;
     }
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
@@ -1136,6 +1291,7 @@ struct mpc_handle {
     // time-varying model parameters: horizon values of one mpc_ocp_solve call, its slab and workspace; this step's p_x_k / p_y_k for
     // mpc_target_solve / mpc_kf_update (mpc_set_model_offsets)
     DevBuf pxy_in, pxy_lin, pxy_ws, off_px, off_py; int off_B = 0; bool off_has_px = false, off_has_py = false;
+    DevBuf msch; int msch_steps = 0; bool msch_px = false, msch_py = false;      // def_px / def_py over the horizon for every step of the fused loop
     DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
     std::map<std::string, std::pair<size_t, int>> log_off;   // name -> (offset in doubles / ints, dim)
     // multi-GPU (one process per GPU): RCCL communicator over the ranks of the job, staging buffers of the collectives
@@ -1424,7 +1580,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     (void)mpc_comm_destroy(h);
     h->coll_send.release(); h->coll_recv.release();
     h->pc_prev.release(); h->pc_valid.release(); h->pc_guess.release(); h->pc_traj.release();
-    h->pxy_in.release(); h->pxy_lin.release(); h->pxy_ws.release(); h->off_px.release(); h->off_py.release();
+    h->pxy_in.release(); h->pxy_lin.release(); h->pxy_ws.release(); h->off_px.release(); h->off_py.release(); h->msch.release();
     for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1798,7 +1954,7 @@ extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32
     for (DevBuf *b : {&h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_Kg, &h->st_Pn, &h->st_tw})
         HIP_TRY(hipMemsetAsync(b->p, 0, b->bytes, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->state_set = false;
+    h->state_set = false; h->msch_steps = 0; h->msch_px = h->msch_py = false;
     if (ensure_ws(h, Bs)) return -10;
     const int sdim = P.ny + P.nu + P.nxp + P.ny;   // ysp usp pxp pyp
     if (h->sch.ensure((size_t)max_steps * sdim * 8)) return -10;
@@ -1898,6 +2054,24 @@ extern "C" int mpc_loop_set_schedule(mpc_handle *h, int32_t nsteps, const double
     return 0;
 }
 
+// def_px / def_py for the fused loop (MPC_code.py:492-497): px [nsteps][N][nx] with px[k][i] = def_px(t_k + i), py [nsteps][N][ny] likewise; either
+// may be NULL; both NULL switches the schedules off again.  With a schedule set mpc_loop_run launches loop_kernel_pxy.
+extern "C" int mpc_loop_set_model_schedule(mpc_handle *h, int32_t nsteps, const double *px, const double *py)
+{
+    if (!h || h->B == 0) return fail(-1, "mpc_loop_alloc first");
+    if (!px && !py) { h->msch_steps = 0; h->msch_px = h->msch_py = false; return 0; }
+    if (nsteps < 1 || nsteps > h->max_steps) return fail(-1, "nsteps %d exceeds the allocated %d", nsteps, h->max_steps);
+    HIP_TRY(hipSetDevice(h->device));
+    const DevProblem &P = h->hp;
+    const size_t npx = (size_t)nsteps * P.N * P.nx, npy = (size_t)nsteps * P.N * P.ny;
+    if (h->msch.ensure((npx + npy) * sizeof(double))) return -10;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (px) HIP_TRY(hipMemcpy(h->msch.p, px, npx * sizeof(double), hipMemcpyHostToDevice));
+    if (py) HIP_TRY(hipMemcpy((double *)h->msch.p + npx, py, npy * sizeof(double), hipMemcpyHostToDevice));
+    h->msch_steps = nsteps; h->msch_px = px != nullptr; h->msch_py = py != nullptr;
+    return 0;
+}
+
 // Which closed-loop kernel: 1 = one instance per lane (loop_kernel; fills the chip from about 65536 instances),
 // 2 = horizon-parallel (loop_kernel_tp; one wave per instance, for batches that leave the chip idle otherwise).
 static int loop_mode(const mpc_handle *h)
@@ -1922,7 +2096,13 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
     const DevProblem &P = h->hp;
     const size_t Bs = h->Bs, ms = h->max_steps;
     const double *sch = (const double *)h->sch.p;
-    const int mode = loop_mode(h);
+    const bool pxy = h->msch_steps > 0;      // def_px / def_py schedules: the instance-per-lane loop with per-block stage data
+    if (pxy && k0 + nsteps > h->msch_steps) return fail(-1, "steps [%d,%d) outside the model-parameter schedule of %d steps", k0, k0 + nsteps, h->msch_steps);
+    if (pxy) {
+        const size_t N = P.N;
+        if (h->pxy_lin.ensure(N * h->L.pxy_lin * Bs * sizeof(double)) || h->pxy_ws.ensure((size_t)h->L.pxy_ws_rows * (N + 2) * Bs * sizeof(double))) return -10;
+    }
+    const int mode = pxy ? 5 : loop_mode(h);
     if (mode != h->ws_mode) {      // the workspace holds another layout (or a per-call solve used it): next OCPs start cold
         HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * Bs * 4, h->stream));
         h->ws_mode = mode;
@@ -1950,6 +2130,14 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs; a.N = P.N;
         a.h = h->h_sample; a.t0 = k * h->h_sample; a.wv_ni = h->wv_ni_opt;
+        a.px_h = a.py_h = nullptr; a.lin = nullptr;
+        if (pxy) {
+            const size_t npx = (size_t)h->msch_steps * P.N * P.nx;
+            a.px_h = h->msch_px ? (const double *)h->msch.p + (size_t)k * P.N * P.nx : nullptr;
+            a.py_h = h->msch_py ? (const double *)h->msch.p + npx + (size_t)k * P.N * P.ny : nullptr;
+            a.lin = (double *)h->pxy_lin.p; a.ws = (double *)h->pxy_ws.p;
+            h->L.loop_pxy(h->dp, a, h->stream);
+        } else
         if (mode == 3) { if (h->L.loop_wv(h->dp, a, h->stream)) return fail(-9, "cannot configure the wave-autonomous kernel (LDS %zu bytes)", h->L.wv_lds); }
         else if (mode == 2) { if (h->L.loop_tp(h->dp, a, h->stream)) return fail(-9, "cannot configure the horizon-parallel kernel (LDS %zu bytes)", h->L.tp_lds); }
         else h->L.loop(h->dp, a, h->stream);

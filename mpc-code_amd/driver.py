@@ -47,21 +47,27 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
         if fused and not p.plant_is_linear and not getattr(s, "fused_plant", False):
             raise ValueError("this solver's library has no compiled plant function (User_fxp_Cont): the plant is simulated on the host, "
                              "call run_closed_loop(..., fused=False)")
-        if fused and p.has_model_params:
-            raise ValueError("time-varying model parameters (def_px / def_py) go through the call-by-call mode: run_closed_loop(..., fused=False)")
         if fused:
             s.loop_alloc(B, nsteps, capi.LOG_ALL)
             s.loop_set_state(x0_p, x0_m)
             s.loop_set_schedule(sched)
+            py0 = np.zeros((nsteps, p.ny))
+            if p.has_model_params:                                   # :492-510: def_px / def_py over the horizon, for every step of the loop
+                hp = [p.horizon_params(k * p.h) for k in range(nsteps)]
+                s.loop_set_model_schedule(np.stack([h_[0] for h_ in hp]) if p.def_px is not None else None,
+                                          np.stack([h_[1] for h_ in hp]) if p.def_py is not None else None)
+                py0 = np.stack([h_[1][0] for h_ in hp])              # p_y_k (zeros without def_py)
+            else:
+                s.loop_set_model_schedule(None, None)
             s.loop_run(0, nsteps)
             s.loop_sync()
             out = {k: s.loop_get_log(k) for k in ("U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT", "STATUS_DYN",
                                                   "STATUS_SS", "ITERS_DYN", "ITERS_SS") if not (k == "D_HAT" and p.nd == 0)}
-            out["Yp"] = out["Xp"] @ p.Cp.T + sched["pyp"][:nsteps, None, :]                                   # :531-534
+            out["Yp"] = out["Xp"] @ p.Cp.T + sched["pyp"][:nsteps, None, :] + py0[:, None, :]                 # :531-534 (p_ymp = p_y_k, :505-507)
             d_prior = np.zeros((nsteps, B, p.nd))
             if p.nd:                                                 # dhat is carried unchanged between steps (:655-668)
                 d_prior[0] = _bcast(p.dhat0, B, p.nd); d_prior[1:] = out["D_HAT"][:-1]
-            out["Y_HAT"] = out["X_HAT"] @ p.C.T + p.fy_const + (d_prior @ p.Cd.T if p.nd else 0.0)             # :524
+            out["Y_HAT"] = out["X_HAT"] @ p.C.T + p.fy_const + (d_prior @ p.Cd.T if p.nd else 0.0) + py0[:, None, :]   # :524
             ms, _ = s.last_kernel_ms()
             out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
         else:

@@ -760,8 +760,33 @@ def test_model_parameters_over_the_horizon(pkg, solver_factory):
         ref_k = np.stack([c[k] for c in cl], axis=1)
         assert np.abs(r[k] - ref_k).max() < 1e-6, k
     assert np.array_equal(r["STATUS_DYN"], np.stack([c["STATUS_DYN"] for c in cl], axis=1))
-    with pytest.raises(ValueError, match="def_px"):
-        run_closed_loop(p, x0, x0, 4, solver=s, fused=True)
+    # the same loop fused (mpc_loop_set_model_schedule: all steps in one launch): the call-by-call numbers, hence the dense statements'
+    f = run_closed_loop(p, x0, x0, 8, solver=s, fused=True)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "Yp", "Y_HAT", "YS", "D_HAT"):
+        assert np.abs(f[k] - r[k]).max() < 1e-8, (k, np.abs(f[k] - r[k]).max())      # (step 0 equal to the bit; then the host's measurement sums in another order)
+        assert np.array_equal(f[k][0], r[k][0]) or k in ("Yp", "Y_HAT", "YS"), k
+        if k in cl[0]:
+            assert np.abs(f[k] - np.stack([c[k] for c in cl], axis=1)).max() < 1e-6, k
+    for k in ("STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"):
+        assert np.array_equal(f[k][0], r[k][0]), (k, f[k].tolist(), r[k].tolist())
+        # (later steps: the two loops' states differ by 1e-10, and an iteration count may sit on a threshold of the algorithm)
+        assert np.array_equal(f[k], r[k]) or (k.startswith("ITERS") and np.abs(f[k] - r[k]).max() <= 3 and (f[k] != r[k]).mean() < 0.2), (k, f[k].tolist(), r[k].tolist())
+    # a ragged batch over two launches, one of the two schedules only, and back to a loop without them on the same handle
+    q = _with_model_params(pkg, def_py=None)
+    assert q.def_py is None and q.has_model_params
+    x1 = rng.uniform([-0.3, -4, -3], [0.3, 4, 3], size=(70, 3))
+    sq = solver_factory(q)
+    a = run_closed_loop(q, x1, x1, 6, solver=sq, fused=False)
+    sq.set_option("steps_per_launch", 4)
+    b = run_closed_loop(q, x1, x1, 6, solver=sq, fused=True)
+    assert np.abs(a["U"] - b["U"]).max() < 1e-8 and np.array_equal(a["STATUS_DYN"], b["STATUS_DYN"]) and np.array_equal(a["ITERS_DYN"][0], b["ITERS_DYN"][0])
+    plain = pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides={"N": 20})
+    sp = solver_factory(plain)
+    c0 = run_closed_loop(plain, x1, x1, 6, solver=sp)
+    sp.loop_alloc(len(x1), 6, 2); sp.loop_set_state(x1, x1); sp.loop_set_schedule(plain.schedules(6))
+    sp.loop_set_model_schedule(np.zeros((6, 20, 3)), None)      # zero parameters through the scheduled kernel: the plain loop's numbers
+    sp.loop_run(0, 6); sp.loop_sync()
+    assert np.abs(sp.loop_get_log("U") - c0["U"]).max() < 1e-7 and np.array_equal(sp.loop_get_log("STATUS_DYN"), c0["STATUS_DYN"])
 
 
 def test_fused_closed_loop_with_the_user_plant(nlplant, xp_nlplant):
