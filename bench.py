@@ -40,7 +40,7 @@ KERNEL_NAMES = {1: "loop_kernel (one instance per lane)", 2: "loop_kernel_tp (ho
 B_PER_GPU = 4096
 SEED = 20250614
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 
 
 def alg_bytes_per_step(p) -> int:
@@ -364,7 +364,7 @@ def main_nmpc(args):
     ne = p.nx + p.nd
     state = p.nxp + p.nx + p.nd + ne * ne + p.nu + p.nx + p.nu
     ab = (2 * state + 2 * p.nw + p.ny + p.nu) * 8              # state in + out, shifted trajectory in + out, set points
-    summary = os.path.join(ROOT, "profiles", "r02_nmpc_pmc_summary.json")
+    summary = os.path.join(ROOT, "profiles", "r03_nmpc_pmc_summary.json")
     if split:
         # the dominant kernel of the split pipeline: one launch = linearisation + QP of one step of every instance
         per_launch_s = float(np.mean(wms)) * 1e-3
