@@ -191,6 +191,14 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
         s.sync()
         out = {k: s.get_log(k) for k in list(s.LOGS) + list(s.ILOGS)}
         out["kernel_ms"] = s.last_kernel_ms()
+        # the reference's remaining result arrays (MPC_code.py:877-895), from the logs: with StateFeedback the measurement is the plant state
+        # (Utilities.py:84-86), yhat_k = Fy_model(xhat_k, dhat_k) with the disturbance estimate of the step before (:524), ys_k = Fy_model(xs_k, dhat_k) (:730)
+        B = len(x0_p)
+        d_prior = np.zeros((nsteps, B, p.nd)); d_prior[1:] = out["D_HAT"][:-1]
+        out["Yp"] = out["Xp"].copy()
+        out["Y_HAT"] = out["X_HAT"] + d_prior @ p.Cd.T
+        out["YS"] = out["XS"] + out["D_HAT"] @ p.Cd.T
+        out["TIME_DYN"] = np.full(nsteps, out["kernel_ms"] * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)      # (one device time for the whole step)
         return out
     finally:
         if solver is None:

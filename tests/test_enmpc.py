@@ -275,6 +275,10 @@ def test_gpu_shipped_example_follows_the_golden_loop(pkg, gold, kernel):
     p, r = _gpu_loop(pkg, None, gold["ship_x0"], 21, kernel=kernel)
     _check(r, gold, "ship_", 21)
     assert int(r["STATUS_MHE"].max()) == 0
+    # the reference's other result arrays (MPC_code.py:877-895): measurement = plant state (StateFeedback), model outputs with the output disturbance
+    assert np.array_equal(r["Yp"], r["Xp"]) and np.allclose(r["YS"], gold["ship_XS"][:21] + gold["ship_D_HAT"][:21] @ p.Cd.T, atol=TOL_U)
+    assert np.allclose(r["Y_HAT"][1:], gold["ship_X_HAT"][1:21] + gold["ship_D_HAT"][:20] @ p.Cd.T, atol=TOL_U) and np.allclose(r["Y_HAT"][0], gold["ship_X_HAT"][0])
+    assert r["TIME_DYN"].shape == (21,) and r["TIME_DYN"].min() > 0
 
 
 @pytest.mark.gpu
