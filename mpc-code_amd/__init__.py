@@ -38,3 +38,23 @@ def load_problem(path, overrides=None):
 
 def example_path(name):
     return _os.path.join(EXAMPLES_DIR, name)
+
+
+def run_example(problem_or_path, x0_p=None, x0_m=None, nsteps=None, overrides=None, **kw):
+    """The reference's ``python MPC_code.py`` for a batch: load an Ex-style file (or take a loaded problem) and run its closed loop on the
+    GPU through the path the problem belongs to - linear (``driver.run_closed_loop``), non-linear tracking (``nmpc.run_nmpc_closed_loop``,
+    ``max_sqp=`` SQP iterations per OCP) or economic with a moving-horizon estimator (``enmpc.run_enmpc_closed_loop``).  ``x0_p`` / ``x0_m``:
+    [B, nxp] / [B, nx] plant and model start states (default: the file's own, one instance); ``nsteps`` default: the file's ``Nsim``.
+    Returns the reference's result arrays (``MPC_code.py:877-895``: ``U, X_HAT, Y_HAT, XS, US, YS, Xp, Yp, D_HAT, TIME_*``) shaped
+    ``[nsteps, B, dim]`` plus status / iteration words.  Raises without a GPU: there is no CPU path."""
+    p = load_problem(problem_or_path, overrides) if isinstance(problem_or_path, (str, bytes, _os.PathLike)) else problem_or_path
+    if isinstance(p, EconomicMPCProblem):
+        from .enmpc import run_enmpc_closed_loop
+        if x0_m is not None:
+            raise ValueError("the economic path starts the model state from the file's x0_m / x_bar (MPC_code.py:449-463); pass x0_p only")
+        return run_enmpc_closed_loop(p, p.x0_p[None] if x0_p is None else x0_p, nsteps, **kw)
+    if isinstance(p, NonlinearMPCProblem):
+        from .nmpc import run_nmpc_closed_loop
+        return run_nmpc_closed_loop(p, x0_p, x0_m, nsteps, **kw)
+    from .driver import run_closed_loop
+    return run_closed_loop(p, x0_p, x0_m, nsteps, **kw)

@@ -144,6 +144,10 @@ class NonlinearMPCProblem:
     def plant_output(self, xp, u, t):
         return self._stack(st.evaluate(self.hp, self._vals(xp=xp, u=u, t=t)), np.shape(xp)[:-1])
 
+    def model_output(self, x, u, d, t):
+        """Fy_model(x, u, d, t) (Utilities.py:208-244; with offree = 'lin' the + Cd d is part of ``hy``)."""
+        return self._stack(st.evaluate(self.hy, self._vals(x=x, u=u, d=d if self.nd else None, t=t)), np.shape(x)[:-1])
+
 
 def _trace(fn, args):
     try:

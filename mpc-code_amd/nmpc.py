@@ -199,6 +199,10 @@ def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = 
         u_prev = np.concatenate([_rows(p.u0, B, p.nu)[None], out["U"][:-1]]) if nsteps else out["U"]
         t = (np.arange(nsteps) * p.h)[:, None]
         out["Yp"] = p.plant_output(out["Xp"], u_prev, t) + p.schedules(nsteps)["pyp"][:, None, :]      # MPC_code.py:531-534
+        d_now = out["D_HAT"] if p.nd else np.zeros((nsteps, B, 0))
+        d_prior = np.concatenate([_rows(p.dhat0, B, p.nd)[None], d_now[:-1]]) if p.nd else d_now       # dhat is carried unchanged between steps (:655-668)
+        out["Y_HAT"] = p.model_output(out["X_HAT"], u_prev, d_prior, t)                                 # :524
+        out["YS"] = p.model_output(out["XS"], out["US"], d_now, t)                                      # :730
     finally:
         if own:
             s.close()
