@@ -69,6 +69,9 @@ int nmpc_sync(nmpc_handle *h);
  * 0 = auto when the model fits: 3 while one round of its waves holds the batch (16 instances per CU: 4096 on an MI355X), 4 beyond;
  * else 1.  nmpc_get_kernel returns the one in force */
 int nmpc_set_kernel(nmpc_handle *h, int32_t kernel);
+/* split pipeline: the batch in `groups` parts (multiples of 64 instances) on HIP streams of their own, so that the lane-style launch of one part runs beside
+ * the wave-style launches of the others; 0 = by batch size (default), 1..3.  Results do not depend on it; with nmpc_time_kernels on, one part. */
+int nmpc_set_groups(nmpc_handle *h, int32_t groups);
 int nmpc_get_kernel(nmpc_handle *h);
 /* logs [nsteps][B][dim] float64: "U","X_HAT","XS","US","Xp","D_HAT"; [nsteps][B] int32: "STATUS_DYN","STATUS_SS","ITERS_DYN"
  * (interior-point iterations of the last QP),"SQP_DYN","SQP_SS" */

@@ -16,7 +16,7 @@ from . import nlcodegen
 from .capi import MpcAmdError
 
 NMPC_EXPORTS = ("nmpc_create", "nmpc_destroy", "nmpc_last_error", "nmpc_build_info", "nmpc_alloc", "nmpc_set_state", "nmpc_set_schedule",
-                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_get_kernel", "nmpc_time_kernels",
+                "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_set_groups", "nmpc_get_kernel", "nmpc_time_kernels",
                 "nmpc_wave_kernel_ms")
 
 _dp = ct.POINTER(ct.c_double)
@@ -48,6 +48,7 @@ def load_nmpc_library(path: str) -> ct.CDLL:
     lib.nmpc_run.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
     lib.nmpc_sync.argtypes = [vp]
     lib.nmpc_set_kernel.argtypes = [vp, ct.c_int32]
+    lib.nmpc_set_groups.argtypes = [vp, ct.c_int32]
     lib.nmpc_get_kernel.argtypes = [vp]
     lib.nmpc_get_log.argtypes = [vp, ct.c_char_p, vp]
     lib.nmpc_last_kernel_ms.argtypes = [vp]; lib.nmpc_last_kernel_ms.restype = ct.c_float
@@ -145,6 +146,10 @@ class NmpcSolver:
     def set_kernel(self, kernel: int):
         """0 auto, 1 one instance per lane, 3 wave-autonomous, 4 split pipeline (the last two: model state <= 4, nu <= 2, N <= 64)."""
         self._chk(self.lib.nmpc_set_kernel(self.h, int(kernel)), "nmpc_set_kernel")
+
+    def set_groups(self, groups: int):
+        """split pipeline: groups of the batch on HIP streams of their own (0: by batch size, 1..3)"""
+        self._chk(self.lib.nmpc_set_groups(self.h, int(groups)), "nmpc_set_groups")
 
     def get_kernel(self) -> int:
         return int(self.lib.nmpc_get_kernel(self.h))

@@ -738,3 +738,30 @@ def test_gpu_short_horizons_with_several_sqp_iterations_follow_the_c_restatement
                 assert np.max(np.abs(r[k][:, ok] - c[k][:, ok]) / (1 + np.abs(c[k][:, ok]))) < 1e-6, (kern, N, k)
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stream_groups_of_the_split_pipeline_do_not_change_the_loop(pkg):
+    """nmpc_set_groups: the batch in one, two or three parts on streams of their own (ragged last part) - the same loop bit for bit."""
+    from mpc_code_amd import nmpc
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = pkg.load_problem(pkg.example_path("cstr_nmpc.py"), overrides={"N": 30})
+    B = 9001
+    rng = np.random.default_rng(9)
+    x0 = p.x0_p * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, p.nx)))
+    s = nmpc.NmpcSolver(p)
+    try:
+        s.set_kernel(4)
+        res = {}
+        for G in (1, 2, 3, 0):
+            s.set_groups(G)
+            res[G] = nmpc.run_nmpc_closed_loop(p, x0, x0, nsteps=5, solver=s, max_sqp=1)
+        for G in (2, 3, 0):
+            for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN"):
+                assert np.array_equal(res[G][k], res[1][k]), (G, k)
+        with pytest.raises(Exception):
+            s.set_groups(4)
+    finally:
+        s.close()

@@ -11,8 +11,9 @@ cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 if [ "${2:-}" = "nmpc" ]; then
     OUT=$OUT/nmpc; rm -rf "$OUT"; mkdir -p "$OUT"
     timeout 600 python3 bench.py --config nmpc --steps 20 --warmup 2 > "$OUT/${TAG}_nmpc_bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -c 600 "$OUT/${TAG}_nmpc_bench.json"
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --config nmpc --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
-    CMD="python3 bench.py --config nmpc --steps 20 --warmup 0 --repeats 2 --no-cpu-baseline"
+    # (--groups 1: the batch on one stream - launches that overlap on streams of their own have no duration of their own)
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --config nmpc --steps 20 --warmup 2 --no-cpu-baseline --groups 1 > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
+    CMD="python3 bench.py --config nmpc --steps 20 --warmup 0 --repeats 2 --no-cpu-baseline --groups 1"
     for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
         tag=$(echo $pass | cut -d' ' -f1)
         timeout 180 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$tag" -- $CMD > "$OUT/pmc_$tag.log" 2>&1; echo "pmc $tag rc=$?"
