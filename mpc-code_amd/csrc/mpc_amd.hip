@@ -96,7 +96,13 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (P.N + 2) + 1) * SL * 64), P.N, SL, (int)threadIdx.x};
     double u0[NU], z1[NS], res[3];
     int it;
-    int st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it);
+    int st, it_sum = 0;
+    for (int pass = 0;; pass++) {      // (terminal equality: up to two more passes with the terminal reference aimed off, mpc_device.hpp:term_aim)
+        st = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it);
+        it_sum += it;
+        if (!(P.term_cons && pass < 2 && st != kInfeasible && term_aim<NS, NU, NC, NX>(P, ws, q))) break;
+    }
+    it = it_sum;
     if (P.term_cons && st != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st = kInfeasible;
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
@@ -174,7 +180,13 @@ __global__ __launch_bounds__(64) void ocp_kernel_pxy(const DevProblem *__restric
     Ws ws{(gv2d *)((v2d *)a.ws + ((size_t)blockIdx.x * (N + 2) + 1) * SL * 64), N, SL, lane};
     double u0[NU], z1[NS], res[3];
     int it;
-    int st = rpdip_lane<NS, NU, DU, NC, true, true>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it, lin, 1, NLIN, NLTV);
+    int st, it_sum = 0;
+    for (int pass = 0;; pass++) {
+        st = rpdip_lane<NS, NU, DU, NC, true, true>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it, lin, 1, NLIN, NLTV);
+        it_sum += it;
+        if (!(P.term_cons && pass < 2 && st != kInfeasible && term_aim<NS, NU, NC, NX>(P, ws, q))) break;
+    }
+    it = it_sum;
     if (P.term_cons && st != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st = kInfeasible;
     a.status[b] = st; a.iters[b] = it;
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
@@ -376,7 +388,13 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
         MPC_UNROLL for (int i = 0; i < ND; i++) delta = dmax(delta, fabs(dh[i] - dh_prev[i]));
         MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - us_prev[i]));
         const bool warm = ws_valid && delta <= kWsDelta && !P.no_warm;
-        int st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm, delta, u0, z1, res, it_dyn);
+        int st_dyn, it_sum = 0;
+        for (int pass = 0;; pass++) {      // (terminal equality: further passes - cold - with the terminal reference aimed off, mpc_device.hpp:term_aim)
+            st_dyn = rpdip_lane<NS, NU, DU, NC, MASKED>(P, C, q, ws, P.max_iter, warm && pass == 0, delta, u0, z1, res, it_dyn);
+            it_sum += it_dyn;
+            if (!(P.term_cons && pass < 2 && st_dyn != kInfeasible && term_aim<NS, NU, NC, NX>(P, ws, q))) break;
+        }
+        it_dyn = it_sum;
         if (P.term_cons && st_dyn != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st_dyn = kInfeasible;
         ws_valid = st_dyn == kSolved;
         if (st_dyn != kInfeasible) {
@@ -528,7 +546,13 @@ __global__ __launch_bounds__(64) void loop_kernel_pxy(const DevProblem *__restri
         }
         double u0[NU], z1[NS], res[3];
         int it_dyn;
-        int st_dyn = rpdip_lane<NS, NU, DU, NC, true, true>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it_dyn, lin, 1, NLIN, NLTV);
+        int st_dyn, it_sum = 0;
+        for (int pass = 0;; pass++) {
+            st_dyn = rpdip_lane<NS, NU, DU, NC, true, true>(P, C, q, ws, P.max_iter, false, 0.0, u0, z1, res, it_dyn, lin, 1, NLIN, NLTV);
+            it_sum += it_dyn;
+            if (!(P.term_cons && pass < 2 && st_dyn != kInfeasible && term_aim<NS, NU, NC, NX>(P, ws, q))) break;
+        }
+        it_dyn = it_sum;
         if (P.term_cons && st_dyn != kInfeasible && term_missed<NS, NU, NC, NX>(P, ws, q)) st_dyn = kInfeasible;
         if (st_dyn != kInfeasible) {
             MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];          // :798
@@ -1681,6 +1705,7 @@ static bool ocp_uses_wave(const mpc_handle *h)
 {
     if (!h->L.ocp_wv || h->hp.N > 64 || h->ocp_kernel_opt == 1) return false;
     if (h->ocp_kernel_opt == 3) return true;
+    if (h->hp.term_cons) return false;      // terminal equality: exact on the lane solver (term_aim), by weight alone on the wave solvers
     double nrm = 0.0;
     for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));
     return nrm <= 1e4;
@@ -2077,6 +2102,7 @@ extern "C" int mpc_loop_set_model_schedule(mpc_handle *h, int32_t nsteps, const 
 static int loop_mode(const mpc_handle *h)
 {
     if (h->loop_kernel_opt != 0) return h->loop_kernel_opt;
+    if (h->hp.term_cons) return 1;      // terminal equality: exact on the lane solver (mpc_device.hpp:term_aim), by weight alone on the wave solvers
     {      // violently unstable open loop: the kernels whose recursions are scans with A^(2^e) lose digits there (see ocp_uses_wave)
         double nrm = 0.0;
         for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));

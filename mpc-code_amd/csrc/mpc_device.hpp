@@ -198,6 +198,7 @@ __device__ __forceinline__ bool sym_inverse(double (&a)[n][n])
 template <int NS, int NU>
 struct OcpInst {
     double z0[NS], zr[NS], ur[NU], c[NS], us[NU], zlo_m[NS], zhi_m[NS];
+    double zrN[NS];      // reference of the terminal cost: zr, or - terminal equality, lane solver - zr moved against the measured miss (term_aim)
     bool ok0;
 };
 
@@ -245,6 +246,7 @@ __device__ __forceinline__ void build_inst(const PT &P, const double (&xhat)[NX]
                 if (j == idx) { q.zlo_m[j] = dmax(q.zlo_m[j], lo); q.zhi_m[j] = dmin(q.zhi_m[j], hi); }
         }
     }
+    MPC_UNROLL for (int i = 0; i < NS; i++) q.zrN[i] = q.zr[i];
 }
 
 // --------------------------------------------------------------------------------------------------------
@@ -524,7 +526,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
             MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = ublk[i] - q.ur[i];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = dlm[NU + i];
-                if (k == N - 1) { MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Pf[i][j] * dz1[j]; }
+                if (k == N - 1) { MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Pf[i][j] * (zblk[j] - q.zrN[j]); }
                 else {
                     MPC_UNROLL for (int j = 0; j < NS; j++) a += C.Q[i][j] * dz1[j];
                     if (HASM) { MPC_UNROLL for (int j = 0; j < NU; j++) a += C.M[i][j] * unext_dev[j]; }
@@ -681,7 +683,7 @@ __device__ int rpdip_lane(const DevProblem &P, const StageConst<NS, NU> &C, cons
                     dlm[i] = lh - ll;
                 }
                 double dz1[NS], du[NU], pv[NS], qu[NU];
-                MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = c2.z[i] - q.zr[i];
+                MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = c2.z[i] - (k == N - 1 ? q.zrN[i] : q.zr[i]);      // (the terminal cost has its own reference)
                 MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = c2.u[i] - q.ur[i];
                 ld_field<NU>(nb, L::U, c2.u); ld_field<NS>(nb, L::Z, c2.z);
                 MPC_UNROLL for (int i = 0; i < NS; i++) {
@@ -795,6 +797,23 @@ __device__ __forceinline__ bool term_missed(const DevProblem &P, const Ws &ws, c
     ld_field<NS>(ws.blk(P.N - 1), L::Z, zN);
     MPC_UNROLL for (int i = 0; i < NX; i++) v = dmax(v, fabs(zN[i] - q.zr[i]) * frcp(dmax(1.0, fabs(q.zr[i]))));
     return !(v <= P.term_tol);
+}
+
+// Exact terminal equality on the lane solver ("aiming off", the method of multipliers written as a shift of the target).  The weight rho on
+// |z_N - zr|^2 leaves a miss c = (multiplier of the equality) / rho - 1e-6 where the multipliers are of order 1e6, the short horizons - and the miss
+// is an affine function of the terminal reference with slope -(1 - O(curvature / rho)): solving again with the terminal reference moved by -c
+// leaves O(curvature / rho) c ~ 1e-12.  Returns true when another pass is worth it: the miss is beyond rounding but small enough to be the
+// penalty's bias (a target the bounds keep out of reach misses by orders more, and stays status 2).
+template <int NS, int NU, int NC, int NX>
+__device__ __forceinline__ bool term_aim(const DevProblem &P, const Ws &ws, OcpInst<NS, NU> &q)
+{
+    using L = BlkLayout<NS, NU, NC>;
+    double zN[NS], v = 0.0;
+    ld_field<NS>(ws.blk(P.N - 1), L::Z, zN);
+    MPC_UNROLL for (int i = 0; i < NX; i++) v = dmax(v, fabs(zN[i] - q.zr[i]) * frcp(dmax(1.0, fabs(q.zr[i]))));
+    if (!(v > 1e-11 && v <= 1e-4)) return false;
+    MPC_UNROLL for (int i = 0; i < NX; i++) q.zrN[i] -= zN[i] - q.zr[i];
+    return true;
 }
 
 // --------------------------------------------------------------------------------------------------------

