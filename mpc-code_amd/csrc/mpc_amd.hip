@@ -56,6 +56,7 @@ extern "C" const char *mpc_last_error(void) { return g_err; }
 // each is carried as one more stage state, see build_problem)
 // ---------------------------------------------------------------------------------------------------
 #ifndef MPC_DIM_LIST
+#define MPC_DEFAULT_DIM_LIST 1
 #define MPC_DIM_LIST(X) \
     X(3, 2, 3, 3, 3, 0, 0) /* Ex_LMPC_CSTR */ \
     X(4, 2, 2, 2, 4, 1, 0) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */ \
@@ -1243,8 +1244,17 @@ static Launchers make_launchers_mode()
                 int ni = a.wv_ni > 0 ? a.wv_ni : (a.B <= simds ? 1 : (a.B <= 2 * simds ? 2 : NI));
                 if (ni > NI) ni = NI;
                 if (ni == 3) ni = 2;
-                if (ni == 1) return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, 1>(p, a, s, dev);
-                if (ni == 2) return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, 2>(p, a, s, dev);
+                // (the one- and two-instance variants cost build time: in the default library - seven dimension sets - only the two BASELINE problems carry
+                // them; a library built for one dimension set always does)
+#ifdef MPC_DEFAULT_DIM_LIST
+                constexpr bool small = (NX == 3 && NU == 2 && NY == 3 && ND == 3 && !DU && NG == 0) || (NX == 4 && NU == 2 && NY == 2 && ND == 2 && NXP == 4 && DU && NG == 0);
+#else
+                constexpr bool small = true;
+#endif
+                if constexpr (small) {
+                    if (ni == 1) return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, 1>(p, a, s, dev);
+                    if (ni == 2) return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, 2>(p, a, s, dev);
+                }
                 return launch_loop_wv<NX, NU, NY, ND, NXP, DU, NG, NC, MASKED, NI>(p, a, s, dev);
             };
             l.wv_ns = NSZ_;
