@@ -49,7 +49,9 @@ static int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(-10, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+#ifndef MPC_PART2
 extern "C" const char *mpc_last_error(void) { return g_err; }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // compiled dimension sets: NX, NU, NY, ND, NXP, DU, NG  (NG = bounded output rows that are not a multiple of one state;
@@ -57,14 +59,25 @@ extern "C" const char *mpc_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------------
 #ifndef MPC_DIM_LIST
 #define MPC_DEFAULT_DIM_LIST 1
-#define MPC_DIM_LIST(X) \
+// The default library is built from two objects compiled side by side (capi.build_library: this file with -DMPC_HAVE_PART2 and with -DMPC_PART2):
+// the first carries the C-ABI and the BASELINE dimension sets, the second the kernels of the other sets behind mpc_part2_launchers().  One object
+// (neither macro: tools, diagnostic builds) carries all of them.
+#define MPC_DIM_LIST_A(X) \
     X(3, 2, 3, 3, 3, 0, 0) /* Ex_LMPC_CSTR */ \
-    X(4, 2, 2, 2, 4, 1, 0) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */ \
+    X(4, 2, 2, 2, 4, 1, 0) /* Ex_LMPC_WB (cost on Delta-u: stage state 6) */
+#define MPC_DIM_LIST_B(X) \
     X(3, 2, 2, 2, 3, 1, 0) /* Ex_LMPC_nlplant (linear controller, Delta-u cost, non-linear plant on the host) */ \
     X(4, 2, 2, 2, 3, 1, 1) /* Ex_LMPCxp_nlplant (model state 4, plant state 3, one general output row: stage state 7) */ \
     X(2, 1, 1, 1, 2, 0, 0) /* double integrator (tests: LQR known answer) */ \
     X(2, 1, 1, 1, 2, 1, 0) \
     X(2, 1, 1, 1, 2, 0, 1) /* double integrator with a bound on x0 + x1 (tests: general output row) */
+#if defined(MPC_PART2)
+#define MPC_DIM_LIST(X) MPC_DIM_LIST_B(X)
+#elif defined(MPC_HAVE_PART2)
+#define MPC_DIM_LIST(X) MPC_DIM_LIST_A(X)
+#else
+#define MPC_DIM_LIST(X) MPC_DIM_LIST_A(X) MPC_DIM_LIST_B(X)
+#endif
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -1134,12 +1147,14 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
 }
 
 // dense [B][nu] copy of u for the all-gather of u* 
+#ifndef MPC_PART2
 __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__ dst, int B, size_t Bs, int nu)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     for (int i = 0; i < nu; i++) dst[(size_t)b * nu + i] = u[i * Bs + b];
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // handle
@@ -1286,6 +1301,25 @@ static Launchers make_launchers(int mode)
     if (NG == 0 && mode == kBoundsInputsOnly) return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NG, NU, false>();
     return make_launchers_mode<NX, NU, NY, ND, NXP, DU, NG, NS + NU, true>();      // output-row states are free at the terminal stage: masks
 }
+
+#ifdef MPC_PART2
+// second object of the default library: nothing but the kernels of its dimension sets
+extern "C" int mpc_part2_launchers(int nx, int nu, int ny, int nd, int nxp, int du, int ng, int mode, void *out)
+{
+    bool found = false;
+#define MPC_TRY_DIM(NX, NU, NY, ND, NXP, DU, NG)                                                              \
+    if (!found && nx == NX && nu == NU && ny == NY && nd == ND && nxp == NXP && (du != 0) == (DU != 0) && ng == NG) { \
+        *(Launchers *)out = make_launchers<NX, NU, NY, ND, NXP, (DU != 0), NG>(mode);                          \
+        found = true;                                                                                         \
+    }
+    MPC_DIM_LIST(MPC_TRY_DIM)
+#undef MPC_TRY_DIM
+    return found ? 1 : 0;
+}
+#else
+#ifdef MPC_HAVE_PART2
+extern "C" int mpc_part2_launchers(int nx, int nu, int ny, int nd, int nxp, int du, int ng, int mode, void *out);
+#endif
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -1575,6 +1609,9 @@ extern "C" int mpc_lin_create(const mpc_lin_desc *d, mpc_handle **out)
     }
     MPC_DIM_LIST(MPC_TRY_DIM)
 #undef MPC_TRY_DIM
+#ifdef MPC_HAVE_PART2
+    if (!found) found = mpc_part2_launchers(d->nx, d->nu, d->ny, d->nd, d->nxp, stage_has_uprev(d) ? 1 : 0, ng, bound_mode(d), &h->L) != 0;
+#endif
     if (!found) {
         delete h;
         return fail(-5, "no kernel compiled for nx=%d nu=%d ny=%d nd=%d nxp=%d du_form=%d general_output_rows=%d (build info: %s)", d->nx, d->nu, d->ny, d->nd, d->nxp, (int)stage_has_uprev(d), ng, mpc_build_info());
@@ -1630,6 +1667,9 @@ extern "C" const char *mpc_build_info(void)
         s = "gfx950;loop_kernels=wave-autonomous(N<=64&ns<=8&nu<=2),horizon-parallel(N<=64;mfma-riccati:ns<=4&nu<=2,else-batch<=16384),instance-per-lane;dims(nx/nu/ny/nd/nxp/du/ng)=";
 #define MPC_INFO_DIM(NX, NU, NY, ND, NXP, DU, NG) s += #NX "/" #NU "/" #NY "/" #ND "/" #NXP "/" #DU "/" #NG ",";
         MPC_DIM_LIST(MPC_INFO_DIM)
+#ifdef MPC_HAVE_PART2
+        MPC_DIM_LIST_B(MPC_INFO_DIM)
+#endif
 #undef MPC_INFO_DIM
         s.pop_back();
 #ifdef MPC_NL_PLANT_HEADER
@@ -2455,3 +2495,4 @@ extern "C" int mpc_closed_loop(mpc_handle *h, int32_t B, int32_t nsteps, double 
     if (U_log && (rc = mpc_loop_get_log(h, "U", U_log))) return rc;
     return 0;
 }
+#endif      // MPC_PART2
