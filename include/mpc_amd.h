@@ -18,6 +18,7 @@
 #ifndef MPC_AMD_H
 #define MPC_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
