@@ -24,6 +24,7 @@ def test_headers_are_self_contained_c99(tmp_path):
         f = tmp_path / name
         f.write_text(text)
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", INC, "-c", str(f), "-o", str(tmp_path / (name + ".o"))])
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-Wno-old-style-cast", "-I", INC, "-c", str(f), "-o", str(tmp_path / (name + ".oo"))])      # and as C++
 
 
 def _build_host(tmp_path):
