@@ -68,8 +68,8 @@ typedef struct mpc_lin_desc {
      * problem then runs in the stage form with input v = u_k - u_{k-1} and state [x; u_prev] (kernel set du = 1) */
     const double *Dumin, *Dumax;
     /* terminal equality x_N = xs of opt_dyn (TermCons, Control_Calc.py:197-198); 0 = none.  P is ignored then (the terminal cost is
-     * zero on the constraint).  Exact (x_N = xs to rounding) on the instance-per-lane kernels, which such a problem takes by default; the wave
-     * kernels ("loop_kernel" / "ocp_kernel" = 2, 3) carry it by a terminal weight alone: a miss of |multiplier| / 1e12 */
+     * zero on the constraint).  Exact (x_N = xs to rounding) on the instance-per-lane and the wave-autonomous kernels; the horizon-parallel
+     * kernel ("loop_kernel" = 2) carries it by a terminal weight alone: a miss of |multiplier| / 1e12 */
     int32_t term_cons;
     /* the simulated process is a user function (User_fxp_Cont, MPC_code.py:176-199) compiled into the library from the traced
      * Ex-file function (one library per plant; capi.Solver builds it); Ap, Bp are ignored then */

@@ -783,6 +783,37 @@ __global__ __launch_bounds__(64 * NW) void loop_kernel_tp(const DevProblem *__re
     }
 }
 
+// Terminal equality on the wave solver (mpc_device.hpp:term_aim): after a solve the lane of the last block measures each instance's miss, aims
+// the instance's terminal reference off by it and notes the iterations spent; returns - wave-uniform - whether any instance wants another pass,
+// with the flags of that pass set (warm, from the iterate as it is: an instance that needs none converges at once).
+template <int NS, int NU, int NC, int NX, int NI, class Cfg>
+__device__ __forceinline__ bool wv_term_aim(int N, double *q, int *iflag, int *aimv, int *itacc, const WvIterA<NS, NU, NC> (&X)[NI], const WvInst (&S)[NI])
+{
+    const int lane = threadIdx.x;
+    if (lane == N - 1) {
+        MPC_UNROLL for (int j = 0; j < NI; j++) {
+            double c[NX], v = 0.0;
+            MPC_UNROLL for (int i = 0; i < NX; i++) { const double zr = q[j * Cfg::QN + NS + i]; c[i] = a_get(X[j].z[i]) - zr; v = dmax(v, fabs(c[i]) * frcp(dmax(1.0, fabs(zr)))); }
+            const int f = iflag[j];
+            const bool again = (f & kWvValid) && (f & kWvOk0) && S[j].status != kInfeasible && v > 1e-11 && v <= 1e-4;
+            if (again) { MPC_UNROLL for (int i = 0; i < NX; i++) q[j * Cfg::QN + Cfg::QZN + i] -= c[i]; q[j * Cfg::QN + 5 * NS + 2 * NU] = v; }
+            aimv[j] = again ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    int any = 0;
+    MPC_UNROLL for (int j = 0; j < NI; j++) any |= aimv[j];
+    any = __builtin_amdgcn_readfirstlane(any);
+    if (any && lane < NI) {
+        int st = S[0].status, it = S[0].iters;
+        MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st = S[j].status; it = S[j].iters; } }
+        const int f = iflag[lane];
+        if ((f & kWvValid) && (f & kWvOk0) && st != kInfeasible) { iflag[lane] = kWvValid | kWvOk0 | kWvWarm | kWvNoShift; itacc[lane] += it; }
+    }
+    __syncthreads();
+    return any != 0;
+}
+
 // The closed loop on autonomous waves (mpc_wave.hpp): one wave = one workgroup = four instances, for all steps of the launch.
 // Lane i < 4 does for instance i what one lane of loop_kernel does (estimator, target, hold rules, plant) on state kept in LDS;
 // all 64 lanes solve the four OCPs.  HBM sees the state at the first and the last step of a launch and the logs in between.
@@ -802,7 +833,7 @@ struct WvKernelCfg {
         const int t = Cfg::t_doubles(N), x = Cfg::GUARD + (Row16Tab<NX, NU, NY, ND>::fits ? 4 * Row16Tab<NX, NU, NY, ND>::XCH : 0);
         return t > x ? t : x;
     }
-    static constexpr size_t lds_bytes(int N) { return sizeof(double) * ((size_t)t_region(N) + NI * Cfg::QN + NI * Cfg::OUT + NI * KEEP + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 16; }
+    static constexpr size_t lds_bytes(int N) { return sizeof(double) * ((size_t)t_region(N) + NI * Cfg::QN + NI * Cfg::OUT + NI * KEEP + (Row16Tab<NX, NU, NY, ND>::fits ? Row16Tab<NX, NU, NY, ND>::DOUBLES : 0)) + sizeof(int) * 24; }
     static constexpr int ni() { return NI; }
 };
 
@@ -816,9 +847,9 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
     const DevProblem &P0 = *Pp;
     const int LD = Cfg::ld(P0.N);
     double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + KC::t_region(P0.N), *const outv = q + NI * Cfg::QN, *const keep = outv + NI * Cfg::OUT;
-    int *const iflag = (int *)(keep + NI * KEEP), *const twv = iflag + 4, *const wsv = twv + 4;
+    int *const iflag = (int *)(keep + NI * KEEP), *const twv = iflag + 4, *const wsv = twv + 4, *const aimv = wsv + 4, *const itacc = aimv + 4;      // (terminal equality: wv_term_aim)
     using RT = Row16Tab<NX, NU, NY, ND>;
-    double *const tab = (double *)(wsv + 8);      // per-row constants of the 16-lanes-per-instance phases
+    double *const tab = (double *)(wsv + 16);      // per-row constants of the 16-lanes-per-instance phases
     // the problem constants are read through the constant address space: immutable by definition, so every access is a scalar
     // load whatever the kernel has stored to global memory in between (as plain global data they turn into vector loads + waits)
     const ConstProblem &P = *(const ConstProblem *)Pp;
@@ -854,9 +885,11 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
         X[j].put(X0);
     }
     MPC_STAMP_INIT
+    int redo = 0;      // terminal equality: passes of this step's OCP with the terminal reference aimed off (wv_term_aim) - the step's loop body once more, solve onwards
     for (int k = 0; k < a.nsteps; k++) {
         unsigned bq = (unsigned)b;      // opaque per step: the address arithmetic of the log arrays stays next to the stores
         asm volatile("" : "+v"(bq));
+        if (redo == 0) {
         if constexpr (RT::fits) {
             // ---- estimator and target with 16 lanes per instance (mpc_wave.hpp) --------------------------------------
             const int b16 = lane >> 4, r16 = lane & 15, b16c = b16 < NI ? b16 : 0;
@@ -963,17 +996,21 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, qi);
             const bool warm = wsv[lane] != 0 && delta <= kWsDelta && !P.no_warm;
             double *qd = q + lane * Cfg::QN;
-            MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; qd[Cfg::QZN + i] = qi.zrN[i]; }
             MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = qi.ur[i]; qd[5 * NS + NU + i] = qi.us[i]; }
             qd[5 * NS + 2 * NU] = delta;
             iflag[lane] = kWvValid | (qi.ok0 ? kWvOk0 : 0) | (warm ? kWvWarm : 0);
+            itacc[lane] = 0;
             MPC_UNROLL for (int i = 0; i < NX; i++) { kp[KC::K_XH + i] = xh[i]; kp[KC::K_XS + i] = xs[i]; }
             MPC_UNROLL for (int i = 0; i < ND; i++) kp[KC::K_DH + i] = dh[i];
             MPC_UNROLL for (int i = 0; i < NU; i++) kp[KC::K_US + i] = us[i];
         } else if (lane < NI) iflag[lane] = 0;
         __syncthreads();
+        }
         MPC_TSTAMP(0);
         wv_solve<NS, NU, DU, NC, MASKED, NI>(P, T, q, iflag, X, S, P.max_iter);
+        if (P.term_cons && redo < 2 && wv_term_aim<NS, NU, NC, NX, NI, Cfg>(P.N, q, iflag, aimv, itacc, X, S)) { redo++; k--; continue; }
+        redo = 0;
         MPC_STAMP_RESET
         // first input and next state of the final iterates: block 0 = lane 0
         if (lane == 0) {
@@ -994,6 +1031,7 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
             int st_dyn = S[0].status, it_dyn = S[0].iters;
             MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st_dyn = S[j].status; it_dyn = S[j].iters; } }
+            if (P.term_cons) it_dyn += itacc[lane];
             if (P.term_cons && st_dyn != kInfeasible && !(outv[lane * Cfg::OUT + NU + NS] <= P.term_tol)) st_dyn = kInfeasible;
             double x[NXP], xh[NX], u[NU];
             MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = kp[KC::K_X + i];
@@ -1066,7 +1104,7 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
     const ConstProblem &P = *(const ConstProblem *)Pp;
     const int N = Pp->N, LD = Cfg::ld(N);
     double *const T = wv_smem + Cfg::GUARD, *const q = wv_smem + Cfg::t_doubles(N), *const outv = q + NI * Cfg::QN;
-    int *const iflag = (int *)(outv + NI * Cfg::OUT);
+    int *const iflag = (int *)(outv + NI * Cfg::OUT), *const aimv = iflag + 4, *const itacc = aimv + 4;
     const size_t Bs = a.Bs;
     const int lane = threadIdx.x;
     const int il = lane < NI ? lane : 0;
@@ -1088,10 +1126,11 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
         MPC_UNROLL for (int i = 0; i < NU; i++) delta = dmax(delta, fabs(us[i] - w.prev[(2 * NX + ND + i) * Bs + b]));
         const bool warm = w.warm_on && w.valid[b] != 0 && delta <= kWsDelta && !P.no_warm;
         double *qd = q + lane * Cfg::QN;
-        MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { qd[i] = qi.z0[i]; qd[NS + i] = qi.zr[i]; qd[2 * NS + i] = qi.c[i]; qd[3 * NS + i] = qi.zlo_m[i]; qd[4 * NS + i] = qi.zhi_m[i]; qd[Cfg::QZN + i] = qi.zrN[i]; }
         MPC_UNROLL for (int i = 0; i < NU; i++) { qd[5 * NS + i] = qi.ur[i]; qd[5 * NS + NU + i] = qi.us[i]; }
         qd[5 * NS + 2 * NU] = delta;
         iflag[lane] = kWvValid | (qi.ok0 ? kWvOk0 : 0) | (warm ? kWvWarm : 0) | ((warm && w.u_guess) ? kWvKeepU : 0);
+        itacc[lane] = 0;
         MPC_UNROLL for (int i = 0; i < ND; i++) w.prev[(NX + i) * Bs + b] = dh[i];
         MPC_UNROLL for (int i = 0; i < NX; i++) w.prev[(NX + ND + i) * Bs + b] = xs[i];
         MPC_UNROLL for (int i = 0; i < NU; i++) w.prev[(2 * NX + ND + i) * Bs + b] = us[i];
@@ -1110,7 +1149,10 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
         MPC_UNROLL for (int i = 0; i < NS; i++) X0.z[i] = 0.0;
         X[j].put(X0);
     }
-    wv_solve<NS, NU, DU, NC, MASKED, NI>(P, T, q, iflag, X, S, P.max_iter);
+    for (int pass = 0;; pass++) {      // (terminal equality: wv_term_aim)
+        wv_solve<NS, NU, DU, NC, MASKED, NI>(P, T, q, iflag, X, S, P.max_iter);
+        if (!P.term_cons || pass == 2 || !wv_term_aim<NS, NU, NC, NX, NI, Cfg>(N, q, iflag, aimv, itacc, X, S)) break;
+    }
     MPC_UNROLL for (int j = 0; j < NI; j++) {
         const size_t bj = (size_t)blockIdx.x * NI + j;
         double *rows = a.ws + (bj * Cfg::ROWS_WS) * 64;
@@ -1135,6 +1177,7 @@ __global__ __launch_bounds__(64, 1) void ocp_kernel_wv(const DevProblem *__restr
     if (valid) {
         int st = S[0].status, it = S[0].iters; double r0 = S[0].res_s, r1 = S[0].res_p, r2 = S[0].mu;
         MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st = S[j].status; it = S[j].iters; r0 = S[j].res_s; r1 = S[j].res_p; r2 = S[j].mu; } }
+        if (P.term_cons) it += itacc[lane];
         if (P.term_cons && st != kInfeasible && !(outv[lane * Cfg::OUT + NU + NS] <= P.term_tol)) st = kInfeasible;
         a.status[b] = st; a.iters[b] = it;
         a.res[0 * Bs + b] = r0; a.res[1 * Bs + b] = r1; a.res[2 * Bs + b] = r2;
@@ -1283,7 +1326,7 @@ static Launchers make_launchers_mode()
                     attr_set[dev] = true;
                 }
                 using Cfg = typename KC::Cfg;
-                const size_t bytes = sizeof(double) * ((size_t)Cfg::t_doubles(N) + NI * Cfg::QN + NI * Cfg::OUT) + sizeof(int) * 8;
+                const size_t bytes = sizeof(double) * ((size_t)Cfg::t_doubles(N) + NI * Cfg::QN + NI * Cfg::OUT) + sizeof(int) * 16;
                 hipLaunchKernelGGL(kern, dim3((a.o.B + NI - 1) / NI), dim3(64), bytes, s, p, a);
                 return 0;
             };
@@ -1755,7 +1798,6 @@ static bool ocp_uses_wave(const mpc_handle *h)
 {
     if (!h->L.ocp_wv || h->hp.N > 64 || h->ocp_kernel_opt == 1) return false;
     if (h->ocp_kernel_opt == 3) return true;
-    if (h->hp.term_cons) return false;      // terminal equality: exact on the lane solver (term_aim), by weight alone on the wave solvers
     double nrm = 0.0;
     for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));
     return nrm <= 1e4;
@@ -2152,7 +2194,7 @@ extern "C" int mpc_loop_set_model_schedule(mpc_handle *h, int32_t nsteps, const 
 static int loop_mode(const mpc_handle *h)
 {
     if (h->loop_kernel_opt != 0) return h->loop_kernel_opt;
-    if (h->hp.term_cons) return 1;      // terminal equality: exact on the lane solver (mpc_device.hpp:term_aim), by weight alone on the wave solvers
+    if (h->hp.term_cons && !(h->L.loop_wv && h->hp.N <= 64)) return 1;      // terminal equality: exact on the lane and the wave-autonomous solver (term_aim), by weight alone on the horizon-parallel one
     {      // violently unstable open loop: the kernels whose recursions are scans with A^(2^e) lose digits there (see ocp_uses_wave)
         double nrm = 0.0;
         for (int i = 0; i < kMaxN; i++) for (int j = 0; j < kMaxN; j++) nrm = std::fmax(nrm, std::fabs(h->hp.Apow[5][i][j]));

@@ -46,7 +46,8 @@ struct WvCfg {
     // A_k (NS x NS), B_k (NS x NU) and the affine term c_k as rows behind the others (35 rows for ns = 3, nu = 2: four workgroups per CU at N = 30)
     static constexpr int RL_A = ROWS, RL_B = RL_A + NS * NS, RL_C = RL_B + NS * NU, ROWS_LTV = RL_C + NS;
     __host__ __device__ static constexpr int t_doubles_ltv(int N) { return GUARD + ROWS_LTV * NI * ld(N); }
-    static constexpr int QN = 5 * NS + 2 * NU + 1;                     // z0 zr c zlo zhi | ur us | ws_delta
+    static constexpr int QZN = 5 * NS + 2 * NU + 1;                    // reference of the terminal cost: zr, or (terminal equality) zr aimed off by the measured miss
+    static constexpr int QN = QZN + NS;                                // z0 zr c zlo zhi | ur us | ws_delta | zrN
     static constexpr int ROWS_WS = NU + 2 * NC;                        // warm start kept in HBM between launches: u | l_lo | l_hi
     static constexpr int OUT = NU + NS + 1;                            // first input / next state of the final iterate, terminal miss
     __host__ __device__ static constexpr size_t lds_doubles(int keep_per_inst, int N) { return (size_t)t_doubles(N) + NI * QN + NI * OUT + NI * keep_per_inst; }
@@ -163,7 +164,8 @@ __device__ __forceinline__ void wv_solve(const PT &P, double *T, const double *q
     auto gradient = [&](const PT &Pl, int j, const Iter &Xj, double (&gu)[NU], double (&gz)[NS]) {
         const double *qd = q + ji(j) * Cfg::QN;
         double dz1[NS], du[NU];
-        MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = Xj.z[i] - qd[NS + i];
+        const double *qz = qd + (last ? Cfg::QZN : NS);      // (the last block's cost is the terminal one, with a reference of its own)
+        MPC_UNROLL for (int i = 0; i < NS; i++) dz1[i] = Xj.z[i] - qz[i];
         MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = Xj.u[i] - qd[5 * NS + i];
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             double a = (NU + i < NC) ? Xj.lh[NU + i < NC ? NU + i : 0] - Xj.ll[NU + i < NC ? NU + i : 0] : 0.0;
