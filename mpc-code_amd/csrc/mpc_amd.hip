@@ -1009,8 +1009,6 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
         }
         MPC_TSTAMP(0);
         wv_solve<NS, NU, DU, NC, MASKED, NI>(P, T, q, iflag, X, S, P.max_iter);
-        if (P.term_cons && redo < 2 && wv_term_aim<NS, NU, NC, NX, NI, Cfg>(P.N, q, iflag, aimv, itacc, X, S)) { redo++; k--; continue; }
-        redo = 0;
         MPC_STAMP_RESET
         // first input and next state of the final iterates: block 0 = lane 0
         if (lane == 0) {
@@ -1019,14 +1017,35 @@ __global__ __launch_bounds__(64, 1) void loop_kernel_wv(const DevProblem *__rest
                 MPC_UNROLL for (int i = 0; i < NS; i++) outv[j * Cfg::OUT + NU + i] = a_get(X[j].z[i]);
             }
         }
-        if (P.term_cons && lane == P.N - 1) {      // terminal equality (mpc_device.hpp:term_missed): the last block is lane N - 1
+        if (P.term_cons && lane == P.N - 1) {      // terminal equality (mpc_device.hpp:term_missed, term_aim): the last block is lane N - 1
             MPC_UNROLL for (int j = 0; j < NI; j++) {
-                double v = 0.0;
-                MPC_UNROLL for (int i = 0; i < NX; i++) { const double zr = q[j * Cfg::QN + NS + i]; v = dmax(v, fabs(a_get(X[j].z[i]) - zr) * frcp(dmax(1.0, fabs(zr)))); }
+                double v = 0.0, c[NX];
+                MPC_UNROLL for (int i = 0; i < NX; i++) { const double zr = q[j * Cfg::QN + NS + i]; c[i] = a_get(X[j].z[i]) - zr; v = dmax(v, fabs(c[i]) * frcp(dmax(1.0, fabs(zr)))); }
                 outv[j * Cfg::OUT + NU + NS] = v;
+                // another pass with the terminal reference aimed off by the miss?  (at most two; not for a target out of reach or a failed solve)
+                const int f = iflag[j];
+                const bool again = redo < 2 && (f & kWvValid) && (f & kWvOk0) && S[j].status != kInfeasible && v > 1e-11 && v <= 1e-4;
+                if (again) { MPC_UNROLL for (int i = 0; i < NX; i++) q[j * Cfg::QN + Cfg::QZN + i] -= c[i]; q[j * Cfg::QN + 5 * NS + 2 * NU] = v; }
+                aimv[j] = again ? 1 : 0;
             }
         }
         __syncthreads();
+        if (P.term_cons && redo < 2) {
+            int any = 0;
+            MPC_UNROLL for (int j = 0; j < NI; j++) any |= aimv[j];
+            if (__builtin_amdgcn_readfirstlane(any)) {      // the step's loop body once more, from the solve onwards: warm, from the iterates as they are
+                if (lane < NI) {
+                    int st = S[0].status, it = S[0].iters;
+                    MPC_UNROLL for (int j = 1; j < NI; j++) { if (lane == j) { st = S[j].status; it = S[j].iters; } }
+                    const int f = iflag[lane];
+                    if ((f & kWvValid) && (f & kWvOk0) && st != kInfeasible) { iflag[lane] = kWvValid | kWvOk0 | kWvWarm | kWvNoShift; itacc[lane] += it; }
+                }
+                __syncthreads();
+                redo++; k--;
+                continue;
+            }
+        }
+        redo = 0;
         if (valid) {
             // ---- accept or hold (MPC_code.py:798-805), plant (MPC_code.py:813-816) ---------------------
             int st_dyn = S[0].status, it_dyn = S[0].iters;
