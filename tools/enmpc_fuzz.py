@@ -17,6 +17,8 @@ for seed in range(s0, s0 + n):
     rng = np.random.default_rng(1000 + seed)
     over = {"K1": float(rng.uniform(0.6, 1.6)), "K2": float(rng.uniform(0.02, 0.2)), "PRICE_B": float(rng.uniform(2.5, 6.0)), "h": float(rng.choice([1.0, 2.0, 3.0])),
             "N": int(rng.integers(8, 41)), "N_mhe": int(rng.integers(3, 15)), "mhe_up": str(rng.choice(["smooth", "filter"]))}
+    if seed % 2:      # odd seeds: other boxes too, and a saturated disturbance estimate (MPC_code.py:657-664)
+        over.update({"umax": [float(rng.uniform(0.8, 3.0))], "xmax": np.array([1.0, float(rng.uniform(0.5, 1.0))]), "dmin": np.array([-0.05, -0.02]), "dmax": np.array([0.03, 0.05])})
     x0 = rng.uniform([0.4, 0.0], [1.0, 0.6], size=(6, 2))
     c = ec.OracleEC(eo.load_problem(EX, overrides=over)).closed_loop(12, x0, nthreads=6)
     p = m.load_problem(EX, overrides=over)
@@ -29,7 +31,8 @@ for seed in range(s0, s0 + n):
         di = max(int(np.abs(r[k].astype(int) - c[k].astype(int)).max()) for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"))
         ok = dv < 1e-7 and st and di <= 4
         bad += not ok
-        msg.append(f"k{kernel}: |dv| {dv:.1e} status {'=' if st else 'DIFFER'} iters +-{di}{'' if ok else '  <-- FAIL'}")
+        where = [f"{k[7:]} step {a} instance {b}: {int(c[k][a, b])} here, {int(r[k][a, b])} on the GPU" for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE") for a, b in zip(*np.nonzero(r[k] != c[k]))]
+        msg.append(f"k{kernel}: |dv| {dv:.1e} status {'=' if st else 'DIFFER (' + ', '.join(where) + ')'} iters +-{di}{'' if ok else '  <-- FAIL'}")
     s.close()
-    print(seed, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in over.items()}, "| status max", int(c["STATUS_DYN"].max()), int(c["STATUS_SS"].max()), int(c["STATUS_MHE"].max()), "|", " ; ".join(msg), flush=True)
+    print(seed, {k: (round(v, 3) if isinstance(v, float) else (np.round(v, 3).tolist() if isinstance(v, (list, np.ndarray)) else v)) for k, v in over.items()}, "| status max", int(c["STATUS_DYN"].max()), int(c["STATUS_SS"].max()), int(c["STATUS_MHE"].max()), "|", " ; ".join(msg), flush=True)
 print("failures:", bad)
