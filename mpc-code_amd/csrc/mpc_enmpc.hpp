@@ -195,8 +195,9 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                 double a = ga;
                 MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0v[j] - xbar[j]);
                 g0[i] = a; ga0[i] = ga;
-                e_st = dmax(e_st, fabs(a - zl0[i] + zh0[i])); s_z += zl0[i] + zh0[i];
-                finite = finite && finite_all(a) && finite_all(x0v[i]);
+                const double r0 = a - zl0[i] + zh0[i];
+                e_st = dmax(e_st, fabs(r0)); s_z += zl0[i] + zh0[i];
+                finite = finite && finite_all(r0) && finite_all(x0v[i]);      // (the residual, as for the other variables: an infinite multiplier must end the solve as failed)
                 if (flx[i]) { cmax = dmax(cmax, sl0[i] * zl0[i]); cmin = dmin(cmin, sl0[i] * zl0[i]); }
                 if (fhx[i]) { cmax = dmax(cmax, sh0[i] * zh0[i]); cmin = dmin(cmin, sh0[i] * zh0[i]); }
             }
