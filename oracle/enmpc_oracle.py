@@ -282,6 +282,9 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
             break
         sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
         stat = gf + J.T @ lam - zl + zh
+        if not np.all(np.isfinite(stat)):      # (an infinite bound multiplier: a slack that rounded to zero - DESIGN.md section 12; enmpc_oracle.c says failed too)
+            status = STATUS_INFEASIBLE
+            break
         s_d = max(S_MAX, (np.abs(lam).sum() + zl.sum() + zh.sum()) / max(m + nb, 1)) / S_MAX
         s_c = max(S_MAX, (zl.sum() + zh.sum()) / max(nb, 1)) / S_MAX
 
@@ -614,7 +617,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
         S.x_bar[:n] = x0_m                                   # Ex-file: x_bar = [x0_m; 0]
     xs_k, us_k = x0_m.copy(), u_k.copy()                     # MPC_code.py:682-684
     w_opt = None; last_ok = True
-    log = {k: [] for k in ("U", "X_HAT", "D_HAT", "XS", "US", "Xp", "Yp", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "ITERS_MHE", "X_ES", "KKT_DYN", "KKT_SS", "KKT_MHE", "P_K")}
+    log = {k: [] for k in ("U", "X_HAT", "D_HAT", "XS", "US", "Xp", "Yp", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "ITERS_MHE", "STATUS_MHE", "X_ES", "KKT_DYN", "KKT_SS", "KKT_MHE", "P_K")}
     for ksim in range(nsteps):
         t_k = ksim * p.h
         log["Xp"].append(x_k.copy()); log["X_HAT"].append(xhat.copy())
@@ -622,7 +625,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
         log["Yp"].append(y_k.copy())
         if p.mhe:
             x_es = mhe_step(p, S, ksim, y_k, u_k, t_k)
-            log["ITERS_MHE"].append(S.last["iters"])
+            log["ITERS_MHE"].append(S.last["iters"]); log["STATUS_MHE"].append(S.last["status"])
             if certify:
                 log["KKT_MHE"].append(max(kkt_nlp(S.last["evalf"], S.last, S.last["lo"], S.last["hi"]).values()))
             log["P_K"].append(S.P_k.copy())
