@@ -436,6 +436,8 @@ void eorc_functions(const EProb *P, const double *x, double u, const double *d, 
     cplx w[NW] = {wv[0], wv[1], wv[2], wv[3]}, v[NY] = {wv[4], wv[5]};
     out[4] = creal(cost_mhe(w, v));
 }
+void eorc_set_safe_slack(int on) { orc_safe_slack = on; }      /* prototype switch, see orc_dense.h */
+
 int eorc_max_threads(void)
 {
 #ifdef _OPENMP

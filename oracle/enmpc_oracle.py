@@ -230,6 +230,25 @@ def push_interior(w, lo, hi):
     return w
 
 
+SAFE_SLACK = False      # prototype for the next round, mirrors orc_dense.h:slack_of; the kernels do not have it
+SLACK_EPS, SLACK_MOVE = float(np.finfo(float).eps), float(np.finfo(float).eps) ** 0.75
+
+
+def _slacks(w, lo, hi, zl, zh, mu, fl, fh):
+    """slacks of the bounds; with SAFE_SLACK IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) becomes min(max(mu / z, eps min(1, mu)), max(s, 0) + eps^(3/4) max(1, |bound|))
+    and the bound of this solve (lo, hi: modified in place) moves by the difference"""
+    sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
+    if SAFE_SLACK:
+        s_min = SLACK_EPS * min(1.0, mu)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for s, z, b, f, sign in ((sl, zl, lo, fl, 1.0), (sh, zh, hi, fh, -1.0)):
+                fix = f & (s < s_min)
+                if fix.any():
+                    s[fix] = np.minimum(np.maximum(mu / z[fix], s_min), np.maximum(s[fix], 0.0) + SLACK_MOVE * np.maximum(1.0, np.abs(b[fix])))
+                    b[fix] = w[fix] - sign * s[fix]
+    return sl, sh
+
+
 def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
     """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n].  Variables with lo == hi are PARAMETERS, as
     IPOPT treats them (fixed_variable_treatment = make_parameter, its default [ext]): the initial state of the OCP (MPC_code.py:734)
@@ -268,6 +287,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
     fl, fh = np.isfinite(lo), np.isfinite(hi)
     w = push_interior(w0, lo, hi)
     zl, zh = np.where(fl, 1.0, 0.0), np.where(fh, 1.0, 0.0)
+    lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)      # (this solve's own bounds: the safe-slack prototype moves them)
     nb = int(fl.sum() + fh.sum())
     lam = None
     mu, delta_last = MU_INIT, 0.0
@@ -280,7 +300,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
         if not (np.all(np.isfinite(w)) and np.all(np.isfinite(gf)) and np.all(np.isfinite(c))):
             status = STATUS_INFEASIBLE
             break
-        sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
+        sl, sh = _slacks(w, lo, hi, zl, zh, mu, fl, fh)
         stat = gf + J.T @ lam - zl + zh
         if not np.all(np.isfinite(stat)):      # (an infinite bound multiplier: a slack that rounded to zero - DESIGN.md section 12; enmpc_oracle.c says failed too)
             status = STATUS_INFEASIBLE
@@ -327,7 +347,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
         w = w + a_pr * dw
         lam = lam + a_pr * (lam_new - lam)
         zl, zh = zl + a_du * dzl, zh + a_du * dzh
-        sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
+        sl, sh = _slacks(w, lo, hi, zl, zh, mu, fl, fh)
         zl = np.where(fl, np.clip(zl, mu / (KAPPA_SIGMA * sl), KAPPA_SIGMA * mu / sl), 0.0)
         zh = np.where(fh, np.clip(zh, mu / (KAPPA_SIGMA * sh), KAPPA_SIGMA * mu / sh), 0.0)
     return dict(w=w, lam=lam, z_lo=zl, z_hi=zh, status=status, iters=it, mu=mu)

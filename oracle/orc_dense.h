@@ -20,6 +20,22 @@ enum { ST_SOLVED = 0, ST_MAXITER = 1, ST_FAILED = 2 };
 #define TAU_MIN 0.99
 #define KAPPA_SIGMA 1e10
 #define S_MAX 100.0
+/* IPOPT's safe slack (IpIpoptCalculatedQuantities.cpp: CalculateSafeSlack, slack_move = eps^(3/4)) - a PROTOTYPE for the next round, off unless orc_safe_slack is set
+   (the kernels do not have it): a slack below eps min(1, mu) becomes min(max(mu / z, eps min(1, mu)), max(s, 0) + slack_move max(1, |bound|)) and the
+   bound of this solve moves by the difference (where the doubles at the bound can show it). */
+#define SLACK_EPS 2.220446049250313e-16
+#define SLACK_MOVE 1.81898940354585648e-12
+static int orc_safe_slack = 0;
+static inline double slack_of(double w, double *bound, double z, double mu, int lower)
+{
+    double s = lower ? w - *bound : *bound - w;
+    const double s_min = SLACK_EPS * fmin(1.0, mu);
+    if (orc_safe_slack && s < s_min) {
+        s = fmin(fmax(mu / z, s_min), fmax(s, 0.0) + SLACK_MOVE * fmax(1.0, fabs(*bound)));
+        *bound = lower ? w - s : w + s;
+    }
+    return s;
+}
 #define DELTA_FIRST 1e-4
 #define DELTA_MAX 1e40
 
@@ -130,9 +146,11 @@ static double push_in(double v, double lo, double hi)
 }
 
 /* n variables (none fixed: the caller has removed parameters), m equalities */
-static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, const double *lo, const double *hi, double tol, int max_iter, int *iters, double *lam_out)
+static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, const double *lo_in, const double *hi_in, double tol, int max_iter, int *iters, double *lam_out)
 {
     const size_t mark_ = arena_mark();
+    double *lo = vec(n), *hi = vec(n);      /* (this solve's own bounds: the safe-slack prototype moves them) */
+    memcpy(lo, lo_in, sizeof(double) * n); memcpy(hi, hi_in, sizeof(double) * n);
     double *zl = vec(n), *zh = vec(n), *lam = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m),
            *sl = vec(n), *sh = vec(n), *Sig = vec(n), *gt = vec(n), *dw = vec(n), *lamn = vec(m), *py = vec(n), *tmp = vec(n), *Hr = vec((size_t)(n - m) * (n - m)), *rz = vec(n), *HZ = vec((size_t)n * (n - m)), *Zc = vec(n);
     int nb = 0, status = ST_MAXITER, it = 0;
@@ -145,7 +163,7 @@ static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, cons
         int finite = 1;
         for (int i = 0; i < n; i++) {
             const int fl = isfinite(lo[i]), fh = isfinite(hi[i]);
-            sl[i] = fl ? w[i] - lo[i] : 1.0; sh[i] = fh ? hi[i] - w[i] : 1.0;
+            sl[i] = fl ? slack_of(w[i], &lo[i], zl[i], mu, 1) : 1.0; sh[i] = fh ? slack_of(w[i], &hi[i], zh[i], mu, 0) : 1.0;
             double r = gf[i] - zl[i] + zh[i];
             for (int j = 0; j < m; j++) r += J[j * n + i] * lam[j];
             e_st = fmax(e_st, fabs(r)); s_z += zl[i] + zh[i];
@@ -216,8 +234,8 @@ static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, cons
         for (int i = 0; i < n; i++) {
             w[i] += apr * dw[i];
             zl[i] += adu * Sig[i]; zh[i] += adu * gt[i];
-            if (isfinite(lo[i])) { const double s = w[i] - lo[i]; zl[i] = fmin(fmax(zl[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
-            if (isfinite(hi[i])) { const double s = hi[i] - w[i]; zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
+            if (isfinite(lo[i])) { const double s = slack_of(w[i], &lo[i], zl[i], mu, 1); zl[i] = fmin(fmax(zl[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
+            if (isfinite(hi[i])) { const double s = slack_of(w[i], &hi[i], zh[i], mu, 0); zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
         }
         for (int j = 0; j < m; j++) lam[j] += apr * (lamn[j] - lam[j]);
     }

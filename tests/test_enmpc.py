@@ -91,6 +91,16 @@ def test_restatements_agree_where_a_slack_rounds_to_zero():
         for k in ("U", "XS", "X_ES"):
             assert np.abs(o[k] - c[k][:, 0]).max() < 1e-11, (seed, k)
         assert abs(c["X_ES"][0, 0, 2] - (-0.05)) < 1e-15 or abs(c["X_ES"][0, 0, 3] - (-0.02)) < 1e-15 or abs(c["X_ES"][0, 0, 2] - 0.03) < 1e-15 or abs(c["X_ES"][0, 0, 3] - 0.05) < 1e-15
+        # the prototype of IPOPT's safe slack in both restatements (off by default: the kernels do not have it): the same solves end "solved", same estimates
+        C = ec.OracleEC(q)
+        try:
+            C.set_safe_slack(True); eo.SAFE_SLACK = True
+            c2 = C.closed_loop(3, x0[inst:inst + 1], nthreads=1)
+            o2 = eo.closed_loop(q, 3, x0_p=x0[inst])
+        finally:
+            C.set_safe_slack(False); eo.SAFE_SLACK = False
+        assert c2["STATUS_MHE"][:, 0].tolist() == [0, 0, 0] == o2["STATUS_MHE"].tolist()
+        assert np.abs(c2["X_ES"] - c["X_ES"]).max() < 1e-8 and np.abs(o2["X_ES"] - c2["X_ES"][:, 0]).max() < 1e-10
 
 
 def test_interval_integration_is_within_the_reference_integrators_tolerance(oprob):
