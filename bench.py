@@ -171,6 +171,33 @@ def dry_run(args):
         print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "local_ranks_seen": seen}), flush=True)
 
 
+def other_configs(args):
+    """The other BASELINE workloads (configs[2], [3], [4]) measured by the SAME command, so that every headline number is the driver's: each runs as
+    a child process of its own (its own per-model library and handle; the same K and W; the GPU is free - this process has not touched it yet) and
+    prints its own full bench line, of which the compact part is kept under ``other_configs``.  A child that fails fails the whole run."""
+    import subprocess
+    out = {}
+    for name in ("nmpc", "enmpc", "mhe"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--min-seconds", str(args.min_seconds), "--cpu-seconds", str(min(args.cpu_seconds, 2.5))] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            sys.stderr.write(r.stderr[-4000:])
+            sys.exit("bench.py: --config %s failed (exit code %d)" % (name, r.returncode))
+        d = json.loads(lines[-1])
+        rf = d["roofline"]
+        out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                     "batch_per_gpu": d["config"]["batch_per_gpu"], "repeats": d["config"]["repeats"], "workload": d["config"]["workload"],
+                     "roofline": {"bound": rf["bound"], "priced_against": rf.get("priced_against"), "kernel": rf["kernel"].split(" (")[0], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
+                                  "frac": rf["frac"], "traffic": rf["traffic"], "avg_launch_ms": rf["avg_launch_ms"], "alg_bytes_per_step": rf["alg_bytes_per_step"],
+                                  "instance_steps_per_launch": rf["instance_steps_per_launch"], "fp64_frac": (rf.get("fp64") or {}).get("frac")},
+                     "solver": d.get("solver"), "cpu_baseline": ({k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "single_core_value", "sample")} if "cpu_baseline" in d else None),
+                     "command": " ".join(["python", "bench.py"] + cmd[2:]), "wall_s": time.perf_counter() - t0}
+    return out
+
+
 ENMPC_CONFIGS = {
     "enmpc": dict(over={"N": 40}, batch=16384, metric="closed-loop economic NMPC steps/sec over batch, Ex_ENMPC N=40 (BASELINE configs[3])",
                   what="BASELINE configs[3]: N = 40 (ships 25), N_mhe = 10; 131072 instances over 8 GPUs = 16384 per GPU"),
@@ -186,7 +213,11 @@ def enmpc_alg(p, it_dyn, it_ss, it_mhe, nw_mean):
     MPC_code.py:764); flops = interior-point iterations x stages x Runge-Kutta stage evaluations x the operations of the generated
     second-order sensitivity code + the Riccati recursions, from the iteration counts of the run."""
     ne = p.nx + p.nd
-    st_mhe = p.nxp + p.nx + p.nd + p.nu + ne + 2 * ne * ne + p.n_w + p.ny + p.N_mhe * (p.ny + p.nu) + p.N_mhe * 3 * ne * ne      # + window, covariance lists
+    # the estimator reads its whole state - prior, window, the three covariance lists of the smoothing update - and writes what a step changes: the prior,
+    # ONE new entry of the window and ONE new entry of each list (the lists shift in place on chip); target and OCP read and write their state
+    mhe_fix = p.nxp + p.nx + p.nd + p.nu + ne + 2 * ne * ne + p.n_w + p.ny
+    mhe_in = mhe_fix + p.N_mhe * (p.ny + p.nu) + p.N_mhe * 3 * ne * ne
+    mhe_out = mhe_fix + (p.ny + p.nu) + 3 * ne * ne
     st_tgt = p.nd + 2 * (p.nx + p.nu)
     st_ocp = p.nxp + p.nx + p.nd + p.nu + 2 * (p.nx + p.nu) + p.nw                                                            # + primal warm start
     npo, npm = p.nx + p.nu, p.nx
@@ -202,7 +233,7 @@ def enmpc_alg(p, it_dyn, it_ss, it_mhe, nw_mean):
     ric_mhe = (ne * (wA + wB) + 2 * ne * ne) + (nw_ * wB + ne * wB + wB) + (ne * wA + wA) + nw_ ** 3 + (2 * nw_ * nw_ * ne + 2 * nw_ * nw_) \
         + (2 * ne * ne * nw_ + 2 * ne * nw_) + (wA + wB) + (wA + wB + 2 * nw_ * ne)      # PA PB pc | Quu Qux qu | Qxx qx | inverse | gains | P p | gradients | forward
     f_mhe = it_mhe * nw_mean * (p.Mx * rk(p.nx, npm) + ric_mhe + 60 * (ne + p.n_w))
-    b = [16 * st_mhe, 16 * st_tgt, 16 * st_ocp]      # in and out, 8 bytes each
+    b = [8 * (mhe_in + mhe_out), 16 * st_tgt, 16 * st_ocp]      # in and out, 8 bytes each
     return [(b[0], float(f_mhe)), (b[1], float(f_ss)), (b[2], float(f_ocp)), (sum(b), float(f_ocp + f_ss + f_mhe))]      # estimator, target, OCP kernels; all in one
 
 
@@ -287,7 +318,7 @@ def main_enmpc(args):
                           "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U inside the timed region" % world,
                           "rccl_ranks": (csolver.comm_rank()[1] if csolver is not None else 1),
                           "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+               "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                             "kernel": kdesc, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
                             "launch_timing": ("HIP events around every launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
                                               "groups on streams of their own)" % (len(pms), K)) if kern == 2 else "HIP events around the timed regions' launches",
@@ -307,7 +338,7 @@ def main_enmpc(args):
             t0 = time.perf_counter(); oc.closed_loop(K, x0[:2], nthreads=1, logs=False); r1 = 2 * K / (time.perf_counter() - t0)      # one core, to size the samples
             tried = {}
             for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
-                nb = int(min(B, max(th, 5.0 * r1 * th / K)))       # about 5 s per thread count
+                nb = int(min(B, max(th, args.cpu_seconds * r1 * th / K)))       # about --cpu-seconds (5 s) per thread count
                 t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
             best = max(tried, key=lambda th: tried[th][0])
             out["cpu_baseline"] = {"value": tried[best][0], "unit": "steps/s", "cores": best, "kind": "port", "single_core_value": r1,
@@ -401,7 +432,7 @@ def main_nmpc(args):
                       "batch_per_gpu": B, "horizon": p.N, "steps_per_run": K, "kernel": kern, "stream_groups": args.groups, "max_sqp": args.max_sqp, "repeats": len(times),
                       "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3},
                       "device_ms_per_run": float(np.mean(kms))},
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+           "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": kdesc, "launches": (wn * len(wms)) if split else len(times), "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
                         "launch_timing": ("HIP events around every wave-style launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
                                           "groups on streams of their own)" % (len(wms), K)) if split else "HIP events around the timed regions' launches",
@@ -420,7 +451,7 @@ def main_nmpc(args):
         t0 = time.perf_counter(); oc.closed_loop(K, x0[:2], max_sqp=args.max_sqp, nthreads=1, logs=False); r1 = 2 * K / (time.perf_counter() - t0)
         tried = {}
         for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
-            nb = int(min(B, max(th, 5.0 * r1 * th / K)))
+            nb = int(min(B, max(th, args.cpu_seconds * r1 * th / K)))
             t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], max_sqp=args.max_sqp, nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
         best = max(tried, key=lambda th: tried[th][0])
         out["cpu_baseline"] = {"value": tried[best][0], "unit": "steps/s", "cores": best, "kind": "port", "single_core_value": r1, "threads_tried": {str(th): tried[th][0] for th in tried},
@@ -450,6 +481,8 @@ def main():
     ap.add_argument("--max-sqp", type=int, default=1, help="nmpc: SQP iterations per OCP (1 = real-time iteration)")
     ap.add_argument("--groups", type=int, default=0, help="nmpc / enmpc / mhe: groups of the batch on HIP streams of their own (0: the library's choice; 1: one stream, "
                     "as the profiles need it - overlapping launches have no duration of their own)")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="nmpc / enmpc / mhe: host seconds per thread count of the CPU baseline's bounded sample")
+    ap.add_argument("--no-other-configs", action="store_true", help="lmpc on one GPU: do not measure BASELINE configs[2..4] next to the metric workload")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: every rank goes through the rendezvous only and rank 0 prints who was there (launcher test)")
     args = ap.parse_args()
     launch_ranks(args)                # --gpus N without a launcher: N child processes, one per GPU (before anything here touches the GPU)
@@ -465,6 +498,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     K, W, B = args.steps, args.warmup, args.batch
     use_dist = world > 1 or args.force_dist
+    others = None
+    if world == 1 and not args.force_dist and not args.no_other_configs and B == B_PER_GPU:
+        others = other_configs(args)      # child processes, before this one touches the GPU
 
     import mpc_code_amd as m
     from mpc_code_amd import capi, shard
@@ -539,7 +575,7 @@ def main():
                        "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U (mpc_allgather_log) inside the timed region" % world,
                        "rccl_ranks": (solver.comm_rank()[1] if use_dist else 1),
                        "repeats": len(times), "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab, "carried_bytes_per_step": carried_bytes_per_step(prob),
@@ -557,6 +593,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, x0, K)
+        if others is not None:
+            out["other_configs"] = others
         line = json.dumps(out)
     if use_dist:      # the gathered block of this rank must be what the kernel logged
         allU = solver.allgather_log("U", 0, K)

@@ -42,8 +42,8 @@ if [ "${2:-}" = "enmpc" ] || [ "${2:-}" = "mhe" ]; then      # the economic work
 fi
 rm -rf "$OUT"; mkdir -p "$OUT"
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -c 900 "$OUT/${TAG}_bench.json"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
-CMD="python3 bench.py --steps 20 --warmup 0 --repeats 4 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
+CMD="python3 bench.py --steps 20 --warmup 0 --repeats 4 --no-cpu-baseline --no-other-configs"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"; do
     tag=$(echo $pass | cut -d' ' -f1)
     timeout 180 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$tag" -- $CMD > "$OUT/pmc_$tag.log" 2>&1; echo "pmc $tag rc=$?"
