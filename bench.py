@@ -336,9 +336,10 @@ def main_enmpc(args):
             oc = eoc.OracleEC(eo.load_problem(m.example_path("reactor_enmpc.py"), overrides=cfg["over"]), fast=True)      # -O3 -march=native, built on this host
             nthr = oc.max_threads()
             t0 = time.perf_counter(); oc.closed_loop(K, x0[:2], nthreads=1, logs=False); r1 = 2 * K / (time.perf_counter() - t0)      # one core, to size the samples
-            tried = {}
-            for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
-                nb = int(min(B, max(th, args.cpu_seconds * r1 * th / K)))       # about --cpu-seconds (5 s) per thread count
+            tried, est = {}, None
+            for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}):      # ascending: each sample sized by the best rate measured so far
+                est = 0.6 * r1 * th if est is None else max(v[0] for v in tried.values())
+                nb = int(min(B, max(th, args.cpu_seconds * est / K)))       # about --cpu-seconds (5 s) per thread count
                 t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
             best = max(tried, key=lambda th: tried[th][0])
             out["cpu_baseline"] = {"value": tried[best][0], "unit": "steps/s", "cores": best, "kind": "port", "single_core_value": r1,
@@ -449,9 +450,10 @@ def main_nmpc(args):
             oc = noc.OracleNC(no.load_problem(m.example_path("cstr_nmpc.py")), fast=True)      # the checker's own reading of the example; -O3 -march=native, built on this host
         nthr = oc.max_threads()
         t0 = time.perf_counter(); oc.closed_loop(K, x0[:2], max_sqp=args.max_sqp, nthreads=1, logs=False); r1 = 2 * K / (time.perf_counter() - t0)
-        tried = {}
-        for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
-            nb = int(min(B, max(th, args.cpu_seconds * r1 * th / K)))
+        tried, est = {}, None
+        for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}):      # ascending: each sample sized by the best rate measured so far
+            est = 0.6 * r1 * th if est is None else max(v[0] for v in tried.values())
+            nb = int(min(B, max(th, args.cpu_seconds * est / K)))
             t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], max_sqp=args.max_sqp, nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
         best = max(tried, key=lambda th: tried[th][0])
         out["cpu_baseline"] = {"value": tried[best][0], "unit": "steps/s", "cores": best, "kind": "port", "single_core_value": r1, "threads_tried": {str(th): tried[th][0] for th in tried},

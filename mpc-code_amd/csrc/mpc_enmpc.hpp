@@ -44,13 +44,6 @@ __device__ __forceinline__ double push_in(double v, double lo, double hi)
 
 template <int NP> __device__ __forceinline__ constexpr int pair_idx(int j, int k) { return j <= k ? j * NP - j * (j - 1) / 2 + (k - j) : k * NP - k * (k - 1) / 2 + (j - k); }
 
-// ---- one stage of a stage-structured NLP, linearised ------------------------------------------------------------------------------
-// x+ = F(x, u), cost l(x, u);  A = F_x, B = F_u, (lx, lu) = grad l, [Q M; M' R] = Hessian of l + pi' F  (pi = costate of x+)
-template <int NS, int NU>
-struct StageLin {
-    double F[NS], A[NS][NS], B[NS][NU], lx[NS], lu[NU], Q[NS][NS], M[NS][NU], R[NU][NU];
-};
-
 // ---- segments of a wave: SEG = 64 (one instance per wave), 32 or 16 lanes per instance (two or four instances side by side when the
 // horizon leaves the lanes idle).  k = lane & (SEG - 1) is the stage; everything "uniform" is uniform within a segment. -------------------
 template <int SEG>
@@ -108,12 +101,23 @@ template <int SEG, int N_> __device__ __forceinline__ void bcast_sym(const doubl
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The interior point method on   min sum_k l_k(x_k, u_k) + Vf(x_N)   s.t.  x_{k+1} = F_k(x_k, u_k),  boxes on u_k and x_{k+1}
-// (k = 0..N-1, lane k holds u_k, x_{k+1}, the costate pi_{k+1} = -(multiplier of x_{k+1} - F_k = 0) and their bound multipliers).
+// (k = 0..N-1, lane k holds u_k, x_{k+1}, the costate pi_{k+1} = -(multiplier of x_{k+1} - F_k = 0), their bound multipliers and - since
+// round 4 - ITS OWN COPY OF THEIR BOUNDS: the safe slack moves them).
 // FREE0 = false: x_0 is given (the OCP; IPOPT makes a variable with equal bounds a parameter, MPC_code.py:734).
 // FREE0 = true:  x_0 is a variable with its own box and the arrival cost 1/2 (x_0 - xbar)' Pinv (x_0 - xbar) (the MHE); every lane
 //                carries the same copy of it.
-// lin(xk, u, pi, L): this lane's stage linearised; term(xn, gv, Hv): terminal cost at this lane's x_{k+1} (used from lane N-1).
-// u / xn come in as the first guess (pushed into the box here) and leave as the final iterate.  Returns the status.
+// The algorithm is the reference solver's as documented in oracle/enmpc_oracle.py:ipm_dense (objective scaling at the caller's point,
+// least-squares multipliers, monotone barrier parameter, filter line search with second-order correction, tiny steps, safe slacks,
+// acceptable stop) - same constants, same order of decisions; what differs is the linear algebra: every Newton system is a Riccati
+// recursion over the lanes, split into a MATRIX pass (gains, cost-to-go matrices; repeated with a larger shift while a stage lacks positive
+// curvature) and a VECTOR pass (feed-forward, cost-to-go gradient) + forward pass, which the second-order corrections repeat alone.
+//   lin(xk, u, L, aux)     this lane's stage at (x_k, u_k): L.F, L.A, L.B, cost value L.l, cost gradient L.lx / L.lu, cost Hessian in L.Q / L.M / L.R;
+//                          aux keeps the second-order sensitivities of the dynamics
+//   addpi(aux, pi, L)      L.Q / L.M / L.R += sum_i pi_i Hessian(F_i)
+//   val(xk, u, F, l)       values only (trial points of the line search)
+//   term(xn, f, gv, Hv)    terminal cost at this lane's x_{k+1} (used from lane N-1)
+// u / xn (/ x0v) come in as the caller's guess and leave as the final iterate.  filt: this segment's FILTER_CAP pairs of doubles in LDS.
+// Returns the status.
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ST: what is known at compile time about the stage matrices - a_kind(i, j) / b_kind(i, j) = 0 (the entry of A / B is zero), 1 (it is one), 2 (general: read
 // L.A[i][j] / L.B[i][j]).  With the loops unrolled the products with zeros and ones disappear and the entries that are never read are never held.
@@ -124,53 +128,246 @@ struct DenseStage {
 #define EC_A(acc, x, i_, j_) do { if (ST::a_kind(i_, j_) == 1) acc += (x); else if (ST::a_kind(i_, j_) == 2) acc += L.A[i_][j_] * (x); } while (0)
 #define EC_B(acc, x, i_, j_) do { if (ST::b_kind(i_, j_) == 1) acc += (x); else if (ST::b_kind(i_, j_) == 2) acc += L.B[i_][j_] * (x); } while (0)
 
-template <int NS, int NU, bool FREE0, int SEG, class ST, class LinF, class TermF>
+constexpr double kEps = 2.220446049250313e-16, kSlackMove = 1.81898940354585648e-12, kScaleMaxGrad = 100.0, kScaleMin = 1e-8, kYInitMax = 1e3, kKappaD = 1e-5,
+                 kGammaTheta = 1e-5, kGammaPhi = 1e-8, kSTheta = 1.1, kSPhi = 2.3, kEtaPhi = 1e-8, kThetaMaxFact = 1e4, kThetaMinFact = 1e-4, kAlphaMinFrac = 0.05,
+                 kObjMaxInc = 5.0, kKappaSoc = 0.99, kTinyStepTol = 10.0 * kEps, kTinyStepYTol = 1e-2, kDualInfTol = 1.0, kConstrViolTol = 1e-4, kComplInfTol = 1e-4,
+                 kAccTol = 1e-6, kAccDualInfTol = 1e10, kAccConstrViolTol = 1e-2, kAccComplInfTol = 1e-2;
+constexpr int kMaxSoc = 4, kAccIter = 15, kFilterCap = 16;
+
+__device__ __forceinline__ bool le_tol(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * kEps * fabs(bas); }      // IPOPT's Compare_le
+// slack of one bound with IPOPT's CalculateSafeSlack; a corrected slack moves `bound`
+__device__ __forceinline__ double safe_slack(double w, double &bound, double z, double mu, bool lower)
+{
+    double s = lower ? w - bound : bound - w;
+    const double s_min = kEps * dmin(1.0, mu);
+    if (s < s_min) {
+        s = dmin(dmax(mu / z, s_min), dmax(s, 0.0) + kSlackMove * dmax(1.0, fabs(bound)));
+        bound = lower ? w - s : w + s;
+    }
+    return s;
+}
+// the filter of one segment (= one instance) in LDS: pairs (phi, theta); every lane of the segment reads the same entries
+__device__ __forceinline__ bool filter_rejects(const double *filt, int nf, double phi_t, double theta_t)
+{
+    bool rej = false;
+    for (int e = 0; e < kFilterCap; e++) { if (e < nf) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (le_tol(ph, phi_t, ph) && le_tol(th, theta_t, th)) rej = true; } }
+    return rej;
+}
+
+template <int NS, int NU>
+struct StageLin {
+    double F[NS], A[NS][NS], B[NS][NU], l, lx[NS], lu[NU], Q[NS][NS], M[NS][NU], R[NU][NU];
+};
+
+// what a lane keeps of the factorised Newton system
+template <int NS, int NU>
+struct RicFac { double K[NU][NS], Qi[NU][NU], Pnx[NS][NS], P0i[NS][NS]; };
+
+// MATRIX pass of the Riccati recursion over the lanes.  Hessian blocks of this lane's stage in (Q, M, R), the diagonal terms Su (inputs), Sxk (x_k, from the
+// neighbour that holds it), terminal block Pt of lane N-1 (Hessian of x_N with its diagonal term).  false for this lane when its stage lacks positive curvature.
+template <int NS, int NU, bool FREE0, int SEG, class ST>
+__device__ __forceinline__ bool ric_matrix(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const double (&Q)[NS][NS], const double (&Mx)[NS][NU], const double (&R)[NU][NU],
+                                           const double (&Su)[NU], const double (&Sxk)[NS], const double (&Pt)[NS][NS], const double (&P0add)[NS][NS], RicFac<NS, NU> &Fc)
+{
+    double Pn[NS][NS];
+    bcast_sym<SEG, NS>(Pt, N - 1, lane, Pn);
+    bool bad = false;
+    for (int kk = N - 1; kk >= 0; kk--) {
+        double PA[NS][NS], PB[NS][NU];
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, Pn[i][l], l, j); PA[i][j] = a; }
+            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, Pn[i][l], l, j); PB[i][j] = a; }
+        }
+        double Quu[NU][NU], Qux[NU][NS], Qxx[NS][NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) {
+            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = R[i][j] + (i == j ? Su[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PB[l][j], l, i); Quu[i][j] = a; }
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Mx[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PA[l][j], l, i); Qux[i][j] = a; }
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Q[i][j] + (i == j ? Sxk[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, PA[l][j], l, i); Qxx[i][j] = a; }
+        }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Quu[i][j] + Quu[j][i]); Quu[i][j] = a; Quu[j][i] = a; } }
+        const bool ok = sym_inverse<NU>(Quu);
+        double Kl[NU][NS], Pk[NS][NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Quu[i][l] * Qux[l][j]; Kl[i][j] = a; } }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Qxx[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += Qux[l][i] * Kl[l][j]; Pk[i][j] = a; } }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Pk[i][j] + Pk[j][i]); Pk[i][j] = a; Pk[j][i] = a; } }
+        if (k == kk) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = Kl[i][j]; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = Quu[i][j]; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.Pnx[i][j] = Pn[i][j]; }
+            if (!ok) bad = true;
+        }
+        bcast_sym<SEG, NS>(Pk, kk, lane, Pn);
+    }
+    if (FREE0) {      // the initial state: value function of stage 0 + arrival cost + its own diagonal term
+        double P0[NS][NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) P0[i][j] = Pn[i][j] + P0add[i][j]; }
+        if (!sym_inverse<NS>(P0)) bad = true;
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.P0i[i][j] = P0[i][j]; }
+    }
+    return !bad;
+}
+
+// VECTOR pass + forward pass: the Newton step (du, dxn, dx0) and the new costates pin for the gradient terms gu (inputs), gxk (x_k: this stage's cost
+// gradient + the diagonal-term gradient of x_k from the neighbour), pt (lane N-1: x_N), p0add (x_0, FREE0) and the constraint right-hand side c.
+template <int NS, int NU, bool FREE0, int SEG, class ST>
+__device__ __forceinline__ void ric_solve(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const RicFac<NS, NU> &Fc, const double (&gu)[NU], const double (&gxk)[NS],
+                                          const double (&pt)[NS], const double (&p0add)[NS], const double (&c)[NS], double (&du)[NU], double (&dxn)[NS], double (&dx0)[NS], double (&pin)[NS])
+{
+    double pn[NS], kff[NU], pnx[NS];
+    MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = 0.0;      // (lanes beyond the horizon never receive theirs: zero, not indeterminate)
+    MPC_UNROLL for (int i = 0; i < NS; i++) pnx[i] = 0.0;
+    bcast_vec<SEG, NS>(pt, N - 1, lane, pn);
+    for (int kk = N - 1; kk >= 0; kk--) {
+        double pc[NS], qu[NU], kl[NU], pk[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pn[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a -= Fc.Pnx[i][l] * c[l]; pc[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, pc[l], l, i); qu[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Fc.Qi[i][l] * qu[l]; kl[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            double a = gxk[i];
+            MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, pc[l], l, i);
+            MPC_UNROLL for (int l = 0; l < NU; l++) a += Fc.K[l][i] * qu[l];      // Qux' kl = K' qu
+            pk[i] = a;
+        }
+        if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = kl[i]; MPC_UNROLL for (int i = 0; i < NS; i++) pnx[i] = pn[i]; }
+        bcast_vec<SEG, NS>(pk, kk, lane, pn);
+    }
+    double dx[NS];
+    if (FREE0) {
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a -= Fc.P0i[i][j] * (pn[j] + p0add[j]); dx0[i] = a; }
+    } else { MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = 0.0; }
+    MPC_UNROLL for (int i = 0; i < NS; i++) { dx[i] = dx0[i]; dxn[i] = 0.0; }
+    MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = 0.0;
+    for (int kk = 0; kk < N; kk++) {
+        double dul[NU], dxl[NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.K[i][j] * dx[j]; dul[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            double a = -c[i];
+            MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, dx[j], i, j);
+            MPC_UNROLL for (int j = 0; j < NU; j++) EC_B(a, dul[j], i, j);
+            dxl[i] = a;
+        }
+        if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dul[i]; MPC_UNROLL for (int i = 0; i < NS; i++) dxn[i] = dxl[i]; }
+        bcast_vec<SEG, NS>(dxl, kk, lane, dx);
+    }
+    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pnx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.Pnx[i][j] * dxn[j]; pin[i] = a; }
+}
+
+template <int NS, int NU, bool FREE0, int SEG, class ST, class AUX, class LinF, class AddPiF, class ValF, class TermF>
 __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
-                                         double (&pi)[NS], const double (&ulo)[NU], const double (&uhi)[NU], const double (&xlo)[NS],
-                                         const double (&xhi)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
-                                         const int max_iter, LinF lin, TermF term, int &iters)
+                                         double (&pi)[NS], const double (&ulo_in)[NU], const double (&uhi_in)[NU], const double (&xlo_in)[NS],
+                                         const double (&xhi_in)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
+                                         const int max_iter, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt)
 {
     using SG = Seg<SEG>;
     const int k = SG::stage(lane);
     const bool on = k < N;
     bool flu[NU], fhu[NU], flx[NS], fhx[NS];
     double zlu[NU], zhu[NU], zlx[NS], zhx[NS], zl0[NS], zh0[NS];
-    int nbl = 0;      // finite bounds per stage
-    MPC_UNROLL for (int i = 0; i < NU; i++) { flu[i] = fin(ulo[i]); fhu[i] = fin(uhi[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); u[i] = push_in(u[i], ulo[i], uhi[i]); }
-    int nbx = 0;
-    MPC_UNROLL for (int i = 0; i < NS; i++) { flx[i] = fin(xlo[i]); fhx[i] = fin(xhi[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); xn[i] = push_in(xn[i], xlo[i], xhi[i]); pi[i] = 0.0; }
-    MPC_UNROLL for (int i = 0; i < NS; i++) { zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0; if (FREE0) x0v[i] = push_in(x0v[i], xlo[i], xhi[i]); }
+    double blu[NU], bhu[NU], blx[NS], bhx[NS], bl0[NS], bh0[NS];      // this solve's own bounds
+    int nbl = 0, nbx = 0;
+    MPC_UNROLL for (int i = 0; i < NU; i++) { blu[i] = ulo_in[i]; bhu[i] = uhi_in[i]; flu[i] = fin(blu[i]); fhu[i] = fin(bhu[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); }
+    MPC_UNROLL for (int i = 0; i < NS; i++) {
+        blx[i] = xlo_in[i]; bhx[i] = xhi_in[i]; bl0[i] = xlo_in[i]; bh0[i] = xhi_in[i];
+        flx[i] = fin(blx[i]); fhx[i] = fin(bhx[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
+        zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0;
+    }
     const double nb = (double)(N * (nbl + nbx) + (FREE0 ? nbx : 0)), meq = (double)(N * NS);
-    // everything below that looks wave-uniform is uniform per SEGMENT (= per instance): mu, the shifts, status, the iteration count.  A
-    // segment that has finished (done) keeps computing with its frozen iterate while its wave neighbours go on; `live` = false marks a
-    // segment without an instance (ragged batch)
-    double mu = kMuInit, delta_last = 0.0;
-    int status = kStMaxIter;
-    bool done = !live;
+    // damping of the variables with one bound [WB 3.7]: +1 (only a lower bound), -1 (only an upper bound), 0
+    auto damp = [&](bool fl_, bool fh_) { return (fl_ && !fh_) ? 1.0 : ((fh_ && !fl_) ? -1.0 : 0.0); };
+    // everything below that looks wave-uniform is uniform per SEGMENT (= per instance): mu, the shifts, the line search's state, status, the iteration
+    // count.  A segment that has finished (done) keeps computing with its frozen iterate while its wave neighbours go on; `live` = false marks a
+    // segment without an instance (ragged batch).  Cross-lane operations (shifts, broadcasts, reductions) are never under a per-segment branch.
+    double mu = kMuInit, tau = dmax(kTauMin, 1.0 - kMuInit), delta_last = 0.0, df = 1.0, theta_max = -1.0, theta_min = -1.0;
+    const double mu_min = dmin(tol, kComplInfTol) / (kKappaEps + 1.0);
+    int status = kStMaxIter, nfilt = 0, acc_count = 0;
+    bool done = !live, tiny_last = false, tiny_flag = false;
     iters = 0;
-    for (int it = 0;; it++) {
-        if (!done) iters = it;
+    enum { PH_RAW = 0, PH_LSQ = 1, PH_MAIN = 2 };
+    int phase = PH_RAW;      // (wave-uniform: every segment goes through the two preparing phases together)
+    int it = 0;
+    for (;;) {
+        if (!done && phase == PH_MAIN) iters = it;
         // ---- linearise this lane's stage at (x_k, u_k); x_k is the neighbour's x_{k+1} ------------------------------------------------
         double xk[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
         StageLin<NS, NU> L;
-        lin(xk, u, pi, L);
-        double gv[NS], Hv[NS][NS];
-        term(xn, gv, Hv);
-        double c[NS], gxA[NS], gnext[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) {
-            c[i] = xn[i] - L.F[i];
-            double a = L.lx[i];
-            MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, pi[j], j, i);
-            gxA[i] = a;
+        AUX aux;
+        lin(xk, u, L, aux);
+        double fv, gv[NS], Hv[NS][NS];
+        term(xn, fv, gv, Hv);
+        // gradient of the objective with respect to this lane's x_{k+1}: the next stage's cost gradient, the terminal cost's at the end
+        double gfx[NS], gf0[NS], e0[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, L.lx[i], k); gfx[i] = k == N - 1 ? gv[i] : sh; }
+        double farr = 0.0;
+        if (FREE0) {
+            MPC_UNROLL for (int i = 0; i < NS; i++) e0[i] = x0v[i] - xbar[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                double a = 0.0;
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * e0[j];
+                farr += 0.5 * e0[i] * a;
+                gf0[i] = SG::bcast(L.lx[i], 0, lane) + a;
+            }
+        } else { MPC_UNROLL for (int i = 0; i < NS; i++) { gf0[i] = 0.0; e0[i] = 0.0; } }
+        if (phase == PH_RAW) {
+            // ---- scaling of the objective at the caller's point (IpGradientScaling), then the push into the box ----------------------------
+            double gm = 0.0;
+            MPC_UNROLL for (int i = 0; i < NU; i++) gm = dmax(gm, fabs(L.lu[i]));
+            MPC_UNROLL for (int i = 0; i < NS; i++) gm = dmax(gm, fabs(gfx[i]));
+            gm = SG::max(on ? gm : 0.0);
+            if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) gm = dmax(gm, fabs(gf0[i])); }
+            df = gm > kScaleMaxGrad ? dmax(kScaleMaxGrad / gm, kScaleMin) : 1.0;
+            bool moved = false;
+            MPC_UNROLL for (int i = 0; i < NU; i++) { const double v = push_in(u[i], blu[i], bhu[i]); moved = moved || (on && v != u[i]); u[i] = v; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = push_in(xn[i], blx[i], bhx[i]); moved = moved || (on && v != xn[i]); xn[i] = v; }
+            if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = push_in(x0v[i], bl0[i], bh0[i]); moved = moved || (v != x0v[i]); x0v[i] = v; } }
+            phase = PH_LSQ;
+            if (__any(moved ? 1 : 0)) continue;      // linearise again, at the pushed point
         }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, gxA[i], k); gnext[i] = k == N - 1 ? gv[i] : sh; }
+        // the scaled problem: df f
+        L.l *= df; fv *= df; farr *= df;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] *= df; MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] *= df; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { L.lx[i] *= df; gfx[i] *= df; gv[i] *= df; gf0[i] *= df; MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] *= df; Hv[i][j] *= df; } MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] *= df; }
+        double c[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) c[i] = xn[i] - L.F[i];
+        RicFac<NS, NU> Fc;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = 0.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Fc.Pnx[i][j] = 0.0; Fc.P0i[i][j] = 0.0; } }
+        if (phase == PH_LSQ) {
+            // ---- least-squares equality multipliers [WB (36)]: the Newton system with the identity for the Hessian, no constraint residual ------------
+            double Iq[NS][NS], Im[NS][NU], Ir[NU][NU], zu_[NU], zx_[NS], gu[NU], gxk[NS], pt[NS], p0a[NS], c0[NS], P0a[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Iq[i][j] = i == j ? 1.0 : 0.0; P0a[i][j] = i == j ? 1.0 : 0.0; } MPC_UNROLL for (int j = 0; j < NU; j++) Im[i][j] = 0.0; zx_[i] = 0.0; c0[i] = 0.0; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Ir[i][j] = i == j ? 1.0 : 0.0; zu_[i] = 0.0; gu[i] = L.lu[i] - zlu[i] + zhu[i]; }
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                const double bz = -zlx[i] + zhx[i];
+                gxk[i] = L.lx[i] + SG::up1(0.0, bz, k); pt[i] = gv[i] + bz;
+                p0a[i] = FREE0 ? (gf0[i] - SG::bcast(L.lx[i], 0, lane) - zl0[i] + zh0[i]) : 0.0;
+            }
+            ric_matrix<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Iq, Im, Ir, zu_, zx_, Iq, P0a, Fc);
+            double du_[NU], dxn_[NS], dx0_[NS], pin_[NS];
+            ric_solve<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Fc, gu, gxk, pt, p0a, c0, du_, dxn_, dx0_, pin_);
+            double ym = 0.0;
+            MPC_UNROLL for (int i = 0; i < NS; i++) ym = dmax(ym, finite_all(pin_[i]) ? fabs(pin_[i]) : INFINITY);
+            ym = SG::max(on ? ym : 0.0);
+            MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = ym <= kYInitMax ? pin_[i] : 0.0;
+            phase = PH_MAIN;
+        }
+        {   // Hessian of the Lagrangian of the scaled problem: df (cost) + pi' F
+            addpi(aux, pi, L);
+        }
+        // ---- slacks (safe: a slack that rounding took below eps min(1, mu) is lifted, its bound moves) ------------------------------------------
         double slu[NU], shu[NU], slx[NS], shx[NS], sl0[NS], sh0[NS];
-        MPC_UNROLL for (int i = 0; i < NU; i++) { slu[i] = flu[i] ? u[i] - ulo[i] : 1.0; shu[i] = fhu[i] ? uhi[i] - u[i] : 1.0; }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { slx[i] = flx[i] ? xn[i] - xlo[i] : 1.0; shx[i] = fhx[i] ? xhi[i] - xn[i] : 1.0; sl0[i] = (FREE0 && flx[i]) ? x0v[i] - xlo[i] : 1.0; sh0[i] = (FREE0 && fhx[i]) ? xhi[i] - x0v[i] : 1.0; }
-        // ---- optimality error (IPOPT's E_mu with its scaling) ----------------------------------------------------------------------------
-        double e_st = 0.0, e_c = 0.0, s_pi = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY;
-        bool finite = true;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { slu[i] = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0; shu[i] = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            slx[i] = flx[i] ? safe_slack(xn[i], blx[i], zlx[i], mu, true) : 1.0; shx[i] = fhx[i] ? safe_slack(xn[i], bhx[i], zhx[i], mu, false) : 1.0;
+            sl0[i] = (FREE0 && flx[i]) ? safe_slack(x0v[i], bl0[i], zl0[i], mu, true) : 1.0; sh0[i] = (FREE0 && fhx[i]) ? safe_slack(x0v[i], bh0[i], zh0[i], mu, false) : 1.0;
+        }
+        // ---- optimality error (IPOPT's E_mu with its scaling), objective, infeasibility -----------------------------------------------------------
+        double gxA[NS], gnext[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = L.lx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, pi[j], j, i); gxA[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, gxA[i], k); gnext[i] = k == N - 1 ? gv[i] : sh; }
+        double e_st = 0.0, e_c = 0.0, s_pi = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY, th_l = 0.0;
+        bool finite = finite_all(L.l);
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             double r = L.lu[i] - zlu[i] + zhu[i];
             MPC_UNROLL for (int j = 0; j < NS; j++) EC_B(r, pi[j], j, i);
@@ -181,121 +378,96 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             const double r = -pi[i] + gnext[i] - zlx[i] + zhx[i];
-            e_st = dmax(e_st, fabs(r)); e_c = dmax(e_c, fabs(c[i])); s_pi += fabs(pi[i]); s_z += zlx[i] + zhx[i];
+            e_st = dmax(e_st, fabs(r)); e_c = dmax(e_c, fabs(c[i])); th_l += fabs(c[i]); s_pi += fabs(pi[i]); s_z += zlx[i] + zhx[i];
             finite = finite && finite_all(r) && finite_all(c[i]) && finite_all(xn[i]);
             if (flx[i]) { cmax = dmax(cmax, slx[i] * zlx[i]); cmin = dmin(cmin, slx[i] * zlx[i]); }
             if (fhx[i]) { cmax = dmax(cmax, shx[i] * zhx[i]); cmin = dmin(cmin, shx[i] * zhx[i]); }
         }
         e_st = SG::max(on ? e_st : 0.0); e_c = SG::max(on ? e_c : 0.0); s_pi = SG::sum(on ? s_pi : 0.0); s_z = SG::sum(on ? s_z : 0.0);
         cmax = SG::max(on ? cmax : -INFINITY); cmin = SG::min(on ? cmin : INFINITY);
-        double g0[NS], ga0[NS];      // gradient with respect to the free initial state: stage 0's part + arrival cost
+        const double theta = SG::sum(on ? th_l : 0.0);
+        double fobj = SG::sum(on ? L.l + (k == N - 1 ? fv : 0.0) : 0.0) + farr;
+        double ga0[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) ga0[i] = 0.0;
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                const double ga = SG::bcast(gxA[i], 0, lane);
-                double a = ga;
-                MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0v[j] - xbar[j]);
-                g0[i] = a; ga0[i] = ga;
-                const double r0 = a - zl0[i] + zh0[i];
+                ga0[i] = SG::bcast(gxA[i], 0, lane);      // stage 0's part of the gradient with respect to the free initial state
+                const double r0 = ga0[i] + (gf0[i] - SG::bcast(L.lx[i], 0, lane)) - zl0[i] + zh0[i];
                 e_st = dmax(e_st, fabs(r0)); s_z += zl0[i] + zh0[i];
-                finite = finite && finite_all(r0) && finite_all(x0v[i]);      // (the residual, as for the other variables: an infinite multiplier must end the solve as failed)
+                finite = finite && finite_all(r0) && finite_all(x0v[i]);
                 if (flx[i]) { cmax = dmax(cmax, sl0[i] * zl0[i]); cmin = dmin(cmin, sl0[i] * zl0[i]); }
                 if (fhx[i]) { cmax = dmax(cmax, sh0[i] * zh0[i]); cmin = dmin(cmin, sh0[i] * zh0[i]); }
             }
         }
         const bool nonfinite = SG::any(on && !finite, lane);
         const double s_d = dmax(kSMax, (s_pi + s_z) / dmax(meq + nb, 1.0)) / kSMax, s_c = dmax(kSMax, s_z / dmax(nb, 1.0)) / kSMax;
-        auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), nb > 0.0 ? dmax(cmax - m_, m_ - cmin) / s_c : 0.0); };
+        auto compl_ = [&](double m_) { return nb > 0.0 ? dmax(cmax - m_, m_ - cmin) : 0.0; };
+        auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
         if (!done) {
+            const double e0_ = err(0.0), c0_ = compl_(0.0);
             if (nonfinite) { status = kStFailed; done = true; }
-            else if (err(0.0) <= tol) { status = kStSolved; done = true; }
-            else if (it >= max_iter) done = true;
+            else if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = kStSolved; done = true; }
+            else {
+                if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = kStSolved; done = true; } }
+                else acc_count = 0;
+                if (!done && it >= max_iter) done = true;
+            }
         }
         if (__all(done ? 1 : 0)) break;
-        for (;;) {      // (per segment) while (mu > tol / 10 && E_mu <= kappa_eps mu) mu = ...
-            const bool dec = !done && mu > tol / 10.0 && err(mu) <= kKappaEps * mu;
-            if (!__any(dec ? 1 : 0)) break;
-            if (dec) mu = dmax(tol / 10.0, dmin(kKappaMu * mu, mu * sqrt(mu)));
+        // ---- barrier parameter (per segment): while (E_mu <= kappa_eps mu or two tiny steps in a row) mu decreases; the filter is emptied with it ---------
+        {
+            bool mu_changed = false, stop_tiny = false, going = !done;
+            for (;;) {
+                const bool dec = going && (err(mu) <= kKappaEps * mu || tiny_flag);
+                if (!__any(dec ? 1 : 0)) break;
+                if (dec) {
+                    const double new_mu = dmax(dmin(kKappaMu * mu, mu * sqrt(mu)), mu_min);
+                    if (new_mu == mu) { stop_tiny = tiny_flag; going = false; }
+                    else { mu = new_mu; mu_changed = true; tiny_flag = false; }
+                }
+            }
+            if (!done && stop_tiny) { status = kStMaxIter; done = true; }      // 'Search_Direction_Becomes_Too_Small': the reference accepts the point
+            tiny_flag = false;
+            if (mu_changed) { nfilt = 0; tau = dmax(kTauMin, 1.0 - mu); }
         }
-        const double tau = dmax(kTauMin, 1.0 - mu);
         // ---- barrier terms; those of x_k come from the neighbour that holds x_k --------------------------------------------------------
         double Su[NU], bu[NU], Sx[NS], bx[NS], Sxk[NS], bxk[NS], S0[NS], b0[NS];
+        double phl = 0.0;      // this lane's part of the barrier function
         MPC_UNROLL for (int i = 0; i < NU; i++) {
-            const double il = flu[i] ? 1.0 / slu[i] : 0.0, ih = fhu[i] ? 1.0 / shu[i] : 0.0;
-            Su[i] = zlu[i] * il + zhu[i] * ih; bu[i] = -mu * il + mu * ih;
+            const double il = flu[i] ? 1.0 / slu[i] : 0.0, ih = fhu[i] ? 1.0 / shu[i] : 0.0, dm = damp(flu[i], fhu[i]);
+            Su[i] = zlu[i] * il + zhu[i] * ih; bu[i] = -mu * il + mu * ih + kKappaD * mu * dm;
+            if (flu[i]) phl -= mu * log(slu[i]);
+            if (fhu[i]) phl -= mu * log(shu[i]);
+            if (dm != 0.0) phl += kKappaD * mu * (dm > 0.0 ? slu[i] : shu[i]);
         }
+        double ph0 = 0.0;
         MPC_UNROLL for (int i = 0; i < NS; i++) {
-            const double il = flx[i] ? 1.0 / slx[i] : 0.0, ih = fhx[i] ? 1.0 / shx[i] : 0.0;
-            Sx[i] = zlx[i] * il + zhx[i] * ih; bx[i] = -mu * il + mu * ih;
+            const double il = flx[i] ? 1.0 / slx[i] : 0.0, ih = fhx[i] ? 1.0 / shx[i] : 0.0, dm = damp(flx[i], fhx[i]);
+            Sx[i] = zlx[i] * il + zhx[i] * ih; bx[i] = -mu * il + mu * ih + kKappaD * mu * dm;
+            if (flx[i]) phl -= mu * log(slx[i]);
+            if (fhx[i]) phl -= mu * log(shx[i]);
+            if (dm != 0.0) phl += kKappaD * mu * (dm > 0.0 ? slx[i] : shx[i]);
             Sxk[i] = SG::up1(0.0, Sx[i], k); bxk[i] = SG::up1(0.0, bx[i], k);
             const double jl = (FREE0 && flx[i]) ? 1.0 / sl0[i] : 0.0, jh = (FREE0 && fhx[i]) ? 1.0 / sh0[i] : 0.0;
-            S0[i] = zl0[i] * jl + zh0[i] * jh; b0[i] = -mu * jl + mu * jh;
+            S0[i] = zl0[i] * jl + zh0[i] * jh; b0[i] = FREE0 ? (-mu * jl + mu * jh + kKappaD * mu * dm) : 0.0;
+            if (FREE0) {
+                if (flx[i]) ph0 -= mu * log(sl0[i]);
+                if (fhx[i]) ph0 -= mu * log(sh0[i]);
+                if (dm != 0.0) ph0 += kKappaD * mu * (dm > 0.0 ? sl0[i] : sh0[i]);
+            }
         }
-        // ---- Riccati factorisation over the lanes, repeated with a larger shift while a stage lacks positive curvature ----------------
-        double K[NU][NS], kff[NU], Pnx[NS][NS], pnx[NS], dx0[NS];
-        // (lanes beyond the horizon never receive theirs: zero, not indeterminate - an indeterminate value lets the optimiser pick what suits it,
-        // and with B = I known at compile time it picked something that broke the lanes inside the horizon, SEG = 64, round 3)
-        MPC_UNROLL for (int i = 0; i < NU; i++) { kff[i] = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) K[i][j] = 0.0; }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { pnx[i] = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) Pnx[i][j] = 0.0; }
+        const double phi = fobj + SG::sum(on ? phl : 0.0) + ph0;
+        // ---- matrix pass, repeated with a larger shift while a stage lacks positive curvature ---------------------------------------------------
         double delta = 0.0;
         bool failed = false;
         for (;;) {
-            double Pt[NS][NS], pt[NS], Pn[NS][NS], pn[NS];
-            MPC_UNROLL for (int i = 0; i < NS; i++) { pt[i] = gv[i] + bx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) Pt[i][j] = Hv[i][j] + (i == j ? Sx[i] + delta : 0.0); }
-            bcast_sym<SEG, NS>(Pt, N - 1, lane, Pn); bcast_vec<SEG, NS>(pt, N - 1, lane, pn);
-            bool bad = false;
-            for (int kk = N - 1; kk >= 0; kk--) {
-                double PA[NS][NS], PB[NS][NU], pc[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, Pn[i][l], l, j); PA[i][j] = a; }
-                    MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, Pn[i][l], l, j); PB[i][j] = a; }
-                    double a = pn[i];
-                    MPC_UNROLL for (int l = 0; l < NS; l++) a -= Pn[i][l] * c[l];
-                    pc[i] = a;
-                }
-                double Quu[NU][NU], Qux[NU][NS], Qxx[NS][NS], qu[NU], qx[NS];
-                MPC_UNROLL for (int i = 0; i < NU; i++) {
-                    MPC_UNROLL for (int j = 0; j < NU; j++) { double a = L.R[i][j] + (i == j ? Su[i] + delta : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PB[l][j], l, i); Quu[i][j] = a; }
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = L.M[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PA[l][j], l, i); Qux[i][j] = a; }
-                    double a = L.lu[i] + bu[i];
-                    MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, pc[l], l, i);
-                    qu[i] = a;
-                }
-                MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = L.Q[i][j] + (i == j ? Sxk[i] + delta : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, PA[l][j], l, i); Qxx[i][j] = a; }
-                    double a = L.lx[i] + bxk[i];
-                    MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, pc[l], l, i);
-                    qx[i] = a;
-                }
-                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Quu[i][j] + Quu[j][i]); Quu[i][j] = a; Quu[j][i] = a; } }
-                const bool ok = sym_inverse<NU>(Quu);
-                double Kl[NU][NS], kl[NU], Pk[NS][NS], pk[NS];
-                MPC_UNROLL for (int i = 0; i < NU; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Quu[i][l] * Qux[l][j]; Kl[i][j] = a; }
-                    double a = 0.0;
-                    MPC_UNROLL for (int l = 0; l < NU; l++) a -= Quu[i][l] * qu[l];
-                    kl[i] = a;
-                }
-                MPC_UNROLL for (int i = 0; i < NS; i++) {
-                    MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Qxx[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += Qux[l][i] * Kl[l][j]; Pk[i][j] = a; }
-                    double a = qx[i];
-                    MPC_UNROLL for (int l = 0; l < NU; l++) a += Qux[l][i] * kl[l];
-                    pk[i] = a;
-                }
-                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Pk[i][j] + Pk[j][i]); Pk[i][j] = a; Pk[j][i] = a; } }
-                if (k == kk) {
-                    MPC_UNROLL for (int i = 0; i < NU; i++) { kff[i] = kl[i]; MPC_UNROLL for (int j = 0; j < NS; j++) K[i][j] = Kl[i][j]; }
-                    MPC_UNROLL for (int i = 0; i < NS; i++) { pnx[i] = pn[i]; MPC_UNROLL for (int j = 0; j < NS; j++) Pnx[i][j] = Pn[i][j]; }
-                    if (!ok) bad = true;
-                }
-                bcast_sym<SEG, NS>(Pk, kk, lane, Pn); bcast_vec<SEG, NS>(pk, kk, lane, pn);
-            }
-            if (FREE0) {      // the initial state: value function of stage 0 + arrival cost + its own barrier
-                double P0[NS][NS], p0[NS];
-                MPC_UNROLL for (int i = 0; i < NS; i++) { p0[i] = pn[i] + (g0[i] - ga0[i]) + b0[i]; MPC_UNROLL for (int j = 0; j < NS; j++) P0[i][j] = Pn[i][j] + 0.5 * (Pinv[i][j] + Pinv[j][i]) + (i == j ? S0[i] : 0.0); }
-                if (!sym_inverse<NS>(P0)) bad = true;
-                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a -= P0[i][j] * p0[j]; dx0[i] = a; }
-            } else { MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = 0.0; }
-            const bool retry = SG::any(bad, lane) && !done && !failed;      // this segment lacks curvature: a larger shift, all over again
+            double Qd[NS][NS], Rd[NU][NU], Pt[NS][NS], P0a[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) {
+                Qd[i][j] = L.Q[i][j] + (i == j ? delta : 0.0); Pt[i][j] = Hv[i][j] + (i == j ? Sx[i] + delta : 0.0);
+                P0a[i][j] = FREE0 ? (df * 0.5 * (Pinv[i][j] + Pinv[j][i]) + (i == j ? S0[i] : 0.0)) : 0.0; } }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Rd[i][j] = L.R[i][j] + (i == j ? delta : 0.0); }
+            const bool okm = ric_matrix<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Qd, L.M, Rd, Su, Sxk, Pt, P0a, Fc);
+            const bool retry = SG::any(!okm, lane) && !done && !failed;      // this segment lacks curvature: a larger shift, all over again
             if (retry) {
                 delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
                 if (delta > kDeltaMax) failed = true;
@@ -304,70 +476,221 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         if (!done && failed) { status = kStFailed; done = true; }
         if (!done && delta > 0.0) delta_last = delta;
-        // ---- Newton direction: forward over the lanes ---------------------------------------------------------------------------------
-        double du[NU], dxn[NS], dx[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { dx[i] = dx0[i]; dxn[i] = 0.0; }
-        MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = 0.0;
-        for (int kk = 0; kk < N; kk++) {
-            double dul[NU], dxl[NS];
-            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += K[i][j] * dx[j]; dul[i] = a; }
-            MPC_UNROLL for (int i = 0; i < NS; i++) {
-                double a = -c[i];
-                MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, dx[j], i, j);
-                MPC_UNROLL for (int j = 0; j < NU; j++) EC_B(a, dul[j], i, j);
-                dxl[i] = a;
-            }
-            if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dul[i]; MPC_UNROLL for (int i = 0; i < NS; i++) dxn[i] = dxl[i]; }
-            bcast_vec<SEG, NS>(dxl, kk, lane, dx);
-        }
-        double pin[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pnx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Pnx[i][j] * dxn[j]; pin[i] = a; }
-        // ---- multiplier steps, fraction to the boundary ------------------------------------------------------------------------------------
-        double dzlu[NU], dzhu[NU], dzlx[NS], dzhx[NS], dzl0[NS], dzh0[NS];
-        double apr = 1.0, adu = 1.0;
+        // ---- Newton direction ------------------------------------------------------------------------------------------------------------------
+        double gu[NU], gxk[NS], pt[NS], p0a[NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) gu[i] = L.lu[i] + bu[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { gxk[i] = L.lx[i] + bxk[i]; pt[i] = gv[i] + bx[i]; p0a[i] = FREE0 ? (gf0[i] - SG::bcast(L.lx[i], 0, lane)) + b0[i] : 0.0; }
+        double du[NU], dxn[NS], dx0[NS], pin[NS];
+        ric_solve<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Fc, gu, gxk, pt, p0a, c, du, dxn, dx0, pin);
+        // fraction to the boundary of a step (du_, dxn_, dx0_)
         auto ratio = [&](double a, double v, double dv) { return dv < 0.0 ? dmin(a, -tau * v / dv) : a; };
+        auto max_step = [&](const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
+            double a = 1.0;
+            MPC_UNROLL for (int i = 0; i < NU; i++) { if (flu[i]) a = ratio(a, slu[i], du_[i]); if (fhu[i]) a = ratio(a, shu[i], -du_[i]); }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { if (flx[i]) a = ratio(a, slx[i], dxn_[i]); if (fhx[i]) a = ratio(a, shx[i], -dxn_[i]); }
+            a = SG::min(on ? a : 1.0);
+            if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { if (flx[i]) a = ratio(a, sl0[i], dx0_[i]); if (fhx[i]) a = ratio(a, sh0[i], -dx0_[i]); } }
+            return a;
+        };
+        const double a_max = max_step(du, dxn, dx0);
+        // directional derivative of the barrier function, size of the step, size of the multiplier step
+        double gbd_l = 0.0, drel = 0.0, dym = 0.0;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { gbd_l += gu[i] * du[i]; drel = dmax(drel, fabs(du[i]) / (1.0 + fabs(u[i]))); }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { gbd_l += (gfx[i] + bx[i]) * dxn[i]; drel = dmax(drel, fabs(dxn[i]) / (1.0 + fabs(xn[i]))); dym = dmax(dym, fabs(pin[i] - pi[i])); }
+        double gbd = SG::sum(on ? gbd_l : 0.0);
+        drel = SG::max(on ? drel : 0.0); dym = SG::max(on ? dym : 0.0);
+        if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { gbd += (gf0[i] + b0[i]) * dx0[i]; drel = dmax(drel, fabs(dx0[i]) / (1.0 + fabs(x0v[i]))); } }
+        // ---- filter line search (per segment, the wave in lockstep) -------------------------------------------------------------------------------
+        double a_min = kGammaTheta;
+        if (gbd < 0.0) {
+            a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
+            if (theta <= theta_min) a_min = dmin(a_min, pow(theta, kSTheta) / pow(-gbd, kSPhi));
+        }
+        a_min *= kAlphaMinFrac;
+        if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
+        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
+        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
+        bool tiny = drel < kTinyStepTol && theta <= 1e-4;
+        enum { LS_TRY = 0, LS_SOC = 1, LS_DONE = 2 };
+        int ls = done ? LS_DONE : LS_TRY, n_steps = 0, soc_cnt = 0;
+        bool accepted = false, soc_taken = false, need_solve = false;
+        double alpha = a_max, a_soc = a_max, theta_old = 0.0, phi_acc = 0.0;
+        double csoc[NS], dsu[NU], dsx[NS], ds0[NS], pins[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { csoc[i] = c[i]; dsx[i] = dxn[i]; ds0[i] = dx0[i]; pins[i] = pin[i]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) dsu[i] = du[i];
+        double ut[NU], xt[NS], x0t[NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i]; x0t[i] = x0v[i]; }
+        for (;;) {
+            const bool busy = ls != LS_DONE;
+            if (!__any(busy ? 1 : 0)) break;
+            if (__any((busy && need_solve) ? 1 : 0)) {      // a second-order correction: the vector passes again, for the corrected constraint residual
+                double du_[NU], dxn_[NS], dx0_[NS], pin_[NS];
+                ric_solve<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Fc, gu, gxk, pt, p0a, csoc, du_, dxn_, dx0_, pin_);
+                const double as_ = max_step(du_, dxn_, dx0_);
+                if (busy && need_solve) {
+                    MPC_UNROLL for (int i = 0; i < NU; i++) dsu[i] = du_[i];
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { dsx[i] = dxn_[i]; ds0[i] = dx0_[i]; pins[i] = pin_[i]; }
+                    a_soc = as_;
+                }
+                need_solve = false;
+            }
+            // the trial point of this round
+            const bool soc_now = ls == LS_SOC;
+            const double a_t = soc_now ? a_soc : alpha;
+            if (busy) {
+                MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i] + a_t * (soc_now ? dsu[i] : du[i]);
+                MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i] + a_t * (soc_now ? dsx[i] : dxn[i]); if (FREE0) x0t[i] = x0v[i] + a_t * (soc_now ? ds0[i] : dx0[i]); }
+            }
+            double xkt[NS], Ft[NS], lt, fvt, gvt[NS], Hvt[NS][NS], ct[NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) xkt[i] = SG::up1(FREE0 ? x0t[i] : x0fix[i], xt[i], k);
+            val(xkt, ut, Ft, lt);
+            term(xt, fvt, gvt, Hvt);
+            double tht = 0.0, pht = 0.0;
+            bool okl = finite_all(lt);
+            MPC_UNROLL for (int i = 0; i < NS; i++) { ct[i] = xt[i] - Ft[i]; tht += fabs(ct[i]); okl = okl && finite_all(ct[i]); }
+            MPC_UNROLL for (int i = 0; i < NU; i++) {
+                double bl_ = blu[i], bh_ = bhu[i];
+                const double dm = damp(flu[i], fhu[i]);
+                const double s1 = flu[i] ? safe_slack(ut[i], bl_, zlu[i], mu, true) : 1.0, s2 = fhu[i] ? safe_slack(ut[i], bh_, zhu[i], mu, false) : 1.0;
+                if (flu[i]) pht -= mu * log(s1);
+                if (fhu[i]) pht -= mu * log(s2);
+                if (dm != 0.0) pht += kKappaD * mu * (dm > 0.0 ? s1 : s2);
+            }
+            double pht0 = 0.0, farrt = 0.0;
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                double bl_ = blx[i], bh_ = bhx[i];
+                const double dm = damp(flx[i], fhx[i]);
+                const double s1 = flx[i] ? safe_slack(xt[i], bl_, zlx[i], mu, true) : 1.0, s2 = fhx[i] ? safe_slack(xt[i], bh_, zhx[i], mu, false) : 1.0;
+                if (flx[i]) pht -= mu * log(s1);
+                if (fhx[i]) pht -= mu * log(s2);
+                if (dm != 0.0) pht += kKappaD * mu * (dm > 0.0 ? s1 : s2);
+                if (FREE0) {
+                    double cl_ = bl0[i], ch_ = bh0[i];
+                    const double t1 = flx[i] ? safe_slack(x0t[i], cl_, zl0[i], mu, true) : 1.0, t2 = fhx[i] ? safe_slack(x0t[i], ch_, zh0[i], mu, false) : 1.0;
+                    if (flx[i]) pht0 -= mu * log(t1);
+                    if (fhx[i]) pht0 -= mu * log(t2);
+                    if (dm != 0.0) pht0 += kKappaD * mu * (dm > 0.0 ? t1 : t2);
+                }
+            }
+            if (FREE0) {
+                MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0t[j] - xbar[j]); farrt += 0.5 * (x0t[i] - xbar[i]) * a; }
+            }
+            const bool ok_t = !SG::any(on && !okl, lane);
+            double theta_t = SG::sum(on ? tht : 0.0);
+            double phi_t = df * (SG::sum(on ? lt + (k == N - 1 ? fvt : 0.0) : 0.0) + farrt) + SG::sum(on ? pht : 0.0) + pht0;
+            if (!ok_t || !finite_all(phi_t)) { theta_t = INFINITY; phi_t = INFINITY; }
+            // acceptable to the current iterate and to the filter?  (the tests of a corrected step keep the original step length)
+            bool acc = false;
+            if (busy && ok_t && finite_all(phi_t) && !(theta_t > theta_max)) {
+                bool ok_;
+                if (alpha > 0.0 && ftype(alpha) && theta <= theta_min) ok_ = le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi);
+                else {
+                    bool too_steep = false;
+                    if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; too_steep = log10(phi_t - phi) > kObjMaxInc + bas; }
+                    ok_ = !too_steep && (le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi));
+                }
+                acc = ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
+            }
+            if (busy) {
+                const bool fin_ok = ok_t && finite_all(phi_t);
+                if (ls == LS_TRY) {
+                    if (tiny && n_steps == 0 && fin_ok) { accepted = true; ls = LS_DONE; phi_acc = phi_t; }      // a tiny step is taken unchecked
+                    else {
+                        if (tiny && n_steps == 0) tiny = false;
+                        if (acc) { accepted = true; ls = LS_DONE; phi_acc = phi_t; }
+                        else if (fin_ok && n_steps == 0 && theta <= theta_t) {      // second-order correction: the first trial step did not reduce the infeasibility
+                            a_soc = alpha; soc_cnt = 0; theta_old = theta_t;
+                            MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = a_soc * c[i] + ct[i];
+                            need_solve = true; ls = LS_SOC;
+                        } else { alpha *= 0.5; n_steps++; if (!(alpha > a_min)) ls = LS_DONE; }
+                    }
+                } else {      // LS_SOC
+                    if (acc) { accepted = true; soc_taken = true; ls = LS_DONE; phi_acc = phi_t; }
+                    else {
+                        soc_cnt++;
+                        if (fin_ok && soc_cnt < kMaxSoc && theta_t <= kKappaSoc * theta_old) {
+                            theta_old = theta_t;
+                            MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = a_soc * csoc[i] + ct[i];
+                            need_solve = true;
+                        } else { ls = LS_TRY; alpha *= 0.5; n_steps++; if (!(alpha > a_min)) ls = LS_DONE; }
+                    }
+                }
+            }
+        }
+        if (!done) {
+            if (!accepted) {      // IPOPT enters its restoration phase here (not restated): infeasible point -> failed; feasible to 1e-2 tol -> the point is kept
+                status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; done = true;
+            } else if (tiny) { tiny_flag = tiny_last; tiny_last = dym < kTinyStepYTol; }
+            else {
+                tiny_last = false;
+                // the filter grows unless the step was an Armijo step on the barrier function.  Every lane of the segment makes the same edit of the
+                // segment's list (same values to the same LDS words, in lockstep); entries the new one dominates are dropped
+                if (!ftype(alpha) || !le_tol(phi_acc - phi, kEtaPhi * alpha * gbd, phi)) {
+                    const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
+                    int k2 = 0;
+                    for (int e = 0; e < kFilterCap; e++) {
+                        if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } }
+                    }
+                    if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
+                    else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
+                    nfilt = k2;
+                }
+            }
+        }
+        // ---- the accepted point: multiplier steps of the direction that was taken, bounds moved with corrected slacks, multipliers within
+        // kappa_Sigma of mu / slack ----------------------------------------------------------------------------------------------------------------
+        double dzlu[NU], dzhu[NU], dzlx[NS], dzhx[NS], dzl0[NS], dzh0[NS];
+        double adu = 1.0;
         MPC_UNROLL for (int i = 0; i < NU; i++) {
-            dzlu[i] = flu[i] ? mu / slu[i] - zlu[i] - zlu[i] / slu[i] * du[i] : 0.0;
-            dzhu[i] = fhu[i] ? mu / shu[i] - zhu[i] + zhu[i] / shu[i] * du[i] : 0.0;
-            if (flu[i]) { apr = ratio(apr, slu[i], du[i]); adu = ratio(adu, zlu[i], dzlu[i]); }
-            if (fhu[i]) { apr = ratio(apr, shu[i], -du[i]); adu = ratio(adu, zhu[i], dzhu[i]); }
+            const double d_ = soc_taken ? dsu[i] : du[i];
+            dzlu[i] = flu[i] ? mu / slu[i] - zlu[i] - zlu[i] / slu[i] * d_ : 0.0;
+            dzhu[i] = fhu[i] ? mu / shu[i] - zhu[i] + zhu[i] / shu[i] * d_ : 0.0;
+            if (flu[i]) adu = ratio(adu, zlu[i], dzlu[i]);
+            if (fhu[i]) adu = ratio(adu, zhu[i], dzhu[i]);
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
-            dzlx[i] = flx[i] ? mu / slx[i] - zlx[i] - zlx[i] / slx[i] * dxn[i] : 0.0;
-            dzhx[i] = fhx[i] ? mu / shx[i] - zhx[i] + zhx[i] / shx[i] * dxn[i] : 0.0;
-            if (flx[i]) { apr = ratio(apr, slx[i], dxn[i]); adu = ratio(adu, zlx[i], dzlx[i]); }
-            if (fhx[i]) { apr = ratio(apr, shx[i], -dxn[i]); adu = ratio(adu, zhx[i], dzhx[i]); }
+            const double d_ = soc_taken ? dsx[i] : dxn[i];
+            dzlx[i] = flx[i] ? mu / slx[i] - zlx[i] - zlx[i] / slx[i] * d_ : 0.0;
+            dzhx[i] = fhx[i] ? mu / shx[i] - zhx[i] + zhx[i] / shx[i] * d_ : 0.0;
+            if (flx[i]) adu = ratio(adu, zlx[i], dzlx[i]);
+            if (fhx[i]) adu = ratio(adu, zhx[i], dzhx[i]);
         }
-        apr = SG::min(on ? apr : 1.0); adu = SG::min(on ? adu : 1.0);
+        adu = SG::min(on ? adu : 1.0);
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                dzl0[i] = flx[i] ? mu / sl0[i] - zl0[i] - zl0[i] / sl0[i] * dx0[i] : 0.0;
-                dzh0[i] = fhx[i] ? mu / sh0[i] - zh0[i] + zh0[i] / sh0[i] * dx0[i] : 0.0;
-                if (flx[i]) { apr = ratio(apr, sl0[i], dx0[i]); adu = ratio(adu, zl0[i], dzl0[i]); }
-                if (fhx[i]) { apr = ratio(apr, sh0[i], -dx0[i]); adu = ratio(adu, zh0[i], dzh0[i]); }
+                const double d_ = soc_taken ? ds0[i] : dx0[i];
+                dzl0[i] = flx[i] ? mu / sl0[i] - zl0[i] - zl0[i] / sl0[i] * d_ : 0.0;
+                dzh0[i] = fhx[i] ? mu / sh0[i] - zh0[i] + zh0[i] / sh0[i] * d_ : 0.0;
+                if (flx[i]) adu = ratio(adu, zl0[i], dzl0[i]);
+                if (fhx[i]) adu = ratio(adu, zh0[i], dzh0[i]);
             }
         }
-        // ---- step; multipliers kept within kappa_Sigma of mu / slack --------------------------------------------------------------------
-        auto clampz = [&](double z, double s) { return dmin(dmax(z, mu / (kKappaSigma * s)), kKappaSigma * mu / s); };
+        auto clampz = [&](double z, double s_) { return dmin(dmax(z, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_); };
         if (!done) {      // (a finished segment keeps its iterate)
-        MPC_UNROLL for (int i = 0; i < NU; i++) {
-            u[i] += apr * du[i];
-            zlu[i] += adu * dzlu[i]; zhu[i] += adu * dzhu[i];
-            if (flu[i]) zlu[i] = clampz(zlu[i], u[i] - ulo[i]);
-            if (fhu[i]) zhu[i] = clampz(zhu[i], uhi[i] - u[i]);
-        }
-        MPC_UNROLL for (int i = 0; i < NS; i++) {
-            xn[i] += apr * dxn[i]; pi[i] += apr * (pin[i] - pi[i]);
-            zlx[i] += adu * dzlx[i]; zhx[i] += adu * dzhx[i];
-            if (flx[i]) zlx[i] = clampz(zlx[i], xn[i] - xlo[i]);
-            if (fhx[i]) zhx[i] = clampz(zhx[i], xhi[i] - xn[i]);
-            if (FREE0) {
-                x0v[i] += apr * dx0[i];
-                zl0[i] += adu * dzl0[i]; zh0[i] += adu * dzh0[i];
-                if (flx[i]) zl0[i] = clampz(zl0[i], x0v[i] - xlo[i]);
-                if (fhx[i]) zh0[i] = clampz(zh0[i], xhi[i] - x0v[i]);
+            const double a_pr = soc_taken ? a_soc : alpha;
+            MPC_UNROLL for (int i = 0; i < NU; i++) {      // (slacks of the new point with the multipliers of the old one, as the trial point had them; the bounds move now)
+                u[i] = ut[i];
+                const double s1 = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0, s2 = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0;
+                zlu[i] += adu * dzlu[i]; zhu[i] += adu * dzhu[i];
+                if (flu[i]) zlu[i] = clampz(zlu[i], s1);
+                if (fhu[i]) zhu[i] = clampz(zhu[i], s2);
             }
-        }
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                xn[i] = xt[i]; pi[i] += a_pr * ((soc_taken ? pins[i] : pin[i]) - pi[i]);
+                const double s1 = flx[i] ? safe_slack(xn[i], blx[i], zlx[i], mu, true) : 1.0, s2 = fhx[i] ? safe_slack(xn[i], bhx[i], zhx[i], mu, false) : 1.0;
+                zlx[i] += adu * dzlx[i]; zhx[i] += adu * dzhx[i];
+                if (flx[i]) zlx[i] = clampz(zlx[i], s1);
+                if (fhx[i]) zhx[i] = clampz(zhx[i], s2);
+                if (FREE0) {
+                    x0v[i] = x0t[i];
+                    const double t1 = flx[i] ? safe_slack(x0v[i], bl0[i], zl0[i], mu, true) : 1.0, t2 = fhx[i] ? safe_slack(x0v[i], bh0[i], zh0[i], mu, false) : 1.0;
+                    zl0[i] += adu * dzl0[i]; zh0[i] += adu * dzh0[i];
+                    if (flx[i]) zl0[i] = clampz(zl0[i], t1);
+                    if (fhx[i]) zh0[i] = clampz(zh0[i], t2);
+                }
+            }
+            it++;
         }
     }
     return status;
@@ -405,28 +728,69 @@ __device__ __forceinline__ bool gj_inverse(const double (&a_in)[n][n], double (&
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Target: min fss(xs, us, ys)  s.t.  Fx_model(xs, us, d) - xs = 0,  xs + Cd d - ys = 0,  boxes   (Target_Calc.py:20-161 with
-// StateFeedback outputs).  Same outer algorithm; the Newton system is reduced to the nu inputs: ys and xs follow from the two
-// (linearised) equalities, so the inertia test is the sign of the nu x nu reduced Hessian.  Wave-uniform: every lane computes it.
-// v = [xs; us; ys] comes in as the first guess (MPC_code.py:696-700).
+// StateFeedback outputs).  The same algorithm as ipm_stage (oracle/enmpc_oracle.py:ipm_dense); the Newton system is reduced to the nu inputs:
+// ys and xs follow from the two (linearised) equalities, so the inertia test is the sign of the nu x nu reduced Hessian.  One instance per
+// lane (or wave-uniform: every lane computes it).  v = [xs; us; ys] comes in as the first guess (MPC_code.py:696-700).
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <class M>
 __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], const double *d, const double (*Bd)[M::ND > 0 ? M::ND : 1],
-                                          const double (*Cd)[M::ND > 0 ? M::ND : 1], const double *lo, const double *hi, double t, double h,
+                                          const double (*Cd)[M::ND > 0 ? M::ND : 1], const double *lo_in, const double *hi_in, double t, double h,
                                           const double tol, const int max_iter, int &iters)
 {
     constexpr int NX = M::NX, NU = M::NU, NY = M::NY, ND = M::ND, NV = NX + NU + NY, NP = NX + NU, NPP = NP * (NP + 1) / 2;
     static_assert(NY == NX, "StateFeedback outputs");
     bool fl[NV], fh[NV];
-    double zl[NV], zh[NV], lam1[NX], lam2[NY];
+    double zl[NV], zh[NV], lo[NV], hi[NV], lam1[NX], lam2[NY], dmp[NV];
     int nbi = 0;
-    MPC_UNROLL for (int i = 0; i < NV; i++) { fl[i] = fin(lo[i]); fh[i] = fin(hi[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nbi += (fl[i] ? 1 : 0) + (fh[i] ? 1 : 0); v[i] = push_in(v[i], lo[i], hi[i]); }
+    MPC_UNROLL for (int i = 0; i < NV; i++) {
+        lo[i] = lo_in[i]; hi[i] = hi_in[i];
+        fl[i] = fin(lo[i]); fh[i] = fin(hi[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nbi += (fl[i] ? 1 : 0) + (fh[i] ? 1 : 0);
+        dmp[i] = (fl[i] && !fh[i]) ? 1.0 : ((fh[i] && !fl[i]) ? -1.0 : 0.0);
+    }
+    // scaling of the objective at the caller's point, then the push into the box
+    double df = 1.0;
+    {
+        double f_, g_[NV], H_[NV][NV], gm = 0.0;
+        M::fss(v, &f_, g_, H_);
+        MPC_UNROLL for (int i = 0; i < NV; i++) gm = dmax(gm, fabs(g_[i]));
+        df = gm > kScaleMaxGrad ? dmax(kScaleMaxGrad / gm, kScaleMin) : 1.0;
+    }
+    MPC_UNROLL for (int i = 0; i < NV; i++) v[i] = push_in(v[i], lo[i], hi[i]);
     MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] = 0.0;
     MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] = 0.0;
     const double nb = (double)nbi, meq = (double)(NX + NY);
-    double mu = kMuInit, delta_last = 0.0;
-    int status = kStMaxIter;
+    const double mu_min = dmin(tol, kComplInfTol) / (kKappaEps + 1.0);
+    double mu = kMuInit, tau = dmax(kTauMin, 1.0 - kMuInit), delta_last = 0.0, theta_max = -1.0, theta_min = -1.0;
+    double filt[2 * kFilterCap];      // (per lane: this kernel's lanes are instances)
+    int status = kStMaxIter, nfilt = 0, acc_count = 0;
+    bool tiny_last = false, tiny_flag = false;
     iters = 0;
-    for (int it = 0;; it++) {
+    // values of cost and constraints at a point (trial points of the line search)
+    auto values = [&](const double (&w)[NV], double &f_, double (&c1_)[NX], double (&c2_)[NY]) {
+        typename M::Ctx cx;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { cx.u[i] = w[NX + i]; cx.us[i] = 0.0; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) cx.d[i] = d[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) cx.xs[i] = 0.0;
+        double Fx[NX], g_[NV], H_[NV][NV];
+        rk4_plain<typename M::Mdl>(w, cx, t, true, h, M::MX, Fx);
+        M::fss(w, &f_, g_, H_);
+        f_ *= df;
+        MPC_UNROLL for (int i = 0; i < NX; i++) { double a = Fx[i] - w[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Bd[i][j] * d[j]; c1_[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NY; i++) { double a = w[i] - w[NX + NU + i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Cd[i][j] * d[j]; c2_[i] = a; }
+    };
+    auto barrier = [&](const double (&w)[NV], double f_, double mu_) {      // with the safe slacks of a trial point (its moved bounds are not kept)
+        double ph = f_;
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            double bl_ = lo[i], bh_ = hi[i];
+            const double s1 = fl[i] ? safe_slack(w[i], bl_, zl[i], mu_, true) : 1.0, s2 = fh[i] ? safe_slack(w[i], bh_, zh[i], mu_, false) : 1.0;
+            if (fl[i]) ph -= mu_ * log(s1);
+            if (fh[i]) ph -= mu_ * log(s2);
+            if (dmp[i] != 0.0) ph += kKappaD * mu_ * (dmp[i] > 0.0 ? s1 : s2);
+        }
+        return ph;
+    };
+    int it = 0;
+    for (;; it++) {
         iters = it;
         typename M::Ctx cx;
         MPC_UNROLL for (int i = 0; i < NU; i++) { cx.u[i] = v[NX + i]; cx.us[i] = 0.0; }
@@ -436,6 +800,8 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         rk4_sens2<typename M::Mdl>(v, cx, t, true, h, M::MX, Fx, S, T);
         double f, g[NV], Hc[NV][NV];
         M::fss(v, &f, g, Hc);
+        f *= df;
+        MPC_UNROLL for (int i = 0; i < NV; i++) { g[i] *= df; MPC_UNROLL for (int j = 0; j < NV; j++) Hc[i][j] *= df; }
         double c1[NX], c2[NY], J1[NX][NX];
         MPC_UNROLL for (int i = 0; i < NX; i++) {
             double a = Fx[i] - v[i];
@@ -444,101 +810,221 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
             MPC_UNROLL for (int j = 0; j < NX; j++) J1[i][j] = S[i][j] - (i == j ? 1.0 : 0.0);
         }
         MPC_UNROLL for (int i = 0; i < NY; i++) { double a = v[i] - v[NX + NU + i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Cd[i][j] * d[j]; c2[i] = a; }
-        // Hessian of the Lagrangian: cost + lam1' Fx
+        // null-space basis Z = [Zx; I; Zx] of the linearised equalities
+        double W[NX][NX];
+        if (!gj_inverse<NX>(J1, W)) { status = kStFailed; break; }
+        double Z[NV][NU];
+        MPC_UNROLL for (int i = 0; i < NX; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NX; l++) a -= W[i][l] * S[l][NX + j]; Z[i][j] = a; Z[NP + i][j] = a; } }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Z[NX + i][j] = (i == j) ? 1.0 : 0.0; }
+        // multipliers of the two equality blocks from the stationarity rows of ys and xs, given (Hessian x step + gradient) in Hd
+        auto mults = [&](const double (&Hd)[NV], double (&l1n)[NX], double (&l2n)[NY]) {
+            MPC_UNROLL for (int i = 0; i < NY; i++) l2n[i] = Hd[NP + i];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NX; j++) a -= W[j][i] * (Hd[j] + l2n[j]); l1n[i] = a; }
+        };
+        if (it == 0) {      // least-squares multipliers [WB (36)]: identity for the Hessian, gradient g - zl + zh, no constraint residual
+            double gg[NV], Hr[NU][NU], rr[NU], dus[NU], Hd[NV], l1n[NX], l2n[NY];
+            MPC_UNROLL for (int i = 0; i < NV; i++) gg[i] = g[i] - zl[i] + zh[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) {
+                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NV; l++) a += Z[l][i] * Z[l][j]; Hr[i][j] = a; }
+                double a = 0.0;
+                MPC_UNROLL for (int l = 0; l < NV; l++) a += Z[l][i] * gg[l];
+                rr[i] = a;
+            }
+            if (sym_inverse<NU>(Hr)) {
+                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a -= Hr[i][j] * rr[j]; dus[i] = a; }
+                MPC_UNROLL for (int i = 0; i < NV; i++) { double a = gg[i]; MPC_UNROLL for (int j = 0; j < NU; j++) a += Z[i][j] * dus[j]; Hd[i] = a; }
+                mults(Hd, l1n, l2n);
+                double ym = 0.0;
+                MPC_UNROLL for (int i = 0; i < NX; i++) ym = dmax(ym, finite_all(l1n[i]) ? fabs(l1n[i]) : INFINITY);
+                MPC_UNROLL for (int i = 0; i < NY; i++) ym = dmax(ym, finite_all(l2n[i]) ? fabs(l2n[i]) : INFINITY);
+                if (ym <= kYInitMax) { MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] = l1n[i]; MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] = l2n[i]; }
+            }
+        }
+        // Hessian of the Lagrangian of the scaled problem: df cost + lam1' Fx
         double H[NV][NV];
         MPC_UNROLL for (int i = 0; i < NV; i++) { MPC_UNROLL for (int j = 0; j < NV; j++) H[i][j] = Hc[i][j]; }
         MPC_UNROLL for (int a = 0; a < NP; a++) { MPC_UNROLL for (int b = 0; b < NP; b++) { double s = 0.0; MPC_UNROLL for (int i = 0; i < NX; i++) s += lam1[i] * T[i][pair_idx<NP>(a, b)]; H[a][b] += s; } }
-        double sl[NV], sh[NV], stat[NV];
-        double e_st = 0.0, e_c = 0.0, s_l = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY;
-        bool finite = true;
+        double sl[NV], sh[NV];
+        double e_st = 0.0, e_c = 0.0, s_l = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY, theta = 0.0;
+        bool finite = finite_all(f);
         MPC_UNROLL for (int i = 0; i < NV; i++) {
-            sl[i] = fl[i] ? v[i] - lo[i] : 1.0; sh[i] = fh[i] ? hi[i] - v[i] : 1.0;
+            sl[i] = fl[i] ? safe_slack(v[i], lo[i], zl[i], mu, true) : 1.0; sh[i] = fh[i] ? safe_slack(v[i], hi[i], zh[i], mu, false) : 1.0;
             double r = g[i] - zl[i] + zh[i];
             if (i < NX) { MPC_UNROLL for (int j = 0; j < NX; j++) r += J1[j][i < NX ? i : 0] * lam1[j]; r += lam2[i < NY ? i : 0]; }      // C = I
             else if (i < NP) { MPC_UNROLL for (int j = 0; j < NX; j++) r += S[j][i < NP ? i : 0] * lam1[j]; }
             else r -= lam2[i >= NP ? i - NP : 0];
-            stat[i] = r;
             e_st = dmax(e_st, fabs(r)); s_z += zl[i] + zh[i];
             finite = finite && finite_all(r) && finite_all(v[i]);
             if (fl[i]) { cmax = dmax(cmax, sl[i] * zl[i]); cmin = dmin(cmin, sl[i] * zl[i]); }
             if (fh[i]) { cmax = dmax(cmax, sh[i] * zh[i]); cmin = dmin(cmin, sh[i] * zh[i]); }
         }
-        MPC_UNROLL for (int i = 0; i < NX; i++) { e_c = dmax(e_c, fabs(c1[i])); s_l += fabs(lam1[i]); finite = finite && finite_all(c1[i]); }
-        MPC_UNROLL for (int i = 0; i < NY; i++) { e_c = dmax(e_c, fabs(c2[i])); s_l += fabs(lam2[i]); }
+        MPC_UNROLL for (int i = 0; i < NX; i++) { e_c = dmax(e_c, fabs(c1[i])); theta += fabs(c1[i]); s_l += fabs(lam1[i]); finite = finite && finite_all(c1[i]); }
+        MPC_UNROLL for (int i = 0; i < NY; i++) { e_c = dmax(e_c, fabs(c2[i])); theta += fabs(c2[i]); s_l += fabs(lam2[i]); finite = finite && finite_all(c2[i]); }
         if (!finite) { status = kStFailed; break; }
         const double s_d = dmax(kSMax, (s_l + s_z) / dmax(meq + nb, 1.0)) / kSMax, s_c = dmax(kSMax, s_z / dmax(nb, 1.0)) / kSMax;
-        auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), nb > 0.0 ? dmax(cmax - m_, m_ - cmin) / s_c : 0.0); };
-        if (err(0.0) <= tol) { status = kStSolved; break; }
+        auto compl_ = [&](double m_) { return nb > 0.0 ? dmax(cmax - m_, m_ - cmin) : 0.0; };
+        auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
+        {
+            const double e0_ = err(0.0), c0_ = compl_(0.0);
+            if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = kStSolved; break; }
+            if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = kStSolved; break; } }
+            else acc_count = 0;
+        }
         if (it >= max_iter) break;
-        while (mu > tol / 10.0 && err(mu) <= kKappaEps * mu) mu = dmax(tol / 10.0, dmin(kKappaMu * mu, mu * sqrt(mu)));
-        const double tau = dmax(kTauMin, 1.0 - mu);
+        {
+            bool mu_changed = false, stop_tiny = false;
+            while (err(mu) <= kKappaEps * mu || tiny_flag) {
+                const double new_mu = dmax(dmin(kKappaMu * mu, mu * sqrt(mu)), mu_min);
+                if (new_mu == mu) { stop_tiny = tiny_flag; break; }
+                mu = new_mu; mu_changed = true; tiny_flag = false;
+            }
+            if (stop_tiny) { status = kStMaxIter; break; }
+            tiny_flag = false;
+            if (mu_changed) { nfilt = 0; tau = dmax(kTauMin, 1.0 - mu); }
+        }
         double Sg[NV], gt[NV];
+        double phi = f;
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             const double il = fl[i] ? 1.0 / sl[i] : 0.0, ih = fh[i] ? 1.0 / sh[i] : 0.0;
-            Sg[i] = zl[i] * il + zh[i] * ih; gt[i] = g[i] - mu * il + mu * ih;
+            Sg[i] = zl[i] * il + zh[i] * ih; gt[i] = g[i] - mu * il + mu * ih + kKappaD * mu * dmp[i];
+            if (fl[i]) phi -= mu * log(sl[i]);
+            if (fh[i]) phi -= mu * log(sh[i]);
+            if (dmp[i] != 0.0) phi += kKappaD * mu * (dmp[i] > 0.0 ? sl[i] : sh[i]);
         }
-        // null-space basis Z = [Zx; I; Zx] and particular step sp = [spx; 0; spx + c2] of the linearised equalities
-        double W[NX][NX];
-        if (!gj_inverse<NX>(J1, W)) { status = kStFailed; break; }
-        double Z[NV][NU], sp[NV];
-        MPC_UNROLL for (int i = 0; i < NX; i++) {
-            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NX; l++) a -= W[i][l] * S[l][NX + j]; Z[i][j] = a; Z[NP + i][j] = a; }
-            double a = 0.0;
-            MPC_UNROLL for (int l = 0; l < NX; l++) a -= W[i][l] * c1[l];
-            sp[i] = a; sp[NP + i] = a + c2[i];
-        }
-        MPC_UNROLL for (int i = 0; i < NU; i++) { sp[NX + i] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Z[NX + i][j] = (i == j) ? 1.0 : 0.0; }
-        double dv[NV], Hd[NV];
+        // reduced Hessian with the shift delta while it lacks positive curvature
+        double Hr[NU][NU];
         double delta = 0.0;
         bool failed = false;
         for (;;) {
-            double HZ[NV][NU], Hr[NU][NU], rr[NU], hs[NV];
-            MPC_UNROLL for (int i = 0; i < NV; i++) {
-                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = (Sg[i] + delta) * Z[i][j]; MPC_UNROLL for (int l = 0; l < NV; l++) a += H[i][l] * Z[l][j]; HZ[i][j] = a; }
-                double a = (Sg[i] + delta) * sp[i] + gt[i];
-                MPC_UNROLL for (int l = 0; l < NV; l++) a += H[i][l] * sp[l];
-                hs[i] = a;
-            }
-            MPC_UNROLL for (int i = 0; i < NU; i++) {
-                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NV; l++) a += Z[l][i] * HZ[l][j]; Hr[i][j] = a; }
-                double a = 0.0;
-                MPC_UNROLL for (int l = 0; l < NV; l++) a += Z[l][i] * hs[l];
-                rr[i] = a;
-            }
+            double HZ[NV][NU];
+            MPC_UNROLL for (int i = 0; i < NV; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) { double a = (Sg[i] + delta) * Z[i][j]; MPC_UNROLL for (int l = 0; l < NV; l++) a += H[i][l] * Z[l][j]; HZ[i][j] = a; } }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NV; l++) a += Z[l][i] * HZ[l][j]; Hr[i][j] = a; } }
             MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Hr[i][j] + Hr[j][i]); Hr[i][j] = a; Hr[j][i] = a; } }
-            if (sym_inverse<NU>(Hr)) {
-                double dus[NU];
-                MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a -= Hr[i][j] * rr[j]; dus[i] = a; }
-                MPC_UNROLL for (int i = 0; i < NV; i++) { double a = sp[i]; MPC_UNROLL for (int j = 0; j < NU; j++) a += Z[i][j] * dus[j]; dv[i] = a; }
-                MPC_UNROLL for (int i = 0; i < NV; i++) { double a = (Sg[i] + delta) * dv[i] + gt[i]; MPC_UNROLL for (int l = 0; l < NV; l++) a += H[i][l] * dv[l]; Hd[i] = a; }
-                break;
-            }
+            if (sym_inverse<NU>(Hr)) break;
             delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
             if (delta > kDeltaMax) { failed = true; break; }
         }
         if (failed) { status = kStFailed; break; }
         if (delta > 0.0) delta_last = delta;
-        // new multipliers from the stationarity rows of ys and xs
-        double l1n[NX], l2n[NY];
-        MPC_UNROLL for (int i = 0; i < NY; i++) l2n[i] = Hd[NP + i];
-        MPC_UNROLL for (int i = 0; i < NX; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NX; j++) a -= W[j][i] * (Hd[j] + l2n[j]); l1n[i] = a; }
-        double apr = 1.0, adu = 1.0, dzl[NV], dzh[NV];
+        // Newton step for a constraint residual (c1_, c2_): particular step of the linearised equalities + reduced step; new multipliers
+        auto direction = [&](const double (&c1_)[NX], const double (&c2_)[NY], double (&dv)[NV], double (&l1n)[NX], double (&l2n)[NY]) {
+            double sp[NV], hs[NV], rr[NU], dus[NU], Hd[NV];
+            MPC_UNROLL for (int i = 0; i < NX; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NX; l++) a -= W[i][l] * c1_[l]; sp[i] = a; sp[NP + i] = a + c2_[i]; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) sp[NX + i] = 0.0;
+            MPC_UNROLL for (int i = 0; i < NV; i++) { double a = (Sg[i] + delta) * sp[i] + gt[i]; MPC_UNROLL for (int l = 0; l < NV; l++) a += H[i][l] * sp[l]; hs[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NV; l++) a += Z[l][i] * hs[l]; rr[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) a -= Hr[i][j] * rr[j]; dus[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NV; i++) { double a = sp[i]; MPC_UNROLL for (int j = 0; j < NU; j++) a += Z[i][j] * dus[j]; dv[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NV; i++) { double a = (Sg[i] + delta) * dv[i] + gt[i]; MPC_UNROLL for (int l = 0; l < NV; l++) a += H[i][l] * dv[l]; Hd[i] = a; }
+            mults(Hd, l1n, l2n);
+        };
         auto ratio = [&](double a, double vv, double dvv) { return dvv < 0.0 ? dmin(a, -tau * vv / dvv) : a; };
-        MPC_UNROLL for (int i = 0; i < NV; i++) {
-            dzl[i] = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * dv[i] : 0.0;
-            dzh[i] = fh[i] ? mu / sh[i] - zh[i] + zh[i] / sh[i] * dv[i] : 0.0;
-            if (fl[i]) { apr = ratio(apr, sl[i], dv[i]); adu = ratio(adu, zl[i], dzl[i]); }
-            if (fh[i]) { apr = ratio(apr, sh[i], -dv[i]); adu = ratio(adu, zh[i], dzh[i]); }
+        auto max_step = [&](const double (&dv_)[NV]) { double a = 1.0; MPC_UNROLL for (int i = 0; i < NV; i++) { if (fl[i]) a = ratio(a, sl[i], dv_[i]); if (fh[i]) a = ratio(a, sh[i], -dv_[i]); } return a; };
+        double dv[NV], l1n[NX], l2n[NY];
+        direction(c1, c2, dv, l1n, l2n);
+        const double a_max = max_step(dv);
+        double gbd = 0.0, drel = 0.0, dym = 0.0;
+        MPC_UNROLL for (int i = 0; i < NV; i++) { gbd += gt[i] * dv[i]; drel = dmax(drel, fabs(dv[i]) / (1.0 + fabs(v[i]))); }
+        MPC_UNROLL for (int i = 0; i < NX; i++) dym = dmax(dym, fabs(l1n[i] - lam1[i]));
+        MPC_UNROLL for (int i = 0; i < NY; i++) dym = dmax(dym, fabs(l2n[i] - lam2[i]));
+        // ---- filter line search ------------------------------------------------------------------------------------------------------------------
+        double a_min = kGammaTheta;
+        if (gbd < 0.0) {
+            a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
+            if (theta <= theta_min) a_min = dmin(a_min, pow(theta, kSTheta) / pow(-gbd, kSPhi));
         }
-        auto clampz = [&](double z, double s) { return dmin(dmax(z, mu / (kKappaSigma * s)), kKappaSigma * mu / s); };
+        a_min *= kAlphaMinFrac;
+        if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
+        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
+        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
+        double vt[NV], c1t[NX], c2t[NY], theta_t = 0.0, phi_t = 0.0;
+        bool ok_t = false;
+        auto trial = [&](double a_, const double (&d_)[NV]) {
+            MPC_UNROLL for (int i = 0; i < NV; i++) vt[i] = v[i] + a_ * d_[i];
+            double ft;
+            values(vt, ft, c1t, c2t);
+            ok_t = finite_all(ft); theta_t = 0.0;
+            MPC_UNROLL for (int i = 0; i < NX; i++) { theta_t += fabs(c1t[i]); ok_t = ok_t && finite_all(c1t[i]); }
+            MPC_UNROLL for (int i = 0; i < NY; i++) { theta_t += fabs(c2t[i]); ok_t = ok_t && finite_all(c2t[i]); }
+            phi_t = barrier(vt, ft, mu);
+            if (!ok_t || !finite_all(phi_t)) { ok_t = false; theta_t = INFINITY; phi_t = INFINITY; }
+        };
+        auto acceptable = [&](double alpha_) {
+            if (!ok_t || theta_t > theta_max) return false;
+            bool ok_;
+            if (alpha_ > 0.0 && ftype(alpha_) && theta <= theta_min) ok_ = le_tol(phi_t - phi, kEtaPhi * alpha_ * gbd, phi);
+            else {
+                if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > kObjMaxInc + bas) return false; }
+                ok_ = le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi);
+            }
+            return ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
+        };
+        bool accepted = false, soc_taken = false;
+        double alpha = a_max, a_soc = a_max;
+        double ds[NV], l1s[NX], l2s[NY];
+        bool tiny = drel < kTinyStepTol && theta <= 1e-4;
+        if (tiny) {
+            trial(a_max, dv);
+            if (ok_t) { accepted = true; tiny_flag = tiny_last; tiny_last = dym < kTinyStepYTol; }
+            else tiny = false;
+        }
+        if (!tiny) {
+            tiny_last = false;
+            int n_steps = 0;
+            while (alpha > a_min || n_steps == 0) {
+                trial(alpha, dv);
+                if (acceptable(alpha)) { accepted = true; break; }
+                if (ok_t && n_steps == 0 && theta <= theta_t) {      // second-order correction
+                    double cs1[NX], cs2[NY], theta_old = 0.0, th_s = theta_t;
+                    MPC_UNROLL for (int i = 0; i < NX; i++) cs1[i] = c1[i];
+                    MPC_UNROLL for (int i = 0; i < NY; i++) cs2[i] = c2[i];
+                    int cnt = 0;
+                    a_soc = alpha;
+                    while (cnt < kMaxSoc && !accepted && (cnt == 0 || th_s <= kKappaSoc * theta_old)) {
+                        theta_old = th_s;
+                        MPC_UNROLL for (int i = 0; i < NX; i++) cs1[i] = a_soc * cs1[i] + c1t[i];
+                        MPC_UNROLL for (int i = 0; i < NY; i++) cs2[i] = a_soc * cs2[i] + c2t[i];
+                        direction(cs1, cs2, ds, l1s, l2s);
+                        a_soc = max_step(ds);
+                        trial(a_soc, ds);
+                        if (acceptable(alpha)) { accepted = true; soc_taken = true; }
+                        else { cnt++; th_s = theta_t; if (!ok_t) break; }
+                    }
+                    if (accepted) break;
+                }
+                alpha *= 0.5;
+                n_steps++;
+            }
+            if (!accepted) { status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; break; }      // IPOPT enters its restoration phase here (not restated)
+            if (!ftype(alpha) || !le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi)) {
+                const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
+                int k2 = 0;
+                for (int e = 0; e < kFilterCap; e++) { if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } } }
+                if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
+                else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
+                nfilt = k2;
+            }
+        }
+        // the accepted point vt: multiplier steps of the direction that was taken
+        const double a_pr = soc_taken ? a_soc : alpha;
+        double adu = 1.0, dzl[NV], dzh[NV];
         MPC_UNROLL for (int i = 0; i < NV; i++) {
-            v[i] += apr * dv[i];
+            const double d_ = soc_taken ? ds[i] : dv[i];
+            dzl[i] = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * d_ : 0.0;
+            dzh[i] = fh[i] ? mu / sh[i] - zh[i] + zh[i] / sh[i] * d_ : 0.0;
+            if (fl[i]) adu = ratio(adu, zl[i], dzl[i]);
+            if (fh[i]) adu = ratio(adu, zh[i], dzh[i]);
+        }
+        auto clampz = [&](double z, double s_) { return dmin(dmax(z, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_); };
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            v[i] = vt[i];
+            const double s1 = fl[i] ? safe_slack(v[i], lo[i], zl[i], mu, true) : 1.0, s2 = fh[i] ? safe_slack(v[i], hi[i], zh[i], mu, false) : 1.0;
             zl[i] += adu * dzl[i]; zh[i] += adu * dzh[i];
-            if (fl[i]) zl[i] = clampz(zl[i], v[i] - lo[i]);
-            if (fh[i]) zh[i] = clampz(zh[i], hi[i] - v[i]);
+            if (fl[i]) zl[i] = clampz(zl[i], s1);
+            if (fh[i]) zh[i] = clampz(zh[i], s2);
         }
-        MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] += apr * (l1n[i] - lam1[i]);
-        MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] += apr * (l2n[i] - lam2[i]);
+        MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] += a_pr * ((soc_taken ? l1s[i] : l1n[i]) - lam1[i]);
+        MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] += a_pr * ((soc_taken ? l2s[i] : l2n[i]) - lam2[i]);
     }
     return status;
 }

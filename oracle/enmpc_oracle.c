@@ -106,14 +106,26 @@ static void interval_derivs(const EProb *P, const double *z, const double *d, co
     for (int a = 0; a < NZ; a++) for (int b = 0; b < a; b++) { const double s = 0.5 * (Hc[a][b] + Hc[b][a]); Hc[a][b] = s; Hc[b][a] = s; }
 }
 
-static void ocp_evalf(void *vctx, const double *w, const double *lam, int want_h, double *f, double *gf, double *g, double *J, double *H)
+static void ocp_evalf(void *vctx, const double *w, const double *lam, int want, double *f, double *gf, double *g, double *J, double *H)
 {
     const OcpCtx *c = (const OcpCtx *)vctx;
     const EProb *P = c->P;
     const int N = P->N, n = NZ * N, m = NX * N;
+    const int want_h = want == WANT_HESS;
+    *f = 0.0;
+    if (want == WANT_VALUES) {      /* a trial point of the line search: cost and constraint values only */
+        for (int k = 0; k < N; k++) {
+            const double *xk = k == 0 ? c->xhat : w + NZ * (k - 1) + 1;
+            cplx z[NZ] = {xk[0], xk[1], w[NZ * k]}, o[3];
+            interval_vals(P, z, c->d, o);
+            *f += creal(o[2]);
+            for (int r = 0; r < NX; r++) g[NX * k + r] = w[NZ * k + 1 + r] - creal(o[r]);
+        }
+        for (int r = 0; r < NX; r++) { const double e = w[NZ * (N - 1) + 1 + r] - c->xs[r]; *f += P->par[6] * e * e; }
+        return;
+    }
     memset(gf, 0, sizeof(double) * n); memset(J, 0, sizeof(double) * m * n);
     if (want_h) memset(H, 0, sizeof(double) * n * n);
-    *f = 0.0;
     /* variable index of u_k: 3k; of x_{k+1}: 3k + 1, 3k + 2 */
     for (int k = 0; k < N; k++) {
         double z[NZ], val[3], Jc[3][NZ], Hc[NZ][NZ], pi[NX];
@@ -153,7 +165,7 @@ static int ocp_solve(const EProb *P, const double *xhat, const double *xs, const
     double *lo = vec(n), *hi = vec(n);
     for (int k = 0; k < N; k++) { lo[NZ * k] = P->umin[0]; hi[NZ * k] = P->umax[0]; for (int r = 0; r < NX; r++) { lo[NZ * k + 1 + r] = P->xmin[r]; hi[NZ * k + 1 + r] = P->xmax[r]; } }
     OcpCtx c = {P, xhat, xs, us, d};
-    const int st = ipm_nullspace(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, iters, NULL);
+    const int st = ipm_ipopt(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, iters, NULL, NULL);
     arena_release(mark_);
     return st;
 }
@@ -166,14 +178,22 @@ static void model_map(const EProb *P, const cplx *z /* x0,x1,u */, const double 
     rk4(P, z, z[2], d, P->Mx, 0, xn, NULL);
     for (int i = 0; i < NX; i++) out[i] = xn[i] + P->Bd[i][0] * d[0] + P->Bd[i][1] * d[1];
 }
-static void tgt_evalf(void *vctx, const double *w, const double *lam, int want_h, double *f, double *gf, double *g, double *J, double *H)
+static void tgt_evalf(void *vctx, const double *w, const double *lam, int want, double *f, double *gf, double *g, double *J, double *H)
 {
     const TgtCtx *c = (const TgtCtx *)vctx;
     const EProb *P = c->P;
     const int n = NV, m = NX + NY;
+    const int want_h = want == WANT_HESS;
+    cplx zc[NZ], o[NX];
+    if (want == WANT_VALUES) {
+        for (int i = 0; i < NZ; i++) zc[i] = w[i];
+        model_map(P, zc, c->d, o);
+        for (int r = 0; r < NX; r++) { g[r] = creal(o[r]) - w[r]; g[NX + r] = w[r] + P->Cd[r][0] * c->d[0] + P->Cd[r][1] * c->d[1] - w[NZ + r]; }
+        *f = w[NX] * (P->par[4] * P->par[0] - P->par[5] * w[NZ + 1]);
+        return;
+    }
     memset(gf, 0, sizeof(double) * n); memset(J, 0, sizeof(double) * m * n);
     if (want_h) memset(H, 0, sizeof(double) * n * n);
-    cplx zc[NZ], o[NX];
     double F[NX], A[NX][NZ];
     for (int j = 0; j < NZ; j++) {
         for (int i = 0; i < NZ; i++) zc[i] = w[i];
@@ -223,14 +243,31 @@ static void mhe_map(const EProb *P, const cplx *xi, double u, const cplx *wn, cp
         out[i] = v;
     }
 }
-static void mhe_evalf(void *vctx, const double *w, const double *lam, int want_h, double *f, double *gf, double *g, double *J, double *H)
+static void mhe_evalf(void *vctx, const double *w, const double *lam, int want, double *f, double *gf, double *g, double *J, double *H)
 {
     const MheCtx *c = (const MheCtx *)vctx;
     const EProb *P = c->P;
     const int N = c->N, n = N * NB + NE, m = N * (NY + NE);
+    const int want_h = want == WANT_HESS;
+    *f = 0.0;
+    if (want == WANT_VALUES) {
+        for (int k = 0; k < N; k++) {
+            const int o0 = NB * k, r0 = (NY + NE) * k;
+            const double *X = w + o0, *V = w + o0 + NE, *W = w + o0 + NE + NY;
+            for (int i = 0; i < NW; i++) *f += 0.5 * W[i] * W[i];
+            for (int i = 0; i < NY; i++) *f += 0.5 * V[i] * V[i];
+            for (int r = 0; r < NY; r++) g[r0 + r] = X[r] + P->Cd[r][0] * X[NX] + P->Cd[r][1] * X[NX + 1] + V[r] - c->Y[NY * k + r];
+            cplx zc[NE + NW], oo[NE];
+            for (int i = 0; i < NE; i++) zc[i] = X[i];
+            for (int i = 0; i < NW; i++) zc[NE + i] = W[i];
+            mhe_map(P, zc, c->U[k], zc + NE, oo);
+            for (int r = 0; r < NE; r++) g[r0 + NY + r] = creal(oo[r]) - w[o0 + NB + r];
+        }
+        for (int i = 0; i < NE; i++) { double s = 0.0; for (int j = 0; j < NE; j++) s += c->Pinv[i * NE + j] * (w[j] - c->xbar[j]); *f += 0.5 * (w[i] - c->xbar[i]) * s; }
+        return;
+    }
     memset(gf, 0, sizeof(double) * n); memset(J, 0, sizeof(double) * m * n);
     if (want_h) memset(H, 0, sizeof(double) * n * n);
-    *f = 0.0;
     for (int k = 0; k < N; k++) {
         const int o0 = NB * k, r0 = (NY + NE) * k;
         const double *X = w + o0, *V = w + o0 + NE, *W = w + o0 + NE + NY;
@@ -329,7 +366,7 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
     double Pinv[NE * NE];
     int ok = inv_small(NE, S->Pk, Pinv);
     MheCtx c = {P, N, S->U, S->Y, S->xbar, Pinv};
-    int st = ipm_nullspace(n, N * (NY + NE), mhe_evalf, &c, w, lo, hi, P->tol_mhe, P->max_iter, iters, NULL);
+    int st = ipm_ipopt(n, N * (NY + NE), mhe_evalf, &c, w, lo, hi, P->tol_mhe, P->max_iter, iters, NULL, NULL);
     if (!ok) st = ST_FAILED;
     const double *Xl = w + NB * (N - 1);
     for (int i = 0; i < NE; i++) xes[i] = Xl[i];
@@ -402,7 +439,7 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
             const double xs_prev[NX] = {xs[0], xs[1]}, us_prev = us;
             double v[NV] = {P->x0m[0], P->x0m[1], P->u0[0], P->x0m[0] + P->Cd[0][0] * dh[0] + P->Cd[0][1] * dh[1], P->x0m[1] + P->Cd[1][0] * dh[0] + P->Cd[1][1] * dh[1]};
             TgtCtx tc = {P, dh};
-            const int ss = ipm_nullspace(NV, NX + NY, tgt_evalf, &tc, v, P->tlo, P->thi, P->tol, P->max_iter, &its, NULL);
+            const int ss = ipm_ipopt(NV, NX + NY, tgt_evalf, &tc, v, P->tlo, P->thi, P->tol, P->max_iter, &its, NULL, NULL);
             if (ss != ST_FAILED) { xs[0] = v[0]; xs[1] = v[1]; us = v[2]; }
             if (!have_w) for (int kk = 0; kk < N; kk++) { wg[NZ * kk] = P->u0[0]; wg[NZ * kk + 1] = P->x0m[0]; wg[NZ * kk + 2] = P->x0m[1]; }
             else if (last_ok) { memcpy(wg, wopt + NZ, sizeof(double) * NZ * (N - 1)); wg[NZ * (N - 1)] = us_prev; wg[NZ * (N - 1) + 1] = xs_prev[0]; wg[NZ * (N - 1) + 2] = xs_prev[1]; }
@@ -436,7 +473,6 @@ void eorc_functions(const EProb *P, const double *x, double u, const double *d, 
     cplx w[NW] = {wv[0], wv[1], wv[2], wv[3]}, v[NY] = {wv[4], wv[5]};
     out[4] = creal(cost_mhe(w, v));
 }
-void eorc_set_safe_slack(int on) { orc_safe_slack = on; }      /* prototype switch, see orc_dense.h */
 
 int eorc_max_threads(void)
 {

@@ -199,16 +199,46 @@ def hess_fd(fun, z, rel=1e-5):
 # ---------------------------------------------------------------------------------------------------
 # dense primal-dual interior point method on  min f(w)  s.t.  g(w) = 0,  lo <= w <= hi
 # ---------------------------------------------------------------------------------------------------
-# The outer algorithm is the reference solver's (IPOPT with the options of MPC_code.py:262-263, i.e. its defaults [ext]): monotone
-# barrier parameter (mu_init 0.1, kappa_eps 10, kappa_mu 0.2, theta_mu 1.5), first guess pushed into the box (bound_push =
-# bound_frac 0.01), bound multipliers started at 1, fraction to the boundary tau = max(0.99, 1 - mu) with separate primal and dual
-# step lengths, multipliers kept within kappa_Sigma = 1e10 of mu / slack, exact Hessian of the Lagrangian shifted by delta I while
-# the reduced Hessian lacks positive curvature (inertia correction: delta = 1e-4, x100 / x8, restarted from a third of the last one),
-# scaled optimality error E_0 <= tol.  Not restated: the filter line search (every step is the full fraction-to-the-boundary
-# step), the least-squares start of the equality multipliers (they start at zero), the restoration phase, the "acceptable" stop.
-# The product runs the SAME outer algorithm with a Riccati factorisation of the same Newton system (csrc/mpc_enmpc.hpp).
+# The algorithm is the reference solver's: IPOPT 3.12 at the options MPC_code.py:262-263 leaves at their defaults [ext] (Waechter & Biegler, Math. Program.
+# 106 (2006), referred to as [WB] below, and the implementation's file names).  The reference's solver is not installable here, so this is a RESTATEMENT
+# FROM ITS PUBLISHED DESCRIPTION - parity with a reference run stays unpinned (header) - of:
+#   * problem scaling (IpGradientScaling): the objective is multiplied by df = min(1, 100 / |grad f(w0)|_inf) at the caller's starting point, before the push;
+#   * first iterate (IpDefaultIterateInitializer): w0 pushed into the box by bound_push = bound_frac = 0.01 [WB 3.6], bound multipliers 1, equality
+#     multipliers by least squares  min |grad f - z_L + z_U + J'y|  [WB (36)], dropped (zero) when |y|_inf > 1000 or the problem is square;
+#   * monotone barrier parameter [WB (7), (8)]: mu_init 0.1, kappa_eps 10, kappa_mu 0.2, theta_mu 1.5, floor tol / (kappa_eps + 1), several decreases in a
+#     row when the error allows; tau = max(0.99, 1 - mu); the filter is emptied whenever mu changes;
+#   * search direction [WB (11), (13)] from the primal-dual system with Sigma = z / s, the Hessian of the Lagrangian shifted by delta I while the
+#     reduced Hessian lacks positive curvature [WB 3.1]: delta = 1e-4 first, x100 / x8, restarted from a third of the last one; damping kappa_d = 1e-5 of
+#     variables with one bound [WB 3.7];
+#   * fraction to the boundary [WB (15)] for primal and dual step separately; equality multipliers move with the primal step length;
+#   * FILTER LINE SEARCH [WB 2.3; IpFilterLSAcceptor, IpBacktrackingLineSearch]: theta = |c|_1, phi = barrier function; switching condition with
+#     s_phi 2.3, s_theta 1.1, delta 1; Armijo eta_phi 1e-8; sufficient decrease gamma_theta 1e-5, gamma_phi 1e-8; theta_max / theta_min = 1e4 / 1e-4
+#     max(1, theta(w0)); backtracking by halves down to alpha_min [WB (23)] with alpha_min_frac 0.05; comparisons relaxed by 10 eps |reference|
+#     (Compare_le); second-order correction [WB 2.4] when the first trial step is rejected and does not reduce theta: up to 4, kappa_soc 0.99; tiny steps
+#     (|dw| / (1 + |w|) < 10 eps with theta <= 1e-4) accepted unchecked, two in a row force mu down or end the solve;
+#   * slacks: IpIpoptCalculatedQuantities::CalculateSafeSlack - a slack below eps min(1, mu) becomes min(max(mu / z, eps min(1, mu)), max(s, 0) +
+#     eps^(3/4) max(1, |bound|)) and the bound of THIS solve moves along; bound multipliers kept within kappa_Sigma = 1e10 of mu / s [WB (16)];
+#   * stop [WB (5), (6); IpOptErrorConvCheck]: scaled error E_0 <= tol with the unscaled side conditions dual_inf_tol 1, constr_viol_tol 1e-4,
+#     compl_inf_tol 1e-4; "acceptable" stop after 15 iterations in a row within 1e-6 (1e10, 1e-2, 1e-2); iteration limit.
+# Not restated: the restoration phase - a line search that falls below alpha_min ends the solve: STATUS_INFEASIBLE when the point is infeasible
+# (IPOPT would enter restoration there; the reference holds the input on 'Infeasible_Problem_Detected' only, MPC_code.py:786), STATUS_MAXITER when it
+# is feasible to 1e-2 tol (IPOPT: 'Restoration_Failed' at an almost feasible point, accepted by the reference) -; the watchdog; constraint scaling (no
+# row of the Jacobian exceeds 100 on the models here: asserted by the tests through ``scale_rows``); the filter's reset heuristic; delta_c.
+# The product runs the SAME algorithm on a Riccati factorisation of the same Newton system (csrc/mpc_enmpc.hpp).
 KAPPA_PUSH, MU_INIT, KAPPA_EPS, KAPPA_MU, THETA_MU, TAU_MIN, KAPPA_SIGMA, S_MAX = 1e-2, 0.1, 10.0, 0.2, 1.5, 0.99, 1e10, 100.0
 DELTA_FIRST, DELTA_MAX = 1e-4, 1e40
+EPS = float(np.finfo(float).eps)
+SLACK_MOVE = EPS ** 0.75
+SCALE_MAX_GRAD, SCALE_MIN = 100.0, 1e-8
+Y_INIT_MAX = 1e3
+KAPPA_D = 1e-5
+GAMMA_THETA, GAMMA_PHI, LS_DELTA, S_THETA, S_PHI, ETA_PHI = 1e-5, 1e-8, 1.0, 1.1, 2.3, 1e-8
+THETA_MAX_FACT, THETA_MIN_FACT, ALPHA_MIN_FRAC, ALPHA_RED, OBJ_MAX_INC = 1e4, 1e-4, 0.05, 0.5, 5.0
+MAX_SOC, KAPPA_SOC = 4, 0.99
+TINY_STEP_TOL, TINY_STEP_Y_TOL = 10.0 * EPS, 1e-2
+DUAL_INF_TOL, CONSTR_VIOL_TOL, COMPL_INF_TOL = 1.0, 1e-4, 1e-4
+ACC_TOL, ACC_ITER, ACC_DUAL_INF_TOL, ACC_CONSTR_VIOL_TOL, ACC_COMPL_INF_TOL = 1e-6, 15, 1e10, 1e-2, 1e-2
+FILTER_CAP = 16     # entries the product keeps (registers); a ninth is merged into the last, conservatively - never seen to happen
 
 
 def _null(E):
@@ -230,29 +260,30 @@ def push_interior(w, lo, hi):
     return w
 
 
-SAFE_SLACK = False      # prototype for the next round, mirrors orc_dense.h:slack_of; the kernels do not have it
-SLACK_EPS, SLACK_MOVE = float(np.finfo(float).eps), float(np.finfo(float).eps) ** 0.75
-
-
-def _slacks(w, lo, hi, zl, zh, mu, fl, fh):
-    """slacks of the bounds; with SAFE_SLACK IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) becomes min(max(mu / z, eps min(1, mu)), max(s, 0) + eps^(3/4) max(1, |bound|))
-    and the bound of this solve (lo, hi: modified in place) moves by the difference"""
+def _safe_slacks(w, lo, hi, zl, zh, mu, fl, fh):
+    """Slacks of the bounds at w with IPOPT's CalculateSafeSlack; returns (sl, sh, lo', hi'): a corrected slack moves its bound (the caller keeps the
+    moved bounds when it keeps the point)."""
+    lo, hi = lo.copy(), hi.copy()
     sl, sh = np.where(fl, w - lo, 1.0), np.where(fh, hi - w, 1.0)
-    if SAFE_SLACK:
-        s_min = SLACK_EPS * min(1.0, mu)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            for s, z, b, f, sign in ((sl, zl, lo, fl, 1.0), (sh, zh, hi, fh, -1.0)):
-                fix = f & (s < s_min)
-                if fix.any():
-                    s[fix] = np.minimum(np.maximum(mu / z[fix], s_min), np.maximum(s[fix], 0.0) + SLACK_MOVE * np.maximum(1.0, np.abs(b[fix])))
-                    b[fix] = w[fix] - sign * s[fix]
-    return sl, sh
+    s_min = EPS * min(1.0, mu)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for s, z, b, f, sign in ((sl, zl, lo, fl, 1.0), (sh, zh, hi, fh, -1.0)):
+            fix = f & (s < s_min)
+            if fix.any():
+                s[fix] = np.minimum(np.maximum(mu / z[fix], s_min), np.maximum(s[fix], 0.0) + SLACK_MOVE * np.maximum(1.0, np.abs(b[fix])))
+                b[fix] = w[fix] - sign * s[fix]
+    return sl, sh, lo, hi
 
 
-def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
-    """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n].  Variables with lo == hi are PARAMETERS, as
-    IPOPT treats them (fixed_variable_treatment = make_parameter, its default [ext]): the initial state of the OCP (MPC_code.py:734)
-    drops out of the variables, and the rows that only restate it (Control_Calc.py:126) drop out of the constraints."""
+def _le(lhs, rhs, bas):
+    """IPOPT's Compare_le: lhs <= rhs up to 10 eps |bas|"""
+    return lhs - rhs <= 10.0 * EPS * abs(bas)
+
+
+def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
+    """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n] (``lam`` of length 0: no Hessian wanted).  Variables with
+    lo == hi are PARAMETERS, as IPOPT treats them (fixed_variable_treatment = make_parameter, its default [ext]): the initial state of the OCP
+    (MPC_code.py:734) drops out of the variables, and the rows that only restate it (Control_Calc.py:126) drop out of the constraints."""
     fixed = lo == hi
     if fixed.any():
         free = ~fixed
@@ -270,7 +301,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
                 lfull[rows] = lam
             f, gf, g, J, H = evalf(wfull, lfull if len(lam) else lam)
             return f, gf[free], g[rows], J[np.ix_(rows, free)], H[np.ix_(free, free)]
-        r = ipm_dense(sub, np.asarray(w0, dtype=float)[free], lo[free], hi[free], tol=tol, max_iter=max_iter, trace=trace)
+        r = ipm_dense(sub, np.asarray(w0, dtype=float)[free], lo[free], hi[free], tol=tol, max_iter=max_iter, trace=trace, info=info)
         wfull = wf.copy(); wfull[free] = r["w"]
         lfull = np.zeros(len(rows)); lfull[rows] = r["lam"]
         # multipliers of the dropped rows / bounds of the fixed variables, for the certificate of the full statement: the rows that
@@ -284,45 +315,103 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
         r.update(w=wfull, lam=lfull, z_lo=zl, z_hi=zh)
         return r
     n = len(w0)
+    lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)      # this solve's own bounds: the safe slack moves them
     fl, fh = np.isfinite(lo), np.isfinite(hi)
+    one_l, one_h = fl & ~fh, fh & ~fl                                   # variables with one bound: damped [WB 3.7]
+    nb = int(fl.sum() + fh.sum())
+    # ---- scaling of the objective at the caller's point (IpGradientScaling) ------------------------------------------------------------
+    w0 = np.asarray(w0, dtype=float)
+    _, gf0, c0, J0, _ = evalf(w0, np.zeros(0))
+    gmax = float(np.abs(gf0).max(initial=0.0))
+    df = max(SCALE_MAX_GRAD / gmax, SCALE_MIN) if gmax > SCALE_MAX_GRAD else 1.0
+    if info is not None:
+        info["df"] = df; info["scale_rows"] = bool(np.abs(J0).max(initial=0.0) > SCALE_MAX_GRAD)
+    m = len(c0)
+
+    def ev(w_, lam_):
+        """the scaled problem: df f, with the Hessian of df f + lam'g"""
+        if len(lam_) or m == 0:
+            f_, gf_, c_, J_, H_ = evalf(w_, lam_ / df if m else lam_)
+            return df * f_, df * gf_, c_, J_, df * H_
+        f_, gf_, c_, J_, H_ = evalf(w_, lam_)
+        return df * f_, df * gf_, c_, J_, H_
+
+    def barrier(f_, sl_, sh_, mu_):
+        return f_ - mu_ * (np.log(sl_[fl]).sum() + np.log(sh_[fh]).sum()) + KAPPA_D * mu_ * (sl_[one_l].sum() + sh_[one_h].sum())
+    # ---- first iterate -------------------------------------------------------------------------------------------------------------------
     w = push_interior(w0, lo, hi)
     zl, zh = np.where(fl, 1.0, 0.0), np.where(fh, 1.0, 0.0)
-    lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)      # (this solve's own bounds: the safe-slack prototype moves them)
-    nb = int(fl.sum() + fh.sum())
-    lam = None
+    lam = np.zeros(m)
+    if 0 < m < n:
+        _, gf, c, J, _ = ev(w, np.zeros(0))
+        if np.all(np.isfinite(gf)) and np.all(np.isfinite(J)):
+            try:
+                y = np.linalg.solve(np.block([[np.eye(n), J.T], [J, np.zeros((m, m))]]), np.concatenate([-(gf - zl + zh), np.zeros(m)]))[n:]
+                if np.all(np.isfinite(y)) and np.abs(y).max() <= Y_INIT_MAX:
+                    lam = y
+            except np.linalg.LinAlgError:
+                pass
     mu, delta_last = MU_INIT, 0.0
+    tau = max(TAU_MIN, 1.0 - mu)
+    filt = []                                        # entries (phi, theta)
+    theta_max = theta_min = -1.0
+    acc_count, tiny_last, tiny_flag = 0, False, False
     status, it = STATUS_MAXITER, 0
+    stats = dict(ls_steps=0, soc=0, tiny=0, filter_max=0, stop="iteration limit")
     for it in range(max_iter + 1):
-        if lam is None:
-            lam = np.zeros(len(evalf(w, np.zeros(0))[2]))
-        f, gf, c, J, H = evalf(w, lam)
-        m = len(c)
-        if not (np.all(np.isfinite(w)) and np.all(np.isfinite(gf)) and np.all(np.isfinite(c))):
-            status = STATUS_INFEASIBLE
+        f, gf, c, J, H = ev(w, lam)
+        if not (np.all(np.isfinite(w)) and np.isfinite(f) and np.all(np.isfinite(gf)) and np.all(np.isfinite(c))):
+            status = STATUS_INFEASIBLE; stats["stop"] = "not finite"
             break
-        sl, sh = _slacks(w, lo, hi, zl, zh, mu, fl, fh)
+        sl, sh, lo, hi = _safe_slacks(w, lo, hi, zl, zh, mu, fl, fh)
         stat = gf + J.T @ lam - zl + zh
-        if not np.all(np.isfinite(stat)):      # (an infinite bound multiplier: a slack that rounded to zero - DESIGN.md section 12; enmpc_oracle.c says failed too)
-            status = STATUS_INFEASIBLE
+        if not np.all(np.isfinite(stat)):
+            status = STATUS_INFEASIBLE; stats["stop"] = "not finite"
             break
         s_d = max(S_MAX, (np.abs(lam).sum() + zl.sum() + zh.sum()) / max(m + nb, 1)) / S_MAX
         s_c = max(S_MAX, (zl.sum() + zh.sum()) / max(nb, 1)) / S_MAX
+        e_st, e_c = float(np.abs(stat).max(initial=0.0)), float(np.abs(c).max(initial=0.0))
+
+        def compl(mu_):
+            return max(np.abs(np.where(fl, sl * zl - mu_, 0.0)).max(initial=0.0), np.abs(np.where(fh, sh * zh - mu_, 0.0)).max(initial=0.0))
 
         def err(mu_):
-            comp = max(np.abs(np.where(fl, sl * zl - mu_, 0.0)).max(), np.abs(np.where(fh, sh * zh - mu_, 0.0)).max())
-            return max(np.abs(stat).max() / s_d, np.abs(c).max(initial=0.0), comp / s_c)
+            return max(e_st / s_d, e_c, compl(mu_) / s_c)
         if trace is not None:
-            trace.append(dict(it=it, f=f, E0=err(0.0), mu=mu, w=w.copy()))
-        if err(0.0) <= tol:
-            status = STATUS_SOLVED
+            trace.append(dict(it=it, f=f / df, E0=err(0.0), mu=mu, w=w.copy()))
+        c0_ = compl(0.0)
+        if err(0.0) <= tol and e_st <= DUAL_INF_TOL and e_c <= CONSTR_VIOL_TOL and c0_ <= COMPL_INF_TOL:
+            status = STATUS_SOLVED; stats["stop"] = "converged"
             break
+        if err(0.0) <= ACC_TOL and e_st <= ACC_DUAL_INF_TOL and e_c <= ACC_CONSTR_VIOL_TOL and c0_ <= ACC_COMPL_INF_TOL:
+            acc_count += 1
+            if acc_count >= ACC_ITER:
+                status = STATUS_SOLVED; stats["stop"] = "acceptable"
+                break
+        else:
+            acc_count = 0
         if it == max_iter:
             break
-        while mu > tol / 10.0 and err(mu) <= KAPPA_EPS * mu:
-            mu = max(tol / 10.0, min(KAPPA_MU * mu, mu ** THETA_MU))
-        tau = max(TAU_MIN, 1.0 - mu)
+        # ---- barrier parameter (IpMonotoneMuUpdate) -----------------------------------------------------------------------------------------
+        mu_min = min(tol, COMPL_INF_TOL) / (KAPPA_EPS + 1.0)
+        mu_changed = False
+        stop_tiny = False
+        while err(mu) <= KAPPA_EPS * mu or tiny_flag:
+            new_mu = max(min(KAPPA_MU * mu, mu ** THETA_MU), mu_min)
+            if new_mu == mu:
+                stop_tiny = tiny_flag
+                break
+            mu, mu_changed, tiny_flag = new_mu, True, False
+        if stop_tiny:
+            status = STATUS_MAXITER; stats["stop"] = "tiny step"      # 'Search_Direction_Becomes_Too_Small': the reference accepts the point
+            break
+        tiny_flag = False
+        if mu_changed:
+            filt = []
+            tau = max(TAU_MIN, 1.0 - mu)
+        # ---- search direction -------------------------------------------------------------------------------------------------------------------
         Sig = np.where(fl, zl / sl, 0.0) + np.where(fh, zh / sh, 0.0)
-        rhs_w = -(gf - np.where(fl, mu / sl, 0.0) + np.where(fh, mu / sh, 0.0))
+        gphi = gf - np.where(fl, mu / sl, 0.0) + np.where(fh, mu / sh, 0.0) + KAPPA_D * mu * (one_l.astype(float) - one_h.astype(float))      # gradient of the barrier function
         Z = _null(J)
         delta = 0.0
         while True:
@@ -332,25 +421,136 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None):
             delta = max(DELTA_FIRST, delta_last / 3.0) if delta == 0.0 else delta * (100.0 if delta_last == 0.0 else 8.0)
             if delta > DELTA_MAX:
                 break
+        if delta > DELTA_MAX:
+            status = STATUS_INFEASIBLE; stats["stop"] = "no curvature"
+            break
         if delta > 0.0:
             delta_last = delta
-        sol = np.linalg.solve(np.block([[Hk, J.T], [J, np.zeros((m, m))]]), np.concatenate([rhs_w, -c]))
-        dw, lam_new = sol[:n], sol[n:]
-        dzl = np.where(fl, mu / sl - zl - zl / sl * dw, 0.0)
-        dzh = np.where(fh, mu / sh - zh + zh / sh * dw, 0.0)
+        KKT = np.block([[Hk, J.T], [J, np.zeros((m, m))]])
+
+        def direction(c_rhs):
+            sol = np.linalg.solve(KKT, np.concatenate([-gphi, -c_rhs]))
+            return sol[:n], sol[n:]                  # dw, the new equality multipliers
 
         def maxstep(v, dv, mask):
             neg = mask & (dv < 0)
             return min(1.0, float(np.min(-tau * v[neg] / dv[neg]))) if neg.any() else 1.0
-        a_pr = min(maxstep(sl, dw, fl), maxstep(sh, -dw, fh))
+        dw, lam_new = direction(c)
+        a_max = min(maxstep(sl, dw, fl), maxstep(sh, -dw, fh))
+        # ---- filter line search ------------------------------------------------------------------------------------------------------------------
+        theta, phi = float(np.abs(c).sum()), barrier(f, sl, sh, mu)
+        gbd = float(gphi @ dw)
+        a_min = GAMMA_THETA
+        if gbd < 0.0:
+            a_min = min(GAMMA_THETA, GAMMA_PHI * theta / (-gbd))
+            if theta <= theta_min:
+                a_min = min(a_min, LS_DELTA * theta ** S_THETA / (-gbd) ** S_PHI)
+        a_min *= ALPHA_MIN_FRAC
+        if theta_max < 0.0:
+            theta_max, theta_min = THETA_MAX_FACT * max(1.0, theta), THETA_MIN_FACT * max(1.0, theta)
+
+        def trial(alpha, d_):
+            wt = w + alpha * d_
+            ft, _, ct, _, _ = ev(wt, np.zeros(0))
+            slt, sht, lot, hit = _safe_slacks(wt, lo, hi, zl, zh, mu, fl, fh)
+            ok = bool(np.isfinite(ft) and np.all(np.isfinite(ct)))
+            return wt, (float(np.abs(ct).sum()) if ok else INF), (barrier(ft, slt, sht, mu) if ok else INF), ct, (slt, sht, lot, hit), ok
+
+        def ftype(alpha):
+            if theta == 0.0 and 0.0 < gbd < 100.0 * EPS:
+                return True
+            return gbd < 0.0 and alpha * (-gbd) ** S_PHI > LS_DELTA * theta ** S_THETA
+
+        def armijo(alpha, phi_t):
+            return _le(phi_t - phi, ETA_PHI * alpha * gbd, phi)
+
+        def acceptable(alpha, theta_t, phi_t):
+            if theta_t > theta_max:
+                return False
+            if alpha > 0.0 and ftype(alpha) and theta <= theta_min:
+                ok = armijo(alpha, phi_t)
+            else:
+                if phi_t > phi:
+                    bas = np.log10(abs(phi)) if abs(phi) > 10.0 else 1.0
+                    if np.log10(phi_t - phi) > OBJ_MAX_INC + bas:
+                        return False
+                ok = _le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) or _le(phi_t - phi, -GAMMA_PHI * theta, phi)
+            if not ok:
+                return False
+            for (ph_j, th_j) in filt:                # acceptable to an entry: better than it in one of the two measures
+                if _le(ph_j, phi_t, ph_j) and _le(th_j, theta_t, th_j):
+                    return False
+            return True
+        tiny = bool((np.abs(dw) / (1.0 + np.abs(w))).max(initial=0.0) < TINY_STEP_TOL and theta <= 1e-4)
+        accepted, alpha, d_acc, lam_acc = None, a_max, dw, lam_new
+        if tiny:
+            T = trial(a_max, dw)
+            if T[5]:
+                accepted = T; stats["tiny"] += 1
+                tiny_flag = tiny_last
+                tiny_last = bool(np.abs(lam_new - lam).max(initial=0.0) < TINY_STEP_Y_TOL)
+            else:
+                tiny = False
+        if not tiny:
+            tiny_last = False
+            n_steps = 0
+            while alpha > a_min or n_steps == 0:
+                T = trial(alpha, dw)
+                if T[5] and acceptable(alpha, T[1], T[2]):
+                    accepted = T
+                    break
+                if T[5] and n_steps == 0 and theta <= T[1]:      # second-order correction: the first trial step did not reduce the infeasibility
+                    c_soc, a_soc, theta_old, theta_t, cnt = c.copy(), alpha, 0.0, T[1], 0
+                    ct = T[3]
+                    while cnt < MAX_SOC and accepted is None and (cnt == 0 or theta_t <= KAPPA_SOC * theta_old):
+                        theta_old = theta_t
+                        c_soc = a_soc * c_soc + ct
+                        d_s, lam_s = direction(c_soc)
+                        a_soc = min(maxstep(sl, d_s, fl), maxstep(sh, -d_s, fh))
+                        Ts = trial(a_soc, d_s)
+                        stats["soc"] += 1
+                        if Ts[5] and acceptable(alpha, Ts[1], Ts[2]):      # (the tests keep the original step length)
+                            accepted, d_acc, lam_acc, alpha_soc = Ts, d_s, lam_s, a_soc
+                        else:
+                            cnt += 1; theta_t, ct = Ts[1], Ts[3]
+                            if not Ts[5]:
+                                break
+                    if accepted is not None:
+                        break
+                alpha *= ALPHA_RED
+                n_steps += 1
+            stats["ls_steps"] += n_steps
+            if accepted is None:
+                # IPOPT enters its restoration phase here (not restated)
+                if theta <= 1e-2 * tol:
+                    status = STATUS_MAXITER; stats["stop"] = "line search failed at a feasible point"
+                else:
+                    status = STATUS_INFEASIBLE; stats["stop"] = "restoration needed"
+                break
+            # the filter grows unless the step was an Armijo step on the barrier function (IpFilterLSAcceptor::UpdateForNextIteration)
+            if not ftype(alpha) or not armijo(alpha, accepted[2]):
+                ent = (phi - GAMMA_PHI * theta, (1.0 - GAMMA_THETA) * theta)
+                filt = [e for e in filt if not (e[0] >= ent[0] and e[1] >= ent[1])]      # entries the new one dominates are dropped
+                if len(filt) >= FILTER_CAP:
+                    filt[-1] = (min(filt[-1][0], ent[0]), min(filt[-1][1], ent[1]))
+                else:
+                    filt.append(ent)
+                stats["filter_max"] = max(stats["filter_max"], len(filt))
+        a_pr = alpha_soc if d_acc is not dw else alpha
+        # ---- the accepted point; bounds move with corrected slacks; multipliers within kappa_Sigma of mu / s ---------------------------
+        dzl = np.where(fl, mu / sl - zl - zl / sl * d_acc, 0.0)      # (of the direction that was taken: the corrected one after a second-order correction)
+        dzh = np.where(fh, mu / sh - zh + zh / sh * d_acc, 0.0)
         a_du = min(maxstep(zl, dzl, fl), maxstep(zh, dzh, fh))
-        w = w + a_pr * dw
-        lam = lam + a_pr * (lam_new - lam)
+        w = accepted[0]
+        sl, sh, lo, hi = accepted[4]
+        lam = lam + a_pr * (lam_acc - lam)
         zl, zh = zl + a_du * dzl, zh + a_du * dzh
-        sl, sh = _slacks(w, lo, hi, zl, zh, mu, fl, fh)
         zl = np.where(fl, np.clip(zl, mu / (KAPPA_SIGMA * sl), KAPPA_SIGMA * mu / sl), 0.0)
         zh = np.where(fh, np.clip(zh, mu / (KAPPA_SIGMA * sh), KAPPA_SIGMA * mu / sh), 0.0)
-    return dict(w=w, lam=lam, z_lo=zl, z_hi=zh, status=status, iters=it, mu=mu)
+    stats["df"] = df
+    if info is not None:
+        info.update(stats)
+    return dict(w=w, lam=lam / df, z_lo=zl / df, z_hi=zh / df, status=status, iters=it, mu=mu, df=df, stop=stats["stop"])      # (multipliers of the unscaled problem)
 
 
 def kkt_nlp(evalf, sol, lo, hi):

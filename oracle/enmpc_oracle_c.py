@@ -85,10 +85,6 @@ class OracleEC:
     def max_threads(self):
         return int(self.lib.eorc_max_threads())
 
-    def set_safe_slack(self, on: bool):
-        """prototype switch (orc_dense.h: slack_of): IPOPT's safe-slack rule with moved bounds; off by default - the kernels do not have it"""
-        self.lib.eorc_set_safe_slack(int(bool(on)))
-
     def closed_loop(self, nsteps, x0_p, x_bar=None, nthreads=0, logs=True):
         x0 = np.ascontiguousarray(np.atleast_2d(x0_p), dtype=np.float64)
         B = len(x0)

@@ -1,9 +1,11 @@
 /* ORACLE (test infrastructure, never shipped): dense linear algebra and the interior point method shared by the C restatements
  * (enmpc_oracle.c, nmpc_oracle.c).  Everything static: each restatement is one translation unit.
  *
- * ipm_nullspace: primal-dual interior point method on  min f(w)  s.t.  g(w) = 0,  lo <= w <= hi  with the outer algorithm documented in
- * enmpc_oracle.py:ipm_dense (the reference solver's, IPOPT at the reference's options), Newton steps by a NULL-SPACE method: Householder
- * QR of the constraint Jacobian, Cholesky of the reduced Hessian (its failure is the inertia test). */
+ * ipm_ipopt: primal-dual interior point method on  min f(w)  s.t.  g(w) = 0,  lo <= w <= hi  - the algorithm documented in
+ * enmpc_oracle.py:ipm_dense (the reference solver's, IPOPT at the reference's options: scaling, least-squares multipliers, monotone barrier
+ * parameter, filter line search with second-order correction, safe slacks), Newton steps by a NULL-SPACE method: Householder QR of the constraint
+ * Jacobian, Cholesky of the reduced Hessian (its failure is the inertia test).  Used by enmpc_oracle.c.
+ * ipm_nullspace: the plain full-step form of it (no line search, no scaling) that nmpc_oracle.c solves its convex QPs with. */
 #ifndef ORC_DENSE_H
 #define ORC_DENSE_H
 #include <math.h>
@@ -20,22 +22,6 @@ enum { ST_SOLVED = 0, ST_MAXITER = 1, ST_FAILED = 2 };
 #define TAU_MIN 0.99
 #define KAPPA_SIGMA 1e10
 #define S_MAX 100.0
-/* IPOPT's safe slack (IpIpoptCalculatedQuantities.cpp: CalculateSafeSlack, slack_move = eps^(3/4)) - a PROTOTYPE for the next round, off unless orc_safe_slack is set
-   (the kernels do not have it): a slack below eps min(1, mu) becomes min(max(mu / z, eps min(1, mu)), max(s, 0) + slack_move max(1, |bound|)) and the
-   bound of this solve moves by the difference (where the doubles at the bound can show it). */
-#define SLACK_EPS 2.220446049250313e-16
-#define SLACK_MOVE 1.81898940354585648e-12
-static int orc_safe_slack = 0;
-static inline double slack_of(double w, double *bound, double z, double mu, int lower)
-{
-    double s = lower ? w - *bound : *bound - w;
-    const double s_min = SLACK_EPS * fmin(1.0, mu);
-    if (orc_safe_slack && s < s_min) {
-        s = fmin(fmax(mu / z, s_min), fmax(s, 0.0) + SLACK_MOVE * fmax(1.0, fabs(*bound)));
-        *bound = lower ? w - s : w + s;
-    }
-    return s;
-}
 #define DELTA_FIRST 1e-4
 #define DELTA_MAX 1e40
 
@@ -149,8 +135,7 @@ static double push_in(double v, double lo, double hi)
 static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, const double *lo_in, const double *hi_in, double tol, int max_iter, int *iters, double *lam_out)
 {
     const size_t mark_ = arena_mark();
-    double *lo = vec(n), *hi = vec(n);      /* (this solve's own bounds: the safe-slack prototype moves them) */
-    memcpy(lo, lo_in, sizeof(double) * n); memcpy(hi, hi_in, sizeof(double) * n);
+    const double *lo = lo_in, *hi = hi_in;
     double *zl = vec(n), *zh = vec(n), *lam = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m),
            *sl = vec(n), *sh = vec(n), *Sig = vec(n), *gt = vec(n), *dw = vec(n), *lamn = vec(m), *py = vec(n), *tmp = vec(n), *Hr = vec((size_t)(n - m) * (n - m)), *rz = vec(n), *HZ = vec((size_t)n * (n - m)), *Zc = vec(n);
     int nb = 0, status = ST_MAXITER, it = 0;
@@ -163,7 +148,7 @@ static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, cons
         int finite = 1;
         for (int i = 0; i < n; i++) {
             const int fl = isfinite(lo[i]), fh = isfinite(hi[i]);
-            sl[i] = fl ? slack_of(w[i], &lo[i], zl[i], mu, 1) : 1.0; sh[i] = fh ? slack_of(w[i], &hi[i], zh[i], mu, 0) : 1.0;
+            sl[i] = fl ? w[i] - lo[i] : 1.0; sh[i] = fh ? hi[i] - w[i] : 1.0;
             double r = gf[i] - zl[i] + zh[i];
             for (int j = 0; j < m; j++) r += J[j * n + i] * lam[j];
             e_st = fmax(e_st, fabs(r)); s_z += zl[i] + zh[i];
@@ -234,13 +219,345 @@ static int ipm_nullspace(int n, int m, evalf_t evalf, void *ctx, double *w, cons
         for (int i = 0; i < n; i++) {
             w[i] += apr * dw[i];
             zl[i] += adu * Sig[i]; zh[i] += adu * gt[i];
-            if (isfinite(lo[i])) { const double s = slack_of(w[i], &lo[i], zl[i], mu, 1); zl[i] = fmin(fmax(zl[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
-            if (isfinite(hi[i])) { const double s = slack_of(w[i], &hi[i], zh[i], mu, 0); zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
+            if (isfinite(lo[i])) { const double s = w[i] - lo[i]; zl[i] = fmin(fmax(zl[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
+            if (isfinite(hi[i])) { const double s = hi[i] - w[i]; zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * s)), KAPPA_SIGMA * mu / s); }
         }
         for (int j = 0; j < m; j++) lam[j] += apr * (lamn[j] - lam[j]);
     }
     *iters = it;
     if (lam_out) memcpy(lam_out, lam, sizeof(double) * m);
+    arena_release(mark_);
+    return status;
+}
+
+
+/* ---- the reference solver's algorithm (enmpc_oracle.py:ipm_dense, same constants, same order of decisions) ---------------------------- */
+#define ORC_EPS 2.220446049250313e-16
+#define SLACK_MOVE 1.81898940354585648e-12      /* eps^(3/4) */
+#define SCALE_MAX_GRAD 100.0
+#define SCALE_MIN 1e-8
+#define Y_INIT_MAX 1e3
+#define KAPPA_D 1e-5
+#define GAMMA_THETA 1e-5
+#define GAMMA_PHI 1e-8
+#define S_THETA 1.1
+#define S_PHI 2.3
+#define ETA_PHI 1e-8
+#define THETA_MAX_FACT 1e4
+#define THETA_MIN_FACT 1e-4
+#define ALPHA_MIN_FRAC 0.05
+#define OBJ_MAX_INC 5.0
+#define MAX_SOC 4
+#define KAPPA_SOC 0.99
+#define TINY_STEP_TOL (10.0 * ORC_EPS)
+#define TINY_STEP_Y_TOL 1e-2
+#define DUAL_INF_TOL 1.0
+#define CONSTR_VIOL_TOL 1e-4
+#define COMPL_INF_TOL 1e-4
+#define ACC_TOL 1e-6
+#define ACC_ITER 15
+#define ACC_DUAL_INF_TOL 1e10
+#define ACC_CONSTR_VIOL_TOL 1e-2
+#define ACC_COMPL_INF_TOL 1e-2
+#define FILTER_CAP 16
+enum { WANT_VALUES = 0, WANT_GRAD = 1, WANT_HESS = 2 };
+/* evalf2(ctx, w, lam, want, ...): want = WANT_VALUES: f and g only; WANT_GRAD: + gf, J; WANT_HESS: + H = Hessian of f + lam'g */
+typedef void (*evalf2_t)(void *ctx, const double *w, const double *lam, int want, double *f, double *gf, double *g, double *J, double *H);
+
+static inline int orc_le(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * ORC_EPS * fabs(bas); }
+/* slack of one bound with IPOPT's CalculateSafeSlack; a corrected slack moves *bound */
+static inline double safe_slack(double w, double *bound, double z, double mu, int lower)
+{
+    double s = lower ? w - *bound : *bound - w;
+    const double s_min = ORC_EPS * fmin(1.0, mu);
+    if (s < s_min) {
+        s = fmin(fmax(mu / z, s_min), fmax(s, 0.0) + SLACK_MOVE * fmax(1.0, fabs(*bound)));
+        *bound = lower ? w - s : w + s;
+    }
+    return s;
+}
+
+typedef struct {
+    int n, m, nz;
+    double *Jt, *tau, *H, *Sig, *Hr, *gphi;      /* QR of J', Hessian, Sigma, Cholesky factor of the reduced Hessian (with delta), gradient of the barrier function */
+    double delta;
+    double *py, *tmp, *rz;
+} NsSys;
+/* Newton step of the primal-dual system for the constraint right-hand side c: dw and the new equality multipliers lamn */
+static void ns_direction(const NsSys *S, const double *c, double *dw, double *lamn)
+{
+    const int n = S->n, m = S->m, nz = S->nz;
+    double *py = S->py, *tmp = S->tmp, *rz = S->rz;
+    for (int i = 0; i < n; i++) py[i] = 0.0;
+    for (int i = 0; i < m; i++) { double s = -c[i]; for (int k = 0; k < i; k++) s -= r_at(m, S->Jt, S->tau, k, i) * py[k]; py[i] = s / r_at(m, S->Jt, S->tau, i, i); }
+    if (m > 0) qr_apply(n, m, S->Jt, S->tau, py, 0);
+    for (int i = 0; i < n; i++) { double s = (S->Sig[i] + S->delta) * py[i] + S->gphi[i]; for (int l = 0; l < n; l++) s += S->H[i * n + l] * py[l]; tmp[i] = s; }
+    if (m > 0) qr_apply(n, m, S->Jt, S->tau, tmp, 1);
+    for (int r = 0; r < nz; r++) rz[r] = -tmp[m + r];
+    if (nz > 0) chol_solve(nz, S->Hr, rz);
+    for (int i = 0; i < n; i++) dw[i] = 0.0;
+    for (int r = 0; r < nz; r++) dw[m + r] = rz[r];
+    if (m > 0) qr_apply(n, m, S->Jt, S->tau, dw, 0);
+    for (int i = 0; i < n; i++) dw[i] += py[i];
+    for (int i = 0; i < n; i++) { double s = (S->Sig[i] + S->delta) * dw[i] + S->gphi[i]; for (int l = 0; l < n; l++) s += S->H[i * n + l] * dw[l]; tmp[i] = s; }
+    if (m > 0) qr_apply(n, m, S->Jt, S->tau, tmp, 1);
+    for (int i = m - 1; i >= 0; i--) { double s = -tmp[i]; for (int k = i + 1; k < m; k++) s -= r_at(m, S->Jt, S->tau, i, k) * lamn[k]; lamn[i] = s / r_at(m, S->Jt, S->tau, i, i); }
+}
+
+typedef struct { int ls_steps, soc, tiny, filter_max, stop; double df; } IpmInfo;      /* stop: 0 converged, 1 acceptable, 2 iteration limit, 3 tiny step, 4 line search failed at a feasible point, 5 restoration needed, 6 not finite, 7 no curvature */
+
+/* n variables (none fixed: the caller has removed parameters), m equalities */
+static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const double *lo_in, const double *hi_in, double tol, int max_iter, int *iters, double *lam_out, IpmInfo *info)
+{
+    const size_t mark_ = arena_mark();
+    const int nz = n - m;
+    double *lo = vec(n), *hi = vec(n), *lot = vec(n), *hit = vec(n);      /* this solve's own bounds: the safe slack moves them; lot / hit: those of a trial point */
+    memcpy(lo, lo_in, sizeof(double) * n); memcpy(hi, hi_in, sizeof(double) * n);
+    double *zl = vec(n), *zh = vec(n), *lam = vec(m), *lams = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m + 2),
+           *sl = vec(n), *sh = vec(n), *slt = vec(n), *sht = vec(n), *Sig = vec(n), *gphi = vec(n), *dw = vec(n), *ds = vec(n), *lamn = vec(m), *lamsoc = vec(m), *Hr = vec((size_t)(nz > 0 ? nz : 1) * (nz > 0 ? nz : 1)),
+           *HZ = vec((size_t)n * (nz > 0 ? nz : 1)), *Zc = vec(n), *tmp = vec(n), *wt = vec(n), *gt = vec(m), *csoc = vec(m), *ctr = vec(m), *gdum = vec(n);
+    unsigned char *fl = (unsigned char *)vec((n + 7) / 8 + 1), *fh = (unsigned char *)vec((n + 7) / 8 + 1);
+    NsSys S = {n, m, nz, Jt, tau, H, Sig, Hr, gphi, 0.0, vec(n), vec(n), vec(n)};
+    int nb = 0, status = ST_MAXITER, it = 0;
+    IpmInfo inf = {0, 0, 0, 0, 2, 1.0};
+    double f, ft;
+    /* scaling of the objective at the caller's point */
+    evalf(ctx, w, lam, WANT_GRAD, &f, gf, g, J, H);
+    double gmax = 0.0;
+    for (int i = 0; i < n; i++) gmax = fmax(gmax, fabs(gf[i]));
+    const double df = gmax > SCALE_MAX_GRAD ? fmax(SCALE_MAX_GRAD / gmax, SCALE_MIN) : 1.0;
+    inf.df = df;
+    for (int i = 0; i < n; i++) { fl[i] = isfinite(lo[i]) ? 1 : 0; fh[i] = isfinite(hi[i]) ? 1 : 0; w[i] = push_in(w[i], lo[i], hi[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nb += fl[i] + fh[i]; }
+    /* least-squares equality multipliers: min |gf - zl + zh + J'y|  (null-space form: R y = -Q1'(gf - zl + zh)) */
+    if (m > 0 && m < n) {
+        evalf(ctx, w, lam, WANT_GRAD, &f, gf, g, J, H);
+        int ok = 1;
+        for (int i = 0; i < n; i++) { tmp[i] = df * gf[i] - zl[i] + zh[i]; ok = ok && isfinite(tmp[i]); for (int j = 0; j < m; j++) Jt[i * m + j] = J[j * n + i]; }
+        if (ok && qr_factor(n, m, Jt, tau)) {
+            qr_apply(n, m, Jt, tau, tmp, 1);
+            double ymax = 0.0;
+            for (int i = m - 1; i >= 0; i--) { double s = -tmp[i]; for (int k = i + 1; k < m; k++) s -= r_at(m, Jt, tau, i, k) * lamn[k]; lamn[i] = s / r_at(m, Jt, tau, i, i); }
+            for (int j = 0; j < m; j++) { ymax = fmax(ymax, fabs(lamn[j])); ok = ok && isfinite(lamn[j]); }
+            if (ok && ymax <= Y_INIT_MAX) memcpy(lam, lamn, sizeof(double) * m);
+        }
+    }
+    double mu = MU_INIT, tau_f = fmax(TAU_MIN, 1.0 - mu), delta_last = 0.0, theta_max = -1.0, theta_min = -1.0;
+    double filt_phi[FILTER_CAP], filt_th[FILTER_CAP];
+    int nfilt = 0, acc_count = 0, tiny_last = 0, tiny_flag = 0;
+    const double mu_min = fmin(tol, COMPL_INF_TOL) / (KAPPA_EPS + 1.0);
+    for (it = 0;; it++) {
+        for (int j = 0; j < m; j++) lams[j] = lam[j] / df;      /* Hessian of df f + lam'g = df (Hessian of f + (lam / df)'g) */
+        evalf(ctx, w, lams, WANT_HESS, &f, gf, g, J, H);
+        f *= df;
+        for (int i = 0; i < n; i++) gf[i] *= df;
+        for (size_t i = 0; i < (size_t)n * n; i++) H[i] *= df;
+        double e_st = 0.0, e_c = 0.0, s_l = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY, theta = 0.0;
+        int finite = isfinite(f);
+        for (int i = 0; i < n; i++) {
+            sl[i] = fl[i] ? safe_slack(w[i], &lo[i], zl[i], mu, 1) : 1.0; sh[i] = fh[i] ? safe_slack(w[i], &hi[i], zh[i], mu, 0) : 1.0;
+            double r = gf[i] - zl[i] + zh[i];
+            for (int j = 0; j < m; j++) r += J[j * n + i] * lam[j];
+            e_st = fmax(e_st, fabs(r)); s_z += zl[i] + zh[i];
+            finite = finite && isfinite(r) && isfinite(w[i]) && isfinite(gf[i]);
+            if (fl[i]) { cmax = fmax(cmax, sl[i] * zl[i]); cmin = fmin(cmin, sl[i] * zl[i]); }
+            if (fh[i]) { cmax = fmax(cmax, sh[i] * zh[i]); cmin = fmin(cmin, sh[i] * zh[i]); }
+        }
+        for (int j = 0; j < m; j++) { e_c = fmax(e_c, fabs(g[j])); theta += fabs(g[j]); s_l += fabs(lam[j]); finite = finite && isfinite(g[j]); }
+        if (!finite) { status = ST_FAILED; inf.stop = 6; break; }
+        const double s_d = fmax(S_MAX, (s_l + s_z) / fmax(m + nb, 1.0)) / S_MAX, s_c = fmax(S_MAX, s_z / fmax(nb, 1.0)) / S_MAX;
+#define COMPL(m_) (nb > 0 ? fmax(cmax - (m_), (m_) - cmin) : 0.0)
+#define ERR(m_) fmax(fmax(e_st / s_d, e_c), COMPL(m_) / s_c)
+        const double e0 = ERR(0.0), c0 = COMPL(0.0);
+        if (e0 <= tol && e_st <= DUAL_INF_TOL && e_c <= CONSTR_VIOL_TOL && c0 <= COMPL_INF_TOL) { status = ST_SOLVED; inf.stop = 0; break; }
+        if (e0 <= ACC_TOL && e_st <= ACC_DUAL_INF_TOL && e_c <= ACC_CONSTR_VIOL_TOL && c0 <= ACC_COMPL_INF_TOL) {
+            if (++acc_count >= ACC_ITER) { status = ST_SOLVED; inf.stop = 1; break; }
+        } else acc_count = 0;
+        if (it >= max_iter) break;
+        /* barrier parameter */
+        int mu_changed = 0, stop_tiny = 0;
+        while (ERR(mu) <= KAPPA_EPS * mu || tiny_flag) {
+            const double new_mu = fmax(fmin(KAPPA_MU * mu, pow(mu, THETA_MU)), mu_min);
+            if (new_mu == mu) { stop_tiny = tiny_flag; break; }
+            mu = new_mu; mu_changed = 1; tiny_flag = 0;
+        }
+#undef ERR
+#undef COMPL
+        if (stop_tiny) { status = ST_MAXITER; inf.stop = 3; break; }
+        tiny_flag = 0;
+        if (mu_changed) { nfilt = 0; tau_f = fmax(TAU_MIN, 1.0 - mu); }
+        /* search direction */
+        double phi = f, gbd = 0.0;
+        for (int i = 0; i < n; i++) {
+            const double il = fl[i] ? 1.0 / sl[i] : 0.0, ih = fh[i] ? 1.0 / sh[i] : 0.0;
+            const int ol = fl[i] && !fh[i], oh = fh[i] && !fl[i];
+            Sig[i] = zl[i] * il + zh[i] * ih; gphi[i] = gf[i] - mu * il + mu * ih + KAPPA_D * mu * ((ol ? 1.0 : 0.0) - (oh ? 1.0 : 0.0));
+            if (fl[i]) phi -= mu * log(sl[i]);
+            if (fh[i]) phi -= mu * log(sh[i]);
+            if (ol) phi += KAPPA_D * mu * sl[i];
+            if (oh) phi += KAPPA_D * mu * sh[i];
+        }
+        for (int i = 0; i < n; i++) for (int j = 0; j < m; j++) Jt[i * m + j] = J[j * n + i];
+        if (m > 0 && !qr_factor(n, m, Jt, tau)) { status = ST_FAILED; inf.stop = 7; break; }
+        double delta = 0.0;
+        int failed = 0;
+        for (;;) {
+            for (int c = 0; c < nz; c++) {
+                for (int i = 0; i < n; i++) Zc[i] = 0.0;
+                Zc[m + c] = 1.0;
+                if (m > 0) qr_apply(n, m, Jt, tau, Zc, 0);
+                for (int i = 0; i < n; i++) { double s = (Sig[i] + delta) * Zc[i]; for (int l = 0; l < n; l++) s += H[i * n + l] * Zc[l]; tmp[i] = s; }
+                if (m > 0) qr_apply(n, m, Jt, tau, tmp, 1);
+                for (int r = 0; r < nz; r++) HZ[r * nz + c] = tmp[m + r];
+            }
+            for (int r = 0; r < nz; r++) for (int c = 0; c < nz; c++) Hr[r * nz + c] = 0.5 * (HZ[r * nz + c] + HZ[c * nz + r]);
+            if (nz == 0 || cholesky(nz, Hr)) break;
+            delta = delta == 0.0 ? fmax(DELTA_FIRST, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
+            if (delta > DELTA_MAX) { failed = 1; break; }
+        }
+        if (failed) { status = ST_FAILED; inf.stop = 7; break; }
+        if (delta > 0.0) delta_last = delta;
+        S.delta = delta;
+        ns_direction(&S, g, dw, lamn);
+        double a_max = 1.0, dmaxrel = 0.0, dymax = 0.0;
+        for (int i = 0; i < n; i++) {
+            if (fl[i] && dw[i] < 0.0) a_max = fmin(a_max, -tau_f * sl[i] / dw[i]);
+            if (fh[i] && -dw[i] < 0.0) a_max = fmin(a_max, -tau_f * sh[i] / (-dw[i]));
+            gbd += gphi[i] * dw[i];
+            dmaxrel = fmax(dmaxrel, fabs(dw[i]) / (1.0 + fabs(w[i])));
+        }
+        for (int j = 0; j < m; j++) dymax = fmax(dymax, fabs(lamn[j] - lam[j]));
+        /* filter line search */
+        double a_min = GAMMA_THETA;
+        if (gbd < 0.0) {
+            a_min = fmin(GAMMA_THETA, GAMMA_PHI * theta / (-gbd));
+            if (theta <= theta_min) a_min = fmin(a_min, pow(theta, S_THETA) / pow(-gbd, S_PHI));
+        }
+        a_min *= ALPHA_MIN_FRAC;
+        if (theta_max < 0.0) { theta_max = THETA_MAX_FACT * fmax(1.0, theta); theta_min = THETA_MIN_FACT * fmax(1.0, theta); }
+        double theta_t = 0.0, phi_t = 0.0;
+        int ok_t = 0;
+#define TRIAL(alpha_, d_) do { \
+            for (int i_ = 0; i_ < n; i_++) { wt[i_] = w[i_] + (alpha_) * (d_)[i_]; lot[i_] = lo[i_]; hit[i_] = hi[i_]; } \
+            evalf(ctx, wt, lam, WANT_VALUES, &ft, gdum, gt, J, H); ft *= df; \
+            ok_t = isfinite(ft); theta_t = 0.0; phi_t = ft; \
+            for (int j_ = 0; j_ < m; j_++) { theta_t += fabs(gt[j_]); ok_t = ok_t && isfinite(gt[j_]); } \
+            for (int i_ = 0; i_ < n; i_++) { \
+                slt[i_] = fl[i_] ? safe_slack(wt[i_], &lot[i_], zl[i_], mu, 1) : 1.0; sht[i_] = fh[i_] ? safe_slack(wt[i_], &hit[i_], zh[i_], mu, 0) : 1.0; \
+                if (fl[i_]) phi_t -= mu * log(slt[i_]); \
+                if (fh[i_]) phi_t -= mu * log(sht[i_]); \
+                if (fl[i_] && !fh[i_]) phi_t += KAPPA_D * mu * slt[i_]; \
+                if (fh[i_] && !fl[i_]) phi_t += KAPPA_D * mu * sht[i_]; \
+            } \
+            if (!ok_t) { theta_t = INFINITY; phi_t = INFINITY; } \
+        } while (0)
+#define FTYPE(alpha_) ((theta == 0.0 && gbd > 0.0 && gbd < 100.0 * ORC_EPS) || (gbd < 0.0 && (alpha_) * pow(-gbd, S_PHI) > pow(theta, S_THETA)))
+#define ARMIJO(alpha_) orc_le(phi_t - phi, ETA_PHI * (alpha_) * gbd, phi)
+        int accepted = 0, soc_taken = 0;
+        double alpha = a_max, a_soc = a_max;
+        int tiny = dmaxrel < TINY_STEP_TOL && theta <= 1e-4;
+        if (tiny) {
+            TRIAL(a_max, dw);
+            if (ok_t) { accepted = 1; inf.tiny++; tiny_flag = tiny_last; tiny_last = dymax < TINY_STEP_Y_TOL; }
+            else tiny = 0;
+        }
+        if (!tiny) {
+            tiny_last = 0;
+            int n_steps = 0;
+            while (alpha > a_min || n_steps == 0) {
+                TRIAL(alpha, dw);
+                int acc = 0;
+                for (int pass = 0; pass < 1; pass++) {      /* acceptable(alpha, theta_t, phi_t) */
+                    if (!ok_t || theta_t > theta_max) break;
+                    int ok;
+                    if (alpha > 0.0 && FTYPE(alpha) && theta <= theta_min) ok = ARMIJO(alpha);
+                    else {
+                        if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > OBJ_MAX_INC + bas) break; }
+                        ok = orc_le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) || orc_le(phi_t - phi, -GAMMA_PHI * theta, phi);
+                    }
+                    if (!ok) break;
+                    int dominated = 0;
+                    for (int e = 0; e < nfilt; e++) if (orc_le(filt_phi[e], phi_t, filt_phi[e]) && orc_le(filt_th[e], theta_t, filt_th[e])) dominated = 1;
+                    acc = !dominated;
+                }
+                if (acc) { accepted = 1; break; }
+                if (ok_t && n_steps == 0 && theta <= theta_t) {      /* second-order correction */
+                    memcpy(csoc, g, sizeof(double) * m);
+                    memcpy(ctr, gt, sizeof(double) * m);
+                    double theta_old = 0.0, th_s = theta_t;
+                    int cnt = 0;
+                    a_soc = alpha;
+                    while (cnt < MAX_SOC && !accepted && (cnt == 0 || th_s <= KAPPA_SOC * theta_old)) {
+                        theta_old = th_s;
+                        for (int j = 0; j < m; j++) csoc[j] = a_soc * csoc[j] + ctr[j];
+                        ns_direction(&S, csoc, ds, lamsoc);
+                        a_soc = 1.0;
+                        for (int i = 0; i < n; i++) {
+                            if (fl[i] && ds[i] < 0.0) a_soc = fmin(a_soc, -tau_f * sl[i] / ds[i]);
+                            if (fh[i] && -ds[i] < 0.0) a_soc = fmin(a_soc, -tau_f * sh[i] / (-ds[i]));
+                        }
+                        TRIAL(a_soc, ds);
+                        inf.soc++;
+                        int acs = 0;
+                        for (int pass = 0; pass < 1; pass++) {      /* acceptable(alpha, ...): the tests keep the original step length */
+                            if (!ok_t || theta_t > theta_max) break;
+                            int ok;
+                            if (alpha > 0.0 && FTYPE(alpha) && theta <= theta_min) ok = ARMIJO(alpha);
+                            else {
+                                if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > OBJ_MAX_INC + bas) break; }
+                                ok = orc_le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) || orc_le(phi_t - phi, -GAMMA_PHI * theta, phi);
+                            }
+                            if (!ok) break;
+                            int dominated = 0;
+                            for (int e = 0; e < nfilt; e++) if (orc_le(filt_phi[e], phi_t, filt_phi[e]) && orc_le(filt_th[e], theta_t, filt_th[e])) dominated = 1;
+                            acs = !dominated;
+                        }
+                        if (acs) { accepted = 1; soc_taken = 1; }
+                        else { cnt++; th_s = theta_t; memcpy(ctr, gt, sizeof(double) * m); if (!ok_t) break; }
+                    }
+                    if (accepted) break;
+                }
+                alpha *= 0.5;
+                n_steps++;
+            }
+            inf.ls_steps += n_steps;
+            if (!accepted) {      /* IPOPT enters its restoration phase here (not restated) */
+                if (theta <= 1e-2 * tol) { status = ST_MAXITER; inf.stop = 4; } else { status = ST_FAILED; inf.stop = 5; }
+                break;
+            }
+            if (!FTYPE(alpha) || !ARMIJO(alpha)) {      /* the filter grows unless the step was an Armijo step on the barrier function */
+                const double e_phi = phi - GAMMA_PHI * theta, e_th = (1.0 - GAMMA_THETA) * theta;
+                int k2 = 0;
+                for (int e = 0; e < nfilt; e++) if (!(filt_phi[e] >= e_phi && filt_th[e] >= e_th)) { filt_phi[k2] = filt_phi[e]; filt_th[k2] = filt_th[e]; k2++; }
+                nfilt = k2;
+                if (nfilt >= FILTER_CAP) { filt_phi[nfilt - 1] = fmin(filt_phi[nfilt - 1], e_phi); filt_th[nfilt - 1] = fmin(filt_th[nfilt - 1], e_th); }
+                else { filt_phi[nfilt] = e_phi; filt_th[nfilt] = e_th; nfilt++; }
+                if (nfilt > inf.filter_max) inf.filter_max = nfilt;
+            }
+        }
+#undef TRIAL
+#undef FTYPE
+#undef ARMIJO
+        /* the accepted point (wt, slt, sht, lot, hit): multiplier steps of the direction that was taken */
+        const double *dacc = soc_taken ? ds : dw, *lacc = soc_taken ? lamsoc : lamn;
+        const double a_pr = soc_taken ? a_soc : alpha;
+        double adu = 1.0;
+        for (int i = 0; i < n; i++) {
+            const double dzl = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * dacc[i] : 0.0, dzh = fh[i] ? mu / sh[i] - zh[i] + zh[i] / sh[i] * dacc[i] : 0.0;
+            if (fl[i] && dzl < 0.0) adu = fmin(adu, -tau_f * zl[i] / dzl);
+            if (fh[i] && dzh < 0.0) adu = fmin(adu, -tau_f * zh[i] / dzh);
+            Sig[i] = dzl; gphi[i] = dzh;      /* (reused as storage) */
+        }
+        for (int i = 0; i < n; i++) {
+            w[i] = wt[i]; lo[i] = lot[i]; hi[i] = hit[i];
+            zl[i] += adu * Sig[i]; zh[i] += adu * gphi[i];
+            if (fl[i]) zl[i] = fmin(fmax(zl[i], mu / (KAPPA_SIGMA * slt[i])), KAPPA_SIGMA * mu / slt[i]);
+            if (fh[i]) zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * sht[i])), KAPPA_SIGMA * mu / sht[i]);
+        }
+        for (int j = 0; j < m; j++) lam[j] += a_pr * (lacc[j] - lam[j]);
+    }
+    *iters = it;
+    if (lam_out) for (int j = 0; j < m; j++) lam_out[j] = lam[j] / df;
+    if (info) *info = inf;
     arena_release(mark_);
     return status;
 }
