@@ -726,6 +726,316 @@ __device__ __forceinline__ bool gj_inverse(const double (&a_in)[n][n], double (&
     return ok;
 }
 
+constexpr double kRestoRho = 1000.0, kRestoKappa = 0.9, kRestoThetaMaxFact = 1e8, kRestoBoundMultReset = 1e3, kRestoFeasFact = 1e2;
+enum : int { kRsRestored = 0, kRsConverged = 1, kRsLimit = 2, kRsFailed = 3 };
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// IPOPT's restoration phase for the target problem (oracle/enmpc_oracle.py:_restore; [WB 3.3]): the same interior point iteration on
+//     min  rho sum(n + p) + sqrt(mu) / 2 |D_R (x - x_R)|^2   s.t.  c(x) + n - p = 0,  lo <= x <= hi,  n, p >= 0
+// from x_R, until orig_ok(x) - the point is enough less infeasible and acceptable to the filter and the iterate of the solve that called.
+// n and p are eliminated from the Newton system: (H + Sigma_x + J' Dc^-1 J) dx = ..., Dc = 1 / Sigma_n + 1 / Sigma_p, whose positive definiteness is
+// the inertia condition of the full system.  One instance per lane.  x: x_R in, the restored point out; lo / hi: the caller's (moved) bounds, moved on.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <class M, class OrigOk>
+__device__ __forceinline__ int target_resto(double (&x)[M::NX + M::NU + M::NY], double (&lo)[M::NX + M::NU + M::NY], double (&hi)[M::NX + M::NU + M::NY],
+                                            const double (&zl_o)[M::NX + M::NU + M::NY], const double (&zh_o)[M::NX + M::NU + M::NY], const double mu_o, const double (&c_r)[M::NX + M::NY],
+                                            const double *d, const double (*Bd)[M::ND > 0 ? M::ND : 1], const double (*Cd)[M::ND > 0 ? M::ND : 1], double t, double h,
+                                            const double tol, const int max_iter, int &it, OrigOk orig_ok)
+{
+    constexpr int NX = M::NX, NU = M::NU, NY = M::NY, ND = M::ND, NV = NX + NU + NY, NP = NX + NU, NPP = NP * (NP + 1) / 2, MC = NX + NY;
+    bool fl[NV], fh[NV];
+    double xr[NV], dr2[NV], zl[NV], zh[NV], dmp[NV], nn[MC], pp[MC], zn[MC], zp[MC], nlo[MC], plo[MC], lam[MC];
+    int nbi = 2 * MC;
+    double mu = mu_o;
+    MPC_UNROLL for (int j = 0; j < MC; j++) mu = dmax(mu, fabs(c_r[j]));
+    MPC_UNROLL for (int i = 0; i < NV; i++) {
+        xr[i] = x[i]; const double dd = 1.0 / dmax(1.0, fabs(x[i])); dr2[i] = dd * dd;
+        fl[i] = fin(lo[i]); fh[i] = fin(hi[i]); nbi += (fl[i] ? 1 : 0) + (fh[i] ? 1 : 0);
+        zl[i] = fl[i] ? dmin(kRestoRho, zl_o[i]) : 0.0; zh[i] = fh[i] ? dmin(kRestoRho, zh_o[i]) : 0.0;
+        dmp[i] = (fl[i] && !fh[i]) ? 1.0 : ((fh[i] && !fl[i]) ? -1.0 : 0.0);
+    }
+    MPC_UNROLL for (int j = 0; j < MC; j++) {
+        const double a = mu / (2.0 * kRestoRho) - 0.5 * c_r[j];
+        nn[j] = a + sqrt(a * a + mu * c_r[j] / (2.0 * kRestoRho)); pp[j] = c_r[j] + nn[j];
+        zn[j] = mu / nn[j]; zp[j] = mu / pp[j]; nlo[j] = 0.0; plo[j] = 0.0; lam[j] = 0.0;
+    }
+    const double nb = (double)nbi, meq = (double)MC;
+    const double mu_min = dmin(tol, kComplInfTol) / (kKappaEps + 1.0);
+    double tau = dmax(kTauMin, 1.0 - mu), delta_last = 0.0, theta_max = -1.0, theta_min = -1.0;
+    double filt[2 * kFilterCap];
+    int nfilt = 0, acc_count = 0, status = kRsLimit;
+    bool tiny_last = false, tiny_flag = false;
+    // constraint values at a point: c(x) + n - p
+    auto cons = [&](const double (&w)[NV], const double (&n_)[MC], const double (&p_)[MC], double (&cb)[MC]) {
+        typename M::Ctx cx;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { cx.u[i] = w[NX + i]; cx.us[i] = 0.0; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) cx.d[i] = d[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) cx.xs[i] = 0.0;
+        double Fx[NX];
+        rk4_plain<typename M::Mdl>(w, cx, t, true, h, M::MX, Fx);
+        MPC_UNROLL for (int i = 0; i < NX; i++) { double a = Fx[i] - w[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Bd[i][j] * d[j]; cb[i] = a + n_[i] - p_[i]; }
+        MPC_UNROLL for (int i = 0; i < NY; i++) { double a = w[i] - w[NX + NU + i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Cd[i][j] * d[j]; cb[NX + i] = a + n_[NX + i] - p_[NX + i]; }
+    };
+    auto objective = [&](const double (&w)[NV], const double (&n_)[MC], const double (&p_)[MC], double mu_) {
+        double s_ = 0.0, q_ = 0.0;
+        MPC_UNROLL for (int j = 0; j < MC; j++) s_ += n_[j] + p_[j];
+        MPC_UNROLL for (int i = 0; i < NV; i++) { const double e = w[i] - xr[i]; q_ += dr2[i] * e * e; }
+        return kRestoRho * s_ + 0.5 * sqrt(mu_) * q_;
+    };
+    auto barrier = [&](const double (&w)[NV], const double (&n_)[MC], const double (&p_)[MC], double f_, double mu_) {      // with the safe slacks of a trial point
+        double ph = f_;
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            double bl_ = lo[i], bh_ = hi[i];
+            const double s1 = fl[i] ? safe_slack(w[i], bl_, zl[i], mu_, true) : 1.0, s2 = fh[i] ? safe_slack(w[i], bh_, zh[i], mu_, false) : 1.0;
+            if (fl[i]) ph -= mu_ * log(s1);
+            if (fh[i]) ph -= mu_ * log(s2);
+            if (dmp[i] != 0.0) ph += kKappaD * mu_ * (dmp[i] > 0.0 ? s1 : s2);
+        }
+        MPC_UNROLL for (int j = 0; j < MC; j++) {
+            double b1 = nlo[j], b2 = plo[j];
+            const double s1 = safe_slack(n_[j], b1, zn[j], mu_, true), s2 = safe_slack(p_[j], b2, zp[j], mu_, true);
+            ph += -mu_ * log(s1) - mu_ * log(s2) + kKappaD * mu_ * (s1 + s2);
+        }
+        return ph;
+    };
+    for (;;) {
+        typename M::Ctx cx;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { cx.u[i] = x[NX + i]; cx.us[i] = 0.0; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) cx.d[i] = d[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) cx.xs[i] = 0.0;
+        double Fx[NX], S[NX][NP], T[NX][NPP];
+        rk4_sens2<typename M::Mdl>(x, cx, t, true, h, M::MX, Fx, S, T);
+        // Jacobian of the constraints with respect to x: rows of c1 = [S_x - I, S_u, 0], rows of c2 = [I, 0, -I]
+        double J[MC][NV], cb[MC];
+        MPC_UNROLL for (int i = 0; i < NX; i++) {
+            double a = Fx[i] - x[i];
+            MPC_UNROLL for (int j = 0; j < ND; j++) a += Bd[i][j] * d[j];
+            cb[i] = a + nn[i] - pp[i];
+            MPC_UNROLL for (int j = 0; j < NV; j++) J[i][j] = j < NP ? S[i][j < NP ? j : 0] - (i == j ? 1.0 : 0.0) : 0.0;
+        }
+        MPC_UNROLL for (int i = 0; i < NY; i++) {
+            double a = x[i] - x[NX + NU + i];
+            MPC_UNROLL for (int j = 0; j < ND; j++) a += Cd[i][j] * d[j];
+            cb[NX + i] = a + nn[NX + i] - pp[NX + i];
+            MPC_UNROLL for (int j = 0; j < NV; j++) J[NX + i][j] = (j == i) ? 1.0 : ((j == NP + i) ? -1.0 : 0.0);
+        }
+        double eta = sqrt(mu), f = objective(x, nn, pp, mu);
+        double sl[NV], sh[NV], sn[MC], sp[MC];
+        double e_st = 0.0, e_c = 0.0, s_l = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY, theta = 0.0;
+        bool finite = finite_all(f);
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            sl[i] = fl[i] ? safe_slack(x[i], lo[i], zl[i], mu, true) : 1.0; sh[i] = fh[i] ? safe_slack(x[i], hi[i], zh[i], mu, false) : 1.0;
+            double r = eta * dr2[i] * (x[i] - xr[i]) - zl[i] + zh[i];
+            MPC_UNROLL for (int j = 0; j < MC; j++) r += J[j][i] * lam[j];
+            e_st = dmax(e_st, fabs(r)); s_z += zl[i] + zh[i];
+            finite = finite && finite_all(r) && finite_all(x[i]);
+            if (fl[i]) { cmax = dmax(cmax, sl[i] * zl[i]); cmin = dmin(cmin, sl[i] * zl[i]); }
+            if (fh[i]) { cmax = dmax(cmax, sh[i] * zh[i]); cmin = dmin(cmin, sh[i] * zh[i]); }
+        }
+        MPC_UNROLL for (int j = 0; j < MC; j++) {
+            sn[j] = safe_slack(nn[j], nlo[j], zn[j], mu, true); sp[j] = safe_slack(pp[j], plo[j], zp[j], mu, true);
+            const double rn = kRestoRho + lam[j] - zn[j], rp = kRestoRho - lam[j] - zp[j];
+            e_st = dmax(e_st, dmax(fabs(rn), fabs(rp))); s_z += zn[j] + zp[j]; s_l += fabs(lam[j]);
+            e_c = dmax(e_c, fabs(cb[j])); theta += fabs(cb[j]);
+            finite = finite && finite_all(rn) && finite_all(rp) && finite_all(cb[j]) && finite_all(nn[j]) && finite_all(pp[j]);
+            cmax = dmax(cmax, dmax(sn[j] * zn[j], sp[j] * zp[j])); cmin = dmin(cmin, dmin(sn[j] * zn[j], sp[j] * zp[j]));
+        }
+        if (!finite) { status = kRsFailed; break; }
+        if (orig_ok(x)) { status = kRsRestored; break; }
+        const double s_d = dmax(kSMax, (s_l + s_z) / dmax(meq + nb, 1.0)) / kSMax, s_c = dmax(kSMax, s_z / dmax(nb, 1.0)) / kSMax;
+        auto compl_ = [&](double m_) { return dmax(cmax - m_, m_ - cmin); };
+        auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
+        {
+            const double e0_ = err(0.0), c0_ = compl_(0.0);
+            if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = kRsConverged; break; }
+            if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = kRsConverged; break; } }
+            else acc_count = 0;
+        }
+        if (it >= max_iter) { status = kRsLimit; break; }
+        {
+            bool mu_changed = false, stop_tiny = false;
+            while (err(mu) <= kKappaEps * mu || tiny_flag) {
+                const double new_mu = dmax(dmin(kKappaMu * mu, mu * sqrt(mu)), mu_min);
+                if (new_mu == mu) { stop_tiny = tiny_flag; break; }
+                mu = new_mu; mu_changed = true; tiny_flag = false;
+            }
+            if (stop_tiny) { status = kRsConverged; break; }
+            tiny_flag = false;
+            if (mu_changed) { nfilt = 0; tau = dmax(kTauMin, 1.0 - mu); eta = sqrt(mu); f = objective(x, nn, pp, mu); }      // (the objective changes with mu)
+        }
+        // gradient of the barrier function, diagonal terms, barrier function
+        double Sg[NV], gx[NV], Sn[MC], Sp[MC], gn[MC], gp[MC];
+        double phi = f;
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            const double il = fl[i] ? 1.0 / sl[i] : 0.0, ih = fh[i] ? 1.0 / sh[i] : 0.0;
+            Sg[i] = zl[i] * il + zh[i] * ih; gx[i] = eta * dr2[i] * (x[i] - xr[i]) - mu * il + mu * ih + kKappaD * mu * dmp[i];
+            if (fl[i]) phi -= mu * log(sl[i]);
+            if (fh[i]) phi -= mu * log(sh[i]);
+            if (dmp[i] != 0.0) phi += kKappaD * mu * (dmp[i] > 0.0 ? sl[i] : sh[i]);
+        }
+        MPC_UNROLL for (int j = 0; j < MC; j++) {
+            Sn[j] = zn[j] / sn[j]; Sp[j] = zp[j] / sp[j];
+            gn[j] = kRestoRho + kKappaD * mu - mu / sn[j]; gp[j] = kRestoRho + kKappaD * mu - mu / sp[j];
+            phi += -mu * log(sn[j]) - mu * log(sp[j]) + kKappaD * mu * (sn[j] + sp[j]);
+        }
+        // Hessian of lam' c with respect to x (only the model's rows are non-linear) + the proximity term
+        double H[NV][NV];
+        MPC_UNROLL for (int i = 0; i < NV; i++) { MPC_UNROLL for (int j = 0; j < NV; j++) H[i][j] = (i == j) ? eta * dr2[i] : 0.0; }
+        MPC_UNROLL for (int a = 0; a < NP; a++) { MPC_UNROLL for (int b = 0; b < NP; b++) { double s_ = 0.0; MPC_UNROLL for (int i = 0; i < NX; i++) s_ += lam[i] * T[i][pair_idx<NP>(a, b)]; H[a][b] += s_; } }
+        double Ai[NV][NV], Dci[MC];
+        double delta = 0.0;
+        bool failed = false;
+        for (;;) {
+            MPC_UNROLL for (int j = 0; j < MC; j++) Dci[j] = 1.0 / (1.0 / (Sn[j] + delta) + 1.0 / (Sp[j] + delta));
+            MPC_UNROLL for (int i = 0; i < NV; i++) { MPC_UNROLL for (int l = 0; l <= i; l++) {
+                double a = H[i][l] + (i == l ? Sg[i] + delta : 0.0);
+                MPC_UNROLL for (int j = 0; j < MC; j++) a += J[j][i] * Dci[j] * J[j][l];
+                Ai[i][l] = a; Ai[l][i] = a; } }
+            if (sym_inverse<NV>(Ai)) break;
+            delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
+            if (delta > kDeltaMax) { failed = true; break; }
+        }
+        if (failed) { status = kRsFailed; break; }
+        if (delta > 0.0) delta_last = delta;
+        // Newton step for a constraint residual cc: dx, dn, dp and the new multipliers
+        auto direction = [&](const double (&cc)[MC], double (&dx)[NV], double (&dn)[MC], double (&dp)[MC], double (&yn)[MC]) {
+            double rc[MC], rhs[NV];
+            MPC_UNROLL for (int j = 0; j < MC; j++) rc[j] = cc[j] - gn[j] / (Sn[j] + delta) + gp[j] / (Sp[j] + delta);
+            MPC_UNROLL for (int i = 0; i < NV; i++) { double a = -gx[i]; MPC_UNROLL for (int j = 0; j < MC; j++) a -= J[j][i] * Dci[j] * rc[j]; rhs[i] = a; }
+            MPC_UNROLL for (int i = 0; i < NV; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NV; l++) a += Ai[i][l] * rhs[l]; dx[i] = a; }
+            MPC_UNROLL for (int j = 0; j < MC; j++) {
+                double a = rc[j];
+                MPC_UNROLL for (int i = 0; i < NV; i++) a += J[j][i] * dx[i];
+                yn[j] = Dci[j] * a;
+                dn[j] = -(gn[j] + yn[j]) / (Sn[j] + delta); dp[j] = (yn[j] - gp[j]) / (Sp[j] + delta);
+            }
+        };
+        auto ratio = [&](double a, double vv, double dvv) { return dvv < 0.0 ? dmin(a, -tau * vv / dvv) : a; };
+        auto max_step = [&](const double (&dx_)[NV], const double (&dn_)[MC], const double (&dp_)[MC]) {
+            double a = 1.0;
+            MPC_UNROLL for (int i = 0; i < NV; i++) { if (fl[i]) a = ratio(a, sl[i], dx_[i]); if (fh[i]) a = ratio(a, sh[i], -dx_[i]); }
+            MPC_UNROLL for (int j = 0; j < MC; j++) { a = ratio(a, sn[j], dn_[j]); a = ratio(a, sp[j], dp_[j]); }
+            return a;
+        };
+        double dx[NV], dn[MC], dp[MC], yn[MC];
+        direction(cb, dx, dn, dp, yn);
+        const double a_max = max_step(dx, dn, dp);
+        double gbd = 0.0, drel = 0.0, dym = 0.0;
+        MPC_UNROLL for (int i = 0; i < NV; i++) { gbd += gx[i] * dx[i]; drel = dmax(drel, fabs(dx[i]) / (1.0 + fabs(x[i]))); }
+        MPC_UNROLL for (int j = 0; j < MC; j++) {
+            gbd += gn[j] * dn[j] + gp[j] * dp[j];
+            drel = dmax(drel, dmax(fabs(dn[j]) / (1.0 + fabs(nn[j])), fabs(dp[j]) / (1.0 + fabs(pp[j])))); dym = dmax(dym, fabs(yn[j] - lam[j]));
+        }
+        double a_min = kGammaTheta;
+        if (gbd < 0.0) {
+            a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
+            if (theta <= theta_min) a_min = dmin(a_min, pow(theta, kSTheta) / pow(-gbd, kSPhi));
+        }
+        a_min *= kAlphaMinFrac;
+        if (theta_max < 0.0) { theta_max = kRestoThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
+        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
+        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
+        double xt[NV], nt[MC], pt[MC], ct[MC], theta_t = 0.0, phi_t = 0.0;
+        bool ok_t = false;
+        auto trial = [&](double a_, const double (&dx_)[NV], const double (&dn_)[MC], const double (&dp_)[MC]) {
+            MPC_UNROLL for (int i = 0; i < NV; i++) xt[i] = x[i] + a_ * dx_[i];
+            MPC_UNROLL for (int j = 0; j < MC; j++) { nt[j] = nn[j] + a_ * dn_[j]; pt[j] = pp[j] + a_ * dp_[j]; }
+            cons(xt, nt, pt, ct);
+            const double ft = objective(xt, nt, pt, mu);
+            ok_t = finite_all(ft); theta_t = 0.0;
+            MPC_UNROLL for (int j = 0; j < MC; j++) { theta_t += fabs(ct[j]); ok_t = ok_t && finite_all(ct[j]); }
+            phi_t = barrier(xt, nt, pt, ft, mu);
+            if (!ok_t || !finite_all(phi_t)) { ok_t = false; theta_t = INFINITY; phi_t = INFINITY; }
+        };
+        auto acceptable = [&](double alpha_) {
+            if (!ok_t || theta_t > theta_max) return false;
+            bool ok_;
+            if (alpha_ > 0.0 && ftype(alpha_) && theta <= theta_min) ok_ = le_tol(phi_t - phi, kEtaPhi * alpha_ * gbd, phi);
+            else {
+                if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > kObjMaxInc + bas) return false; }
+                ok_ = le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi);
+            }
+            return ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
+        };
+        bool accepted = false, soc_taken = false;
+        double alpha = a_max, a_soc = a_max;
+        double dsx[NV], dsn[MC], dsp[MC], ys[MC];
+        bool tiny = drel < kTinyStepTol && theta <= 1e-4;
+        if (tiny) {
+            trial(a_max, dx, dn, dp);
+            if (ok_t) { accepted = true; tiny_flag = tiny_last; tiny_last = dym < kTinyStepYTol; }
+            else tiny = false;
+        }
+        if (!tiny) {
+            tiny_last = false;
+            int n_steps = 0;
+            while (alpha > a_min || n_steps == 0) {
+                trial(alpha, dx, dn, dp);
+                if (acceptable(alpha)) { accepted = true; break; }
+                if (ok_t && n_steps == 0 && theta <= theta_t) {      // second-order correction
+                    double cs[MC], theta_old = 0.0, th_s = theta_t;
+                    MPC_UNROLL for (int j = 0; j < MC; j++) cs[j] = cb[j];
+                    int cnt = 0;
+                    a_soc = alpha;
+                    while (cnt < kMaxSoc && !accepted && (cnt == 0 || th_s <= kKappaSoc * theta_old)) {
+                        theta_old = th_s;
+                        MPC_UNROLL for (int j = 0; j < MC; j++) cs[j] = a_soc * cs[j] + ct[j];
+                        direction(cs, dsx, dsn, dsp, ys);
+                        a_soc = max_step(dsx, dsn, dsp);
+                        trial(a_soc, dsx, dsn, dsp);
+                        if (acceptable(alpha)) { accepted = true; soc_taken = true; }
+                        else { cnt++; th_s = theta_t; if (!ok_t) break; }
+                    }
+                    if (accepted) break;
+                }
+                alpha *= 0.5;
+                n_steps++;
+            }
+            if (!accepted) { status = kRsFailed; break; }      // (no restoration inside the restoration phase: 'Restoration_Failed')
+            if (!ftype(alpha) || !le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi)) {
+                const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
+                int k2 = 0;
+                for (int e = 0; e < kFilterCap; e++) { if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } } }
+                if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
+                else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
+                nfilt = k2;
+            }
+        }
+        // the accepted point: multiplier steps of the direction that was taken
+        const double a_pr = soc_taken ? a_soc : alpha;
+        double adu = 1.0, dzl[NV], dzh[NV], dzn[MC], dzp[MC];
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            const double d_ = soc_taken ? dsx[i] : dx[i];
+            dzl[i] = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * d_ : 0.0;
+            dzh[i] = fh[i] ? mu / sh[i] - zh[i] + zh[i] / sh[i] * d_ : 0.0;
+            if (fl[i]) adu = ratio(adu, zl[i], dzl[i]);
+            if (fh[i]) adu = ratio(adu, zh[i], dzh[i]);
+        }
+        MPC_UNROLL for (int j = 0; j < MC; j++) {
+            dzn[j] = mu / sn[j] - zn[j] - zn[j] / sn[j] * (soc_taken ? dsn[j] : dn[j]);
+            dzp[j] = mu / sp[j] - zp[j] - zp[j] / sp[j] * (soc_taken ? dsp[j] : dp[j]);
+            adu = ratio(adu, zn[j], dzn[j]); adu = ratio(adu, zp[j], dzp[j]);
+        }
+        auto clampz = [&](double z, double s_) { return dmin(dmax(z, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_); };
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            x[i] = xt[i];
+            const double s1 = fl[i] ? safe_slack(x[i], lo[i], zl[i], mu, true) : 1.0, s2 = fh[i] ? safe_slack(x[i], hi[i], zh[i], mu, false) : 1.0;
+            zl[i] += adu * dzl[i]; zh[i] += adu * dzh[i];
+            if (fl[i]) zl[i] = clampz(zl[i], s1);
+            if (fh[i]) zh[i] = clampz(zh[i], s2);
+        }
+        MPC_UNROLL for (int j = 0; j < MC; j++) {
+            nn[j] = nt[j]; pp[j] = pt[j];
+            const double s1 = safe_slack(nn[j], nlo[j], zn[j], mu, true), s2 = safe_slack(pp[j], plo[j], zp[j], mu, true);
+            zn[j] += adu * dzn[j]; zp[j] += adu * dzp[j];
+            zn[j] = clampz(zn[j], s1); zp[j] = clampz(zp[j], s2);
+            lam[j] += a_pr * ((soc_taken ? ys[j] : yn[j]) - lam[j]);
+        }
+        it++;
+    }
+    return status;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Target: min fss(xs, us, ys)  s.t.  Fx_model(xs, us, d) - xs = 0,  xs + Cd d - ys = 0,  boxes   (Target_Calc.py:20-161 with
 // StateFeedback outputs).  The same algorithm as ipm_stage (oracle/enmpc_oracle.py:ipm_dense); the Newton system is reduced to the nu inputs:
@@ -995,15 +1305,67 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
                 alpha *= 0.5;
                 n_steps++;
             }
-            if (!accepted) { status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; break; }      // IPOPT enters its restoration phase here (not restated)
-            if (!ftype(alpha) || !le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi)) {
+            auto augment = [&]() {      // the filter grows by the current point (entries it dominates are dropped)
                 const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
                 int k2 = 0;
                 for (int e = 0; e < kFilterCap; e++) { if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } } }
                 if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
                 else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
                 nfilt = k2;
+            };
+            if (!accepted) {
+                // ---- IPOPT's restoration phase ---------------------------------------------------------------------------------------------------
+                if (theta <= 1e-2 * tol) { status = kStMaxIter; break; }      // 'Restoration_Failed' at a feasible point: the reference accepts the point
+                augment();                                                    // the point the restoration starts from is never returned to
+                auto orig_ok = [&](const double (&x_)[NV]) {      // enough less infeasible, acceptable to the filter and to the point left
+                    double f_, a1[NX], a2[NY], th_t = 0.0;
+                    values(x_, f_, a1, a2);
+                    bool ok_ = finite_all(f_);
+                    MPC_UNROLL for (int i = 0; i < NX; i++) { th_t += fabs(a1[i]); ok_ = ok_ && finite_all(a1[i]); }
+                    MPC_UNROLL for (int i = 0; i < NY; i++) { th_t += fabs(a2[i]); ok_ = ok_ && finite_all(a2[i]); }
+                    if (!ok_ || th_t > kRestoKappa * theta) return false;
+                    const double ph_t = barrier(x_, f_, mu);
+                    return !filter_rejects(filt, nfilt, ph_t, th_t) && (le_tol(th_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(ph_t - phi, -kGammaPhi * theta, phi));
+                };
+                double xr_[NV], cr_[NX + NY];
+                MPC_UNROLL for (int i = 0; i < NV; i++) xr_[i] = v[i];
+                MPC_UNROLL for (int i = 0; i < NX; i++) cr_[i] = c1[i];
+                MPC_UNROLL for (int i = 0; i < NY; i++) cr_[NX + i] = c2[i];
+                int it_r = it + 1;
+                const int rs = target_resto<M>(xr_, lo, hi, zl, zh, mu, cr_, d, Bd, Cd, t, h, tol, max_iter, it_r, orig_ok);
+                it = it_r - 1; iters = it;
+                if (rs != kRsRestored) {
+                    if (rs == kRsLimit) status = kStMaxIter;
+                    else if (rs == kRsConverged) {      // the restoration problem has a minimiser here: infeasible, or feasible and not acceptable
+                        double f_, a1[NX], a2[NY], cm = 0.0;
+                        values(xr_, f_, a1, a2);
+                        MPC_UNROLL for (int i = 0; i < NX; i++) cm = dmax(cm, fabs(a1[i]));
+                        MPC_UNROLL for (int i = 0; i < NY; i++) cm = dmax(cm, fabs(a2[i]));
+                        status = cm <= kRestoFeasFact * tol ? kStMaxIter : kStFailed;
+                    } else status = kStMaxIter;      // 'Restoration_Failed': the reference accepts the point
+                    break;
+                }
+                // back from the restoration: bound multipliers as if the whole move had been one Newton step, reset to 1 beyond 1e3; equality multipliers zero
+                double adu_ = 1.0, zmax = 0.0, dzl_[NV], dzh_[NV], st1[NV], st2[NV];
+                MPC_UNROLL for (int i = 0; i < NV; i++) {
+                    st1[i] = fl[i] ? safe_slack(xr_[i], lo[i], zl[i], mu, true) : 1.0; st2[i] = fh[i] ? safe_slack(xr_[i], hi[i], zh[i], mu, false) : 1.0;
+                    dzl_[i] = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * (st1[i] - sl[i]) : 0.0;
+                    dzh_[i] = fh[i] ? mu / sh[i] - zh[i] - zh[i] / sh[i] * (st2[i] - sh[i]) : 0.0;
+                    if (fl[i]) adu_ = ratio(adu_, zl[i], dzl_[i]);
+                    if (fh[i]) adu_ = ratio(adu_, zh[i], dzh_[i]);
+                }
+                MPC_UNROLL for (int i = 0; i < NV; i++) { zl[i] += adu_ * dzl_[i]; zh[i] += adu_ * dzh_[i]; zmax = dmax(zmax, dmax(zl[i], zh[i])); }
+                MPC_UNROLL for (int i = 0; i < NV; i++) {
+                    if (zmax > kRestoBoundMultReset) { zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; }
+                    v[i] = xr_[i];
+                    if (fl[i]) zl[i] = dmin(dmax(zl[i], mu / (kKappaSigma * st1[i])), kKappaSigma * mu / st1[i]);
+                    if (fh[i]) zh[i] = dmin(dmax(zh[i], mu / (kKappaSigma * st2[i])), kKappaSigma * mu / st2[i]);
+                }
+                MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] = 0.0;
+                MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] = 0.0;
+                continue;      // (the loop's increment counts the restoration's return as an iteration)
             }
+            if (!ftype(alpha) || !le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi)) augment();
         }
         // the accepted point vt: multiplier steps of the direction that was taken
         const double a_pr = soc_taken ? a_soc : alpha;

@@ -165,7 +165,7 @@ static int ocp_solve(const EProb *P, const double *xhat, const double *xs, const
     double *lo = vec(n), *hi = vec(n);
     for (int k = 0; k < N; k++) { lo[NZ * k] = P->umin[0]; hi[NZ * k] = P->umax[0]; for (int r = 0; r < NX; r++) { lo[NZ * k + 1 + r] = P->xmin[r]; hi[NZ * k + 1 + r] = P->xmax[r]; } }
     OcpCtx c = {P, xhat, xs, us, d};
-    const int st = ipm_ipopt(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, iters, NULL, NULL);
+    const int st = ipm_ipopt(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, 0, iters, NULL, NULL);
     arena_release(mark_);
     return st;
 }
@@ -366,7 +366,7 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
     double Pinv[NE * NE];
     int ok = inv_small(NE, S->Pk, Pinv);
     MheCtx c = {P, N, S->U, S->Y, S->xbar, Pinv};
-    int st = ipm_ipopt(n, N * (NY + NE), mhe_evalf, &c, w, lo, hi, P->tol_mhe, P->max_iter, iters, NULL, NULL);
+    int st = ipm_ipopt(n, N * (NY + NE), mhe_evalf, &c, w, lo, hi, P->tol_mhe, P->max_iter, 0, iters, NULL, NULL);
     if (!ok) st = ST_FAILED;
     const double *Xl = w + NB * (N - 1);
     for (int i = 0; i < NE; i++) xes[i] = Xl[i];
@@ -439,7 +439,7 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
             const double xs_prev[NX] = {xs[0], xs[1]}, us_prev = us;
             double v[NV] = {P->x0m[0], P->x0m[1], P->u0[0], P->x0m[0] + P->Cd[0][0] * dh[0] + P->Cd[0][1] * dh[1], P->x0m[1] + P->Cd[1][0] * dh[0] + P->Cd[1][1] * dh[1]};
             TgtCtx tc = {P, dh};
-            const int ss = ipm_ipopt(NV, NX + NY, tgt_evalf, &tc, v, P->tlo, P->thi, P->tol, P->max_iter, &its, NULL, NULL);
+            const int ss = ipm_ipopt(NV, NX + NY, tgt_evalf, &tc, v, P->tlo, P->thi, P->tol, P->max_iter, 1, &its, NULL, NULL);      /* (the target: with the restoration phase, as in the product) */
             if (ss != ST_FAILED) { xs[0] = v[0]; xs[1] = v[1]; us = v[2]; }
             if (!have_w) for (int kk = 0; kk < N; kk++) { wg[NZ * kk] = P->u0[0]; wg[NZ * kk + 1] = P->x0m[0]; wg[NZ * kk + 2] = P->x0m[1]; }
             else if (last_ok) { memcpy(wg, wopt + NZ, sizeof(double) * NZ * (N - 1)); wg[NZ * (N - 1)] = us_prev; wg[NZ * (N - 1) + 1] = xs_prev[0]; wg[NZ * (N - 1) + 2] = xs_prev[1]; }

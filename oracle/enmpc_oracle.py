@@ -280,7 +280,7 @@ def _le(lhs, rhs, bas):
     return lhs - rhs <= 10.0 * EPS * abs(bas)
 
 
-def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
+def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None, resto=False):
     """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n] (``lam`` of length 0: no Hessian wanted).  Variables with
     lo == hi are PARAMETERS, as IPOPT treats them (fixed_variable_treatment = make_parameter, its default [ext]): the initial state of the OCP
     (MPC_code.py:734) drops out of the variables, and the rows that only restate it (Control_Calc.py:126) drop out of the constraints."""
@@ -301,7 +301,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
                 lfull[rows] = lam
             f, gf, g, J, H = evalf(wfull, lfull if len(lam) else lam)
             return f, gf[free], g[rows], J[np.ix_(rows, free)], H[np.ix_(free, free)]
-        r = ipm_dense(sub, np.asarray(w0, dtype=float)[free], lo[free], hi[free], tol=tol, max_iter=max_iter, trace=trace, info=info)
+        r = ipm_dense(sub, np.asarray(w0, dtype=float)[free], lo[free], hi[free], tol=tol, max_iter=max_iter, trace=trace, info=info, resto=resto)
         wfull = wf.copy(); wfull[free] = r["w"]
         lfull = np.zeros(len(rows)); lfull[rows] = r["lam"]
         # multipliers of the dropped rows / bounds of the fixed variables, for the certificate of the full statement: the rows that
@@ -317,27 +317,21 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
     n = len(w0)
     lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)      # this solve's own bounds: the safe slack moves them
     fl, fh = np.isfinite(lo), np.isfinite(hi)
-    one_l, one_h = fl & ~fh, fh & ~fl                                   # variables with one bound: damped [WB 3.7]
-    nb = int(fl.sum() + fh.sum())
     # ---- scaling of the objective at the caller's point (IpGradientScaling) ------------------------------------------------------------
     w0 = np.asarray(w0, dtype=float)
     _, gf0, c0, J0, _ = evalf(w0, np.zeros(0))
     gmax = float(np.abs(gf0).max(initial=0.0))
     df = max(SCALE_MAX_GRAD / gmax, SCALE_MIN) if gmax > SCALE_MAX_GRAD else 1.0
-    if info is not None:
-        info["df"] = df; info["scale_rows"] = bool(np.abs(J0).max(initial=0.0) > SCALE_MAX_GRAD)
+    stats = dict(ls_steps=0, soc=0, tiny=0, filter_max=0, resto=0, resto_iters=0, stop="iteration limit", df=df, scale_rows=bool(np.abs(J0).max(initial=0.0) > SCALE_MAX_GRAD))
     m = len(c0)
 
-    def ev(w_, lam_):
+    def ev(w_, lam_, mu_=None):
         """the scaled problem: df f, with the Hessian of df f + lam'g"""
-        if len(lam_) or m == 0:
-            f_, gf_, c_, J_, H_ = evalf(w_, lam_ / df if m else lam_)
+        if len(lam_) and m:
+            f_, gf_, c_, J_, H_ = evalf(w_, lam_ / df)
             return df * f_, df * gf_, c_, J_, df * H_
         f_, gf_, c_, J_, H_ = evalf(w_, lam_)
-        return df * f_, df * gf_, c_, J_, H_
-
-    def barrier(f_, sl_, sh_, mu_):
-        return f_ - mu_ * (np.log(sl_[fl]).sum() + np.log(sh_[fh]).sum()) + KAPPA_D * mu_ * (sl_[one_l].sum() + sh_[one_h].sum())
+        return df * f_, df * gf_, c_, J_, (df * H_ if np.size(H_) else H_)
     # ---- first iterate -------------------------------------------------------------------------------------------------------------------
     w = push_interior(w0, lo, hi)
     zl, zh = np.where(fl, 1.0, 0.0), np.where(fh, 1.0, 0.0)
@@ -351,22 +345,46 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
                     lam = y
             except np.linalg.LinAlgError:
                 pass
-    mu, delta_last = MU_INIT, 0.0
+    r = _ipm_core(ev, w, lo, hi, zl, zh, lam, MU_INIT, tol, max_iter, 0, THETA_MAX_FACT, None, resto, stats, trace, df)
+    if info is not None:
+        info.update(stats)
+    return dict(w=r["w"], lam=r["lam"] / df, z_lo=r["zl"] / df, z_hi=r["zh"] / df, status=r["status"], iters=r["it"], mu=r["mu"], df=df, stop=stats["stop"])      # (multipliers of the unscaled problem)
+
+
+RESTO_RHO, RESTO_KAPPA, RESTO_THETA_MAX_FACT, RESTO_BOUND_MULT_RESET, RESTO_FEAS_FACT = 1000.0, 0.9, 1e8, 1e3, 1e2
+
+
+def _ipm_core(ev, w, lo, hi, zl, zh, lam, mu, tol, max_iter, it0, theta_max_fact, hook, resto, stats, trace, df):
+    """The iteration of ipm_dense from a given first iterate (w, zl, zh, lam, mu); ev(w, lam, mu) evaluates the problem (its objective may depend on mu: the
+    restoration problem's does).  hook(w) -> True ends the solve (the restoration phase's own test); resto: whether a failed line search may enter the
+    restoration phase.  lo / hi are modified in place (moved bounds)."""
+    n, m = len(w), len(lam)
+    fl, fh = np.isfinite(lo), np.isfinite(hi)
+    one_l, one_h = fl & ~fh, fh & ~fl                                   # variables with one bound: damped [WB 3.7]
+    nb = int(fl.sum() + fh.sum())
+
+    def barrier(f_, sl_, sh_, mu_):
+        return f_ - mu_ * (np.log(sl_[fl]).sum() + np.log(sh_[fh]).sum()) + KAPPA_D * mu_ * (sl_[one_l].sum() + sh_[one_h].sum())
+    delta_last = 0.0
     tau = max(TAU_MIN, 1.0 - mu)
     filt = []                                        # entries (phi, theta)
     theta_max = theta_min = -1.0
     acc_count, tiny_last, tiny_flag = 0, False, False
-    status, it = STATUS_MAXITER, 0
-    stats = dict(ls_steps=0, soc=0, tiny=0, filter_max=0, stop="iteration limit")
-    for it in range(max_iter + 1):
-        f, gf, c, J, H = ev(w, lam)
+    status, it = STATUS_MAXITER, it0
+    it = it0
+    while True:
+        f, gf, c, J, H = ev(w, lam, mu)
         if not (np.all(np.isfinite(w)) and np.isfinite(f) and np.all(np.isfinite(gf)) and np.all(np.isfinite(c))):
             status = STATUS_INFEASIBLE; stats["stop"] = "not finite"
             break
-        sl, sh, lo, hi = _safe_slacks(w, lo, hi, zl, zh, mu, fl, fh)
+        sl, sh, lo_, hi_ = _safe_slacks(w, lo, hi, zl, zh, mu, fl, fh)
+        lo[:], hi[:] = lo_, hi_
         stat = gf + J.T @ lam - zl + zh
         if not np.all(np.isfinite(stat)):
             status = STATUS_INFEASIBLE; stats["stop"] = "not finite"
+            break
+        if hook is not None and hook(w):
+            status = STATUS_SOLVED; stats["stop"] = "restored"
             break
         s_d = max(S_MAX, (np.abs(lam).sum() + zl.sum() + zh.sum()) / max(m + nb, 1)) / S_MAX
         s_c = max(S_MAX, (zl.sum() + zh.sum()) / max(nb, 1)) / S_MAX
@@ -377,7 +395,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
 
         def err(mu_):
             return max(e_st / s_d, e_c, compl(mu_) / s_c)
-        if trace is not None:
+        if trace is not None and hook is None:
             trace.append(dict(it=it, f=f / df, E0=err(0.0), mu=mu, w=w.copy()))
         c0_ = compl(0.0)
         if err(0.0) <= tol and e_st <= DUAL_INF_TOL and e_c <= CONSTR_VIOL_TOL and c0_ <= COMPL_INF_TOL:
@@ -390,7 +408,8 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
                 break
         else:
             acc_count = 0
-        if it == max_iter:
+        if it >= max_iter:
+            stats["stop"] = "iteration limit"
             break
         # ---- barrier parameter (IpMonotoneMuUpdate) -----------------------------------------------------------------------------------------
         mu_min = min(tol, COMPL_INF_TOL) / (KAPPA_EPS + 1.0)
@@ -409,6 +428,8 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
         if mu_changed:
             filt = []
             tau = max(TAU_MIN, 1.0 - mu)
+            if hook is not None:                     # (the restoration problem's objective changes with mu)
+                f, gf, c, J, H = ev(w, lam, mu)
         # ---- search direction -------------------------------------------------------------------------------------------------------------------
         Sig = np.where(fl, zl / sl, 0.0) + np.where(fh, zh / sh, 0.0)
         gphi = gf - np.where(fl, mu / sl, 0.0) + np.where(fh, mu / sh, 0.0) + KAPPA_D * mu * (one_l.astype(float) - one_h.astype(float))      # gradient of the barrier function
@@ -447,11 +468,11 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
                 a_min = min(a_min, LS_DELTA * theta ** S_THETA / (-gbd) ** S_PHI)
         a_min *= ALPHA_MIN_FRAC
         if theta_max < 0.0:
-            theta_max, theta_min = THETA_MAX_FACT * max(1.0, theta), THETA_MIN_FACT * max(1.0, theta)
+            theta_max, theta_min = theta_max_fact * max(1.0, theta), THETA_MIN_FACT * max(1.0, theta)
 
         def trial(alpha, d_):
             wt = w + alpha * d_
-            ft, _, ct, _, _ = ev(wt, np.zeros(0))
+            ft, _, ct, _, _ = ev(wt, np.zeros(0), mu)
             slt, sht, lot, hit = _safe_slacks(wt, lo, hi, zl, zh, mu, fl, fh)
             ok = bool(np.isfinite(ft) and np.all(np.isfinite(ct)))
             return wt, (float(np.abs(ct).sum()) if ok else INF), (barrier(ft, slt, sht, mu) if ok else INF), ct, (slt, sht, lot, hit), ok
@@ -464,23 +485,31 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
         def armijo(alpha, phi_t):
             return _le(phi_t - phi, ETA_PHI * alpha * gbd, phi)
 
+        def to_iterate(theta_t, phi_t, from_resto=False):
+            if not from_resto and phi_t > phi:
+                bas = np.log10(abs(phi)) if abs(phi) > 10.0 else 1.0
+                if np.log10(phi_t - phi) > OBJ_MAX_INC + bas:
+                    return False
+            return _le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) or _le(phi_t - phi, -GAMMA_PHI * theta, phi)
+
+        def to_filter(theta_t, phi_t):               # acceptable to an entry: better than it in one of the two measures
+            return not any(_le(ph_j, phi_t, ph_j) and _le(th_j, theta_t, th_j) for (ph_j, th_j) in filt)
+
         def acceptable(alpha, theta_t, phi_t):
             if theta_t > theta_max:
                 return False
-            if alpha > 0.0 and ftype(alpha) and theta <= theta_min:
-                ok = armijo(alpha, phi_t)
+            ok = armijo(alpha, phi_t) if (alpha > 0.0 and ftype(alpha) and theta <= theta_min) else to_iterate(theta_t, phi_t)
+            return ok and to_filter(theta_t, phi_t)
+
+        def augment():
+            nonlocal filt
+            ent = (phi - GAMMA_PHI * theta, (1.0 - GAMMA_THETA) * theta)
+            filt = [e for e in filt if not (e[0] >= ent[0] and e[1] >= ent[1])]      # entries the new one dominates are dropped
+            if len(filt) >= FILTER_CAP:
+                filt[-1] = (min(filt[-1][0], ent[0]), min(filt[-1][1], ent[1]))
             else:
-                if phi_t > phi:
-                    bas = np.log10(abs(phi)) if abs(phi) > 10.0 else 1.0
-                    if np.log10(phi_t - phi) > OBJ_MAX_INC + bas:
-                        return False
-                ok = _le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) or _le(phi_t - phi, -GAMMA_PHI * theta, phi)
-            if not ok:
-                return False
-            for (ph_j, th_j) in filt:                # acceptable to an entry: better than it in one of the two measures
-                if _le(ph_j, phi_t, ph_j) and _le(th_j, theta_t, th_j):
-                    return False
-            return True
+                filt.append(ent)
+            stats["filter_max"] = max(stats["filter_max"], len(filt))
         tiny = bool((np.abs(dw) / (1.0 + np.abs(w))).max(initial=0.0) < TINY_STEP_TOL and theta <= 1e-4)
         accepted, alpha, d_acc, lam_acc = None, a_max, dw, lam_new
         if tiny:
@@ -521,36 +550,112 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None):
                 n_steps += 1
             stats["ls_steps"] += n_steps
             if accepted is None:
-                # IPOPT enters its restoration phase here (not restated)
+                # ---- IPOPT's restoration phase (IpRestoMinC_1Nrm, IpRestoIpoptNLP, IpRestoFilterConvCheck) -----------------------------------------
                 if theta <= 1e-2 * tol:
-                    status = STATUS_MAXITER; stats["stop"] = "line search failed at a feasible point"
-                else:
+                    status = STATUS_MAXITER; stats["stop"] = "line search failed at a feasible point"      # 'Restoration_Failed': the reference accepts the point
+                    break
+                if not resto or hook is not None:
+                    # not restated for this problem (the OCP and the estimator in the product: their Newton systems would need another recursion) / no
+                    # restoration inside the restoration phase ('Restoration_Failed' there: the caller decides)
                     status = STATUS_INFEASIBLE; stats["stop"] = "restoration needed"
-                break
+                    break
+                augment()                            # the point the restoration starts from is never returned to
+                stats["resto"] += 1
+
+                def orig_ok(x_):                     # the restoration phase's own test: enough less infeasible, acceptable to the filter and to the point left
+                    ft, _, ct, _, _ = ev(x_, np.zeros(0), mu)
+                    if not (np.isfinite(ft) and np.all(np.isfinite(ct))):
+                        return False
+                    th_t = float(np.abs(ct).sum())
+                    if th_t > RESTO_KAPPA * theta:
+                        return False
+                    slt, sht, _, _ = _safe_slacks(x_, lo, hi, zl, zh, mu, fl, fh)
+                    ph_t = barrier(ft, slt, sht, mu)
+                    return to_filter(th_t, ph_t) and to_iterate(th_t, ph_t, from_resto=True)
+                rr = _restore(ev, w, lo, hi, zl, zh, mu, c, tol, max_iter, it + 1, orig_ok, stats, df)
+                it = rr["it"] - 1
+                if rr["status"] != "restored":
+                    if rr["status"] == "limit":
+                        status = STATUS_MAXITER; stats["stop"] = "iteration limit"
+                    elif rr["status"] == "converged":      # the restoration problem has a minimiser here: infeasible, or feasible and not acceptable
+                        cx = ev(rr["x"], np.zeros(0), mu)[2]
+                        if np.abs(cx).max(initial=0.0) <= RESTO_FEAS_FACT * tol:
+                            status = STATUS_MAXITER; stats["stop"] = "restoration converged to a feasible point"
+                        else:
+                            status = STATUS_INFEASIBLE; stats["stop"] = "locally infeasible"
+                    else:
+                        status = STATUS_MAXITER; stats["stop"] = "restoration failed"      # 'Restoration_Failed': the reference accepts the point
+                    break
+                # back from the restoration: bound multipliers as if the whole move had been one Newton step, reset to 1 when they grew beyond 1e3; equality
+                # multipliers zero (constr_mult_reset_threshold 0)
+                x_new = rr["x"]
+                slt, sht, lot, hit = _safe_slacks(x_new, lo, hi, zl, zh, mu, fl, fh)
+                dzl = np.where(fl, mu / sl - zl - zl / sl * (slt - sl), 0.0)
+                dzh = np.where(fh, mu / sh - zh - zh / sh * (sht - sh), 0.0)
+                a_du = min(maxstep(zl, dzl, fl), maxstep(zh, dzh, fh))
+                zl, zh = zl + a_du * dzl, zh + a_du * dzh
+                if max(zl.max(initial=0.0), zh.max(initial=0.0)) > RESTO_BOUND_MULT_RESET:
+                    zl, zh = np.where(fl, 1.0, 0.0), np.where(fh, 1.0, 0.0)
+                w, lam = x_new, np.zeros(m)
+                lo[:], hi[:] = lot, hit
+                zl = np.where(fl, np.clip(zl, mu / (KAPPA_SIGMA * slt), KAPPA_SIGMA * mu / slt), 0.0)
+                zh = np.where(fh, np.clip(zh, mu / (KAPPA_SIGMA * sht), KAPPA_SIGMA * mu / sht), 0.0)
+                it += 1
+                continue
             # the filter grows unless the step was an Armijo step on the barrier function (IpFilterLSAcceptor::UpdateForNextIteration)
             if not ftype(alpha) or not armijo(alpha, accepted[2]):
-                ent = (phi - GAMMA_PHI * theta, (1.0 - GAMMA_THETA) * theta)
-                filt = [e for e in filt if not (e[0] >= ent[0] and e[1] >= ent[1])]      # entries the new one dominates are dropped
-                if len(filt) >= FILTER_CAP:
-                    filt[-1] = (min(filt[-1][0], ent[0]), min(filt[-1][1], ent[1]))
-                else:
-                    filt.append(ent)
-                stats["filter_max"] = max(stats["filter_max"], len(filt))
+                augment()
         a_pr = alpha_soc if d_acc is not dw else alpha
         # ---- the accepted point; bounds move with corrected slacks; multipliers within kappa_Sigma of mu / s ---------------------------
         dzl = np.where(fl, mu / sl - zl - zl / sl * d_acc, 0.0)      # (of the direction that was taken: the corrected one after a second-order correction)
         dzh = np.where(fh, mu / sh - zh + zh / sh * d_acc, 0.0)
         a_du = min(maxstep(zl, dzl, fl), maxstep(zh, dzh, fh))
         w = accepted[0]
-        sl, sh, lo, hi = accepted[4]
+        sl, sh, lo_, hi_ = accepted[4]
+        lo[:], hi[:] = lo_, hi_
         lam = lam + a_pr * (lam_acc - lam)
         zl, zh = zl + a_du * dzl, zh + a_du * dzh
         zl = np.where(fl, np.clip(zl, mu / (KAPPA_SIGMA * sl), KAPPA_SIGMA * mu / sl), 0.0)
         zh = np.where(fh, np.clip(zh, mu / (KAPPA_SIGMA * sh), KAPPA_SIGMA * mu / sh), 0.0)
-    stats["df"] = df
-    if info is not None:
-        info.update(stats)
-    return dict(w=w, lam=lam / df, z_lo=zl / df, z_hi=zh / df, status=status, iters=it, mu=mu, df=df, stop=stats["stop"])      # (multipliers of the unscaled problem)
+        it += 1
+    return dict(w=w, lam=lam, zl=zl, zh=zh, mu=mu, status=status, it=it)
+
+
+def _restore(ev, x_r, lo, hi, zl, zh, mu, c_r, tol, max_iter, it0, orig_ok, stats, df):
+    """IPOPT's restoration phase: the same interior point iteration on
+        min  rho sum(n + p) + eta(mu) / 2 |D_R (x - x_R)|^2   s.t.  c(x) + n - p = 0,  lo <= x <= hi,  n, p >= 0
+    (rho = 1000, eta = sqrt(mu), D_R = diag(1 / max(1, |x_R|)); [WB 3.3]) from x_R with n, p from [WB (32), (33)] at mu_R = max(mu, |c(x_R)|_inf), until
+    ``orig_ok(x)``.  Returns status 'restored' | 'converged' | 'limit' | 'failed', x, the iteration counter."""
+    n, m = len(x_r), len(c_r)
+    d_r = 1.0 / np.maximum(1.0, np.abs(x_r))
+    mu_r = max(mu, float(np.abs(c_r).max(initial=0.0)))
+    a = mu_r / (2.0 * RESTO_RHO) - 0.5 * c_r
+    nn = a + np.sqrt(a * a + mu_r * c_r / (2.0 * RESTO_RHO))
+    pp = c_r + nn
+    wb = np.concatenate([x_r, nn, pp])
+    lob, hib = np.concatenate([lo, np.zeros(2 * m)]), np.concatenate([hi, np.full(2 * m, INF)])
+    zlb = np.concatenate([np.minimum(RESTO_RHO, zl), mu_r / nn, mu_r / pp]); zhb = np.concatenate([np.minimum(RESTO_RHO, zh), np.zeros(2 * m)])
+    zlb[:n] = np.where(np.isfinite(lo), zlb[:n], 0.0)
+    Im = np.eye(m)
+
+    def ev_r(wb_, lam_, mu_):
+        x_, n_, p_ = wb_[:n], wb_[n:n + m], wb_[n + m:]
+        eta = np.sqrt(mu_)
+        _, _, c_, J_, _ = ev(x_, np.zeros(0), mu_)
+        e_ = d_r * (x_ - x_r)
+        f_ = RESTO_RHO * (n_.sum() + p_.sum()) + 0.5 * eta * float(e_ @ e_)
+        gf_ = np.concatenate([eta * d_r * e_, np.full(2 * m, RESTO_RHO)])
+        Hb = np.zeros((0, 0))
+        if len(lam_):
+            Hc = ev(x_, lam_, mu_)[4] - ev(x_, np.zeros(m), mu_)[4]      # Hessian of lam'c alone
+            Hb = np.zeros((n + 2 * m, n + 2 * m)); Hb[:n, :n] = Hc + eta * np.diag(d_r * d_r)
+        return f_, gf_, c_ + n_ - p_, np.hstack([J_, Im, -Im]), Hb
+    sub = dict(ls_steps=0, soc=0, tiny=0, filter_max=0, resto=0, resto_iters=0, stop="")
+    r = _ipm_core(ev_r, wb, lob, hib, zlb, zhb, np.zeros(m), mu_r, tol, max_iter, it0, RESTO_THETA_MAX_FACT, lambda wb_: orig_ok(wb_[:n]), False, sub, None, df)
+    stats["resto_iters"] += r["it"] - it0
+    lo[:], hi[:] = lob[:n], hib[:n]                  # (bounds the restoration moved stay moved)
+    st = {"restored": "restored", "converged": "converged", "acceptable": "converged", "tiny step": "converged", "iteration limit": "limit"}.get(sub["stop"], "failed")
+    return dict(status=st, x=r["w"][:n], it=r["it"])
 
 
 def kkt_nlp(evalf, sol, lo, hi):
@@ -679,7 +784,7 @@ def target_solve(p, d, t=0.0, usp=None, ysp=None, xsp=None, max_iter=None, tol=1
     evalf, lo, hi = target_eval(p, d, usp, ysp, xsp, t)
     y0 = fy_model(p, p.x0_m.reshape(-1, 1), d.reshape(-1, 1))[:, 0]
     w0 = np.concatenate([p.x0_m, p.u0, y0])                 # MPC_code.py:696-700: cold start, every step
-    sol = ipm_dense(evalf, w0, lo, hi, tol=tol, max_iter=max_iter)
+    sol = ipm_dense(evalf, w0, lo, hi, tol=tol, max_iter=max_iter, resto=True)      # (the target: with the restoration phase, as in the product)
     sol["evalf"], sol["lo"], sol["hi"] = evalf, lo, hi
     sol["xs"], sol["us"], sol["ys"] = sol["w"][:p.nx], sol["w"][p.nx:p.nx + p.nu], sol["w"][p.nx + p.nu:]
     return sol

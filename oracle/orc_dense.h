@@ -304,53 +304,77 @@ static void ns_direction(const NsSys *S, const double *c, double *dw, double *la
     for (int i = m - 1; i >= 0; i--) { double s = -tmp[i]; for (int k = i + 1; k < m; k++) s -= r_at(m, S->Jt, S->tau, i, k) * lamn[k]; lamn[i] = s / r_at(m, S->Jt, S->tau, i, i); }
 }
 
-typedef struct { int ls_steps, soc, tiny, filter_max, stop; double df; } IpmInfo;      /* stop: 0 converged, 1 acceptable, 2 iteration limit, 3 tiny step, 4 line search failed at a feasible point, 5 restoration needed, 6 not finite, 7 no curvature */
+typedef struct { int ls_steps, soc, tiny, filter_max, stop, resto, resto_iters; double df; } IpmInfo;
+/* stop: 0 converged, 1 acceptable, 2 iteration limit, 3 tiny step, 4 line search failed at a feasible point, 5 restoration needed, 6 not finite, 7 no curvature,
+   8 restored (the restoration phase's own test), 9 restoration converged to a feasible point, 10 locally infeasible, 11 restoration failed */
+#define RESTO_RHO 1000.0
+#define RESTO_KAPPA 0.9
+#define RESTO_THETA_MAX_FACT 1e8
+#define RESTO_BOUND_MULT_RESET 1e3
+#define RESTO_FEAS_FACT 1e2
 
-/* n variables (none fixed: the caller has removed parameters), m equalities */
-static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const double *lo_in, const double *hi_in, double tol, int max_iter, int *iters, double *lam_out, IpmInfo *info)
+/* a problem as the iteration sees it: ev evaluates objective (possibly depending on mu: the restoration problem's does), constraints and derivatives */
+typedef struct IpmProb {
+    int n, m;
+    void (*ev)(struct IpmProb *P, const double *w, const double *lam, double mu, int want, double *f, double *gf, double *g, double *J, double *H);
+    int (*hook)(struct IpmProb *P, const double *w);      /* ends the solve when it returns 1 (the restoration phase's test), or NULL */
+    void *ctx;
+} IpmProb;
+
+/* what the restoration phase's test needs of the iteration that called it */
+typedef struct {
+    IpmProb *P; int n, m; double mu, theta, phi; const double *lo, *hi, *zl, *zh; const unsigned char *fl, *fh; const double *filt_phi, *filt_th; int nfilt; double *gt, *gdum, *J, *H;
+} OrigRef;
+
+static double barrier_of(int n, const double *w, double f, const double *lo, const double *hi, const double *zl, const double *zh, const unsigned char *fl, const unsigned char *fh, double mu)
+{
+    double phi = f;
+    for (int i = 0; i < n; i++) {
+        double bl = lo[i], bh = hi[i];
+        const double s1 = fl[i] ? safe_slack(w[i], &bl, zl[i], mu, 1) : 1.0, s2 = fh[i] ? safe_slack(w[i], &bh, zh[i], mu, 0) : 1.0;
+        if (fl[i]) phi -= mu * log(s1);
+        if (fh[i]) phi -= mu * log(s2);
+        if (fl[i] && !fh[i]) phi += KAPPA_D * mu * s1;
+        if (fh[i] && !fl[i]) phi += KAPPA_D * mu * s2;
+    }
+    return phi;
+}
+static int to_iterate(double theta, double phi, double theta_t, double phi_t, int from_resto)
+{
+    if (!from_resto && phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > OBJ_MAX_INC + bas) return 0; }
+    return orc_le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) || orc_le(phi_t - phi, -GAMMA_PHI * theta, phi);
+}
+static int to_filter(const double *fp, const double *ft, int nf, double theta_t, double phi_t)
+{
+    for (int e = 0; e < nf; e++) if (orc_le(fp[e], phi_t, fp[e]) && orc_le(ft[e], theta_t, ft[e])) return 0;
+    return 1;
+}
+static int resto_hook(IpmProb *R, const double *wb);
+static int ipm_restore(IpmProb *P, OrigRef *O, const double *x_r, double *lo, double *hi, const double *zl, const double *zh, double mu, const double *c_r, double tol, int max_iter, int it0,
+                       double *x_out, int *it_out, IpmInfo *inf);
+
+/* the iteration from a given first iterate (w, zl, zh, lam, mu); lo / hi are this solve's own bounds (moved by the safe slack) */
+static int ipm_core(IpmProb *P, double *w, double *lo, double *hi, double *zl, double *zh, double *lam, double mu, double tol, int max_iter, int it0, double theta_max_fact, int resto_ok,
+                    int *it_out, IpmInfo *inf)
 {
     const size_t mark_ = arena_mark();
-    const int nz = n - m;
-    double *lo = vec(n), *hi = vec(n), *lot = vec(n), *hit = vec(n);      /* this solve's own bounds: the safe slack moves them; lot / hit: those of a trial point */
-    memcpy(lo, lo_in, sizeof(double) * n); memcpy(hi, hi_in, sizeof(double) * n);
-    double *zl = vec(n), *zh = vec(n), *lam = vec(m), *lams = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m + 2),
+    const int n = P->n, m = P->m, nz = n - m;
+    double *lot = vec(n), *hit = vec(n);
+    double *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m + 2),
            *sl = vec(n), *sh = vec(n), *slt = vec(n), *sht = vec(n), *Sig = vec(n), *gphi = vec(n), *dw = vec(n), *ds = vec(n), *lamn = vec(m), *lamsoc = vec(m), *Hr = vec((size_t)(nz > 0 ? nz : 1) * (nz > 0 ? nz : 1)),
-           *HZ = vec((size_t)n * (nz > 0 ? nz : 1)), *Zc = vec(n), *tmp = vec(n), *wt = vec(n), *gt = vec(m), *csoc = vec(m), *ctr = vec(m), *gdum = vec(n);
+           *HZ = vec((size_t)n * (nz > 0 ? nz : 1)), *Zc = vec(n), *tmp = vec(n), *wt = vec(n), *gt = vec(m), *csoc = vec(m), *ctr = vec(m), *gdum = vec(n), *xr = vec(n);
     unsigned char *fl = (unsigned char *)vec((n + 7) / 8 + 1), *fh = (unsigned char *)vec((n + 7) / 8 + 1);
     NsSys S = {n, m, nz, Jt, tau, H, Sig, Hr, gphi, 0.0, vec(n), vec(n), vec(n)};
-    int nb = 0, status = ST_MAXITER, it = 0;
-    IpmInfo inf = {0, 0, 0, 0, 2, 1.0};
+    int nb = 0, status = ST_MAXITER, it = it0;
     double f, ft;
-    /* scaling of the objective at the caller's point */
-    evalf(ctx, w, lam, WANT_GRAD, &f, gf, g, J, H);
-    double gmax = 0.0;
-    for (int i = 0; i < n; i++) gmax = fmax(gmax, fabs(gf[i]));
-    const double df = gmax > SCALE_MAX_GRAD ? fmax(SCALE_MAX_GRAD / gmax, SCALE_MIN) : 1.0;
-    inf.df = df;
-    for (int i = 0; i < n; i++) { fl[i] = isfinite(lo[i]) ? 1 : 0; fh[i] = isfinite(hi[i]) ? 1 : 0; w[i] = push_in(w[i], lo[i], hi[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nb += fl[i] + fh[i]; }
-    /* least-squares equality multipliers: min |gf - zl + zh + J'y|  (null-space form: R y = -Q1'(gf - zl + zh)) */
-    if (m > 0 && m < n) {
-        evalf(ctx, w, lam, WANT_GRAD, &f, gf, g, J, H);
-        int ok = 1;
-        for (int i = 0; i < n; i++) { tmp[i] = df * gf[i] - zl[i] + zh[i]; ok = ok && isfinite(tmp[i]); for (int j = 0; j < m; j++) Jt[i * m + j] = J[j * n + i]; }
-        if (ok && qr_factor(n, m, Jt, tau)) {
-            qr_apply(n, m, Jt, tau, tmp, 1);
-            double ymax = 0.0;
-            for (int i = m - 1; i >= 0; i--) { double s = -tmp[i]; for (int k = i + 1; k < m; k++) s -= r_at(m, Jt, tau, i, k) * lamn[k]; lamn[i] = s / r_at(m, Jt, tau, i, i); }
-            for (int j = 0; j < m; j++) { ymax = fmax(ymax, fabs(lamn[j])); ok = ok && isfinite(lamn[j]); }
-            if (ok && ymax <= Y_INIT_MAX) memcpy(lam, lamn, sizeof(double) * m);
-        }
-    }
-    double mu = MU_INIT, tau_f = fmax(TAU_MIN, 1.0 - mu), delta_last = 0.0, theta_max = -1.0, theta_min = -1.0;
+    for (int i = 0; i < n; i++) { fl[i] = isfinite(lo[i]) ? 1 : 0; fh[i] = isfinite(hi[i]) ? 1 : 0; nb += fl[i] + fh[i]; }
+    double tau_f = fmax(TAU_MIN, 1.0 - mu), delta_last = 0.0, theta_max = -1.0, theta_min = -1.0;
     double filt_phi[FILTER_CAP], filt_th[FILTER_CAP];
     int nfilt = 0, acc_count = 0, tiny_last = 0, tiny_flag = 0;
     const double mu_min = fmin(tol, COMPL_INF_TOL) / (KAPPA_EPS + 1.0);
-    for (it = 0;; it++) {
-        for (int j = 0; j < m; j++) lams[j] = lam[j] / df;      /* Hessian of df f + lam'g = df (Hessian of f + (lam / df)'g) */
-        evalf(ctx, w, lams, WANT_HESS, &f, gf, g, J, H);
-        f *= df;
-        for (int i = 0; i < n; i++) gf[i] *= df;
-        for (size_t i = 0; i < (size_t)n * n; i++) H[i] *= df;
+    inf->stop = 2;
+    for (;;) {
+        P->ev(P, w, lam, mu, WANT_HESS, &f, gf, g, J, H);
         double e_st = 0.0, e_c = 0.0, s_l = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY, theta = 0.0;
         int finite = isfinite(f);
         for (int i = 0; i < n; i++) {
@@ -363,16 +387,17 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
             if (fh[i]) { cmax = fmax(cmax, sh[i] * zh[i]); cmin = fmin(cmin, sh[i] * zh[i]); }
         }
         for (int j = 0; j < m; j++) { e_c = fmax(e_c, fabs(g[j])); theta += fabs(g[j]); s_l += fabs(lam[j]); finite = finite && isfinite(g[j]); }
-        if (!finite) { status = ST_FAILED; inf.stop = 6; break; }
+        if (!finite) { status = ST_FAILED; inf->stop = 6; break; }
+        if (P->hook && P->hook(P, w)) { status = ST_SOLVED; inf->stop = 8; break; }
         const double s_d = fmax(S_MAX, (s_l + s_z) / fmax(m + nb, 1.0)) / S_MAX, s_c = fmax(S_MAX, s_z / fmax(nb, 1.0)) / S_MAX;
 #define COMPL(m_) (nb > 0 ? fmax(cmax - (m_), (m_) - cmin) : 0.0)
 #define ERR(m_) fmax(fmax(e_st / s_d, e_c), COMPL(m_) / s_c)
         const double e0 = ERR(0.0), c0 = COMPL(0.0);
-        if (e0 <= tol && e_st <= DUAL_INF_TOL && e_c <= CONSTR_VIOL_TOL && c0 <= COMPL_INF_TOL) { status = ST_SOLVED; inf.stop = 0; break; }
+        if (e0 <= tol && e_st <= DUAL_INF_TOL && e_c <= CONSTR_VIOL_TOL && c0 <= COMPL_INF_TOL) { status = ST_SOLVED; inf->stop = 0; break; }
         if (e0 <= ACC_TOL && e_st <= ACC_DUAL_INF_TOL && e_c <= ACC_CONSTR_VIOL_TOL && c0 <= ACC_COMPL_INF_TOL) {
-            if (++acc_count >= ACC_ITER) { status = ST_SOLVED; inf.stop = 1; break; }
+            if (++acc_count >= ACC_ITER) { status = ST_SOLVED; inf->stop = 1; break; }
         } else acc_count = 0;
-        if (it >= max_iter) break;
+        if (it >= max_iter) { inf->stop = 2; break; }
         /* barrier parameter */
         int mu_changed = 0, stop_tiny = 0;
         while (ERR(mu) <= KAPPA_EPS * mu || tiny_flag) {
@@ -382,9 +407,12 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
         }
 #undef ERR
 #undef COMPL
-        if (stop_tiny) { status = ST_MAXITER; inf.stop = 3; break; }
+        if (stop_tiny) { status = ST_MAXITER; inf->stop = 3; break; }
         tiny_flag = 0;
-        if (mu_changed) { nfilt = 0; tau_f = fmax(TAU_MIN, 1.0 - mu); }
+        if (mu_changed) {
+            nfilt = 0; tau_f = fmax(TAU_MIN, 1.0 - mu);
+            if (P->hook) P->ev(P, w, lam, mu, WANT_HESS, &f, gf, g, J, H);      /* (the restoration problem's objective changes with mu) */
+        }
         /* search direction */
         double phi = f, gbd = 0.0;
         for (int i = 0; i < n; i++) {
@@ -397,7 +425,7 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
             if (oh) phi += KAPPA_D * mu * sh[i];
         }
         for (int i = 0; i < n; i++) for (int j = 0; j < m; j++) Jt[i * m + j] = J[j * n + i];
-        if (m > 0 && !qr_factor(n, m, Jt, tau)) { status = ST_FAILED; inf.stop = 7; break; }
+        if (m > 0 && !qr_factor(n, m, Jt, tau)) { status = ST_FAILED; inf->stop = 7; break; }
         double delta = 0.0;
         int failed = 0;
         for (;;) {
@@ -414,7 +442,7 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
             delta = delta == 0.0 ? fmax(DELTA_FIRST, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
             if (delta > DELTA_MAX) { failed = 1; break; }
         }
-        if (failed) { status = ST_FAILED; inf.stop = 7; break; }
+        if (failed) { status = ST_FAILED; inf->stop = 7; break; }
         if (delta > 0.0) delta_last = delta;
         S.delta = delta;
         ns_direction(&S, g, dw, lamn);
@@ -433,12 +461,12 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
             if (theta <= theta_min) a_min = fmin(a_min, pow(theta, S_THETA) / pow(-gbd, S_PHI));
         }
         a_min *= ALPHA_MIN_FRAC;
-        if (theta_max < 0.0) { theta_max = THETA_MAX_FACT * fmax(1.0, theta); theta_min = THETA_MIN_FACT * fmax(1.0, theta); }
+        if (theta_max < 0.0) { theta_max = theta_max_fact * fmax(1.0, theta); theta_min = THETA_MIN_FACT * fmax(1.0, theta); }
         double theta_t = 0.0, phi_t = 0.0;
         int ok_t = 0;
 #define TRIAL(alpha_, d_) do { \
             for (int i_ = 0; i_ < n; i_++) { wt[i_] = w[i_] + (alpha_) * (d_)[i_]; lot[i_] = lo[i_]; hit[i_] = hi[i_]; } \
-            evalf(ctx, wt, lam, WANT_VALUES, &ft, gdum, gt, J, H); ft *= df; \
+            P->ev(P, wt, lam, mu, WANT_VALUES, &ft, gdum, gt, J, H); \
             ok_t = isfinite(ft); theta_t = 0.0; phi_t = ft; \
             for (int j_ = 0; j_ < m; j_++) { theta_t += fabs(gt[j_]); ok_t = ok_t && isfinite(gt[j_]); } \
             for (int i_ = 0; i_ < n; i_++) { \
@@ -452,12 +480,22 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
         } while (0)
 #define FTYPE(alpha_) ((theta == 0.0 && gbd > 0.0 && gbd < 100.0 * ORC_EPS) || (gbd < 0.0 && (alpha_) * pow(-gbd, S_PHI) > pow(theta, S_THETA)))
 #define ARMIJO(alpha_) orc_le(phi_t - phi, ETA_PHI * (alpha_) * gbd, phi)
-        int accepted = 0, soc_taken = 0;
+#define ACCEPTABLE(alpha_) (ok_t && !(theta_t > theta_max) && ((((alpha_) > 0.0 && FTYPE(alpha_) && theta <= theta_min) ? ARMIJO(alpha_) : to_iterate(theta, phi, theta_t, phi_t, 0)) && to_filter(filt_phi, filt_th, nfilt, theta_t, phi_t)))
+#define AUGMENT() do { \
+            const double e_phi = phi - GAMMA_PHI * theta, e_th = (1.0 - GAMMA_THETA) * theta; \
+            int k2 = 0; \
+            for (int e = 0; e < nfilt; e++) if (!(filt_phi[e] >= e_phi && filt_th[e] >= e_th)) { filt_phi[k2] = filt_phi[e]; filt_th[k2] = filt_th[e]; k2++; } \
+            nfilt = k2; \
+            if (nfilt >= FILTER_CAP) { filt_phi[nfilt - 1] = fmin(filt_phi[nfilt - 1], e_phi); filt_th[nfilt - 1] = fmin(filt_th[nfilt - 1], e_th); } \
+            else { filt_phi[nfilt] = e_phi; filt_th[nfilt] = e_th; nfilt++; } \
+            if (nfilt > inf->filter_max) inf->filter_max = nfilt; \
+        } while (0)
+        int accepted = 0, soc_taken = 0, restored = 0;
         double alpha = a_max, a_soc = a_max;
         int tiny = dmaxrel < TINY_STEP_TOL && theta <= 1e-4;
         if (tiny) {
             TRIAL(a_max, dw);
-            if (ok_t) { accepted = 1; inf.tiny++; tiny_flag = tiny_last; tiny_last = dymax < TINY_STEP_Y_TOL; }
+            if (ok_t) { accepted = 1; inf->tiny++; tiny_flag = tiny_last; tiny_last = dymax < TINY_STEP_Y_TOL; }
             else tiny = 0;
         }
         if (!tiny) {
@@ -465,21 +503,7 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
             int n_steps = 0;
             while (alpha > a_min || n_steps == 0) {
                 TRIAL(alpha, dw);
-                int acc = 0;
-                for (int pass = 0; pass < 1; pass++) {      /* acceptable(alpha, theta_t, phi_t) */
-                    if (!ok_t || theta_t > theta_max) break;
-                    int ok;
-                    if (alpha > 0.0 && FTYPE(alpha) && theta <= theta_min) ok = ARMIJO(alpha);
-                    else {
-                        if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > OBJ_MAX_INC + bas) break; }
-                        ok = orc_le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) || orc_le(phi_t - phi, -GAMMA_PHI * theta, phi);
-                    }
-                    if (!ok) break;
-                    int dominated = 0;
-                    for (int e = 0; e < nfilt; e++) if (orc_le(filt_phi[e], phi_t, filt_phi[e]) && orc_le(filt_th[e], theta_t, filt_th[e])) dominated = 1;
-                    acc = !dominated;
-                }
-                if (acc) { accepted = 1; break; }
+                if (ACCEPTABLE(alpha)) { accepted = 1; break; }
                 if (ok_t && n_steps == 0 && theta <= theta_t) {      /* second-order correction */
                     memcpy(csoc, g, sizeof(double) * m);
                     memcpy(ctr, gt, sizeof(double) * m);
@@ -496,22 +520,8 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
                             if (fh[i] && -ds[i] < 0.0) a_soc = fmin(a_soc, -tau_f * sh[i] / (-ds[i]));
                         }
                         TRIAL(a_soc, ds);
-                        inf.soc++;
-                        int acs = 0;
-                        for (int pass = 0; pass < 1; pass++) {      /* acceptable(alpha, ...): the tests keep the original step length */
-                            if (!ok_t || theta_t > theta_max) break;
-                            int ok;
-                            if (alpha > 0.0 && FTYPE(alpha) && theta <= theta_min) ok = ARMIJO(alpha);
-                            else {
-                                if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > OBJ_MAX_INC + bas) break; }
-                                ok = orc_le(theta_t, (1.0 - GAMMA_THETA) * theta, theta) || orc_le(phi_t - phi, -GAMMA_PHI * theta, phi);
-                            }
-                            if (!ok) break;
-                            int dominated = 0;
-                            for (int e = 0; e < nfilt; e++) if (orc_le(filt_phi[e], phi_t, filt_phi[e]) && orc_le(filt_th[e], theta_t, filt_th[e])) dominated = 1;
-                            acs = !dominated;
-                        }
-                        if (acs) { accepted = 1; soc_taken = 1; }
+                        inf->soc++;
+                        if (ACCEPTABLE(alpha)) { accepted = 1; soc_taken = 1; }      /* (the tests keep the original step length) */
                         else { cnt++; th_s = theta_t; memcpy(ctr, gt, sizeof(double) * m); if (!ok_t) break; }
                     }
                     if (accepted) break;
@@ -519,24 +529,55 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
                 alpha *= 0.5;
                 n_steps++;
             }
-            inf.ls_steps += n_steps;
-            if (!accepted) {      /* IPOPT enters its restoration phase here (not restated) */
-                if (theta <= 1e-2 * tol) { status = ST_MAXITER; inf.stop = 4; } else { status = ST_FAILED; inf.stop = 5; }
-                break;
-            }
-            if (!FTYPE(alpha) || !ARMIJO(alpha)) {      /* the filter grows unless the step was an Armijo step on the barrier function */
-                const double e_phi = phi - GAMMA_PHI * theta, e_th = (1.0 - GAMMA_THETA) * theta;
-                int k2 = 0;
-                for (int e = 0; e < nfilt; e++) if (!(filt_phi[e] >= e_phi && filt_th[e] >= e_th)) { filt_phi[k2] = filt_phi[e]; filt_th[k2] = filt_th[e]; k2++; }
-                nfilt = k2;
-                if (nfilt >= FILTER_CAP) { filt_phi[nfilt - 1] = fmin(filt_phi[nfilt - 1], e_phi); filt_th[nfilt - 1] = fmin(filt_th[nfilt - 1], e_th); }
-                else { filt_phi[nfilt] = e_phi; filt_th[nfilt] = e_th; nfilt++; }
-                if (nfilt > inf.filter_max) inf.filter_max = nfilt;
-            }
+            inf->ls_steps += n_steps;
+            if (!accepted) {      /* IPOPT's restoration phase */
+                if (theta <= 1e-2 * tol) { status = ST_MAXITER; inf->stop = 4; break; }
+                if (!resto_ok || P->hook) { status = ST_FAILED; inf->stop = 5; break; }      /* (not restated for this problem / none inside the restoration phase) */
+                AUGMENT();
+                inf->resto++;
+                OrigRef O = {P, n, m, mu, theta, phi, lo, hi, zl, zh, fl, fh, filt_phi, filt_th, nfilt, gt, gdum, J, H};
+                int it_r = it + 1;
+                IpmInfo sub = {0, 0, 0, 0, 2, 0, 0, inf->df};
+                const int rs = ipm_restore(P, &O, w, lo, hi, zl, zh, mu, g, tol, max_iter, it + 1, xr, &it_r, &sub);
+                inf->resto_iters += it_r - (it + 1);
+                it = it_r - 1;
+                if (rs != 8) {
+                    if (rs == 2) { status = ST_MAXITER; inf->stop = 2; }
+                    else if (rs == 0 || rs == 1 || rs == 3) {      /* the restoration problem has a minimiser here: infeasible, or feasible and not acceptable */
+                        P->ev(P, xr, lam, mu, WANT_VALUES, &ft, gdum, gt, J, H);
+                        double cm = 0.0;
+                        for (int j = 0; j < m; j++) cm = fmax(cm, fabs(gt[j]));
+                        if (cm <= RESTO_FEAS_FACT * tol) { status = ST_MAXITER; inf->stop = 9; } else { status = ST_FAILED; inf->stop = 10; }
+                    } else { status = ST_MAXITER; inf->stop = 11; }
+                    break;
+                }
+                /* back from the restoration: bound multipliers as if the whole move had been one Newton step, reset to 1 beyond 1e3; equality multipliers zero */
+                double adu = 1.0, zmax = 0.0;
+                for (int i = 0; i < n; i++) {
+                    lot[i] = lo[i]; hit[i] = hi[i];
+                    slt[i] = fl[i] ? safe_slack(xr[i], &lot[i], zl[i], mu, 1) : 1.0; sht[i] = fh[i] ? safe_slack(xr[i], &hit[i], zh[i], mu, 0) : 1.0;
+                    const double dzl = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * (slt[i] - sl[i]) : 0.0, dzh = fh[i] ? mu / sh[i] - zh[i] - zh[i] / sh[i] * (sht[i] - sh[i]) : 0.0;
+                    if (fl[i] && dzl < 0.0) adu = fmin(adu, -tau_f * zl[i] / dzl);
+                    if (fh[i] && dzh < 0.0) adu = fmin(adu, -tau_f * zh[i] / dzh);
+                    Sig[i] = dzl; gphi[i] = dzh;
+                }
+                for (int i = 0; i < n; i++) { zl[i] += adu * Sig[i]; zh[i] += adu * gphi[i]; zmax = fmax(zmax, fmax(zl[i], zh[i])); }
+                for (int i = 0; i < n; i++) {
+                    if (zmax > RESTO_BOUND_MULT_RESET) { zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; }
+                    w[i] = xr[i]; lo[i] = lot[i]; hi[i] = hit[i];
+                    if (fl[i]) zl[i] = fmin(fmax(zl[i], mu / (KAPPA_SIGMA * slt[i])), KAPPA_SIGMA * mu / slt[i]);
+                    if (fh[i]) zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * sht[i])), KAPPA_SIGMA * mu / sht[i]);
+                }
+                for (int j = 0; j < m; j++) lam[j] = 0.0;
+                restored = 1;
+            } else if (!FTYPE(alpha) || !ARMIJO(alpha)) AUGMENT();      /* the filter grows unless the step was an Armijo step on the barrier function */
         }
 #undef TRIAL
 #undef FTYPE
 #undef ARMIJO
+#undef ACCEPTABLE
+#undef AUGMENT
+        if (restored) { it++; continue; }
         /* the accepted point (wt, slt, sht, lot, hit): multiplier steps of the direction that was taken */
         const double *dacc = soc_taken ? ds : dw, *lacc = soc_taken ? lamsoc : lamn;
         const double a_pr = soc_taken ? a_soc : alpha;
@@ -554,8 +595,118 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
             if (fh[i]) zh[i] = fmin(fmax(zh[i], mu / (KAPPA_SIGMA * sht[i])), KAPPA_SIGMA * mu / sht[i]);
         }
         for (int j = 0; j < m; j++) lam[j] += a_pr * (lacc[j] - lam[j]);
+        it++;
     }
-    *iters = it;
+    *it_out = it;
+    arena_release(mark_);
+    return status;
+}
+
+/* ---- the restoration phase: the same iteration on  min rho sum(n + p) + eta(mu) / 2 |D_R (x - x_R)|^2  s.t.  c(x) + n - p = 0, bounds, n, p >= 0 ---- */
+typedef struct { IpmProb *P; OrigRef *O; const double *x_r, *d_r; int n, m; double *Ja, *Ha, *Hb, *ga, *zero; } RestoCtx;
+static void resto_ev(IpmProb *R, const double *wb, const double *lam, double mu, int want, double *f, double *gf, double *g, double *J, double *H)
+{
+    RestoCtx *C = (RestoCtx *)R->ctx;
+    const int n = C->n, m = C->m, nb = n + 2 * m;
+    const double eta = sqrt(mu);
+    double fo;
+    C->P->ev(C->P, wb, lam, mu, want == WANT_VALUES ? WANT_VALUES : WANT_GRAD, &fo, C->ga, g, C->Ja, C->Ha);
+    double s = 0.0, q = 0.0;
+    for (int j = 0; j < m; j++) { s += wb[n + j] + wb[n + m + j]; g[j] += wb[n + j] - wb[n + m + j]; }
+    for (int i = 0; i < n; i++) { const double e = C->d_r[i] * (wb[i] - C->x_r[i]); q += e * e; }
+    *f = RESTO_RHO * s + 0.5 * eta * q;
+    if (want == WANT_VALUES) return;
+    for (int i = 0; i < n; i++) gf[i] = eta * C->d_r[i] * C->d_r[i] * (wb[i] - C->x_r[i]);
+    for (int i = n; i < nb; i++) gf[i] = RESTO_RHO;
+    memset(J, 0, sizeof(double) * m * nb);
+    for (int j = 0; j < m; j++) { for (int i = 0; i < n; i++) J[j * nb + i] = C->Ja[j * n + i]; J[j * nb + n + j] = 1.0; J[j * nb + n + m + j] = -1.0; }
+    if (want != WANT_HESS) return;
+    memset(H, 0, sizeof(double) * nb * nb);
+    C->P->ev(C->P, wb, lam, mu, WANT_HESS, &fo, C->ga, C->zero + m, C->Ja, C->Ha);        /* Hessian of (objective + lam'c) ... */
+    C->P->ev(C->P, wb, C->zero, mu, WANT_HESS, &fo, C->ga, C->zero + m, C->Ja, C->Hb);    /* ... minus that of the objective alone: lam'c */
+    for (int i = 0; i < m; i++) C->zero[m + i] = 0.0;
+    for (int i = 0; i < n; i++) for (int l = 0; l < n; l++) H[i * nb + l] = C->Ha[i * n + l] - C->Hb[i * n + l] + (i == l ? eta * C->d_r[i] * C->d_r[i] : 0.0);
+}
+static int resto_hook(IpmProb *R, const double *wb)
+{
+    RestoCtx *C = (RestoCtx *)R->ctx;
+    OrigRef *O = C->O;
+    double ft, th = 0.0;
+    O->P->ev(O->P, wb, C->zero, O->mu, WANT_VALUES, &ft, O->gdum, O->gt, O->J, O->H);
+    int ok = isfinite(ft);
+    for (int j = 0; j < O->m; j++) { th += fabs(O->gt[j]); ok = ok && isfinite(O->gt[j]); }
+    if (!ok || th > RESTO_KAPPA * O->theta) return 0;
+    const double ph = barrier_of(O->n, wb, ft, O->lo, O->hi, O->zl, O->zh, O->fl, O->fh, O->mu);
+    return to_filter(O->filt_phi, O->filt_th, O->nfilt, th, ph) && to_iterate(O->theta, O->phi, th, ph, 1);
+}
+static int ipm_restore(IpmProb *P, OrigRef *O, const double *x_r, double *lo, double *hi, const double *zl, const double *zh, double mu, const double *c_r, double tol, int max_iter, int it0,
+                       double *x_out, int *it_out, IpmInfo *inf)
+{
+    const size_t mark_ = arena_mark();
+    const int n = P->n, m = P->m, nb = n + 2 * m;
+    double *wb = vec(nb), *lob = vec(nb), *hib = vec(nb), *zlb = vec(nb), *zhb = vec(nb), *lam = vec(m), *d_r = vec(n);
+    double mu_r = mu;
+    for (int j = 0; j < m; j++) mu_r = fmax(mu_r, fabs(c_r[j]));
+    for (int i = 0; i < n; i++) { wb[i] = x_r[i]; d_r[i] = 1.0 / fmax(1.0, fabs(x_r[i])); lob[i] = lo[i]; hib[i] = hi[i]; zlb[i] = isfinite(lo[i]) ? fmin(RESTO_RHO, zl[i]) : 0.0; zhb[i] = isfinite(hi[i]) ? fmin(RESTO_RHO, zh[i]) : 0.0; }
+    for (int j = 0; j < m; j++) {
+        const double a = mu_r / (2.0 * RESTO_RHO) - 0.5 * c_r[j], nn = a + sqrt(a * a + mu_r * c_r[j] / (2.0 * RESTO_RHO)), pp = c_r[j] + nn;
+        wb[n + j] = nn; wb[n + m + j] = pp;
+        lob[n + j] = 0.0; lob[n + m + j] = 0.0; hib[n + j] = INFINITY; hib[n + m + j] = INFINITY;
+        zlb[n + j] = mu_r / nn; zlb[n + m + j] = mu_r / pp; zhb[n + j] = 0.0; zhb[n + m + j] = 0.0;
+    }
+    RestoCtx C = {P, O, x_r, d_r, n, m, vec((size_t)m * n), vec((size_t)n * n), vec((size_t)n * n), vec(n), vec(2 * m)};
+    IpmProb R = {nb, m, resto_ev, resto_hook, &C};
+    (void)ipm_core(&R, wb, lob, hib, zlb, zhb, lam, mu_r, tol, max_iter, it0, RESTO_THETA_MAX_FACT, 0, it_out, inf);
+    for (int i = 0; i < n; i++) { x_out[i] = wb[i]; lo[i] = lob[i]; hi[i] = hib[i]; }      /* (bounds the restoration moved stay moved) */
+    const int stop = inf->stop;
+    arena_release(mark_);
+    return stop;
+}
+
+/* ---- the problem as the callers pose it: scaling, first iterate, least-squares multipliers, then the iteration -------------------------------------------- */
+typedef struct { evalf2_t evalf; void *ctx; double df; double *lams; int m; } MainCtx;
+static void main_ev(IpmProb *P, const double *w, const double *lam, double mu, int want, double *f, double *gf, double *g, double *J, double *H)
+{
+    MainCtx *C = (MainCtx *)P->ctx;
+    (void)mu;
+    if (want == WANT_HESS) for (int j = 0; j < C->m; j++) C->lams[j] = lam[j] / C->df;      /* Hessian of df f + lam'g = df (Hessian of f + (lam / df)'g) */
+    C->evalf(C->ctx, w, want == WANT_HESS ? C->lams : lam, want, f, gf, g, J, H);
+    *f *= C->df;
+    if (want != WANT_VALUES) for (int i = 0; i < P->n; i++) gf[i] *= C->df;
+    if (want == WANT_HESS) for (size_t i = 0; i < (size_t)P->n * P->n; i++) H[i] *= C->df;
+}
+
+/* n variables (none fixed: the caller has removed parameters), m equalities; resto: whether a failed line search may enter the restoration phase */
+static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const double *lo_in, const double *hi_in, double tol, int max_iter, int resto, int *iters, double *lam_out, IpmInfo *info)
+{
+    const size_t mark_ = arena_mark();
+    double *lo = vec(n), *hi = vec(n), *zl = vec(n), *zh = vec(n), *lam = vec(m), *lamn = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m + 2), *tmp = vec(n);
+    memcpy(lo, lo_in, sizeof(double) * n); memcpy(hi, hi_in, sizeof(double) * n);
+    IpmInfo inf = {0, 0, 0, 0, 2, 0, 0, 1.0};
+    double f;
+    /* scaling of the objective at the caller's point */
+    evalf(ctx, w, lam, WANT_GRAD, &f, gf, g, J, H);
+    double gmax = 0.0;
+    for (int i = 0; i < n; i++) gmax = fmax(gmax, fabs(gf[i]));
+    const double df = gmax > SCALE_MAX_GRAD ? fmax(SCALE_MAX_GRAD / gmax, SCALE_MIN) : 1.0;
+    inf.df = df;
+    for (int i = 0; i < n; i++) { w[i] = push_in(w[i], lo[i], hi[i]); zl[i] = isfinite(lo[i]) ? 1.0 : 0.0; zh[i] = isfinite(hi[i]) ? 1.0 : 0.0; }
+    /* least-squares equality multipliers: min |gf - zl + zh + J'y|  (null-space form: R y = -Q1'(gf - zl + zh)) */
+    if (m > 0 && m < n) {
+        evalf(ctx, w, lam, WANT_GRAD, &f, gf, g, J, H);
+        int ok = 1;
+        for (int i = 0; i < n; i++) { tmp[i] = df * gf[i] - zl[i] + zh[i]; ok = ok && isfinite(tmp[i]); for (int j = 0; j < m; j++) Jt[i * m + j] = J[j * n + i]; }
+        if (ok && qr_factor(n, m, Jt, tau)) {
+            qr_apply(n, m, Jt, tau, tmp, 1);
+            double ymax = 0.0;
+            for (int i = m - 1; i >= 0; i--) { double s = -tmp[i]; for (int k = i + 1; k < m; k++) s -= r_at(m, Jt, tau, i, k) * lamn[k]; lamn[i] = s / r_at(m, Jt, tau, i, i); }
+            for (int j = 0; j < m; j++) { ymax = fmax(ymax, fabs(lamn[j])); ok = ok && isfinite(lamn[j]); }
+            if (ok && ymax <= Y_INIT_MAX) memcpy(lam, lamn, sizeof(double) * m);
+        }
+    }
+    MainCtx C = {evalf, ctx, df, vec(m), m};
+    IpmProb P = {n, m, main_ev, NULL, &C};
+    const int status = ipm_core(&P, w, lo, hi, zl, zh, lam, MU_INIT, tol, max_iter, 0, THETA_MAX_FACT, resto, iters, &inf);
     if (lam_out) for (int j = 0; j < m; j++) lam_out[j] = lam[j] / df;
     if (info) *info = inf;
     arena_release(mark_);
