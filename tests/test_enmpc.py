@@ -44,8 +44,9 @@ def prob(pkg):
 def test_golden_vectors_certify_themselves(gold):
     for pre in ("ship_", "c4_", "c5_"):
         assert int(gold[pre + "STATUS_DYN"].max()) == 0 and int(gold[pre + "STATUS_SS"].max()) == 0
-        for k in ("KKT_DYN", "KKT_SS", "KKT_MHE"):      # every NLP's own first-order conditions: what IPOPT terminates on (tol 1e-8)
-            assert float(gold[pre + k].max()) < 1e-8, (pre, k)
+        for k in ("KKT_DYN", "KKT_SS", "KKT_MHE"):      # every NLP's own first-order conditions: what IPOPT terminates on (tol 1e-8) - on the problem as IPOPT
+            # scales it: the OCP's cost is multiplied by df = 100 / |grad f(w0)|_inf (0.07 - 0.2 on the cold steps), so its unscaled residual may reach 1e-8 / df
+            assert float(gold[pre + k].max()) < (2e-7 if k == "KKT_DYN" else 1e-8), (pre, k)
     # the economics: the loop settles at the profit-optimal steady state of the reactor (u = 1.0430, cB = 0.4671)
     assert abs(gold["ship_U"][-1, 0, 0] - 1.04297536) < 1e-7 and abs(gold["ship_XS"][-1, 0, 1] - 0.46708998) < 1e-7
 
@@ -71,36 +72,49 @@ def test_c_restatement_follows_the_golden_loops(gold):
 
 def test_restatements_agree_where_a_slack_rounds_to_zero():
     """dmin / dmax as bounds of the estimator (MPC_code.py:657-664) and an estimate of step 0 that ends on its bound with a vanishing multiplier: the
-    slack rounds to zero, kappa_Sigma's clamp makes the multiplier infinite and both restatements label the (converged) solve failed - DESIGN.md
-    section 12; IPOPT's safe slack is not restated.  Same iterates, iteration counts and labels in NumPy (dense LU) and C (null space)."""
+    last Newton steps leave a slack below the spacing of the doubles at the bound.  Round 3's restatement ended such a solve "failed" with an infinite
+    multiplier; with IPOPT's safe slack - the slack lifted, the bound of the solve moved along - it ends solved, on the bound, in
+    NumPy (dense LU) and C (null space) with the same iterates and iteration counts."""
     import warnings
     import enmpc_oracle_c as ec
-    for seed, inst in ((15, 3), (17, 2)):      # (the draws of tools/enmpc_fuzz.py and of the GPU test with these seeds)
-        rng = np.random.default_rng(1000 + seed)
-        over = {"K1": float(rng.uniform(0.6, 1.6)), "K2": float(rng.uniform(0.02, 0.2)), "PRICE_B": float(rng.uniform(2.5, 6.0)), "h": float(rng.choice([1.0, 2.0, 3.0])),
-                "N": int(rng.integers(8, 41)), "N_mhe": int(rng.integers(3, 15)), "mhe_up": str(rng.choice(["smooth", "filter"]))}
-        over.update({"umax": [float(rng.uniform(0.8, 3.0))], "xmax": np.array([1.0, float(rng.uniform(0.5, 1.0))]), "dmin": np.array([-0.05, -0.02]), "dmax": np.array([0.03, 0.05])})
-        x0 = rng.uniform([0.4, 0.0], [1.0, 0.6], size=(6, 2))
+    from enmpc_cases import draw
+    for seed, inst in ((15, 3), (17, 2)):
+        over, x0 = draw(seed)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             q = eo.load_problem(EX, overrides=over)
         c = ec.OracleEC(q).closed_loop(3, x0[inst:inst + 1], nthreads=1)
         o = eo.closed_loop(q, 3, x0_p=x0[inst])
-        assert c["STATUS_MHE"][:, 0].tolist() == [2, 0, 0] == o["STATUS_MHE"].tolist()
+        assert c["STATUS_MHE"][:, 0].tolist() == [0, 0, 0] == o["STATUS_MHE"].tolist()
         assert c["ITERS_MHE"][:, 0].tolist() == o["ITERS_MHE"].tolist()
         for k in ("U", "XS", "X_ES"):
             assert np.abs(o[k] - c[k][:, 0]).max() < 1e-11, (seed, k)
-        assert abs(c["X_ES"][0, 0, 2] - (-0.05)) < 1e-15 or abs(c["X_ES"][0, 0, 3] - (-0.02)) < 1e-15 or abs(c["X_ES"][0, 0, 2] - 0.03) < 1e-15 or abs(c["X_ES"][0, 0, 3] - 0.05) < 1e-15
-        # the prototype of IPOPT's safe slack in both restatements (off by default: the kernels do not have it): the same solves end "solved", same estimates
-        C = ec.OracleEC(q)
-        try:
-            C.set_safe_slack(True); eo.SAFE_SLACK = True
-            c2 = C.closed_loop(3, x0[inst:inst + 1], nthreads=1)
-            o2 = eo.closed_loop(q, 3, x0_p=x0[inst])
-        finally:
-            C.set_safe_slack(False); eo.SAFE_SLACK = False
-        assert c2["STATUS_MHE"][:, 0].tolist() == [0, 0, 0] == o2["STATUS_MHE"].tolist()
-        assert np.abs(c2["X_ES"] - c["X_ES"]).max() < 1e-8 and np.abs(o2["X_ES"] - c2["X_ES"][:, 0]).max() < 1e-10
+        assert min(abs(c["X_ES"][0, 0, 2] - (-0.05)), abs(c["X_ES"][0, 0, 3] - (-0.02)), abs(c["X_ES"][0, 0, 2] - 0.03), abs(c["X_ES"][0, 0, 3] - 0.05)) < 1e-8      # on its bound (to the estimator's tolerance)
+
+
+@pytest.mark.parametrize("seed", [7, 13, 19, 23])
+def test_restatements_agree_on_the_models_that_need_the_line_search(seed):
+    """The randomised models on which round 3's full-step iteration and IPOPT parted (tests/enmpc_cases.py): model 13 - an OCP of 153 / 173 full steps,
+    42 with the line search -, models 19 and 23 - target problems that jam on a state bound and leave through the restoration phase -, model 7 - the
+    longest target solve left.  NumPy (dense LU on all variables, restoration problem in (x, n, p)) and C (null-space steps) take the same iterations to the
+    same points, every status word is "solved"."""
+    import warnings
+    import enmpc_oracle_c as ec
+    from enmpc_cases import draw
+    over, x0 = draw(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        q = eo.load_problem(EX, overrides=over)
+    ns = 4
+    c = ec.OracleEC(q).closed_loop(ns, x0[:2], nthreads=2)
+    for b in range(2):
+        o = eo.closed_loop(q, ns, x0_p=x0[b])
+        for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+            assert o[k].tolist() == c[k][:, b].tolist() == [0] * ns, (seed, b, k)
+        for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+            assert np.abs(o[k].astype(int) - c[k][:, b].astype(int)).max() <= 1, (seed, b, k, o[k].tolist(), c[k][:, b].tolist())
+        for k in ("U", "XS", "US", "X_ES"):
+            assert np.abs(o[k] - c[k][:, b]).max() < 1e-8, (seed, b, k)
 
 
 def test_interval_integration_is_within_the_reference_integrators_tolerance(oprob):
@@ -136,7 +150,8 @@ def test_ocp_minimum_is_found_by_an_independent_solver(oprob):
     for k in range(1, N + 1):
         wg[k * nz - m:k * nz] = p.u0; wg[k * nz:k * nz + n] = p.x0_m
     sol = eo.ocp_solve(p, xhat, ts["xs"], ts["us"], np.zeros(2), wg)
-    assert sol["status"] == 0 and max(eo.kkt_nlp(sol["evalf"], sol, sol["lo"], sol["hi"]).values()) < 1e-8
+    # (the tolerance applies to the problem as IPOPT scales it: the unscaled residual may reach 1e-8 / df, df = 0.036 here)
+    assert sol["status"] == 0 and max(eo.kkt_nlp(sol["evalf"], sol, sol["lo"], sol["hi"]).values()) < 1.05e-8 / sol["df"]
     evalf, lo, hi = sol["evalf"], sol["lo"], sol["hi"]
     free = lo != hi
     w0 = sol["w"].copy()
@@ -485,31 +500,30 @@ def test_gpu_edge_horizons_and_iteration_limits_follow_the_c_restatement(pkg, ov
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 15, 17])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4] + list(range(5, 37)))
 def test_gpu_randomised_reactor_models_follow_the_c_restatement(pkg, seed):
-    """Other reactors than the shipped one: rate constants, prices, the sampling time, both horizons and the estimator's update drawn at random
-    (each model gets its own generated library: the constants are compiled in), six starts, twelve steps - every launch style against the C
-    restatement evaluated with the same constants: values, status words, iteration counts of all three NLPs.  Seeds 15 and 17 (as the odd seeds of
-    tools/enmpc_fuzz.py) also draw other boxes and make the disturbance bounds bounds of the estimator (MPC_code.py:657-664): there the estimate of
-    step 0 ends on a bound with a slack that rounds to zero, and the estimator's status must be 2 on both sides (round 3: the kernels said 0)."""
+    """Other reactors than the shipped one (tests/enmpc_cases.py: round 3's tools/enmpc_fuzz.py as a test): rate constants, prices, the sampling time, both
+    horizons and the estimator's update drawn at random (each model gets its own generated library: the constants are compiled in), six starts, twelve
+    steps - every launch style against the C restatement evaluated with the same constants: values, status words, iteration counts of all three NLPs.
+    Seeds 5 - 36 are the 32 models on which round 3's restated iteration (full steps, no safe slack) and IPOPT parted: the odd ones draw other boxes and make
+    the disturbance bounds bounds of the estimator (MPC_code.py:657-664).  With the filter line search, the safe slack and - for the target - the restoration
+    phase: NO status 2 on any of the 6912 solves, no solve above 60 iterations except the one documented in enmpc_cases.FUZZ_LONG_SOLVES."""
     import warnings
     import enmpc_oracle_c as ec
+    from enmpc_cases import draw, FUZZ_STEPS, FUZZ_LONG_SOLVES
     from mpc_code_amd import enmpc
-    rng = np.random.default_rng(1000 + seed)
-    over = {"K1": float(rng.uniform(0.6, 1.6)), "K2": float(rng.uniform(0.02, 0.2)), "PRICE_B": float(rng.uniform(2.5, 6.0)), "h": float(rng.choice([1.0, 2.0, 3.0])),
-            "N": int(rng.integers(8, 41)), "N_mhe": int(rng.integers(3, 15)), "mhe_up": str(rng.choice(["smooth", "filter"]))}
-    if seed % 2 and seed > 4:
-        over.update({"umax": [float(rng.uniform(0.8, 3.0))], "xmax": np.array([1.0, float(rng.uniform(0.5, 1.0))]), "dmin": np.array([-0.05, -0.02]), "dmax": np.array([0.03, 0.05])})
-    x0 = rng.uniform([0.4, 0.0], [1.0, 0.6], size=(6, 2))
-    nsteps = 12
+    over, x0 = draw(seed)
+    nsteps = FUZZ_STEPS
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         p = pkg.load_problem(EX, overrides=over)
         q = eo.load_problem(EX, overrides=over)
-    c = ec.OracleEC(q).closed_loop(nsteps, x0, nthreads=6)
+    c = ec.OracleEC(q).closed_loop(nsteps, x0, nthreads=0)
     assert np.isfinite(c["U"]).all()
-    if seed > 4:
-        assert (c["STATUS_MHE"][0] == 2).any() and (c["STATUS_MHE"] == 0).mean() > 0.9      # the case this seed is here for
+    for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+        assert int(c[k].max()) == 0, (seed, k)
+    for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+        assert int(c[k].max()) <= (FUZZ_LONG_SOLVES[seed][1] if FUZZ_LONG_SOLVES.get(seed, ("",))[0] == k else 60), (seed, k, int(c[k].max()))
     s = enmpc.EnmpcSolver(p)
     try:
         for kernel in (1, 2):

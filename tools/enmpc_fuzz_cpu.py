@@ -5,20 +5,11 @@ restatement beside it): status words, iteration counts, how the solves ended.
 import os, sys, warnings
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 warnings.simplefilter("ignore")
 import enmpc_oracle as eo, enmpc_oracle_c as ec
+from enmpc_cases import draw
 EX = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc.py")
-
-
-def draw(seed):
-    rng = np.random.default_rng(1000 + seed)
-    over = {"K1": float(rng.uniform(0.6, 1.6)), "K2": float(rng.uniform(0.02, 0.2)), "PRICE_B": float(rng.uniform(2.5, 6.0)), "h": float(rng.choice([1.0, 2.0, 3.0])),
-            "N": int(rng.integers(8, 41)), "N_mhe": int(rng.integers(3, 15)), "mhe_up": str(rng.choice(["smooth", "filter"]))}
-    if seed % 2:      # odd seeds: other boxes too, and a saturated disturbance estimate (MPC_code.py:657-664)
-        over.update({"umax": [float(rng.uniform(0.8, 3.0))], "xmax": np.array([1.0, float(rng.uniform(0.5, 1.0))]), "dmin": np.array([-0.05, -0.02]), "dmax": np.array([0.03, 0.05])})
-    x0 = rng.uniform([0.4, 0.0], [1.0, 0.6], size=(6, 2))
-    return over, x0
 
 
 if __name__ == "__main__":

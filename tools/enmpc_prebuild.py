@@ -4,14 +4,14 @@
 import os, sys, warnings
 from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 warnings.simplefilter("ignore")
 
 
 def build(seed):
     import mpc_code_amd as m
     from mpc_code_amd import econcodegen
-    from enmpc_fuzz_cpu import draw
+    from enmpc_cases import draw
     over, _ = draw(seed)
     return seed, econcodegen.build_enmpc_library(m.load_problem(m.example_path("reactor_enmpc.py"), overrides=over))
 
