@@ -19,6 +19,7 @@
 //     (A - I) and the reduced Hessian is nu x nu; computed redundantly by every lane (wave-uniform).
 #pragma once
 #include "mpc_tp.hpp"
+#define EC_UNI(x) mpc::uni(x)
 #include "mpc_rk4s2.hpp"
 
 namespace enm {
@@ -147,11 +148,24 @@ __device__ __forceinline__ double safe_slack(double w, double &bound, double z, 
     return s;
 }
 // the filter of one segment (= one instance) in LDS: pairs (phi, theta); every lane of the segment reads the same entries
+template <int FS = 1>      // FS: stride between a list's words (1: a list of its own; 64: lists of the 64 lanes of a wave side by side in LDS)
 __device__ __forceinline__ bool filter_rejects(const double *filt, int nf, double phi_t, double theta_t)
 {
     bool rej = false;
-    for (int e = 0; e < kFilterCap; e++) { if (e < nf) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (le_tol(ph, phi_t, ph) && le_tol(th, theta_t, th)) rej = true; } }
+    for (int e = 0; e < kFilterCap; e++) { if (e < nf) { const double ph = filt[(2 * e) * FS], th = filt[(2 * e + 1) * FS]; if (le_tol(ph, phi_t, ph) && le_tol(th, theta_t, th)) rej = true; } }
     return rej;
+}
+// the filter grows by (e_phi, e_th); entries the new one dominates are dropped; a full list merges it into its last entry.  Returns the new length.
+template <int FS = 1>
+__device__ __forceinline__ int filter_add(double *filt, int nf, double e_phi, double e_th)
+{
+    int k2 = 0;
+    for (int e = 0; e < kFilterCap; e++) {
+        if (e < nf) { const double ph = filt[(2 * e) * FS], th = filt[(2 * e + 1) * FS]; if (!(ph >= e_phi && th >= e_th)) { filt[(2 * k2) * FS] = ph; filt[(2 * k2 + 1) * FS] = th; k2++; } }
+    }
+    if (k2 >= kFilterCap) { filt[(2 * (k2 - 1)) * FS] = dmin(filt[(2 * (k2 - 1)) * FS], e_phi); filt[(2 * (k2 - 1) + 1) * FS] = dmin(filt[(2 * (k2 - 1) + 1) * FS], e_th); }
+    else { filt[(2 * k2) * FS] = e_phi; filt[(2 * k2 + 1) * FS] = e_th; k2++; }
+    return k2;
 }
 
 template <int NS, int NU>
@@ -159,88 +173,97 @@ struct StageLin {
     double F[NS], A[NS][NS], B[NS][NU], l, lx[NS], lu[NU], Q[NS][NS], M[NS][NU], R[NU][NU];
 };
 
-// what a lane keeps of the factorised Newton system
+// what a lane keeps of the factorised Newton system (K, Quu^-1, the cost-to-go behind its stage; P0i: the free initial state's block, segment-uniform)
+// and of one solve with it (feed-forward, cost-to-go gradient behind its stage, step of the initial state)
 template <int NS, int NU>
 struct RicFac { double K[NU][NS], Qi[NU][NU], Pnx[NS][NS], P0i[NS][NS]; };
+template <int NS, int NU>
+struct RicVec { double kff[NU], pnx[NS], dx0[NS]; };
 
-// MATRIX pass of the Riccati recursion over the lanes.  Hessian blocks of this lane's stage in (Q, M, R), the diagonal terms Su (inputs), Sxk (x_k, from the
-// neighbour that holds it), terminal block Pt of lane N-1 (Hessian of x_N with its diagonal term).  false for this lane when its stage lacks positive curvature.
-template <int NS, int NU, bool FREE0, int SEG, class ST>
-__device__ __forceinline__ bool ric_matrix(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const double (&Q)[NS][NS], const double (&Mx)[NS][NU], const double (&R)[NU][NU],
-                                           const double (&Su)[NU], const double (&Sxk)[NS], const double (&Pt)[NS][NS], const double (&P0add)[NS][NS], RicFac<NS, NU> &Fc)
+// BACKWARD sweep of the Riccati recursion over the lanes: all lanes compute the stage update with the broadcast cost-to-go of the stage behind them, lane kk's
+// result is the valid one and is broadcast on.  MATRIX = true: gains and cost-to-go matrices from the Hessian blocks (Q, M, R) of this lane's stage, the
+// diagonal terms Su (inputs), Sxk (x_k, from the neighbour that holds it), the terminal block Pt of lane N-1, the initial state's own block P0add - and,
+// in the same sweep, the vector part; false: the vector part alone with the stored factors (second-order corrections).  Vector part: gradient terms gu
+// (inputs), gxk (x_k), pt (lane N-1: x_N), p0add (x_0) and the constraint residual c.  Returns false for a lane whose stage lacks positive curvature.
+template <int NS, int NU, bool FREE0, int SEG, class ST, bool MATRIX>
+__device__ __forceinline__ bool ric_backward(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const double (&Q)[NS][NS], const double (&Mx)[NS][NU], const double (&R)[NU][NU],
+                                             const double (&Su)[NU], const double (&Sxk)[NS], const double (&Pt)[NS][NS], const double (&P0add)[NS][NS],
+                                             const double (&gu)[NU], const double (&gxk)[NS], const double (&pt)[NS], const double (&p0add)[NS], const double (&c)[NS],
+                                             RicFac<NS, NU> &Fc, RicVec<NS, NU> &Vc)
 {
-    double Pn[NS][NS];
-    bcast_sym<SEG, NS>(Pt, N - 1, lane, Pn);
+    double Pn[NS][NS], pn[NS];
+    if (MATRIX) bcast_sym<SEG, NS>(Pt, N - 1, lane, Pn);
+    bcast_vec<SEG, NS>(pt, N - 1, lane, pn);
+    MPC_UNROLL for (int i = 0; i < NU; i++) Vc.kff[i] = 0.0;      // (lanes beyond the horizon never receive theirs: zero, not indeterminate)
+    MPC_UNROLL for (int i = 0; i < NS; i++) Vc.pnx[i] = 0.0;
     bool bad = false;
     for (int kk = N - 1; kk >= 0; kk--) {
-        double PA[NS][NS], PB[NS][NU];
-        MPC_UNROLL for (int i = 0; i < NS; i++) {
-            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, Pn[i][l], l, j); PA[i][j] = a; }
-            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, Pn[i][l], l, j); PB[i][j] = a; }
+        double Kl[NU][NS], Qil[NU][NU], Pk[NS][NS];
+        bool ok = true;
+        if (MATRIX) {
+            double PA[NS][NS], PB[NS][NU];
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, Pn[i][l], l, j); PA[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, Pn[i][l], l, j); PB[i][j] = a; }
+            }
+            double Qux[NU][NS], Qxx[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NU; i++) {
+                MPC_UNROLL for (int j = 0; j < NU; j++) { double a = R[i][j] + (i == j ? Su[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PB[l][j], l, i); Qil[i][j] = a; }
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Mx[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PA[l][j], l, i); Qux[i][j] = a; }
+            }
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Q[i][j] + (i == j ? Sxk[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, PA[l][j], l, i); Qxx[i][j] = a; }
+            }
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Qil[i][j] + Qil[j][i]); Qil[i][j] = a; Qil[j][i] = a; } }
+            ok = sym_inverse<NU>(Qil);
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) Qil[i][j] = Qil[j][i]; }      // (one value per pair: the inverse is held once)
+            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Qil[i][l] * Qux[l][j]; Kl[i][j] = a; } }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Qxx[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += Qux[l][i] * Kl[l][j]; Pk[i][j] = a; } }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Pk[i][j] + Pk[j][i]); Pk[i][j] = a; Pk[j][i] = a; } }
+            if (k == kk) {
+                MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = Kl[i][j]; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = Qil[i][j]; }
+                MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.Pnx[i][j] = Pn[i][j]; }
+                if (!ok) bad = true;
+            }
         }
-        double Quu[NU][NU], Qux[NU][NS], Qxx[NS][NS];
-        MPC_UNROLL for (int i = 0; i < NU; i++) {
-            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = R[i][j] + (i == j ? Su[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PB[l][j], l, i); Quu[i][j] = a; }
-            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Mx[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PA[l][j], l, i); Qux[i][j] = a; }
-        }
-        MPC_UNROLL for (int i = 0; i < NS; i++) {
-            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Q[i][j] + (i == j ? Sxk[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, PA[l][j], l, i); Qxx[i][j] = a; }
-        }
-        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Quu[i][j] + Quu[j][i]); Quu[i][j] = a; Quu[j][i] = a; } }
-        const bool ok = sym_inverse<NU>(Quu);
-        double Kl[NU][NS], Pk[NS][NS];
-        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Quu[i][l] * Qux[l][j]; Kl[i][j] = a; } }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Qxx[i][j]; MPC_UNROLL for (int l = 0; l < NU; l++) a += Qux[l][i] * Kl[l][j]; Pk[i][j] = a; } }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Pk[i][j] + Pk[j][i]); Pk[i][j] = a; Pk[j][i] = a; } }
-        if (k == kk) {
-            MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = Kl[i][j]; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = Quu[i][j]; }
-            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.Pnx[i][j] = Pn[i][j]; }
-            if (!ok) bad = true;
-        }
-        bcast_sym<SEG, NS>(Pk, kk, lane, Pn);
-    }
-    if (FREE0) {      // the initial state: value function of stage 0 + arrival cost + its own diagonal term
-        double P0[NS][NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) P0[i][j] = Pn[i][j] + P0add[i][j]; }
-        if (!sym_inverse<NS>(P0)) bad = true;
-        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.P0i[i][j] = P0[i][j]; }
-    }
-    return !bad;
-}
-
-// VECTOR pass + forward pass: the Newton step (du, dxn, dx0) and the new costates pin for the gradient terms gu (inputs), gxk (x_k: this stage's cost
-// gradient + the diagonal-term gradient of x_k from the neighbour), pt (lane N-1: x_N), p0add (x_0, FREE0) and the constraint right-hand side c.
-template <int NS, int NU, bool FREE0, int SEG, class ST>
-__device__ __forceinline__ void ric_solve(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const RicFac<NS, NU> &Fc, const double (&gu)[NU], const double (&gxk)[NS],
-                                          const double (&pt)[NS], const double (&p0add)[NS], const double (&c)[NS], double (&du)[NU], double (&dxn)[NS], double (&dx0)[NS], double (&pin)[NS])
-{
-    double pn[NS], kff[NU], pnx[NS];
-    MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = 0.0;      // (lanes beyond the horizon never receive theirs: zero, not indeterminate)
-    MPC_UNROLL for (int i = 0; i < NS; i++) pnx[i] = 0.0;
-    bcast_vec<SEG, NS>(pt, N - 1, lane, pn);
-    for (int kk = N - 1; kk >= 0; kk--) {
+        // vector part: every lane with ITS stored factors (lane kk's are the ones of this stage)
         double pc[NS], qu[NU], kl[NU], pk[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pn[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a -= Fc.Pnx[i][l] * c[l]; pc[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pn[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a -= (MATRIX ? Pn[i][l] : Fc.Pnx[i][l]) * c[l]; pc[i] = a; }
         MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, pc[l], l, i); qu[i] = a; }
-        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Fc.Qi[i][l] * qu[l]; kl[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= (MATRIX ? Qil[i][l] : Fc.Qi[i][l]) * qu[l]; kl[i] = a; }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             double a = gxk[i];
             MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, pc[l], l, i);
-            MPC_UNROLL for (int l = 0; l < NU; l++) a += Fc.K[l][i] * qu[l];      // Qux' kl = K' qu
+            MPC_UNROLL for (int l = 0; l < NU; l++) a += (MATRIX ? Kl[l][i] : Fc.K[l][i]) * qu[l];      // Qux' kl = K' qu
             pk[i] = a;
         }
-        if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) kff[i] = kl[i]; MPC_UNROLL for (int i = 0; i < NS; i++) pnx[i] = pn[i]; }
+        if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) Vc.kff[i] = kl[i]; MPC_UNROLL for (int i = 0; i < NS; i++) Vc.pnx[i] = pn[i]; }
+        if (MATRIX) bcast_sym<SEG, NS>(Pk, kk, lane, Pn);
         bcast_vec<SEG, NS>(pk, kk, lane, pn);
     }
+    if (FREE0) {      // the initial state: value function of stage 0 + arrival cost + its own diagonal term
+        if (MATRIX) {
+            double P0[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) P0[i][j] = Pn[i][j] + P0add[i][j]; }
+            if (!sym_inverse<NS>(P0)) bad = true;
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.P0i[i][j] = j < i ? P0[j][i] : P0[i][j]; }
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a -= Fc.P0i[i][j] * (pn[j] + p0add[j]); Vc.dx0[i] = a; }
+    } else { MPC_UNROLL for (int i = 0; i < NS; i++) Vc.dx0[i] = 0.0; }
+    return !bad;
+}
+
+// FORWARD sweep: the Newton step (du, dxn; dx0 in Vc) and the new costates pin
+template <int NS, int NU, int SEG, class ST>
+__device__ __forceinline__ void ric_forward(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const RicFac<NS, NU> &Fc, const RicVec<NS, NU> &Vc, const double (&c)[NS],
+                                            double (&du)[NU], double (&dxn)[NS], double (&pin)[NS])
+{
     double dx[NS];
-    if (FREE0) {
-        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a -= Fc.P0i[i][j] * (pn[j] + p0add[j]); dx0[i] = a; }
-    } else { MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = 0.0; }
-    MPC_UNROLL for (int i = 0; i < NS; i++) { dx[i] = dx0[i]; dxn[i] = 0.0; }
+    MPC_UNROLL for (int i = 0; i < NS; i++) { dx[i] = Vc.dx0[i]; dxn[i] = 0.0; }
     MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = 0.0;
     for (int kk = 0; kk < N; kk++) {
         double dul[NU], dxl[NS];
-        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.K[i][j] * dx[j]; dul[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = Vc.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.K[i][j] * dx[j]; dul[i] = a; }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             double a = -c[i];
             MPC_UNROLL for (int j = 0; j < NS; j++) EC_A(a, dx[j], i, j);
@@ -250,14 +273,15 @@ __device__ __forceinline__ void ric_solve(const int N, const int lane, const int
         if (k == kk) { MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dul[i]; MPC_UNROLL for (int i = 0; i < NS; i++) dxn[i] = dxl[i]; }
         bcast_vec<SEG, NS>(dxl, kk, lane, dx);
     }
-    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pnx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.Pnx[i][j] * dxn[j]; pin[i] = a; }
+    MPC_UNROLL for (int i = 0; i < NS; i++) { double a = Vc.pnx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.Pnx[i][j] * dxn[j]; pin[i] = a; }
 }
 
-template <int NS, int NU, bool FREE0, int SEG, class ST, class AUX, class LinF, class AddPiF, class ValF, class TermF>
+//   grd(xk, u, L)          cost value / gradient only (L.l, L.lx, L.lu): the caller's point, where IPOPT takes the scaling of the objective from
+template <int NS, int NU, bool FREE0, int SEG, class ST, class AUX, class GrdF, class LinF, class AddPiF, class ValF, class TermF>
 __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
                                          double (&pi)[NS], const double (&ulo_in)[NU], const double (&uhi_in)[NU], const double (&xlo_in)[NS],
                                          const double (&xhi_in)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
-                                         const int max_iter, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt)
+                                         const int max_iter, GrdF grd, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt, double *const park)
 {
     using SG = Seg<SEG>;
     const int k = SG::stage(lane);
@@ -272,6 +296,17 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         flx[i] = fin(blx[i]); fhx[i] = fin(bhx[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
         zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0;
     }
+    // Bound multipliers and the (moved) bounds are PARKED IN LDS while the stage is linearised (`park`: rows of 64 lanes, this lane's column): the Runge-Kutta
+    // loop with its second-order sensitivities takes the whole register file, and whatever else lives across it is spilled to scratch memory and reloaded
+    // inside that loop (measured: 226 KB of scratch traffic per instance-step, a quarter of the wave-cycles waiting).  They are read back after the
+    // linearisation and stored again at the end of the iteration.
+    auto park_io = [&](const bool store) {
+        int slot = 0;
+        auto one = [&](double &v, bool used) { if (used) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; } slot++; };
+        MPC_UNROLL for (int i = 0; i < NU; i++) { one(zlu[i], flu[i]); one(blu[i], flu[i]); one(zhu[i], fhu[i]); one(bhu[i], fhu[i]); }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { one(zlx[i], flx[i]); one(blx[i], flx[i]); one(zhx[i], fhx[i]); one(bhx[i], fhx[i]); }
+        if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { one(zl0[i], flx[i]); one(bl0[i], flx[i]); one(zh0[i], fhx[i]); one(bh0[i], fhx[i]); } }
+    };
     const double nb = (double)(N * (nbl + nbx) + (FREE0 ? nbx : 0)), meq = (double)(N * NS);
     // damping of the variables with one bound [WB 3.7]: +1 (only a lower bound), -1 (only an upper bound), 0
     auto damp = [&](bool fl_, bool fh_) { return (fl_ && !fh_) ? 1.0 : ((fh_ && !fl_) ? -1.0 : 0.0); };
@@ -283,11 +318,34 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
     int status = kStMaxIter, nfilt = 0, acc_count = 0;
     bool done = !live, tiny_last = false, tiny_flag = false;
     iters = 0;
-    enum { PH_RAW = 0, PH_LSQ = 1, PH_MAIN = 2 };
-    int phase = PH_RAW;      // (wave-uniform: every segment goes through the two preparing phases together)
+    // ---- scaling of the objective at the caller's point (IpGradientScaling), then the push into the box --------------------------------------------
+    {
+        double xk[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
+        StageLin<NS, NU> L;
+        grd(xk, u, L);
+        double fv, gv[NS], Hv[NS][NS], gm = 0.0;
+        term(xn, fv, gv, Hv);
+        MPC_UNROLL for (int i = 0; i < NU; i++) gm = dmax(gm, fabs(L.lu[i]));
+        MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, L.lx[i], k); gm = dmax(gm, fabs(k == N - 1 ? gv[i] : sh)); }
+        gm = SG::max(on ? gm : 0.0);
+        if (FREE0) {
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                double a = SG::bcast(L.lx[i], 0, lane);
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0v[j] - xbar[j]);
+                gm = dmax(gm, fabs(a));
+            }
+        }
+        df = gm > kScaleMaxGrad ? dmax(kScaleMaxGrad / gm, kScaleMin) : 1.0;
+        MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = push_in(u[i], blu[i], bhu[i]);
+        MPC_UNROLL for (int i = 0; i < NS; i++) xn[i] = push_in(xn[i], blx[i], bhx[i]);
+        if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) x0v[i] = push_in(x0v[i], bl0[i], bh0[i]); }
+    }
+    park_io(true);
+    bool first = true;      // (wave-uniform: every segment's first iteration starts with the least-squares multipliers)
     int it = 0;
     for (;;) {
-        if (!done && phase == PH_MAIN) iters = it;
+        if (!done) iters = it;
         // ---- linearise this lane's stage at (x_k, u_k); x_k is the neighbour's x_{k+1} ------------------------------------------------
         double xk[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
@@ -296,44 +354,32 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         lin(xk, u, L, aux);
         double fv, gv[NS], Hv[NS][NS];
         term(xn, fv, gv, Hv);
-        // gradient of the objective with respect to this lane's x_{k+1}: the next stage's cost gradient, the terminal cost's at the end
-        double gfx[NS], gf0[NS], e0[NS];
+        park_io(false);
+        // the scaled problem: df f
+        L.l *= df; fv *= df;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] *= df; MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] *= df; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { L.lx[i] *= df; gv[i] *= df; MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] *= df; Hv[i][j] *= df; } MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] *= df; }
+        // gradient of the objective with respect to this lane's x_{k+1}: the next stage's cost gradient, the terminal cost's at the end; with respect to the
+        // free initial state: stage 0's cost gradient + the arrival cost's (ga0)
+        double gfx[NS], ga0[NS], lx0[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, L.lx[i], k); gfx[i] = k == N - 1 ? gv[i] : sh; }
         double farr = 0.0;
         if (FREE0) {
-            MPC_UNROLL for (int i = 0; i < NS; i++) e0[i] = x0v[i] - xbar[i];
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 double a = 0.0;
-                MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * e0[j];
-                farr += 0.5 * e0[i] * a;
-                gf0[i] = SG::bcast(L.lx[i], 0, lane) + a;
+                MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0v[j] - xbar[j]);
+                farr += 0.5 * (x0v[i] - xbar[i]) * a;
+                ga0[i] = df * a; lx0[i] = SG::bcast(L.lx[i], 0, lane);
             }
-        } else { MPC_UNROLL for (int i = 0; i < NS; i++) { gf0[i] = 0.0; e0[i] = 0.0; } }
-        if (phase == PH_RAW) {
-            // ---- scaling of the objective at the caller's point (IpGradientScaling), then the push into the box ----------------------------
-            double gm = 0.0;
-            MPC_UNROLL for (int i = 0; i < NU; i++) gm = dmax(gm, fabs(L.lu[i]));
-            MPC_UNROLL for (int i = 0; i < NS; i++) gm = dmax(gm, fabs(gfx[i]));
-            gm = SG::max(on ? gm : 0.0);
-            if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) gm = dmax(gm, fabs(gf0[i])); }
-            df = gm > kScaleMaxGrad ? dmax(kScaleMaxGrad / gm, kScaleMin) : 1.0;
-            bool moved = false;
-            MPC_UNROLL for (int i = 0; i < NU; i++) { const double v = push_in(u[i], blu[i], bhu[i]); moved = moved || (on && v != u[i]); u[i] = v; }
-            MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = push_in(xn[i], blx[i], bhx[i]); moved = moved || (on && v != xn[i]); xn[i] = v; }
-            if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { const double v = push_in(x0v[i], bl0[i], bh0[i]); moved = moved || (v != x0v[i]); x0v[i] = v; } }
-            phase = PH_LSQ;
-            if (__any(moved ? 1 : 0)) continue;      // linearise again, at the pushed point
-        }
-        // the scaled problem: df f
-        L.l *= df; fv *= df; farr *= df;
-        MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] *= df; MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] *= df; }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { L.lx[i] *= df; gfx[i] *= df; gv[i] *= df; gf0[i] *= df; MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] *= df; Hv[i][j] *= df; } MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] *= df; }
+            farr *= df;
+        } else { MPC_UNROLL for (int i = 0; i < NS; i++) { ga0[i] = 0.0; lx0[i] = 0.0; } }
         double c[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) c[i] = xn[i] - L.F[i];
         RicFac<NS, NU> Fc;
+        RicVec<NS, NU> Vc;
         MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = 0.0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Fc.Pnx[i][j] = 0.0; Fc.P0i[i][j] = 0.0; } }
-        if (phase == PH_LSQ) {
+        if (first) {
             // ---- least-squares equality multipliers [WB (36)]: the Newton system with the identity for the Hessian, no constraint residual ------------
             double Iq[NS][NS], Im[NS][NU], Ir[NU][NU], zu_[NU], zx_[NS], gu[NU], gxk[NS], pt[NS], p0a[NS], c0[NS], P0a[NS][NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Iq[i][j] = i == j ? 1.0 : 0.0; P0a[i][j] = i == j ? 1.0 : 0.0; } MPC_UNROLL for (int j = 0; j < NU; j++) Im[i][j] = 0.0; zx_[i] = 0.0; c0[i] = 0.0; }
@@ -341,20 +387,18 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 const double bz = -zlx[i] + zhx[i];
                 gxk[i] = L.lx[i] + SG::up1(0.0, bz, k); pt[i] = gv[i] + bz;
-                p0a[i] = FREE0 ? (gf0[i] - SG::bcast(L.lx[i], 0, lane) - zl0[i] + zh0[i]) : 0.0;
+                p0a[i] = FREE0 ? (ga0[i] - zl0[i] + zh0[i]) : 0.0;
             }
-            ric_matrix<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Iq, Im, Ir, zu_, zx_, Iq, P0a, Fc);
-            double du_[NU], dxn_[NS], dx0_[NS], pin_[NS];
-            ric_solve<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Fc, gu, gxk, pt, p0a, c0, du_, dxn_, dx0_, pin_);
+            ric_backward<NS, NU, FREE0, SEG, ST, true>(N, lane, k, L, Iq, Im, Ir, zu_, zx_, Iq, P0a, gu, gxk, pt, p0a, c0, Fc, Vc);
+            double du_[NU], dxn_[NS], pin_[NS];
+            ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vc, c0, du_, dxn_, pin_);
             double ym = 0.0;
             MPC_UNROLL for (int i = 0; i < NS; i++) ym = dmax(ym, finite_all(pin_[i]) ? fabs(pin_[i]) : INFINITY);
             ym = SG::max(on ? ym : 0.0);
             MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = ym <= kYInitMax ? pin_[i] : 0.0;
-            phase = PH_MAIN;
+            first = false;
         }
-        {   // Hessian of the Lagrangian of the scaled problem: df (cost) + pi' F
-            addpi(aux, pi, L);
-        }
+        addpi(aux, pi, L);      // Hessian of the Lagrangian of the scaled problem: df (cost) + pi' F
         // ---- slacks (safe: a slack that rounding took below eps min(1, mu) is lifted, its bound moves) ------------------------------------------
         double slu[NU], shu[NU], slx[NS], shx[NS], sl0[NS], sh0[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) { slu[i] = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0; shu[i] = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0; }
@@ -386,13 +430,10 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         e_st = SG::max(on ? e_st : 0.0); e_c = SG::max(on ? e_c : 0.0); s_pi = SG::sum(on ? s_pi : 0.0); s_z = SG::sum(on ? s_z : 0.0);
         cmax = SG::max(on ? cmax : -INFINITY); cmin = SG::min(on ? cmin : INFINITY);
         const double theta = SG::sum(on ? th_l : 0.0);
-        double fobj = SG::sum(on ? L.l + (k == N - 1 ? fv : 0.0) : 0.0) + farr;
-        double ga0[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) ga0[i] = 0.0;
+        const double fobj = SG::sum(on ? L.l + (k == N - 1 ? fv : 0.0) : 0.0) + farr;
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                ga0[i] = SG::bcast(gxA[i], 0, lane);      // stage 0's part of the gradient with respect to the free initial state
-                const double r0 = ga0[i] + (gf0[i] - SG::bcast(L.lx[i], 0, lane)) - zl0[i] + zh0[i];
+                const double r0 = SG::bcast(gxA[i], 0, lane) + ga0[i] - zl0[i] + zh0[i];      // stage 0's part of the gradient with respect to the free initial state + arrival cost
                 e_st = dmax(e_st, fabs(r0)); s_z += zl0[i] + zh0[i];
                 finite = finite && finite_all(r0) && finite_all(x0v[i]);
                 if (flx[i]) { cmax = dmax(cmax, sl0[i] * zl0[i]); cmin = dmin(cmin, sl0[i] * zl0[i]); }
@@ -457,7 +498,10 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
         }
         const double phi = fobj + SG::sum(on ? phl : 0.0) + ph0;
-        // ---- matrix pass, repeated with a larger shift while a stage lacks positive curvature ---------------------------------------------------
+        // ---- Newton direction: backward sweep (repeated with a larger shift while a stage lacks positive curvature), forward sweep -----------------
+        double gu[NU], gxk[NS], pt[NS], p0a[NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) gu[i] = L.lu[i] + bu[i];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { gxk[i] = L.lx[i] + bxk[i]; pt[i] = gv[i] + bx[i]; p0a[i] = FREE0 ? ga0[i] + b0[i] : 0.0; }
         double delta = 0.0;
         bool failed = false;
         for (;;) {
@@ -466,7 +510,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                 Qd[i][j] = L.Q[i][j] + (i == j ? delta : 0.0); Pt[i][j] = Hv[i][j] + (i == j ? Sx[i] + delta : 0.0);
                 P0a[i][j] = FREE0 ? (df * 0.5 * (Pinv[i][j] + Pinv[j][i]) + (i == j ? S0[i] : 0.0)) : 0.0; } }
             MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Rd[i][j] = L.R[i][j] + (i == j ? delta : 0.0); }
-            const bool okm = ric_matrix<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Qd, L.M, Rd, Su, Sxk, Pt, P0a, Fc);
+            const bool okm = ric_backward<NS, NU, FREE0, SEG, ST, true>(N, lane, k, L, Qd, L.M, Rd, Su, Sxk, Pt, P0a, gu, gxk, pt, p0a, c, Fc, Vc);
             const bool retry = SG::any(!okm, lane) && !done && !failed;      // this segment lacks curvature: a larger shift, all over again
             if (retry) {
                 delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
@@ -476,12 +520,9 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         if (!done && failed) { status = kStFailed; done = true; }
         if (!done && delta > 0.0) delta_last = delta;
-        // ---- Newton direction ------------------------------------------------------------------------------------------------------------------
-        double gu[NU], gxk[NS], pt[NS], p0a[NS];
-        MPC_UNROLL for (int i = 0; i < NU; i++) gu[i] = L.lu[i] + bu[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { gxk[i] = L.lx[i] + bxk[i]; pt[i] = gv[i] + bx[i]; p0a[i] = FREE0 ? (gf0[i] - SG::bcast(L.lx[i], 0, lane)) + b0[i] : 0.0; }
         double du[NU], dxn[NS], dx0[NS], pin[NS];
-        ric_solve<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Fc, gu, gxk, pt, p0a, c, du, dxn, dx0, pin);
+        ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vc, c, du, dxn, pin);
+        MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = Vc.dx0[i];
         // fraction to the boundary of a step (du_, dxn_, dx0_)
         auto ratio = [&](double a, double v, double dv) { return dv < 0.0 ? dmin(a, -tau * v / dv) : a; };
         auto max_step = [&](const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
@@ -499,7 +540,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NS; i++) { gbd_l += (gfx[i] + bx[i]) * dxn[i]; drel = dmax(drel, fabs(dxn[i]) / (1.0 + fabs(xn[i]))); dym = dmax(dym, fabs(pin[i] - pi[i])); }
         double gbd = SG::sum(on ? gbd_l : 0.0);
         drel = SG::max(on ? drel : 0.0); dym = SG::max(on ? dym : 0.0);
-        if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { gbd += (gf0[i] + b0[i]) * dx0[i]; drel = dmax(drel, fabs(dx0[i]) / (1.0 + fabs(x0v[i]))); } }
+        if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { gbd += (lx0[i] + ga0[i] + b0[i]) * dx0[i]; drel = dmax(drel, fabs(dx0[i]) / (1.0 + fabs(x0v[i]))); } }
         // ---- filter line search (per segment, the wave in lockstep) -------------------------------------------------------------------------------
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
@@ -510,39 +551,13 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
         const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
         auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
-        bool tiny = drel < kTinyStepTol && theta <= 1e-4;
-        enum { LS_TRY = 0, LS_SOC = 1, LS_DONE = 2 };
-        int ls = done ? LS_DONE : LS_TRY, n_steps = 0, soc_cnt = 0;
-        bool accepted = false, soc_taken = false, need_solve = false;
-        double alpha = a_max, a_soc = a_max, theta_old = 0.0, phi_acc = 0.0;
-        double csoc[NS], dsu[NU], dsx[NS], ds0[NS], pins[NS];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { csoc[i] = c[i]; dsx[i] = dxn[i]; ds0[i] = dx0[i]; pins[i] = pin[i]; }
-        MPC_UNROLL for (int i = 0; i < NU; i++) dsu[i] = du[i];
-        double ut[NU], xt[NS], x0t[NS];
-        MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i];
-        MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i]; x0t[i] = x0v[i]; }
-        for (;;) {
-            const bool busy = ls != LS_DONE;
-            if (!__any(busy ? 1 : 0)) break;
-            if (__any((busy && need_solve) ? 1 : 0)) {      // a second-order correction: the vector passes again, for the corrected constraint residual
-                double du_[NU], dxn_[NS], dx0_[NS], pin_[NS];
-                ric_solve<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Fc, gu, gxk, pt, p0a, csoc, du_, dxn_, dx0_, pin_);
-                const double as_ = max_step(du_, dxn_, dx0_);
-                if (busy && need_solve) {
-                    MPC_UNROLL for (int i = 0; i < NU; i++) dsu[i] = du_[i];
-                    MPC_UNROLL for (int i = 0; i < NS; i++) { dsx[i] = dxn_[i]; ds0[i] = dx0_[i]; pins[i] = pin_[i]; }
-                    a_soc = as_;
-                }
-                need_solve = false;
-            }
-            // the trial point of this round
-            const bool soc_now = ls == LS_SOC;
-            const double a_t = soc_now ? a_soc : alpha;
-            if (busy) {
-                MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i] + a_t * (soc_now ? dsu[i] : du[i]);
-                MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i] + a_t * (soc_now ? dsx[i] : dxn[i]); if (FREE0) x0t[i] = x0v[i] + a_t * (soc_now ? ds0[i] : dx0[i]); }
-            }
-            double xkt[NS], Ft[NS], lt, fvt, gvt[NS], Hvt[NS][NS], ct[NS];
+        // a trial point u + a_ du_ ...: infeasibility, barrier function (safe slacks; their moved bounds are not kept), constraint values
+        double theta_t = 0.0, phi_t = 0.0, ct[NS];
+        bool fin_t = false;
+        auto trial = [&](const double a_, const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
+            double ut[NU], xt[NS], x0t[NS], xkt[NS], Ft[NS], lt, fvt, gvt[NS], Hvt[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i] + a_ * du_[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i] + a_ * dxn_[i]; x0t[i] = FREE0 ? x0v[i] + a_ * dx0_[i] : 0.0; }
             MPC_UNROLL for (int i = 0; i < NS; i++) xkt[i] = SG::up1(FREE0 ? x0t[i] : x0fix[i], xt[i], k);
             val(xkt, ut, Ft, lt);
             term(xt, fvt, gvt, Hvt);
@@ -577,65 +592,84 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0t[j] - xbar[j]); farrt += 0.5 * (x0t[i] - xbar[i]) * a; }
             }
             const bool ok_t = !SG::any(on && !okl, lane);
-            double theta_t = SG::sum(on ? tht : 0.0);
-            double phi_t = df * (SG::sum(on ? lt + (k == N - 1 ? fvt : 0.0) : 0.0) + farrt) + SG::sum(on ? pht : 0.0) + pht0;
-            if (!ok_t || !finite_all(phi_t)) { theta_t = INFINITY; phi_t = INFINITY; }
-            // acceptable to the current iterate and to the filter?  (the tests of a corrected step keep the original step length)
-            bool acc = false;
-            if (busy && ok_t && finite_all(phi_t) && !(theta_t > theta_max)) {
-                bool ok_;
-                if (alpha > 0.0 && ftype(alpha) && theta <= theta_min) ok_ = le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi);
-                else {
-                    bool too_steep = false;
-                    if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; too_steep = log10(phi_t - phi) > kObjMaxInc + bas; }
-                    ok_ = !too_steep && (le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi));
-                }
-                acc = ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
+            theta_t = SG::sum(on ? tht : 0.0);
+            phi_t = df * (SG::sum(on ? lt + (k == N - 1 ? fvt : 0.0) : 0.0) + farrt) + SG::sum(on ? pht : 0.0) + pht0;
+            fin_t = ok_t && finite_all(phi_t);
+            if (!fin_t) { theta_t = INFINITY; phi_t = INFINITY; }
+        };
+        // acceptable to the current iterate and to the filter?  (alpha_: the step length of the Newton step, also for a corrected step)
+        auto acceptable = [&](double alpha_) {
+            if (!fin_t || theta_t > theta_max) return false;
+            bool ok_;
+            if (alpha_ > 0.0 && ftype(alpha_) && theta <= theta_min) ok_ = le_tol(phi_t - phi, kEtaPhi * alpha_ * gbd, phi);
+            else {
+                bool too_steep = false;
+                if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; too_steep = log10(phi_t - phi) > kObjMaxInc + bas; }
+                ok_ = !too_steep && (le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi));
             }
-            if (busy) {
-                const bool fin_ok = ok_t && finite_all(phi_t);
-                if (ls == LS_TRY) {
-                    if (tiny && n_steps == 0 && fin_ok) { accepted = true; ls = LS_DONE; phi_acc = phi_t; }      // a tiny step is taken unchecked
-                    else {
-                        if (tiny && n_steps == 0) tiny = false;
-                        if (acc) { accepted = true; ls = LS_DONE; phi_acc = phi_t; }
-                        else if (fin_ok && n_steps == 0 && theta <= theta_t) {      // second-order correction: the first trial step did not reduce the infeasibility
-                            a_soc = alpha; soc_cnt = 0; theta_old = theta_t;
-                            MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = a_soc * c[i] + ct[i];
-                            need_solve = true; ls = LS_SOC;
-                        } else { alpha *= 0.5; n_steps++; if (!(alpha > a_min)) ls = LS_DONE; }
-                    }
-                } else {      // LS_SOC
-                    if (acc) { accepted = true; soc_taken = true; ls = LS_DONE; phi_acc = phi_t; }
-                    else {
-                        soc_cnt++;
-                        if (fin_ok && soc_cnt < kMaxSoc && theta_t <= kKappaSoc * theta_old) {
-                            theta_old = theta_t;
-                            MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = a_soc * csoc[i] + ct[i];
-                            need_solve = true;
-                        } else { ls = LS_TRY; alpha *= 0.5; n_steps++; if (!(alpha > a_min)) ls = LS_DONE; }
-                    }
+            return ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
+        };
+        bool tiny = drel < kTinyStepTol && theta <= 1e-4;
+        bool searching = !done, accepted = false;
+        int n_steps = 0;
+        double alpha = a_max, a_pr = a_max, phi_acc = 0.0;
+        for (;;) {
+            if (!__any(searching ? 1 : 0)) break;
+            trial(alpha, du, dxn, dx0);
+            const bool acc = searching && acceptable(alpha);
+            bool want_soc = false;
+            if (searching) {
+                if (tiny && n_steps == 0 && fin_t) { accepted = true; searching = false; phi_acc = phi_t; a_pr = alpha; }      // a tiny step is taken unchecked
+                else {
+                    if (tiny && n_steps == 0) tiny = false;
+                    if (acc) { accepted = true; searching = false; phi_acc = phi_t; a_pr = alpha; }
+                    else if (fin_t && n_steps == 0 && theta <= theta_t) want_soc = true;      // the first trial step did not reduce the infeasibility
+                    else { alpha *= 0.5; n_steps++; if (!(alpha > a_min)) searching = false; }
+                }
+            }
+            if (__any(want_soc ? 1 : 0)) {
+                // ---- second-order correction [WB 2.4]: the vector sweeps again for the corrected constraint residual, up to four times -----------------
+                double csoc[NS], a_soc = alpha, theta_old = 0.0, th_s = theta_t;
+                MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = c[i];
+                int cnt = 0;
+                bool soc = want_soc;
+                for (;;) {
+                    if (!__any(soc ? 1 : 0)) break;
+                    if (soc) { theta_old = th_s; MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = a_soc * csoc[i] + ct[i]; }
+                    RicVec<NS, NU> Vs;
+                    double dsu[NU], dsx[NS], ds0[NS], pins[NS];
+                    ric_backward<NS, NU, FREE0, SEG, ST, false>(N, lane, k, L, L.Q, L.M, L.R, Su, Sxk, Hv, Hv, gu, gxk, pt, p0a, csoc, Fc, Vs);
+                    ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vs, csoc, dsu, dsx, pins);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) ds0[i] = Vs.dx0[i];
+                    const double as_ = max_step(dsu, dsx, ds0);
+                    if (soc) a_soc = as_;
+                    double ctk[NS];      // (the constraint values of the step before stay with the segments that are not correcting)
+                    MPC_UNROLL for (int i = 0; i < NS; i++) ctk[i] = ct[i];
+                    const double th_keep = theta_t, ph_keep = phi_t; const bool fin_keep = fin_t;
+                    trial(a_soc, dsu, dsx, ds0);
+                    const bool acs = soc && acceptable(alpha);      // (the tests keep the original step length)
+                    if (soc) {
+                        if (acs) {      // the corrected step replaces the Newton step
+                            accepted = true; searching = false; soc = false; phi_acc = phi_t; a_pr = a_soc;
+                            MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = dsu[i];
+                            MPC_UNROLL for (int i = 0; i < NS; i++) { dxn[i] = dsx[i]; dx0[i] = ds0[i]; pin[i] = pins[i]; }
+                        } else {
+                            cnt++; th_s = theta_t;
+                            if (!(fin_t && cnt < kMaxSoc && th_s <= kKappaSoc * theta_old)) { soc = false; alpha *= 0.5; n_steps++; if (!(alpha > a_min)) searching = false; }      // back to shorter Newton steps
+                        }
+                    } else { MPC_UNROLL for (int i = 0; i < NS; i++) ct[i] = ctk[i]; theta_t = th_keep; phi_t = ph_keep; fin_t = fin_keep; }
                 }
             }
         }
         if (!done) {
-            if (!accepted) {      // IPOPT enters its restoration phase here (not restated): infeasible point -> failed; feasible to 1e-2 tol -> the point is kept
+            if (!accepted) {      // IPOPT enters its restoration phase here (not restated for this recursion): infeasible point -> failed; feasible to 1e-2 tol -> the point is kept
                 status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; done = true;
             } else if (tiny) { tiny_flag = tiny_last; tiny_last = dym < kTinyStepYTol; }
             else {
                 tiny_last = false;
                 // the filter grows unless the step was an Armijo step on the barrier function.  Every lane of the segment makes the same edit of the
                 // segment's list (same values to the same LDS words, in lockstep); entries the new one dominates are dropped
-                if (!ftype(alpha) || !le_tol(phi_acc - phi, kEtaPhi * alpha * gbd, phi)) {
-                    const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
-                    int k2 = 0;
-                    for (int e = 0; e < kFilterCap; e++) {
-                        if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } }
-                    }
-                    if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
-                    else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
-                    nfilt = k2;
-                }
+                if (!ftype(alpha) || !le_tol(phi_acc - phi, kEtaPhi * alpha * gbd, phi)) nfilt = filter_add(filt, nfilt, phi - kGammaPhi * theta, (1.0 - kGammaTheta) * theta);
             }
         }
         // ---- the accepted point: multiplier steps of the direction that was taken, bounds moved with corrected slacks, multipliers within
@@ -643,47 +677,43 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         double dzlu[NU], dzhu[NU], dzlx[NS], dzhx[NS], dzl0[NS], dzh0[NS];
         double adu = 1.0;
         MPC_UNROLL for (int i = 0; i < NU; i++) {
-            const double d_ = soc_taken ? dsu[i] : du[i];
-            dzlu[i] = flu[i] ? mu / slu[i] - zlu[i] - zlu[i] / slu[i] * d_ : 0.0;
-            dzhu[i] = fhu[i] ? mu / shu[i] - zhu[i] + zhu[i] / shu[i] * d_ : 0.0;
+            dzlu[i] = flu[i] ? mu / slu[i] - zlu[i] - zlu[i] / slu[i] * du[i] : 0.0;
+            dzhu[i] = fhu[i] ? mu / shu[i] - zhu[i] + zhu[i] / shu[i] * du[i] : 0.0;
             if (flu[i]) adu = ratio(adu, zlu[i], dzlu[i]);
             if (fhu[i]) adu = ratio(adu, zhu[i], dzhu[i]);
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
-            const double d_ = soc_taken ? dsx[i] : dxn[i];
-            dzlx[i] = flx[i] ? mu / slx[i] - zlx[i] - zlx[i] / slx[i] * d_ : 0.0;
-            dzhx[i] = fhx[i] ? mu / shx[i] - zhx[i] + zhx[i] / shx[i] * d_ : 0.0;
+            dzlx[i] = flx[i] ? mu / slx[i] - zlx[i] - zlx[i] / slx[i] * dxn[i] : 0.0;
+            dzhx[i] = fhx[i] ? mu / shx[i] - zhx[i] + zhx[i] / shx[i] * dxn[i] : 0.0;
             if (flx[i]) adu = ratio(adu, zlx[i], dzlx[i]);
             if (fhx[i]) adu = ratio(adu, zhx[i], dzhx[i]);
         }
         adu = SG::min(on ? adu : 1.0);
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                const double d_ = soc_taken ? ds0[i] : dx0[i];
-                dzl0[i] = flx[i] ? mu / sl0[i] - zl0[i] - zl0[i] / sl0[i] * d_ : 0.0;
-                dzh0[i] = fhx[i] ? mu / sh0[i] - zh0[i] + zh0[i] / sh0[i] * d_ : 0.0;
+                dzl0[i] = flx[i] ? mu / sl0[i] - zl0[i] - zl0[i] / sl0[i] * dx0[i] : 0.0;
+                dzh0[i] = fhx[i] ? mu / sh0[i] - zh0[i] + zh0[i] / sh0[i] * dx0[i] : 0.0;
                 if (flx[i]) adu = ratio(adu, zl0[i], dzl0[i]);
                 if (fhx[i]) adu = ratio(adu, zh0[i], dzh0[i]);
             }
         }
         auto clampz = [&](double z, double s_) { return dmin(dmax(z, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_); };
         if (!done) {      // (a finished segment keeps its iterate)
-            const double a_pr = soc_taken ? a_soc : alpha;
-            MPC_UNROLL for (int i = 0; i < NU; i++) {      // (slacks of the new point with the multipliers of the old one, as the trial point had them; the bounds move now)
-                u[i] = ut[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) {      // (the accepted trial point again, to the bit; its slacks with the multipliers of the old point, as the trial had them; the bounds move now)
+                u[i] = u[i] + a_pr * du[i];
                 const double s1 = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0, s2 = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0;
                 zlu[i] += adu * dzlu[i]; zhu[i] += adu * dzhu[i];
                 if (flu[i]) zlu[i] = clampz(zlu[i], s1);
                 if (fhu[i]) zhu[i] = clampz(zhu[i], s2);
             }
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                xn[i] = xt[i]; pi[i] += a_pr * ((soc_taken ? pins[i] : pin[i]) - pi[i]);
+                xn[i] = xn[i] + a_pr * dxn[i]; pi[i] += a_pr * (pin[i] - pi[i]);
                 const double s1 = flx[i] ? safe_slack(xn[i], blx[i], zlx[i], mu, true) : 1.0, s2 = fhx[i] ? safe_slack(xn[i], bhx[i], zhx[i], mu, false) : 1.0;
                 zlx[i] += adu * dzlx[i]; zhx[i] += adu * dzhx[i];
                 if (flx[i]) zlx[i] = clampz(zlx[i], s1);
                 if (fhx[i]) zhx[i] = clampz(zhx[i], s2);
                 if (FREE0) {
-                    x0v[i] = x0t[i];
+                    x0v[i] = x0v[i] + a_pr * dx0[i];
                     const double t1 = flx[i] ? safe_slack(x0v[i], bl0[i], zl0[i], mu, true) : 1.0, t2 = fhx[i] ? safe_slack(x0v[i], bh0[i], zh0[i], mu, false) : 1.0;
                     zl0[i] += adu * dzl0[i]; zh0[i] += adu * dzh0[i];
                     if (flx[i]) zl0[i] = clampz(zl0[i], t1);
@@ -692,6 +722,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
             it++;
         }
+        park_io(true);
     }
     return status;
 }
@@ -736,13 +767,52 @@ enum : int { kRsRestored = 0, kRsConverged = 1, kRsLimit = 2, kRsFailed = 3 };
 // n and p are eliminated from the Newton system: (H + Sigma_x + J' Dc^-1 J) dx = ..., Dc = 1 / Sigma_n + 1 / Sigma_p, whose positive definiteness is
 // the inertia condition of the full system.  One instance per lane.  x: x_R in, the restored point out; lo / hi: the caller's (moved) bounds, moved on.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <class M, class OrigOk>
-__device__ __forceinline__ int target_resto(double (&x)[M::NX + M::NU + M::NY], double (&lo)[M::NX + M::NU + M::NY], double (&hi)[M::NX + M::NU + M::NY],
-                                            const double (&zl_o)[M::NX + M::NU + M::NY], const double (&zh_o)[M::NX + M::NU + M::NY], const double mu_o, const double (&c_r)[M::NX + M::NY],
-                                            const double *d, const double (*Bd)[M::ND > 0 ? M::ND : 1], const double (*Cd)[M::ND > 0 ? M::ND : 1], double t, double h,
-                                            const double tol, const int max_iter, int &it, OrigOk orig_ok)
+// what the target's interior point hands to its restoration phase and gets back.  The restoration is a function of its own (not inlined: it is entered by one
+// solve in a thousand, and inlined its registers were the target kernel's - 3 KB of scratch per lane): the caller copies its state here, calls, copies back.
+template <class M>
+struct TgtRestoIO {
+    static constexpr int NV = M::NX + M::NU + M::NY, MC = M::NX + M::NY, NDD = M::ND > 0 ? M::ND : 1;
+    double x[NV], lo[NV], hi[NV], zl[NV], zh[NV], c[MC], d[NDD], Bd[M::NX][NDD], Cd[M::NY][NDD], filt[2 * kFilterCap];
+    double mu, theta, phi, df, t, h, tol;
+    int nfilt, max_iter, it;
+};
+template <class M>
+__device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
 {
     constexpr int NX = M::NX, NU = M::NU, NY = M::NY, ND = M::ND, NV = NX + NU + NY, NP = NX + NU, NPP = NP * (NP + 1) / 2, MC = NX + NY;
+    double x[NV], lo[NV], hi[NV], zl_o[NV], zh_o[NV], c_r[MC], d[ND > 0 ? ND : 1], Bd[NX][ND > 0 ? ND : 1], Cd[NY][ND > 0 ? ND : 1];
+    MPC_UNROLL for (int i = 0; i < NV; i++) { x[i] = io.x[i]; lo[i] = io.lo[i]; hi[i] = io.hi[i]; zl_o[i] = io.zl[i]; zh_o[i] = io.zh[i]; }
+    MPC_UNROLL for (int j = 0; j < MC; j++) c_r[j] = io.c[j];
+    MPC_UNROLL for (int j = 0; j < ND; j++) { d[j] = io.d[j]; MPC_UNROLL for (int i = 0; i < NX; i++) Bd[i][j] = io.Bd[i][j]; MPC_UNROLL for (int i = 0; i < NY; i++) Cd[i][j] = io.Cd[i][j]; }
+    const double mu_o = io.mu, t = io.t, h = io.h, tol = io.tol;
+    const int max_iter = io.max_iter;
+    int it = io.it;
+    // the test of the solve that called: enough less infeasible, acceptable to its filter and to the point it left (its bounds, multipliers, mu, scaling)
+    auto orig_ok = [&](const double (&w)[NV]) {
+        typename M::Ctx cx;
+        MPC_UNROLL for (int i = 0; i < NU; i++) { cx.u[i] = w[NX + i]; cx.us[i] = 0.0; }
+        MPC_UNROLL for (int i = 0; i < ND; i++) cx.d[i] = d[i];
+        MPC_UNROLL for (int i = 0; i < NX; i++) cx.xs[i] = 0.0;
+        double Fx[NX], f_, g_[NV], H_[NV][NV], th_t = 0.0;
+        rk4_plain<typename M::Mdl>(w, cx, t, true, h, M::MX, Fx);
+        M::fss(w, &f_, g_, H_);
+        f_ *= io.df;
+        bool ok_ = finite_all(f_);
+        MPC_UNROLL for (int i = 0; i < NX; i++) { double a = Fx[i] - w[i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Bd[i][j] * d[j]; th_t += fabs(a); ok_ = ok_ && finite_all(a); }
+        MPC_UNROLL for (int i = 0; i < NY; i++) { double a = w[i] - w[NX + NU + i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Cd[i][j] * d[j]; th_t += fabs(a); ok_ = ok_ && finite_all(a); }
+        if (!ok_ || th_t > kRestoKappa * io.theta) return false;
+        double ph_t = f_;
+        MPC_UNROLL for (int i = 0; i < NV; i++) {
+            double bl_ = io.lo[i], bh_ = io.hi[i];
+            const bool fl_ = fin(bl_), fh_ = fin(bh_);
+            const double s1 = fl_ ? safe_slack(w[i], bl_, io.zl[i], mu_o, true) : 1.0, s2 = fh_ ? safe_slack(w[i], bh_, io.zh[i], mu_o, false) : 1.0;
+            if (fl_) ph_t -= mu_o * log(s1);
+            if (fh_) ph_t -= mu_o * log(s2);
+            if (fl_ && !fh_) ph_t += kKappaD * mu_o * s1;
+            if (fh_ && !fl_) ph_t += kKappaD * mu_o * s2;
+        }
+        return !filter_rejects(io.filt, io.nfilt, ph_t, th_t) && (le_tol(th_t, (1.0 - kGammaTheta) * io.theta, io.theta) || le_tol(ph_t - io.phi, -kGammaPhi * io.theta, io.phi));
+    };
     bool fl[NV], fh[NV];
     double xr[NV], dr2[NV], zl[NV], zh[NV], dmp[NV], nn[MC], pp[MC], zn[MC], zp[MC], nlo[MC], plo[MC], lam[MC];
     int nbi = 2 * MC;
@@ -992,14 +1062,7 @@ __device__ __forceinline__ int target_resto(double (&x)[M::NX + M::NU + M::NY], 
                 n_steps++;
             }
             if (!accepted) { status = kRsFailed; break; }      // (no restoration inside the restoration phase: 'Restoration_Failed')
-            if (!ftype(alpha) || !le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi)) {
-                const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
-                int k2 = 0;
-                for (int e = 0; e < kFilterCap; e++) { if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } } }
-                if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
-                else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
-                nfilt = k2;
-            }
+            if (!ftype(alpha) || !le_tol(phi_t - phi, kEtaPhi * alpha * gbd, phi)) nfilt = filter_add(filt, nfilt, phi - kGammaPhi * theta, (1.0 - kGammaTheta) * theta);
         }
         // the accepted point: multiplier steps of the direction that was taken
         const double a_pr = soc_taken ? a_soc : alpha;
@@ -1033,6 +1096,8 @@ __device__ __forceinline__ int target_resto(double (&x)[M::NX + M::NU + M::NY], 
         }
         it++;
     }
+    MPC_UNROLL for (int i = 0; i < NV; i++) { io.x[i] = x[i]; io.lo[i] = lo[i]; io.hi[i] = hi[i]; }      // (bounds the restoration moved stay moved)
+    io.it = it;
     return status;
 }
 
@@ -1042,10 +1107,10 @@ __device__ __forceinline__ int target_resto(double (&x)[M::NX + M::NU + M::NY], 
 // ys and xs follow from the two (linearised) equalities, so the inertia test is the sign of the nu x nu reduced Hessian.  One instance per
 // lane (or wave-uniform: every lane computes it).  v = [xs; us; ys] comes in as the first guess (MPC_code.py:696-700).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <class M>
+template <class M, int FS>      // filt: this solve's filter list (FS: stride between its words, see filter_rejects)
 __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], const double *d, const double (*Bd)[M::ND > 0 ? M::ND : 1],
                                           const double (*Cd)[M::ND > 0 ? M::ND : 1], const double *lo_in, const double *hi_in, double t, double h,
-                                          const double tol, const int max_iter, int &iters)
+                                          const double tol, const int max_iter, int &iters, double *const filt)
 {
     constexpr int NX = M::NX, NU = M::NU, NY = M::NY, ND = M::ND, NV = NX + NU + NY, NP = NX + NU, NPP = NP * (NP + 1) / 2;
     static_assert(NY == NX, "StateFeedback outputs");
@@ -1071,7 +1136,6 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
     const double nb = (double)nbi, meq = (double)(NX + NY);
     const double mu_min = dmin(tol, kComplInfTol) / (kKappaEps + 1.0);
     double mu = kMuInit, tau = dmax(kTauMin, 1.0 - kMuInit), delta_last = 0.0, theta_max = -1.0, theta_min = -1.0;
-    double filt[2 * kFilterCap];      // (per lane: this kernel's lanes are instances)
     int status = kStMaxIter, nfilt = 0, acc_count = 0;
     bool tiny_last = false, tiny_flag = false;
     iters = 0;
@@ -1267,7 +1331,7 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
                 if (phi_t > phi) { const double bas = fabs(phi) > 10.0 ? log10(fabs(phi)) : 1.0; if (log10(phi_t - phi) > kObjMaxInc + bas) return false; }
                 ok_ = le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi);
             }
-            return ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
+            return ok_ && !filter_rejects<FS>(filt, nfilt, phi_t, theta_t);
         };
         bool accepted = false, soc_taken = false;
         double alpha = a_max, a_soc = a_max;
@@ -1305,34 +1369,22 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
                 alpha *= 0.5;
                 n_steps++;
             }
-            auto augment = [&]() {      // the filter grows by the current point (entries it dominates are dropped)
-                const double e_phi = phi - kGammaPhi * theta, e_th = (1.0 - kGammaTheta) * theta;
-                int k2 = 0;
-                for (int e = 0; e < kFilterCap; e++) { if (e < nfilt) { const double ph = filt[2 * e], th = filt[2 * e + 1]; if (!(ph >= e_phi && th >= e_th)) { filt[2 * k2] = ph; filt[2 * k2 + 1] = th; k2++; } } }
-                if (k2 >= kFilterCap) { filt[2 * (k2 - 1)] = dmin(filt[2 * (k2 - 1)], e_phi); filt[2 * (k2 - 1) + 1] = dmin(filt[2 * (k2 - 1) + 1], e_th); }
-                else { filt[2 * k2] = e_phi; filt[2 * k2 + 1] = e_th; k2++; }
-                nfilt = k2;
-            };
+            auto augment = [&]() { nfilt = filter_add<FS>(filt, nfilt, phi - kGammaPhi * theta, (1.0 - kGammaTheta) * theta); };      // the filter grows by the current point
             if (!accepted) {
                 // ---- IPOPT's restoration phase ---------------------------------------------------------------------------------------------------
                 if (theta <= 1e-2 * tol) { status = kStMaxIter; break; }      // 'Restoration_Failed' at a feasible point: the reference accepts the point
                 augment();                                                    // the point the restoration starts from is never returned to
-                auto orig_ok = [&](const double (&x_)[NV]) {      // enough less infeasible, acceptable to the filter and to the point left
-                    double f_, a1[NX], a2[NY], th_t = 0.0;
-                    values(x_, f_, a1, a2);
-                    bool ok_ = finite_all(f_);
-                    MPC_UNROLL for (int i = 0; i < NX; i++) { th_t += fabs(a1[i]); ok_ = ok_ && finite_all(a1[i]); }
-                    MPC_UNROLL for (int i = 0; i < NY; i++) { th_t += fabs(a2[i]); ok_ = ok_ && finite_all(a2[i]); }
-                    if (!ok_ || th_t > kRestoKappa * theta) return false;
-                    const double ph_t = barrier(x_, f_, mu);
-                    return !filter_rejects(filt, nfilt, ph_t, th_t) && (le_tol(th_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(ph_t - phi, -kGammaPhi * theta, phi));
-                };
-                double xr_[NV], cr_[NX + NY];
-                MPC_UNROLL for (int i = 0; i < NV; i++) xr_[i] = v[i];
-                MPC_UNROLL for (int i = 0; i < NX; i++) cr_[i] = c1[i];
-                MPC_UNROLL for (int i = 0; i < NY; i++) cr_[NX + i] = c2[i];
-                int it_r = it + 1;
-                const int rs = target_resto<M>(xr_, lo, hi, zl, zh, mu, cr_, d, Bd, Cd, t, h, tol, max_iter, it_r, orig_ok);
+                TgtRestoIO<M> io;
+                MPC_UNROLL for (int i = 0; i < NV; i++) { io.x[i] = v[i]; io.lo[i] = lo[i]; io.hi[i] = hi[i]; io.zl[i] = zl[i]; io.zh[i] = zh[i]; }
+                MPC_UNROLL for (int i = 0; i < NX; i++) io.c[i] = c1[i];
+                MPC_UNROLL for (int i = 0; i < NY; i++) io.c[NX + i] = c2[i];
+                MPC_UNROLL for (int j = 0; j < ND; j++) { io.d[j] = d[j]; MPC_UNROLL for (int i = 0; i < NX; i++) io.Bd[i][j] = Bd[i][j]; MPC_UNROLL for (int i = 0; i < NY; i++) io.Cd[i][j] = Cd[i][j]; }
+                for (int e = 0; e < 2 * kFilterCap; e++) io.filt[e] = e < 2 * nfilt ? filt[e * FS] : 0.0;
+                io.mu = mu; io.theta = theta; io.phi = phi; io.df = df; io.t = t; io.h = h; io.tol = tol; io.nfilt = nfilt; io.max_iter = max_iter; io.it = it + 1;
+                const int rs = target_resto<M>(io);
+                double xr_[NV];
+                MPC_UNROLL for (int i = 0; i < NV; i++) { xr_[i] = io.x[i]; lo[i] = io.lo[i]; hi[i] = io.hi[i]; }
+                const int it_r = io.it;
                 it = it_r - 1; iters = it;
                 if (rs != kRsRestored) {
                     if (rs == kRsLimit) status = kStMaxIter;
