@@ -249,10 +249,9 @@ def main_enmpc(args):
     B = args.batch if args.batch != B_PER_GPU else cfg["batch"]
     p = m.load_problem(m.example_path("reactor_enmpc.py"), overrides=cfg["over"])
     s = enmpc.EnmpcSolver(p, device=local_rank)      # raises without the GPU: no CPU fallback
-    comm = csolver = None
-    if world > 1 or args.force_dist:                 # the job's communicator: RCCL inside libmpc_amd.so, on this rank's GPU
-        csolver = capi.Solver(m.load_problem(m.example_path("cstr_lmpc.py")), device=local_rank)
-        comm = shard.RcclComm(csolver, rank, world)
+    comm = None
+    if world > 1 or args.force_dist:                 # the job's communicator: RCCL inside this model's own library (enmpc_comm_*), on this rank's GPU
+        comm = shard.RcclComm(s, rank, world)
     rng = np.random.default_rng(SEED)
     x0 = rng.uniform([0.5, 0.0], [1.0, 0.5], size=(B * world, 2))[rank * B:(rank + 1) * B]
     ns = max(K, W, 1)
@@ -268,10 +267,12 @@ def main_enmpc(args):
         if comm is not None:
             comm.barrier()
         t0 = time.perf_counter()
-        s.run(0, K); s.sync()
+        s.run(0, K)
         if comm is not None:
-            allU = comm.allgather(s.get_log("U")[:K])      # every rank's controls on every rank (RCCL all-gather)
+            s.allgather_log("U", 0, K, to_host=False)      # every rank's controls on every rank: one RCCL all-gather, device log to device memory
             comm.barrier()
+        else:
+            s.sync()
         dt = time.perf_counter() - t0
         if comm is not None:
             dt = comm.max(dt)
@@ -280,6 +281,7 @@ def main_enmpc(args):
             break
     dt = float(np.median(times))
     if comm is not None:
+        allU = s.allgather_log("U", 0, K)
         assert np.array_equal(allU[rank], s.get_log("U")[:K]), "all-gather of U corrupted the data"
     if kern == 2:
         # the split pipeline's launches one by one: passes of the same K steps with HIP events around every launch (which puts the batch on one
@@ -316,7 +318,7 @@ def main_enmpc(args):
                                       "target NLP + OCP NLP (each to its KKT point, tol 1e-8 / 1e-10) + plant per step" % (cfg["what"], SEED),
                           "batch_per_gpu": B, "horizon": p.N, "mhe_horizon": p.N_mhe, "quad_steps": p.quad_steps, "steps_per_run": K, "kernel": kern, "stream_groups": args.groups, "repeats": len(times),
                           "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U inside the timed region" % world,
-                          "rccl_ranks": (csolver.comm_rank()[1] if csolver is not None else 1),
+                          "rccl_ranks": (s.comm_rank()[1] if comm is not None else 1),
                           "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
                "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                             "kernel": kdesc, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
@@ -354,8 +356,6 @@ def main_enmpc(args):
     if comm is not None:
         comm.barrier()
     s.close()
-    if csolver is not None:
-        csolver.close()
 
 
 def main_nmpc(args):
@@ -471,6 +471,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="instances per GPU (default: BASELINE configs[1])")
+    ap.add_argument("--total-batch", type=int, default=0, help="lmpc: instances of the WHOLE job, split evenly over the GPUs (strong scaling; BASELINE.md section 3 / the target: 65536 over 8 GPUs); "
+                    "0: --batch instances per GPU (weak scaling, the default)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="closed-loop steps per kernel launch (0: library default)")
     ap.add_argument("--loop-kernel", type=int, default=0, help="0: library default, 1: instance per lane, 2: horizon-parallel, 3: wave-autonomous")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions (0: as many as fill --min-seconds)")
@@ -499,9 +501,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     K, W, B = args.steps, args.warmup, args.batch
+    strong = args.total_batch > 0
+    if strong:
+        if args.total_batch % world:
+            sys.exit(f"bench.py: --total-batch {args.total_batch} does not split evenly over {world} GPUs")
+        B = args.total_batch // world
     use_dist = world > 1 or args.force_dist
     others = None
-    if world == 1 and not args.force_dist and not args.no_other_configs and B == B_PER_GPU:
+    if world == 1 and not args.force_dist and not args.no_other_configs and B == B_PER_GPU and not strong:
         others = other_configs(args)      # child processes, before this one touches the GPU
 
     import mpc_code_amd as m
@@ -569,11 +576,11 @@ def main():
         out = {
             "metric": "closed-loop MPC steps/sec over batch, LMPC-CSTR N=50",
             "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Ex_LMPC_CSTR (nx=3,nu=2,ny=3,nd=3), N=50, batch=%d per GPU, x0~U([-0.5,0.5]x[-8,8]x[-5,5]) seed %d, "
                                    "closed loop from t=0: Kalman filter + target QP + OCP (Riccati-PDIP) + plant per step" % (B, SEED),
-                       "batch_per_gpu": B, "horizon": prob.N, "steps_per_launch": K / max(n_launch, 1), "loop_kernel": KERNEL_NAMES[loop_kernel],
+                       "batch_per_gpu": B, "total_batch": B * world, "horizon": prob.N, "steps_per_launch": K / max(n_launch, 1), "loop_kernel": KERNEL_NAMES[loop_kernel],
                        "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U (mpc_allgather_log) inside the timed region" % world,
                        "rccl_ranks": (solver.comm_rank()[1] if use_dist else 1),
                        "repeats": len(times), "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},

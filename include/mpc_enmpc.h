@@ -83,6 +83,44 @@ float enmpc_last_kernel_ms(enmpc_handle *h);      /* device time of the last enm
 int enmpc_time_kernels(enmpc_handle *h, int32_t on);
 int enmpc_phase_ms(enmpc_handle *h, float *ms3, int32_t *launches);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI; as mpc_comm_* / mpc_allgather_log of mpc_amd.h ---------------------
+ * The batch shards over the ranks with no data-path collective (instances are independent); the one exchange is the all-gather of the controls.
+ * Rank 0 makes the 128-byte id (enmpc_comm_unique_id) and hands it to the others by any channel (mpc-code_amd/shard.py: a file); every rank then
+ * calls enmpc_comm_init on its own handle.  Without a communicator every entry below degenerates to a copy. */
+#define ENMPC_COMM_ID_BYTES 128
+int enmpc_comm_unique_id(char *out128);
+int enmpc_comm_init(enmpc_handle *h, int32_t rank, int32_t world, const char *id128);
+int enmpc_comm_destroy(enmpc_handle *h);
+int enmpc_comm_rank(enmpc_handle *h, int32_t *rank, int32_t *world);
+/* host buffers, `bytes` per rank: rank r's block lands at recv + r * bytes (status words, ragged shards) */
+int enmpc_comm_allgather(enmpc_handle *h, const void *send, size_t bytes, void *recv);
+int enmpc_comm_allreduce_max(enmpc_handle *h, double *inout, int32_t n);
+int enmpc_comm_barrier(enmpc_handle *h);      /* everything queued on every rank's stream has completed */
+/* steps [k0, k0 + nsteps) of a float64 log ("U", ...) of every rank: ONE ncclAllGather, device to device, straight from the device log, asynchronous on
+ * the handle's stream; out (host, optional) receives [world][nsteps][B][dim] */
+int enmpc_allgather_log(enmpc_handle *h, const char *name, int32_t k0, int32_t nsteps, double *out);
+
+/* ---- per-call seam: the reference's three solver calls of one closed-loop step, each for the whole batch -----------------------------
+ * The reference's loop body calls, per step: defEstimator(..., 'mhe') (MPC_code.py:577-650), solver_ss(lbx, ubx, x0, p, lbg, ubg) (:704-709) and
+ * solver(lbx, ubx, x0, p, lbg, ubg) (:776-781), with the plant in between (:531-534, :813-816).  These entries are those calls for B instances with
+ * caller-owned host arrays [B][dim]; the same kernels as enmpc_run's split pipeline, one launch per call, blocking.  What the handle keeps
+ * between the calls is what the reference's driver keeps: the estimator's window, prior and covariance lists (mhe()'s arguments), the targets of the
+ * step before (xs_prev, us_prev: the tail of the shifted guess) and the OCP's last optimum (w_guess of :764).  enmpc_alloc + enmpc_set_state first
+ * (they give the estimator's prior and the first guesses); then, per step and in this order, enmpc_mhe_update, enmpc_target_solve,
+ * enmpc_ocp_solve - a step of the closed loop is exactly one call of each (tests/test_enmpc.py: the three calls + enmpc_plant_step reproduce
+ * enmpc_run bit for bit).  status words as everywhere: 0 solved, 1 accepted without convergence, 2 the reference's hold rule. */
+/* y [B][ny]: the measurement of this step (StateFeedback: the plant state); u_prev [B][nu]: the input applied over the step before (u0 at the first).
+ * Out: xhat [B][nx], dhat [B][nd] (saturated by dmin / dmax when given, MPC_code.py:657-664), xes [B][nx+nd] the estimator's corrected [x; d] (or NULL) */
+int enmpc_mhe_update(enmpc_handle *h, const double *y, const double *u_prev, double *xhat, double *dhat, double *xes, int32_t *status, int32_t *iters);
+/* cold-started from (x0_m, u0) as the reference's (MPC_code.py:696-700); a failed solve (status 2) returns the targets of the step before (:714-718) */
+int enmpc_target_solve(enmpc_handle *h, const double *dhat, double *xs, double *us, int32_t *status, int32_t *iters);
+/* u_out [B][nu] = the optimal first input, xnext_out [B][nx] = the optimiser's next state (MPC_code.py:798-799); with status 2 the held input and
+ * the model's propagation (:804-805) */
+int enmpc_ocp_solve(enmpc_handle *h, const double *xhat, const double *dhat, const double *xs, const double *us, double *u_out, double *xnext_out,
+                    int32_t *status, int32_t *iters);
+/* the simulator's side, for callers without a plant of their own: x_p <- Fx_p(x_p, u) (Utilities.py:58-82), in place */
+int enmpc_plant_step(enmpc_handle *h, const double *u, double *x_p);
+
 #ifdef __cplusplus
 }
 #endif

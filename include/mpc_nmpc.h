@@ -83,6 +83,26 @@ float nmpc_last_kernel_ms(nmpc_handle *h);      /* device time of the last nmpc_
 int nmpc_time_kernels(nmpc_handle *h, int32_t on);
 int nmpc_wave_kernel_ms(nmpc_handle *h, float *total_ms, int32_t *launches);
 
+/* ---- per-call seam: the reference's three solver calls of one closed-loop step, each for the whole batch -----------------------------
+ * defEstimator(..., 'ekf' | 'lue') (MPC_code.py:577-650), solver_ss(lbx, ubx, x0, p, lbg, ubg) (:704-709), solver(lbx, ubx, x0, p, lbg, ubg) (:776-781), with
+ * the plant in between (:531-534, :813-816): caller-owned host arrays [B][dim], blocking, one launch of the instance-per-lane kernel per call.  The
+ * handle keeps between the calls what the reference's driver keeps - the last optimum, i.e. the shifted guess of :764 - and what this solver's warm
+ * start compares against (estimate and targets before their updates).  nmpc_alloc + nmpc_set_state first; then per step, in this order,
+ * nmpc_ekf_update, nmpc_target_solve, nmpc_ocp_solve: with nmpc_plant_step in between they reproduce nmpc_run (kernel 1) bit for bit
+ * (tests/test_nmpc.py). */
+/* y [B][ny] this step's measurement, u_prev [B][nu] the input applied over the step before; xhat [B][nx], dhat [B][nd], P [B][(nx+nd)^2]: the
+ * estimator's state, prior in / posterior out (P is not used by the fixed-gain observer); dhat is saturated by dmin / dmax when given */
+int nmpc_ekf_update(nmpc_handle *h, const double *y, const double *u_prev, double *xhat, double *dhat, double *P);
+/* ysp [ny], usp [nu]: this step's set points; xs [B][nx], us [B][nu]: the targets of the step before in (first guess of the SQP and us_prev of the
+ * input-move cost), this step's out - unchanged when status is 2 (MPC_code.py:714-718); sqp: SQP iterations taken */
+int nmpc_target_solve(nmpc_handle *h, const double *dhat, const double *ysp, const double *usp, double *xs, double *us, int32_t *status, int32_t *sqp);
+/* u_out [B][nu] the optimal first input, xnext_out [B][nx] the optimiser's next state (MPC_code.py:798-799); the held input and the model's
+ * propagation with status 2 (:804-805); iters: interior-point iterations of the last QP */
+int nmpc_ocp_solve(nmpc_handle *h, const double *xhat, const double *dhat, const double *xs, const double *us, const double *u_prev, int32_t max_sqp, double sqp_tol,
+                   double *u_out, double *xnext_out, int32_t *status, int32_t *iters, int32_t *sqp);
+/* the simulator's side, for callers without a plant of their own: x_p <- Fx_p(x_p, u) + pxp (pxp [nxp] or NULL), in place (Utilities.py:21-100) */
+int nmpc_plant_step(nmpc_handle *h, const double *u, double *x_p, const double *pxp);
+
 #ifdef __cplusplus
 }
 #endif

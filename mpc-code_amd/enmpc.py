@@ -20,6 +20,7 @@ ENMPC_EXPORTS = ("enmpc_create", "enmpc_destroy", "enmpc_last_error", "enmpc_bui
                  "enmpc_phase_ms", "enmpc_set_groups")
 
 _dp = ct.POINTER(ct.c_double)
+_ip = ct.POINTER(ct.c_int32)
 
 
 class _EDesc(ct.Structure):
@@ -52,6 +53,18 @@ def load_enmpc_library(path: str) -> ct.CDLL:
     lib.enmpc_get_kernel.argtypes = [vp]
     lib.enmpc_time_kernels.argtypes = [vp, ct.c_int32]
     lib.enmpc_phase_ms.argtypes = [vp, ct.POINTER(ct.c_float), ct.POINTER(ct.c_int32)]
+    lib.enmpc_mhe_update.argtypes = [vp] + [_dp] * 5 + [_ip] * 2
+    lib.enmpc_comm_unique_id.argtypes = [ct.c_char_p]
+    lib.enmpc_comm_init.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_char_p]
+    lib.enmpc_comm_destroy.argtypes = [vp]
+    lib.enmpc_comm_rank.argtypes = [vp, _ip, _ip]
+    lib.enmpc_comm_allgather.argtypes = [vp, vp, ct.c_size_t, vp]
+    lib.enmpc_comm_allreduce_max.argtypes = [vp, _dp, ct.c_int32]
+    lib.enmpc_comm_barrier.argtypes = [vp]
+    lib.enmpc_allgather_log.argtypes = [vp, ct.c_char_p, ct.c_int32, ct.c_int32, _dp]
+    lib.enmpc_target_solve.argtypes = [vp] + [_dp] * 3 + [_ip] * 2
+    lib.enmpc_ocp_solve.argtypes = [vp] + [_dp] * 6 + [_ip] * 2
+    lib.enmpc_plant_step.argtypes = [vp] + [_dp] * 2
     _libs[path] = lib
     return lib
 
@@ -157,6 +170,78 @@ class EnmpcSolver:
     def last_kernel_ms(self) -> float:
         return float(self.lib.enmpc_last_kernel_ms(self.h))
 
+    # ---- multi-GPU: the job's communicator (RCCL inside the library; mpc-code_amd/shard.py:RcclComm drives these) -----------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = ct.create_string_buffer(128)
+        self._chk(self.lib.enmpc_comm_unique_id(buf), "enmpc_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, uid: bytes):
+        self._chk(self.lib.enmpc_comm_init(self.h, int(rank), int(world), uid), "enmpc_comm_init")
+
+    def comm_rank(self):
+        r, w = ct.c_int32(0), ct.c_int32(1)
+        self._chk(self.lib.enmpc_comm_rank(self.h, ct.byref(r), ct.byref(w)), "enmpc_comm_rank")
+        return int(r.value), int(w.value)
+
+    def comm_allgather(self, array: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(array)
+        out = np.empty((self.comm_rank()[1],) + a.shape, dtype=a.dtype)
+        self._chk(self.lib.enmpc_comm_allgather(self.h, a.ctypes.data_as(ct.c_void_p), a.nbytes, out.ctypes.data_as(ct.c_void_p)), "enmpc_comm_allgather")
+        return out
+
+    def comm_allreduce_max(self, values) -> np.ndarray:
+        a = np.ascontiguousarray(np.asarray(values, dtype=np.float64)).copy()
+        self._chk(self.lib.enmpc_comm_allreduce_max(self.h, a.ctypes.data_as(_dp), a.size), "enmpc_comm_allreduce_max")
+        return a
+
+    def comm_barrier(self):
+        self._chk(self.lib.enmpc_comm_barrier(self.h), "enmpc_comm_barrier")
+
+    def allgather_log(self, name: str, k0: int, nsteps: int, to_host: bool = True):
+        """steps [k0, k0 + nsteps) of a float64 log of every rank: one RCCL all-gather, device to device; ``to_host``: also return [world, nsteps, B, dim]"""
+        d = self.p.nx + self.p.nd if name == "X_ES" else getattr(self.p, self.LOGS[name])
+        out = np.empty((self.comm_rank()[1], nsteps, self.B, d)) if to_host else None
+        self._chk(self.lib.enmpc_allgather_log(self.h, name.encode(), int(k0), int(nsteps), None if out is None else out.ctypes.data_as(_dp)), "enmpc_allgather_log")
+        return out
+
+    # ---- per-call seam: the reference's three solver calls of a step (include/mpc_enmpc.h) -------------------------------------------------
+    def mhe_update(self, y, u_prev):
+        """defEstimator(..., 'mhe') for the batch (MPC_code.py:577-650): measurement ``y [B, ny]``, the input applied over the step before ``[B, nu]``;
+        returns ``xhat, dhat, xes, status, iters``"""
+        p, B = self.p, self.B
+        y, u = _rows(y, B, p.ny), _rows(u_prev, B, p.nu)
+        xh, dh, xe = np.empty((B, p.nx)), np.empty((B, p.nd)), np.empty((B, p.nx + p.nd))
+        st, it = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        self._chk(self.lib.enmpc_mhe_update(self.h, y.ctypes.data_as(_dp), u.ctypes.data_as(_dp), xh.ctypes.data_as(_dp), dh.ctypes.data_as(_dp), xe.ctypes.data_as(_dp),
+                                            st.ctypes.data_as(_ip), it.ctypes.data_as(_ip)), "enmpc_mhe_update")
+        return xh, dh, xe, st, it
+
+    def target_solve(self, dhat):
+        """solver_ss(...) for the batch (MPC_code.py:693-718); returns ``xs, us, status, iters``"""
+        p, B = self.p, self.B
+        dh = _rows(dhat, B, p.nd)
+        xs, us = np.empty((B, p.nx)), np.empty((B, p.nu))
+        st, it = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        self._chk(self.lib.enmpc_target_solve(self.h, dh.ctypes.data_as(_dp), xs.ctypes.data_as(_dp), us.ctypes.data_as(_dp), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip)), "enmpc_target_solve")
+        return xs, us, st, it
+
+    def ocp_solve(self, xhat, dhat, xs, us):
+        """solver(...) for the batch (MPC_code.py:733-805); returns ``u, xhat_next, status, iters``"""
+        p, B = self.p, self.B
+        a = [_rows(xhat, B, p.nx), _rows(dhat, B, p.nd), _rows(xs, B, p.nx), _rows(us, B, p.nu)]
+        u, xn = np.empty((B, p.nu)), np.empty((B, p.nx))
+        st, it = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        self._chk(self.lib.enmpc_ocp_solve(self.h, *[v.ctypes.data_as(_dp) for v in a], u.ctypes.data_as(_dp), xn.ctypes.data_as(_dp), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip)), "enmpc_ocp_solve")
+        return u, xn, st, it
+
+    def plant_step(self, u, x_p):
+        """Fx_p for the batch on the device (Utilities.py:58-82); returns the next plant state"""
+        p, B = self.p, self.B
+        uu, x = _rows(u, B, p.nu), _rows(x_p, B, p.nxp).copy()
+        self._chk(self.lib.enmpc_plant_step(self.h, uu.ctypes.data_as(_dp), x.ctypes.data_as(_dp)), "enmpc_plant_step")
+        return x
+
     def get_log(self, name: str) -> np.ndarray:
         p = self.p
         if name in self.LOGS:
@@ -168,6 +253,37 @@ class EnmpcSolver:
             raise KeyError(name)
         self._chk(self.lib.enmpc_get_log(self.h, name.encode(), out.ctypes.data_as(ct.c_void_p)), "enmpc_get_log")
         return out
+
+
+def run_enmpc_stepwise(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, solver: Optional[EnmpcSolver] = None, plant=None):
+    """The reference's loop body call by call (MPC_code.py:485-827): per step the measurement, ``mhe_update`` (defEstimator), ``target_solve`` (solver_ss),
+    ``ocp_solve`` (solver) and the plant - ``plant(x_p [B, nxp], u [B, nu]) -> x_p+`` of the caller, or the device's.  Same result arrays as
+    :func:`run_enmpc_closed_loop`; with the device's plant, the same numbers to the bit."""
+    p = problem
+    nsteps = p.Nsim if nsteps is None else int(nsteps)
+    x_p = np.atleast_2d(np.asarray(x0_p, dtype=np.float64)).copy()
+    B = len(x_p)
+    s = solver or EnmpcSolver(p, device=device)
+    try:
+        s.alloc(B, 1)
+        s.set_state(x_p)
+        u = _rows(p.u0, B, p.nu)
+        xhat = _rows(p.x0_m, B, p.nx)
+        out = {k: [] for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "X_ES", "STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")}
+        for _ in range(nsteps):
+            out["Xp"].append(x_p.copy()); out["X_HAT"].append(xhat.copy())
+            y = x_p                                        # Fy_p with StateFeedback (Utilities.py:84-86)
+            xhat, dhat, xes, st_m, it_m = s.mhe_update(y, u)
+            xs, us, st_s, it_s = s.target_solve(dhat)
+            u, xhat, st_d, it_d = s.ocp_solve(xhat, dhat, xs, us)
+            x_p = s.plant_step(u, x_p) if plant is None else np.asarray(plant(x_p, u), dtype=np.float64)
+            for k, v in (("U", u), ("XS", xs), ("US", us), ("D_HAT", dhat), ("X_ES", xes), ("STATUS_DYN", st_d), ("STATUS_SS", st_s), ("STATUS_MHE", st_m),
+                         ("ITERS_DYN", it_d), ("ITERS_SS", it_s), ("ITERS_MHE", it_m)):
+                out[k].append(np.array(v))
+        return {k: np.stack(v) for k, v in out.items()}
+    finally:
+        if solver is None:
+            s.close()
 
 
 def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, steps_per_launch: int = 0, solver: Optional[EnmpcSolver] = None,

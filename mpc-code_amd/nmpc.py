@@ -54,6 +54,10 @@ def load_nmpc_library(path: str) -> ct.CDLL:
     lib.nmpc_last_kernel_ms.argtypes = [vp]; lib.nmpc_last_kernel_ms.restype = ct.c_float
     lib.nmpc_time_kernels.argtypes = [vp, ct.c_int32]
     lib.nmpc_wave_kernel_ms.argtypes = [vp, ct.POINTER(ct.c_float), _ip]
+    lib.nmpc_ekf_update.argtypes = [vp] + [_dp] * 5
+    lib.nmpc_target_solve.argtypes = [vp] + [_dp] * 5 + [_ip] * 2
+    lib.nmpc_ocp_solve.argtypes = [vp] + [_dp] * 5 + [ct.c_int32, ct.c_double] + [_dp] * 2 + [_ip] * 3
+    lib.nmpc_plant_step.argtypes = [vp] + [_dp] * 3
     _libs[path] = lib
     return lib
 
@@ -137,6 +141,45 @@ class NmpcSolver:
                                              None if pxp is None else pxp.ctypes.data_as(_dp), None if pyp is None else pyp.ctypes.data_as(_dp)), "nmpc_set_schedule")
         self.steps = ysp.shape[0]
 
+    # ---- per-call seam: the reference's three solver calls of a step (include/mpc_nmpc.h) --------------------------------------------------
+    def ekf_update(self, y, u_prev, xhat, dhat, P):
+        """defEstimator(..., 'ekf' | 'lue') for the batch (MPC_code.py:577-650); returns the posterior ``xhat, dhat, P``"""
+        p, B = self.p, self.B
+        ne = p.nx + p.nd
+        y, u = _rows(y, B, p.ny), _rows(u_prev, B, p.nu)
+        xh, dh = _rows(xhat, B, p.nx).copy(), _rows(dhat, B, max(p.nd, 1)).copy()
+        Pk = np.ascontiguousarray(np.broadcast_to(np.asarray(P, dtype=np.float64).reshape(-1, ne * ne), (B, ne * ne))).copy()
+        self._chk(self.lib.nmpc_ekf_update(self.h, *[v.ctypes.data_as(_dp) for v in (y, u, xh, dh, Pk)]), "nmpc_ekf_update")
+        return xh, dh, Pk
+
+    def target_solve(self, dhat, ysp, usp, xs, us):
+        """solver_ss(...) for the batch (MPC_code.py:693-718): the targets of the step before in, this step's out; returns ``xs, us, status, sqp``"""
+        p, B = self.p, self.B
+        dh, xs, us = _rows(dhat, B, max(p.nd, 1)), _rows(xs, B, p.nx).copy(), _rows(us, B, p.nu).copy()
+        ysp, usp = _c(ysp).reshape(p.ny), _c(usp).reshape(p.nu)
+        st, sq = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        self._chk(self.lib.nmpc_target_solve(self.h, dh.ctypes.data_as(_dp), ysp.ctypes.data_as(_dp), usp.ctypes.data_as(_dp), xs.ctypes.data_as(_dp), us.ctypes.data_as(_dp),
+                                             st.ctypes.data_as(_ip), sq.ctypes.data_as(_ip)), "nmpc_target_solve")
+        return xs, us, st, sq
+
+    def ocp_solve(self, xhat, dhat, xs, us, u_prev, max_sqp: int = 1, sqp_tol: float = 1e-9):
+        """solver(...) for the batch (MPC_code.py:733-805); returns ``u, xhat_next, status, iters, sqp``"""
+        p, B = self.p, self.B
+        a = [_rows(xhat, B, p.nx), _rows(dhat, B, max(p.nd, 1)), _rows(xs, B, p.nx), _rows(us, B, p.nu), _rows(u_prev, B, p.nu)]
+        u, xn = np.empty((B, p.nu)), np.empty((B, p.nx))
+        st, it, sq = (np.empty(B, dtype=np.int32) for _ in range(3))
+        self._chk(self.lib.nmpc_ocp_solve(self.h, *[v.ctypes.data_as(_dp) for v in a], int(max_sqp), float(sqp_tol), u.ctypes.data_as(_dp), xn.ctypes.data_as(_dp),
+                                          st.ctypes.data_as(_ip), it.ctypes.data_as(_ip), sq.ctypes.data_as(_ip)), "nmpc_ocp_solve")
+        return u, xn, st, it, sq
+
+    def plant_step(self, u, x_p, pxp=None):
+        """Fx_p for the batch on the device (Utilities.py:21-100) + the plant's disturbance of this step; returns the next plant state"""
+        p, B = self.p, self.B
+        uu, x = _rows(u, B, p.nu), _rows(x_p, B, p.nxp).copy()
+        px = None if pxp is None else _c(pxp).reshape(p.nxp)
+        self._chk(self.lib.nmpc_plant_step(self.h, uu.ctypes.data_as(_dp), x.ctypes.data_as(_dp), None if px is None else px.ctypes.data_as(_dp)), "nmpc_plant_step")
+        return x
+
     def run(self, k0: int, nsteps: int, max_sqp: int = 1, sqp_tol: float = 1e-9):
         self._chk(self.lib.nmpc_run(self.h, int(k0), int(nsteps), int(max_sqp), float(sqp_tol)), "nmpc_run")
 
@@ -178,6 +221,44 @@ class NmpcSolver:
         if out.size:
             self._chk(self.lib.nmpc_get_log(self.h, name.encode(), out.ctypes.data_as(ct.c_void_p)), "nmpc_get_log")
         return out
+
+
+def run_nmpc_stepwise(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[NmpcSolver] = None, max_sqp: int = 1, sqp_tol: float = 1e-9,
+                      device: int = 0, plant=None) -> Dict[str, np.ndarray]:
+    """The reference's loop body call by call (MPC_code.py:485-827): per step the measurement (the Ex-file's plant output on the host), ``ekf_update``
+    (defEstimator), ``target_solve`` (solver_ss), ``ocp_solve`` (solver) and the plant - ``plant(x_p [B, nxp], u [B, nu], t) -> x_p+`` of the caller, or the
+    device's.  With the device's plant: :func:`run_nmpc_closed_loop` on the instance-per-lane kernel to the bit (when the plant output is exact on the host)."""
+    p = problem
+    nsteps = p.Nsim if nsteps is None else int(nsteps)
+    x_p = (p.x0_p[None] if x0_p is None else np.atleast_2d(np.asarray(x0_p, dtype=np.float64))).copy()
+    x0_m = p.x0_m[None] if x0_m is None else np.atleast_2d(x0_m)
+    B = x_p.shape[0]
+    own = solver is None
+    s = NmpcSolver(p, device=device) if own else solver
+    try:
+        s.alloc(B, 1)
+        s.set_state(x_p, x0_m)
+        sch = p.schedules(nsteps)
+        ne = p.nx + p.nd
+        xhat, dhat = _rows(x0_m, B, p.nx).copy(), _rows(p.dhat0, B, max(p.nd, 1)).copy()
+        P = np.ascontiguousarray(np.broadcast_to(np.asarray(p.P0, dtype=np.float64).reshape(-1, ne * ne), (B, ne * ne))).copy()
+        u, xs, us = _rows(p.u0, B, p.nu).copy(), xhat.copy(), _rows(p.u0, B, p.nu).copy()
+        keys = ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "SQP_DYN", "SQP_SS")
+        out = {k: [] for k in keys}
+        for k in range(nsteps):
+            t = k * p.h
+            out["Xp"].append(x_p.copy()); out["X_HAT"].append(xhat.copy())
+            y = p.plant_output(x_p, u, t) + sch["pyp"][k]                    # MPC_code.py:531-534
+            xhat, dhat, P = s.ekf_update(y, u, xhat, dhat, P)
+            xs, us, st_s, sq_s = s.target_solve(dhat, sch["ysp"][k], sch["usp"][k], xs, us)
+            u, xhat, st_d, it_d, sq_d = s.ocp_solve(xhat, dhat, xs, us, u, max_sqp, sqp_tol)
+            x_p = s.plant_step(u, x_p, sch["pxp"][k]) if plant is None else np.asarray(plant(x_p, u, t), dtype=np.float64) + sch["pxp"][k]
+            for kk, v in (("U", u), ("XS", xs), ("US", us), ("D_HAT", dhat[:, :p.nd]), ("STATUS_DYN", st_d), ("STATUS_SS", st_s), ("ITERS_DYN", it_d), ("SQP_DYN", sq_d), ("SQP_SS", sq_s)):
+                out[kk].append(np.array(v))
+        return {k: np.stack(v) for k, v in out.items() if not (k == "D_HAT" and p.nd == 0)}
+    finally:
+        if own:
+            s.close()
 
 
 def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[NmpcSolver] = None,

@@ -49,3 +49,39 @@ def test_single_rank_communicator_gathers_what_the_kernel_logged_and_keeps_stdou
             s.comm_init(0, 1, uid)          # a handle has one communicator
     finally:
         s.close()
+
+
+def test_the_economic_librarys_own_communicator_gathers_its_device_log(pkg):
+    """BASELINE configs[3] / [4] shard over eight GPUs: the per-model library carries the collective itself (enmpc_comm_*, enmpc_allgather_log: one
+    ncclAllGather from the device log), no second library and no download in between; here with the one rank of the box, through shard.RcclComm - the
+    object bench.py drives for N > 1."""
+    from mpc_code_amd import enmpc, shard
+    p = pkg.load_problem(pkg.example_path("reactor_enmpc.py"))
+    s = enmpc.EnmpcSolver(p, device=0)
+    B, K = 130, 5
+    x0 = np.random.default_rng(5).uniform([0.5, 0.0], [1.0, 0.5], size=(B, 2))
+    try:
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")
+        with tempfile.TemporaryFile() as cap:
+            saved = os.dup(1)
+            os.dup2(cap.fileno(), 1)
+            try:
+                comm = shard.RcclComm(s, 0, 1, rendezvous_file=os.path.join(tempfile.gettempdir(), f"mpc_amd_test_{os.getpid()}.id"))
+            finally:
+                os.dup2(saved, 1); os.close(saved)
+            cap.seek(0)
+            assert cap.read() == b""
+        assert s.comm_rank() == (0, 1)
+        s.alloc(B, K); s.set_state(x0); s.run(0, K)
+        s.allgather_log("U", 0, K, to_host=False)      # asynchronous, device to device, behind the run on the handle's stream
+        comm.barrier()
+        U = s.get_log("U")
+        g = s.allgather_log("U", 0, K)
+        assert g.shape == (1, K, B, p.nu) and np.array_equal(g[0], U)
+        assert np.array_equal(s.allgather_log("X_ES", 1, 3)[0], s.get_log("X_ES")[1:4])
+        assert comm.max(2.5) == 2.5
+        st = s.get_log("STATUS_DYN")
+        assert np.array_equal(comm.allgather(st)[0], st)
+        assert np.array_equal(shard.allgather_rows(U[-1], B, comm), U[-1])
+    finally:
+        s.close()

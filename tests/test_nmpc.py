@@ -377,6 +377,27 @@ def test_gpu_launch_chunks_continue_the_same_loop(nl, solver):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_sqp", [1, 20])
+def test_gpu_the_three_solver_calls_of_a_step_reproduce_the_fused_loop(nl, solver, max_sqp):
+    """The per-call seam of include/mpc_nmpc.h - nmpc_ekf_update, nmpc_target_solve, nmpc_ocp_solve: the reference's defEstimator(..., 'ekf'),
+    solver_ss(...), solver(...) of one step (MPC_code.py:577-650, :704-709, :776-781) for the whole batch, caller-owned host arrays - with the device's
+    plant in between is the fused closed loop of the instance-per-lane kernel BIT FOR BIT through the feed-flow step: values, status words, SQP and
+    interior-point iteration counts; with a plant of the caller's (the Ex-file's, NumPy Runge-Kutta) the same loop to rounding."""
+    from mpc_code_amd import nmpc
+    B, ns = 70, 30
+    rng = np.random.default_rng(4)
+    x0 = np.tile(nl.x0_p, (B, 1)) * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, 3)))
+    solver.set_kernel(1)
+    a = nmpc.run_nmpc_closed_loop(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=max_sqp, sqp_tol=1e-9)
+    b = nmpc.run_nmpc_stepwise(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=max_sqp, sqp_tol=1e-9)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "SQP_DYN", "SQP_SS"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k].astype(float) - b[k].astype(float)).max()))
+    c = nmpc.run_nmpc_stepwise(nl, x0[:8], x0[:8], nsteps=ns, solver=solver, max_sqp=max_sqp, sqp_tol=1e-9, plant=lambda x, u, t: nl.plant_step(x, u, t))
+    assert np.max(np.abs(c["U"] - a["U"][:, :8]) / (1 + np.abs(c["U"]))) < 1e-8 and np.array_equal(c["STATUS_DYN"], a["STATUS_DYN"][:, :8])
+    solver.set_kernel(0)
+
+
+@pytest.mark.gpu
 def test_gpu_error_paths(nl, solver):
     from mpc_code_amd.capi import MpcAmdError
     solver.alloc(4, 3)
