@@ -140,6 +140,10 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     n_w = ns["w"].size1()
     if ny != nx or nd != ny:
         raise UnsupportedProblem("StateFeedback with an output disturbance needs ny = nx = nd")
+    if nxp != nx:
+        raise UnsupportedProblem("StateFeedback: the measurement is the plant state, so the plant needs the model's state dimension (nxp = nx)")
+    if has("dhat0") and np.any(np.asarray(ns["dhat0"], dtype=float) != 0.0):      # MPC_code.py:459-462 seeds dhat_k with it; this path starts from zero
+        raise UnsupportedProblem("a non-zero dhat0 is outside the economic path built so far")
     N_mhe = int(ns["N_mhe"])
     if N_mhe < 2 or N_mhe > 63 or int(ns["N"]) < 2 or int(ns["N"]) > 64:
         raise UnsupportedProblem("horizons: 2 <= N <= 64, 2 <= N_mhe <= 63 (one stage per lane of a wavefront)")

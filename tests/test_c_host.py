@@ -48,3 +48,24 @@ def test_gpu_c_host_gets_the_lqr_law(pkg, tmp_path):
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok: first moves equal the LQR law" in r.stdout, (r.returncode, r.stdout, r.stderr)
     assert r.stdout.count("status 0") == 5
+
+
+@pytest.mark.gpu
+def test_gpu_c_host_of_the_economic_seam_follows_the_golden_loop(pkg, tmp_path):
+    """examples/c_host/enmpc_host.c - plain C99, the per-call seam of include/mpc_enmpc.h (enmpc_mhe_update, enmpc_target_solve, enmpc_ocp_solve, the plant)
+    linked against the shipped example's per-model library - walks the golden closed loop of tests/golden/enmpc_reactor.npz."""
+    import numpy as np
+    from mpc_code_amd import econcodegen
+    lib = econcodegen.build_enmpc_library(pkg.load_problem(pkg.example_path("reactor_enmpc.py")))
+    exe = str(tmp_path / "enmpc_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", INC, os.path.join(HOST, "enmpc_host.c"), lib, "-o", exe, "-lm"])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(lib) + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, "5"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "enmpc_reactor.npz"))
+    rows = [l for l in r.stdout.splitlines() if l.startswith("step") and "instance 0" in l]
+    assert len(rows) == 5
+    for k, l in enumerate(rows):
+        v = l.split()
+        assert abs(float(v[5]) - g["ship_U"][k, 0, 0]) < 1e-7 and abs(float(v[7]) - g["ship_XS"][k, 0, 0]) < 1e-7 and abs(float(v[10]) - g["ship_US"][k, 0, 0]) < 1e-7, l
+        assert v[12] == "0/0/0" and int(v[14].split("/")[0]) == int(g["ship_ITERS_DYN"][k, 0]), l
