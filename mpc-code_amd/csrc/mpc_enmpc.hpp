@@ -307,6 +307,13 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NS; i++) { one(zlx[i], flx[i]); one(blx[i], flx[i]); one(zhx[i], fhx[i]); one(bhx[i], fhx[i]); }
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { one(zl0[i], flx[i]); one(bl0[i], flx[i]); one(zh0[i], fhx[i]); one(bh0[i], fhx[i]); } }
     };
+    // ... and, with the slacks of the iterate, while the Newton system is factorised and solved (the sweeps over the lanes keep a dozen small matrices alive)
+    auto park_slacks = [&](const bool store, double (&slu)[NU], double (&shu)[NU], double (&slx)[NS], double (&shx)[NS], double (&sl0)[NS], double (&sh0)[NS]) {
+        int slot = 4 * (NU + NS) + (FREE0 ? 4 * NS : 0);
+        auto one = [&](double &v, bool used) { if (used) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; } slot++; };
+        MPC_UNROLL for (int i = 0; i < NU; i++) { one(slu[i], flu[i]); one(shu[i], fhu[i]); }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { one(slx[i], flx[i]); one(shx[i], fhx[i]); if (FREE0) { one(sl0[i], flx[i]); one(sh0[i], fhx[i]); } }
+    };
     const double nb = (double)(N * (nbl + nbx) + (FREE0 ? nbx : 0)), meq = (double)(N * NS);
     // damping of the variables with one bound [WB 3.7]: +1 (only a lower bound), -1 (only an upper bound), 0
     auto damp = [&](bool fl_, bool fh_) { return (fl_ && !fh_) ? 1.0 : ((fh_ && !fl_) ? -1.0 : 0.0); };
@@ -355,10 +362,16 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         double fv, gv[NS], Hv[NS][NS];
         term(xn, fv, gv, Hv);
         park_io(false);
-        // the scaled problem: df f
+        // the scaled problem: df f.  (An entry the generated code knows to be zero stays a literal zero - 0 * df would be a run-time value to the compiler, and the
+        // sweeps below would multiply and keep in registers what the estimator's structure - constant diagonal cost Hessian, no cross terms - lets them drop.)
+        auto scaled = [&](double x_) { return (__builtin_constant_p(x_) && x_ == 0.0) ? 0.0 : x_ * df; };
         L.l *= df; fv *= df;
-        MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] *= df; MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] *= df; }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { L.lx[i] *= df; gv[i] *= df; MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] *= df; Hv[i][j] *= df; } MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] *= df; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] = scaled(L.lu[i]); MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] = scaled(L.R[i][j]); }
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            L.lx[i] = scaled(L.lx[i]); gv[i] = scaled(gv[i]);
+            MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] = scaled(L.Q[i][j]); Hv[i][j] = scaled(Hv[i][j]); }
+            MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] = scaled(L.M[i][j]);
+        }
         // gradient of the objective with respect to this lane's x_{k+1}: the next stage's cost gradient, the terminal cost's at the end; with respect to the
         // free initial state: stage 0's cost gradient + the arrival cost's (ga0)
         double gfx[NS], ga0[NS], lx0[NS];
@@ -379,7 +392,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         RicVec<NS, NU> Vc;
         MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = 0.0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Fc.Pnx[i][j] = 0.0; Fc.P0i[i][j] = 0.0; } }
-        if (first) {
+        if (__builtin_expect(first, 0)) {
             // ---- least-squares equality multipliers [WB (36)]: the Newton system with the identity for the Hessian, no constraint residual ------------
             double Iq[NS][NS], Im[NS][NU], Ir[NU][NU], zu_[NU], zx_[NS], gu[NU], gxk[NS], pt[NS], p0a[NS], c0[NS], P0a[NS][NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Iq[i][j] = i == j ? 1.0 : 0.0; P0a[i][j] = i == j ? 1.0 : 0.0; } MPC_UNROLL for (int j = 0; j < NU; j++) Im[i][j] = 0.0; zx_[i] = 0.0; c0[i] = 0.0; }
@@ -502,6 +515,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         double gu[NU], gxk[NS], pt[NS], p0a[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) gu[i] = L.lu[i] + bu[i];
         MPC_UNROLL for (int i = 0; i < NS; i++) { gxk[i] = L.lx[i] + bxk[i]; pt[i] = gv[i] + bx[i]; p0a[i] = FREE0 ? ga0[i] + b0[i] : 0.0; }
+        park_io(true); park_slacks(true, slu, shu, slx, shx, sl0, sh0);
         double delta = 0.0;
         bool failed = false;
         for (;;) {
@@ -516,13 +530,14 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                 delta = delta == 0.0 ? dmax(kDeltaFirst, delta_last / 3.0) : delta * (delta_last == 0.0 ? 100.0 : 8.0);
                 if (delta > kDeltaMax) failed = true;
             }
-            if (!__any((retry && !failed) ? 1 : 0)) break;      // (segments that were fine recompute the same numbers with their own shift)
+            if (__builtin_expect(!__any((retry && !failed) ? 1 : 0), 1)) break;      // (segments that were fine recompute the same numbers with their own shift)
         }
         if (!done && failed) { status = kStFailed; done = true; }
         if (!done && delta > 0.0) delta_last = delta;
         double du[NU], dxn[NS], dx0[NS], pin[NS];
         ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vc, c, du, dxn, pin);
         MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = Vc.dx0[i];
+        park_io(false); park_slacks(false, slu, shu, slx, shx, sl0, sh0);
         // fraction to the boundary of a step (du_, dxn_, dx0_)
         auto ratio = [&](double a, double v, double dv) { return dv < 0.0 ? dmin(a, -tau * v / dv) : a; };
         auto max_step = [&](const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
@@ -627,7 +642,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                     else { alpha *= 0.5; n_steps++; if (!(alpha > a_min)) searching = false; }
                 }
             }
-            if (__any(want_soc ? 1 : 0)) {
+            if (__builtin_expect(__any(want_soc ? 1 : 0), 0)) {      // (rare: the hint keeps its operands from crowding the common path's registers)
                 // ---- second-order correction [WB 2.4]: the vector sweeps again for the corrected constraint residual, up to four times -----------------
                 double csoc[NS], a_soc = alpha, theta_old = 0.0, th_s = theta_t;
                 MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = c[i];
