@@ -107,7 +107,7 @@ template <int SEG, int N_> __device__ __forceinline__ void bcast_sym(const doubl
 // FREE0 = false: x_0 is given (the OCP; IPOPT makes a variable with equal bounds a parameter, MPC_code.py:734).
 // FREE0 = true:  x_0 is a variable with its own box and the arrival cost 1/2 (x_0 - xbar)' Pinv (x_0 - xbar) (the MHE); every lane
 //                carries the same copy of it.
-// The algorithm is the reference solver's as documented in oracle/enmpc_oracle.py:ipm_dense (objective scaling at the caller's point,
+// The algorithm is the reference solver's as documented in DESIGN.md section 10, "Solver" (objective scaling at the caller's point,
 // least-squares multipliers, monotone barrier parameter, filter line search with second-order correction, tiny steps, safe slacks,
 // acceptable stop) - same constants, same order of decisions; what differs is the linear algebra: every Newton system is a Riccati
 // recursion over the lanes, split into a MATRIX pass (gains, cost-to-go matrices; repeated with a larger shift while a stage lacks positive
@@ -134,6 +134,18 @@ constexpr double kEps = 2.220446049250313e-16, kSlackMove = 1.81898940354585648e
                  kObjMaxInc = 5.0, kKappaSoc = 0.99, kTinyStepTol = 10.0 * kEps, kTinyStepYTol = 1e-2, kDualInfTol = 1.0, kConstrViolTol = 1e-4, kComplInfTol = 1e-4,
                  kAccTol = 1e-6, kAccDualInfTol = 1e10, kAccConstrViolTol = 1e-2, kAccComplInfTol = 1e-2;
 constexpr int kMaxSoc = 4, kAccIter = 15, kFilterCap = 16;
+
+// Diagnostic build only (-DMPC_STAMPS, tools/enmpc_ipm_stamps.py): shader-clock ticks per part of an interior point iteration, accumulated per wave into
+// mpc_ipm_stamp_buf[wave][16] by the first 256 waves of a launch.  Never compiled into the product library; the values reach no output of the solver.
+#ifdef MPC_STAMPS
+__device__ unsigned long long mpc_ipm_stamp_buf[256 * 16];
+#define EC_IPM_STAMP_INIT unsigned long long ipm_prev_ = __builtin_amdgcn_s_memtime();
+#define EC_IPM_STAMP(slot) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+    if (threadIdx.x == 0 && blockIdx.x < 256) mpc_ipm_stamp_buf[blockIdx.x * 16 + (slot)] += t_ - ipm_prev_; ipm_prev_ = t_; } while (0)
+#else
+#define EC_IPM_STAMP_INIT
+#define EC_IPM_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool le_tol(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * kEps * fabs(bas); }      // IPOPT's Compare_le
 // slack of one bound with IPOPT's CalculateSafeSlack; a corrected slack moves `bound`
@@ -167,6 +179,9 @@ __device__ __forceinline__ int filter_add(double *filt, int nf, double e_phi, do
     else { filt[(2 * k2) * FS] = e_phi; filt[(2 * k2 + 1) * FS] = e_th; k2++; }
     return k2;
 }
+
+// rows of 64 doubles ipm_stage wants in LDS per wave (`park`)
+template <int NS, int NU, bool FREE0, bool UB> constexpr int ipm_park_rows() { return 6 * ((UB ? NU : 0) + NS + (FREE0 ? NS : 0)) + NU + 2 * NS + (FREE0 ? NS : 0); }
 
 template <int NS, int NU>
 struct StageLin {
@@ -277,20 +292,24 @@ __device__ __forceinline__ void ric_forward(const int N, const int lane, const i
 }
 
 //   grd(xk, u, L)          cost value / gradient only (L.l, L.lx, L.lu): the caller's point, where IPOPT takes the scaling of the objective from
-template <int NS, int NU, bool FREE0, int SEG, class ST, class AUX, class GrdF, class LinF, class AddPiF, class ValF, class TermF>
+template <int NS, int NU, bool FREE0, bool UB, int SEG, class ST, class AUX, class GrdF, class LinF, class AddPiF, class ValF, class TermF>
 __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
                                          double (&pi)[NS], const double (&ulo_in)[NU], const double (&uhi_in)[NU], const double (&xlo_in)[NS],
                                          const double (&xhi_in)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
                                          const int max_iter, GrdF grd, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt, double *const park)
 {
     using SG = Seg<SEG>;
+    // Large stages (the estimator: 4 + 4 here) do not keep the factors of the Newton system across the line search - with the trial point's integration they
+    // would not fit the register file, and what the compiler then moves to scratch memory is paid for in every iteration.  The second-order correction, which
+    // alone needs them again (one iteration in some hundred), runs the matrix pass once more.
+    constexpr bool kSocRefactor = NS * NS + NU * NS >= 24;
     const int k = SG::stage(lane);
     const bool on = k < N;
     bool flu[NU], fhu[NU], flx[NS], fhx[NS];
     double zlu[NU], zhu[NU], zlx[NS], zhx[NS], zl0[NS], zh0[NS];
     double blu[NU], bhu[NU], blx[NS], bhx[NS], bl0[NS], bh0[NS];      // this solve's own bounds
     int nbl = 0, nbx = 0;
-    MPC_UNROLL for (int i = 0; i < NU; i++) { blu[i] = ulo_in[i]; bhu[i] = uhi_in[i]; flu[i] = fin(blu[i]); fhu[i] = fin(bhu[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { blu[i] = ulo_in[i]; bhu[i] = uhi_in[i]; flu[i] = UB && fin(blu[i]); fhu[i] = UB && fin(bhu[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); }
     MPC_UNROLL for (int i = 0; i < NS; i++) {
         blx[i] = xlo_in[i]; bhx[i] = xhi_in[i]; bl0[i] = xlo_in[i]; bh0[i] = xhi_in[i];
         flx[i] = fin(blx[i]); fhx[i] = fin(bhx[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
@@ -300,19 +319,28 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
     // loop with its second-order sensitivities takes the whole register file, and whatever else lives across it is spilled to scratch memory and reloaded
     // inside that loop (measured: 226 KB of scratch traffic per instance-step, a quarter of the wave-cycles waiting).  They are read back after the
     // linearisation and stored again at the end of the iteration.
+    // Rows (ipm_park_rows): per variable that may have bounds 2 x (multiplier, bound), then 2 slacks; then the iterate itself.
+    constexpr int NBV = (UB ? NU : 0) + NS + (FREE0 ? NS : 0);
     auto park_io = [&](const bool store) {
         int slot = 0;
         auto one = [&](double &v, bool used) { if (used) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; } slot++; };
-        MPC_UNROLL for (int i = 0; i < NU; i++) { one(zlu[i], flu[i]); one(blu[i], flu[i]); one(zhu[i], fhu[i]); one(bhu[i], fhu[i]); }
+        if (UB) { MPC_UNROLL for (int i = 0; i < NU; i++) { one(zlu[i], flu[i]); one(blu[i], flu[i]); one(zhu[i], fhu[i]); one(bhu[i], fhu[i]); } }
         MPC_UNROLL for (int i = 0; i < NS; i++) { one(zlx[i], flx[i]); one(blx[i], flx[i]); one(zhx[i], fhx[i]); one(bhx[i], fhx[i]); }
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { one(zl0[i], flx[i]); one(bl0[i], flx[i]); one(zh0[i], fhx[i]); one(bh0[i], fhx[i]); } }
     };
     // ... and, with the slacks of the iterate, while the Newton system is factorised and solved (the sweeps over the lanes keep a dozen small matrices alive)
     auto park_slacks = [&](const bool store, double (&slu)[NU], double (&shu)[NU], double (&slx)[NS], double (&shx)[NS], double (&sl0)[NS], double (&sh0)[NS]) {
-        int slot = 4 * (NU + NS) + (FREE0 ? 4 * NS : 0);
+        int slot = 4 * NBV;
         auto one = [&](double &v, bool used) { if (used) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; } slot++; };
-        MPC_UNROLL for (int i = 0; i < NU; i++) { one(slu[i], flu[i]); one(shu[i], fhu[i]); }
+        if (UB) { MPC_UNROLL for (int i = 0; i < NU; i++) { one(slu[i], flu[i]); one(shu[i], fhu[i]); } }
         MPC_UNROLL for (int i = 0; i < NS; i++) { one(slx[i], flx[i]); one(shx[i], fhx[i]); if (FREE0) { one(sl0[i], flx[i]); one(sh0[i], fhx[i]); } }
+    };
+    // ... and the iterate (it is not touched between the linearisation and the first trial point)
+    auto park_iter = [&](const bool store) {
+        int slot = 6 * NBV;
+        auto one = [&](double &v) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; slot++; };
+        MPC_UNROLL for (int i = 0; i < NU; i++) one(u[i]);
+        MPC_UNROLL for (int i = 0; i < NS; i++) { one(xn[i]); one(pi[i]); if (FREE0) one(x0v[i]); }
     };
     const double nb = (double)(N * (nbl + nbx) + (FREE0 ? nbx : 0)), meq = (double)(N * NS);
     // damping of the variables with one bound [WB 3.7]: +1 (only a lower bound), -1 (only an upper bound), 0
@@ -325,6 +353,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
     int status = kStMaxIter, nfilt = 0, acc_count = 0;
     bool done = !live, tiny_last = false, tiny_flag = false;
     iters = 0;
+    EC_IPM_STAMP_INIT
     // ---- scaling of the objective at the caller's point (IpGradientScaling), then the push into the box --------------------------------------------
     {
         double xk[NS];
@@ -349,6 +378,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) x0v[i] = push_in(x0v[i], bl0[i], bh0[i]); }
     }
     park_io(true);
+    EC_IPM_STAMP(0);      // scaling, push
     bool first = true;      // (wave-uniform: every segment's first iteration starts with the least-squares multipliers)
     int it = 0;
     for (;;) {
@@ -361,6 +391,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         lin(xk, u, L, aux);
         double fv, gv[NS], Hv[NS][NS];
         term(xn, fv, gv, Hv);
+        EC_IPM_STAMP(1);      // linearisation
         park_io(false);
         // the scaled problem: df f.  (An entry the generated code knows to be zero stays a literal zero - 0 * df would be a run-time value to the compiler, and the
         // sweeps below would multiply and keep in registers what the estimator's structure - constant diagonal cost Hessian, no cross terms - lets them drop.)
@@ -392,6 +423,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         RicVec<NS, NU> Vc;
         MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = 0.0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Fc.Pnx[i][j] = 0.0; Fc.P0i[i][j] = 0.0; } }
+        EC_IPM_STAMP(2);      // scaling of the stage, gradients
         if (__builtin_expect(first, 0)) {
             // ---- least-squares equality multipliers [WB (36)]: the Newton system with the identity for the Hessian, no constraint residual ------------
             double Iq[NS][NS], Im[NS][NU], Ir[NU][NU], zu_[NU], zx_[NS], gu[NU], gxk[NS], pt[NS], p0a[NS], c0[NS], P0a[NS][NS];
@@ -411,6 +443,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             MPC_UNROLL for (int i = 0; i < NS; i++) pi[i] = ym <= kYInitMax ? pin_[i] : 0.0;
             first = false;
         }
+        EC_IPM_STAMP(3);      // least-squares multipliers (first iteration)
         addpi(aux, pi, L);      // Hessian of the Lagrangian of the scaled problem: df (cost) + pi' F
         // ---- slacks (safe: a slack that rounding took below eps min(1, mu) is lifted, its bound moves) ------------------------------------------
         double slu[NU], shu[NU], slx[NS], shx[NS], sl0[NS], sh0[NS];
@@ -467,6 +500,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                 if (!done && it >= max_iter) done = true;
             }
         }
+        EC_IPM_STAMP(4);      // slacks, optimality error, stopping tests
         if (__all(done ? 1 : 0)) break;
         // ---- barrier parameter (per segment): while (E_mu <= kappa_eps mu or two tiny steps in a row) mu decreases; the filter is emptied with it ---------
         {
@@ -515,7 +549,8 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         double gu[NU], gxk[NS], pt[NS], p0a[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) gu[i] = L.lu[i] + bu[i];
         MPC_UNROLL for (int i = 0; i < NS; i++) { gxk[i] = L.lx[i] + bxk[i]; pt[i] = gv[i] + bx[i]; p0a[i] = FREE0 ? ga0[i] + b0[i] : 0.0; }
-        park_io(true); park_slacks(true, slu, shu, slx, shx, sl0, sh0);
+        EC_IPM_STAMP(5);      // barrier parameter, barrier terms
+        park_io(true); park_slacks(true, slu, shu, slx, shx, sl0, sh0); park_iter(true);
         double delta = 0.0;
         bool failed = false;
         for (;;) {
@@ -534,10 +569,12 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         if (!done && failed) { status = kStFailed; done = true; }
         if (!done && delta > 0.0) delta_last = delta;
+        EC_IPM_STAMP(6);      // backward sweep(s)
         double du[NU], dxn[NS], dx0[NS], pin[NS];
         ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vc, c, du, dxn, pin);
         MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = Vc.dx0[i];
-        park_io(false); park_slacks(false, slu, shu, slx, shx, sl0, sh0);
+        park_io(false); park_slacks(false, slu, shu, slx, shx, sl0, sh0); park_iter(false);
+        EC_IPM_STAMP(7);      // forward sweep
         // fraction to the boundary of a step (du_, dxn_, dx0_)
         auto ratio = [&](double a, double v, double dv) { return dv < 0.0 ? dmin(a, -tau * v / dv) : a; };
         auto max_step = [&](const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
@@ -576,6 +613,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             MPC_UNROLL for (int i = 0; i < NS; i++) xkt[i] = SG::up1(FREE0 ? x0t[i] : x0fix[i], xt[i], k);
             val(xkt, ut, Ft, lt);
             term(xt, fvt, gvt, Hvt);
+            park_io(false);      // (unchanged since they were parked: read again rather than kept alive across the integration)
             double tht = 0.0, pht = 0.0;
             bool okl = finite_all(lt);
             MPC_UNROLL for (int i = 0; i < NS; i++) { ct[i] = xt[i] - Ft[i]; tht += fabs(ct[i]); okl = okl && finite_all(ct[i]); }
@@ -624,6 +662,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
             return ok_ && !filter_rejects(filt, nfilt, phi_t, theta_t);
         };
+        EC_IPM_STAMP(8);      // step sizes, directional derivative, the line search's thresholds
         bool tiny = drel < kTinyStepTol && theta <= 1e-4;
         bool searching = !done, accepted = false;
         int n_steps = 0;
@@ -631,6 +670,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         for (;;) {
             if (!__any(searching ? 1 : 0)) break;
             trial(alpha, du, dxn, dx0);
+            EC_IPM_STAMP(9);      // trial points
             const bool acc = searching && acceptable(alpha);
             bool want_soc = false;
             if (searching) {
@@ -644,6 +684,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
             if (__builtin_expect(__any(want_soc ? 1 : 0), 0)) {      // (rare: the hint keeps its operands from crowding the common path's registers)
                 // ---- second-order correction [WB 2.4]: the vector sweeps again for the corrected constraint residual, up to four times -----------------
+                EC_IPM_STAMP(10);      // acceptance tests
                 double csoc[NS], a_soc = alpha, theta_old = 0.0, th_s = theta_t;
                 MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = c[i];
                 int cnt = 0;
@@ -653,8 +694,21 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                     if (soc) { theta_old = th_s; MPC_UNROLL for (int i = 0; i < NS; i++) csoc[i] = a_soc * csoc[i] + ct[i]; }
                     RicVec<NS, NU> Vs;
                     double dsu[NU], dsx[NS], ds0[NS], pins[NS];
-                    ric_backward<NS, NU, FREE0, SEG, ST, false>(N, lane, k, L, L.Q, L.M, L.R, Su, Sxk, Hv, Hv, gu, gxk, pt, p0a, csoc, Fc, Vs);
-                    ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vs, csoc, dsu, dsx, pins);
+                    if (kSocRefactor) {      // the matrix pass again, with the shift the Newton step was computed with
+                        RicFac<NS, NU> Fs;
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fs.K[i][j] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Fs.Qi[i][j] = 0.0; }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { Fs.Pnx[i][j] = 0.0; Fs.P0i[i][j] = 0.0; } }
+                        double Qd[NS][NS], Rd[NU][NU], Pt[NS][NS], P0a[NS][NS];
+                        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) {
+                            Qd[i][j] = L.Q[i][j] + (i == j ? delta : 0.0); Pt[i][j] = Hv[i][j] + (i == j ? Sx[i] + delta : 0.0);
+                            P0a[i][j] = FREE0 ? (df * 0.5 * (Pinv[i][j] + Pinv[j][i]) + (i == j ? S0[i] : 0.0)) : 0.0; } }
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Rd[i][j] = L.R[i][j] + (i == j ? delta : 0.0); }
+                        ric_backward<NS, NU, FREE0, SEG, ST, true>(N, lane, k, L, Qd, L.M, Rd, Su, Sxk, Pt, P0a, gu, gxk, pt, p0a, csoc, Fs, Vs);
+                        ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fs, Vs, csoc, dsu, dsx, pins);
+                    } else {
+                        ric_backward<NS, NU, FREE0, SEG, ST, false>(N, lane, k, L, L.Q, L.M, L.R, Su, Sxk, Hv, Hv, gu, gxk, pt, p0a, csoc, Fc, Vs);
+                        ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vs, csoc, dsu, dsx, pins);
+                    }
                     MPC_UNROLL for (int i = 0; i < NS; i++) ds0[i] = Vs.dx0[i];
                     const double as_ = max_step(dsu, dsx, ds0);
                     if (soc) a_soc = as_;
@@ -674,8 +728,11 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                         }
                     } else { MPC_UNROLL for (int i = 0; i < NS; i++) ct[i] = ctk[i]; theta_t = th_keep; phi_t = ph_keep; fin_t = fin_keep; }
                 }
+                EC_IPM_STAMP(11);      // second-order corrections
             }
         }
+        EC_IPM_STAMP(10);
+        park_slacks(false, slu, shu, slx, shx, sl0, sh0);      // (likewise)
         if (!done) {
             if (!accepted) {      // IPOPT enters its restoration phase here (not restated for this recursion): infeasible point -> failed; feasible to 1e-2 tol -> the point is kept
                 status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; done = true;
@@ -738,6 +795,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             it++;
         }
         park_io(true);
+        EC_IPM_STAMP(12);      // filter, multiplier steps, the new iterate
     }
     return status;
 }
@@ -776,7 +834,7 @@ constexpr double kRestoRho = 1000.0, kRestoKappa = 0.9, kRestoThetaMaxFact = 1e8
 enum : int { kRsRestored = 0, kRsConverged = 1, kRsLimit = 2, kRsFailed = 3 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// IPOPT's restoration phase for the target problem (oracle/enmpc_oracle.py:_restore; [WB 3.3]): the same interior point iteration on
+// IPOPT's restoration phase for the target problem ([WB 3.3]): the same interior point iteration on
 //     min  rho sum(n + p) + sqrt(mu) / 2 |D_R (x - x_R)|^2   s.t.  c(x) + n - p = 0,  lo <= x <= hi,  n, p >= 0
 // from x_R, until orig_ok(x) - the point is enough less infeasible and acceptable to the filter and the iterate of the solve that called.
 // n and p are eliminated from the Newton system: (H + Sigma_x + J' Dc^-1 J) dx = ..., Dc = 1 / Sigma_n + 1 / Sigma_p, whose positive definiteness is
@@ -932,6 +990,9 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
         auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
         {
             const double e0_ = err(0.0), c0_ = compl_(0.0);
+#ifdef EC_TRACE_TGT      /* diagnostic build only (tools/scratch): the first instance of a launch prints its iterations */
+            if (blockIdx.x == 0 && threadIdx.x == 0) printf("R it=%3d mu=%.3e E0=%.6e e_st=%.3e e_c=%.3e compl=%.3e theta=%.6e\n", it, mu, e0_, e_st, e_c, c0_, theta);
+#endif
             if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = kRsConverged; break; }
             if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = kRsConverged; break; } }
             else acc_count = 0;
@@ -989,10 +1050,14 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
             MPC_UNROLL for (int i = 0; i < NV; i++) { double a = -gx[i]; MPC_UNROLL for (int j = 0; j < MC; j++) a -= J[j][i] * Dci[j] * rc[j]; rhs[i] = a; }
             MPC_UNROLL for (int i = 0; i < NV; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NV; l++) a += Ai[i][l] * rhs[l]; dx[i] = a; }
             MPC_UNROLL for (int j = 0; j < MC; j++) {
-                double a = rc[j];
-                MPC_UNROLL for (int i = 0; i < NV; i++) a += J[j][i] * dx[i];
+                double a = rc[j], lin = cc[j];
+                MPC_UNROLL for (int i = 0; i < NV; i++) { a += J[j][i] * dx[i]; lin += J[j][i] * dx[i]; }
                 yn[j] = Dci[j] * a;
-                dn[j] = -(gn[j] + yn[j]) / (Sn[j] + delta); dp[j] = (yn[j] - gp[j]) / (Sp[j] + delta);
+                // Of n_j and p_j one sits at its bound (Sigma large), the other carries the infeasibility (Sigma = mu / p^2 -> 0): the first takes its step from its own
+                // row of the Newton system, the second from the linearised constraint J dx + dn - dp = -cc - dividing by the small Sigma would multiply the rounding
+                // of (multiplier - gradient) by 1 / Sigma and leave the constraint violated by as much (1e-8 .. 1e-5 near the end of a restoration: it then never converged)
+                if (Sn[j] >= Sp[j]) { dn[j] = -(gn[j] + yn[j]) / (Sn[j] + delta); dp[j] = lin + dn[j]; }
+                else { dp[j] = (yn[j] - gp[j]) / (Sp[j] + delta); dn[j] = dp[j] - lin; }
             }
         };
         auto ratio = [&](double a, double vv, double dvv) { return dvv < 0.0 ? dmin(a, -tau * vv / dvv) : a; };
@@ -1118,7 +1183,7 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Target: min fss(xs, us, ys)  s.t.  Fx_model(xs, us, d) - xs = 0,  xs + Cd d - ys = 0,  boxes   (Target_Calc.py:20-161 with
-// StateFeedback outputs).  The same algorithm as ipm_stage (oracle/enmpc_oracle.py:ipm_dense); the Newton system is reduced to the nu inputs:
+// StateFeedback outputs).  The same algorithm as ipm_stage; the Newton system is reduced to the nu inputs:
 // ys and xs follow from the two (linearised) equalities, so the inertia test is the sign of the nu x nu reduced Hessian.  One instance per
 // lane (or wave-uniform: every lane computes it).  v = [xs; us; ys] comes in as the first guess (MPC_code.py:696-700).
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1255,6 +1320,9 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
         {
             const double e0_ = err(0.0), c0_ = compl_(0.0);
+#ifdef EC_TRACE_TGT      /* diagnostic build only (tools/scratch): the first instance of a launch prints its iterations */
+            if (blockIdx.x == 0 && threadIdx.x == 0) printf("  it=%3d mu=%.3e E0=%.6e e_st=%.3e e_c=%.3e compl=%.3e theta=%.6e\n", it, mu, e0_, e_st, e_c, c0_, theta);
+#endif
             if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = kStSolved; break; }
             if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = kStSolved; break; } }
             else acc_count = 0;

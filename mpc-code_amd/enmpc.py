@@ -17,7 +17,9 @@ from .capi import MpcAmdError
 
 ENMPC_EXPORTS = ("enmpc_create", "enmpc_destroy", "enmpc_last_error", "enmpc_build_info", "enmpc_alloc", "enmpc_set_state", "enmpc_run",
                  "enmpc_sync", "enmpc_get_log", "enmpc_last_kernel_ms", "enmpc_set_kernel", "enmpc_get_kernel", "enmpc_time_kernels",
-                 "enmpc_phase_ms", "enmpc_set_groups")
+                 "enmpc_phase_ms", "enmpc_set_groups", "enmpc_comm_unique_id", "enmpc_comm_init", "enmpc_comm_destroy", "enmpc_comm_rank",
+                 "enmpc_comm_allgather", "enmpc_comm_allreduce_max", "enmpc_comm_barrier", "enmpc_allgather_log", "enmpc_mhe_update",
+                 "enmpc_target_solve", "enmpc_ocp_solve", "enmpc_plant_step")
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)

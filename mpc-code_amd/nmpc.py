@@ -17,7 +17,7 @@ from .capi import MpcAmdError
 
 NMPC_EXPORTS = ("nmpc_create", "nmpc_destroy", "nmpc_last_error", "nmpc_build_info", "nmpc_alloc", "nmpc_set_state", "nmpc_set_schedule",
                 "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_set_groups", "nmpc_get_kernel", "nmpc_time_kernels",
-                "nmpc_wave_kernel_ms")
+                "nmpc_wave_kernel_ms", "nmpc_ekf_update", "nmpc_target_solve", "nmpc_ocp_solve", "nmpc_plant_step")
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)

@@ -395,8 +395,8 @@ def _ipm_core(ev, w, lo, hi, zl, zh, lam, mu, tol, max_iter, it0, theta_max_fact
 
         def err(mu_):
             return max(e_st / s_d, e_c, compl(mu_) / s_c)
-        if trace is not None and hook is None:
-            trace.append(dict(it=it, f=f / df, E0=err(0.0), mu=mu, w=w.copy()))
+        if trace is not None:
+            trace.append(dict(it=it, f=f / df, E0=err(0.0), mu=mu, w=w.copy(), e_st=e_st, e_c=e_c, compl=compl(0.0), theta=float(np.abs(c).sum()), resto=hook is not None))
         c0_ = compl(0.0)
         if err(0.0) <= tol and e_st <= DUAL_INF_TOL and e_c <= CONSTR_VIOL_TOL and c0_ <= COMPL_INF_TOL:
             status = STATUS_SOLVED; stats["stop"] = "converged"
@@ -572,7 +572,7 @@ def _ipm_core(ev, w, lo, hi, zl, zh, lam, mu, tol, max_iter, it0, theta_max_fact
                     slt, sht, _, _ = _safe_slacks(x_, lo, hi, zl, zh, mu, fl, fh)
                     ph_t = barrier(ft, slt, sht, mu)
                     return to_filter(th_t, ph_t) and to_iterate(th_t, ph_t, from_resto=True)
-                rr = _restore(ev, w, lo, hi, zl, zh, mu, c, tol, max_iter, it + 1, orig_ok, stats, df)
+                rr = _restore(ev, w, lo, hi, zl, zh, mu, c, tol, max_iter, it + 1, orig_ok, stats, df, trace)
                 it = rr["it"] - 1
                 if rr["status"] != "restored":
                     if rr["status"] == "limit":
@@ -621,7 +621,7 @@ def _ipm_core(ev, w, lo, hi, zl, zh, lam, mu, tol, max_iter, it0, theta_max_fact
     return dict(w=w, lam=lam, zl=zl, zh=zh, mu=mu, status=status, it=it)
 
 
-def _restore(ev, x_r, lo, hi, zl, zh, mu, c_r, tol, max_iter, it0, orig_ok, stats, df):
+def _restore(ev, x_r, lo, hi, zl, zh, mu, c_r, tol, max_iter, it0, orig_ok, stats, df, trace=None):
     """IPOPT's restoration phase: the same interior point iteration on
         min  rho sum(n + p) + eta(mu) / 2 |D_R (x - x_R)|^2   s.t.  c(x) + n - p = 0,  lo <= x <= hi,  n, p >= 0
     (rho = 1000, eta = sqrt(mu), D_R = diag(1 / max(1, |x_R|)); [WB 3.3]) from x_R with n, p from [WB (32), (33)] at mu_R = max(mu, |c(x_R)|_inf), until
@@ -651,7 +651,7 @@ def _restore(ev, x_r, lo, hi, zl, zh, mu, c_r, tol, max_iter, it0, orig_ok, stat
             Hb = np.zeros((n + 2 * m, n + 2 * m)); Hb[:n, :n] = Hc + eta * np.diag(d_r * d_r)
         return f_, gf_, c_ + n_ - p_, np.hstack([J_, Im, -Im]), Hb
     sub = dict(ls_steps=0, soc=0, tiny=0, filter_max=0, resto=0, resto_iters=0, stop="")
-    r = _ipm_core(ev_r, wb, lob, hib, zlb, zhb, np.zeros(m), mu_r, tol, max_iter, it0, RESTO_THETA_MAX_FACT, lambda wb_: orig_ok(wb_[:n]), False, sub, None, df)
+    r = _ipm_core(ev_r, wb, lob, hib, zlb, zhb, np.zeros(m), mu_r, tol, max_iter, it0, RESTO_THETA_MAX_FACT, lambda wb_: orig_ok(wb_[:n]), False, sub, trace, df)
     stats["resto_iters"] += r["it"] - it0
     lo[:], hi[:] = lob[:n], hib[:n]                  # (bounds the restoration moved stay moved)
     st = {"restored": "restored", "converged": "converged", "acceptable": "converged", "tiny step": "converged", "iteration limit": "limit"}.get(sub["stop"], "failed")
