@@ -149,16 +149,34 @@ __device__ unsigned long long mpc_ipm_stamp_buf[256 * 16];
 
 __device__ __forceinline__ bool le_tol(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * kEps * fabs(bas); }      // IPOPT's Compare_le
 // slack of one bound with IPOPT's CalculateSafeSlack; a corrected slack moves `bound`
-__device__ __forceinline__ double safe_slack(double w, double &bound, double z, double mu, bool lower)
+template <class BoundRef>      // (double & or a row of the LDS area)
+__device__ __forceinline__ double safe_slack(double w, BoundRef &&bound, double z, double mu, bool lower)
 {
-    double s = lower ? w - bound : bound - w;
+    const double b = bound;
+    double s = lower ? w - b : b - w;
     const double s_min = kEps * dmin(1.0, mu);
     if (s < s_min) {
-        s = dmin(dmax(mu / z, s_min), dmax(s, 0.0) + kSlackMove * dmax(1.0, fabs(bound)));
+        s = dmin(dmax(mu / z, s_min), dmax(s, 0.0) + kSlackMove * dmax(1.0, fabs(b)));
         bound = lower ? w - s : w + s;
     }
     return s;
 }
+// Per-lane arrays that live in LDS: row r of the wave's area is 64 doubles, one per lane.  REAL = false: the array does not exist (a variable class without
+// bounds) - reads give `dflt`, writes vanish; with the loops unrolled nothing of it is left.
+template <bool REAL>
+struct LRow {
+    double *p; double dflt;
+    __device__ __forceinline__ operator double() const { return REAL ? *p : dflt; }
+    __device__ __forceinline__ void operator=(double v) const { if (REAL) *p = v; }
+    __device__ __forceinline__ void operator+=(double v) const { if (REAL) *p = *p + v; }
+};
+template <bool REAL>
+struct LRows {
+    double *base; double dflt;
+    __device__ __forceinline__ LRow<REAL> operator[](int i) const { return LRow<REAL>{base + i * 64, dflt}; }
+};
+// the compiler forgets what it knows of memory: values read from LDS before this point are read again after it instead of being kept in registers
+#define EC_LDS_FENCE() asm volatile("" ::: "memory")
 // the filter of one segment (= one instance) in LDS: pairs (phi, theta); every lane of the segment reads the same entries
 template <int FS = 1>      // FS: stride between a list's words (1: a list of its own; 64: lists of the 64 lanes of a wave side by side in LDS)
 __device__ __forceinline__ bool filter_rejects(const double *filt, int nf, double phi_t, double theta_t)
@@ -306,38 +324,29 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
     const int k = SG::stage(lane);
     const bool on = k < N;
     bool flu[NU], fhu[NU], flx[NS], fhx[NS];
-    double zlu[NU], zhu[NU], zlx[NS], zhx[NS], zl0[NS], zh0[NS];
-    double blu[NU], bhu[NU], blx[NS], bhx[NS], bl0[NS], bh0[NS];      // this solve's own bounds
+    // Bound multipliers z, this solve's own bounds b (the safe slack moves them) and the slacks s of the iterate LIVE IN LDS (`park`: rows of 64 lanes, this
+    // lane's column; ipm_park_rows), for the inputs (u; UB), the states x_{k+1} (x) and the free initial state (0; FREE0).  They are read where they are used:
+    // kept in registers (round 3; then parked across the linearisation and the sweeps) they were what the compiler moved to scratch memory around every
+    // larger piece of an iteration - 400 scratch accesses per iteration of the estimator at one wave per SIMD, each waited for.
+    constexpr int NUB = UB ? NU : 0, N0 = FREE0 ? NS : 0, NBV = NUB + NS + N0;
+    constexpr int R_ZLU = 0, R_BLU = R_ZLU + NUB, R_ZHU = R_BLU + NUB, R_BHU = R_ZHU + NUB, R_ZLX = R_BHU + NUB, R_BLX = R_ZLX + NS, R_ZHX = R_BLX + NS, R_BHX = R_ZHX + NS,
+                  R_ZL0 = R_BHX + NS, R_BL0 = R_ZL0 + N0, R_ZH0 = R_BL0 + N0, R_BH0 = R_ZH0 + N0, R_SLU = R_BH0 + N0, R_SHU = R_SLU + NUB, R_SLX = R_SHU + NUB, R_SHX = R_SLX + NS,
+                  R_SL0 = R_SHX + NS, R_SH0 = R_SL0 + N0, R_IT = R_SH0 + N0;
+    static_assert(R_IT == 6 * NBV, "rows of the LDS area");
+    double *const pk = park + lane;
+    const LRows<UB> zlu{pk + 64 * R_ZLU, 0.0}, blu{pk + 64 * R_BLU, -INFINITY}, zhu{pk + 64 * R_ZHU, 0.0}, bhu{pk + 64 * R_BHU, INFINITY}, slu{pk + 64 * R_SLU, 1.0}, shu{pk + 64 * R_SHU, 1.0};
+    const LRows<true> zlx{pk + 64 * R_ZLX, 0.0}, blx{pk + 64 * R_BLX, -INFINITY}, zhx{pk + 64 * R_ZHX, 0.0}, bhx{pk + 64 * R_BHX, INFINITY}, slx{pk + 64 * R_SLX, 1.0}, shx{pk + 64 * R_SHX, 1.0};
+    const LRows<FREE0> zl0{pk + 64 * R_ZL0, 0.0}, bl0{pk + 64 * R_BL0, -INFINITY}, zh0{pk + 64 * R_ZH0, 0.0}, bh0{pk + 64 * R_BH0, INFINITY}, sl0{pk + 64 * R_SL0, 1.0}, sh0{pk + 64 * R_SH0, 1.0};
     int nbl = 0, nbx = 0;
-    MPC_UNROLL for (int i = 0; i < NU; i++) { blu[i] = ulo_in[i]; bhu[i] = uhi_in[i]; flu[i] = UB && fin(blu[i]); fhu[i] = UB && fin(bhu[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { blu[i] = ulo_in[i]; bhu[i] = uhi_in[i]; flu[i] = UB && fin(ulo_in[i]); fhu[i] = UB && fin(uhi_in[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); }
     MPC_UNROLL for (int i = 0; i < NS; i++) {
         blx[i] = xlo_in[i]; bhx[i] = xhi_in[i]; bl0[i] = xlo_in[i]; bh0[i] = xhi_in[i];
-        flx[i] = fin(blx[i]); fhx[i] = fin(bhx[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
+        flx[i] = fin(xlo_in[i]); fhx[i] = fin(xhi_in[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
         zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0;
     }
-    // Bound multipliers and the (moved) bounds are PARKED IN LDS while the stage is linearised (`park`: rows of 64 lanes, this lane's column): the Runge-Kutta
-    // loop with its second-order sensitivities takes the whole register file, and whatever else lives across it is spilled to scratch memory and reloaded
-    // inside that loop (measured: 226 KB of scratch traffic per instance-step, a quarter of the wave-cycles waiting).  They are read back after the
-    // linearisation and stored again at the end of the iteration.
-    // Rows (ipm_park_rows): per variable that may have bounds 2 x (multiplier, bound), then 2 slacks; then the iterate itself.
-    constexpr int NBV = (UB ? NU : 0) + NS + (FREE0 ? NS : 0);
-    auto park_io = [&](const bool store) {
-        int slot = 0;
-        auto one = [&](double &v, bool used) { if (used) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; } slot++; };
-        if (UB) { MPC_UNROLL for (int i = 0; i < NU; i++) { one(zlu[i], flu[i]); one(blu[i], flu[i]); one(zhu[i], fhu[i]); one(bhu[i], fhu[i]); } }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { one(zlx[i], flx[i]); one(blx[i], flx[i]); one(zhx[i], fhx[i]); one(bhx[i], fhx[i]); }
-        if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { one(zl0[i], flx[i]); one(bl0[i], flx[i]); one(zh0[i], fhx[i]); one(bh0[i], fhx[i]); } }
-    };
-    // ... and, with the slacks of the iterate, while the Newton system is factorised and solved (the sweeps over the lanes keep a dozen small matrices alive)
-    auto park_slacks = [&](const bool store, double (&slu)[NU], double (&shu)[NU], double (&slx)[NS], double (&shx)[NS], double (&sl0)[NS], double (&sh0)[NS]) {
-        int slot = 4 * NBV;
-        auto one = [&](double &v, bool used) { if (used) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; } slot++; };
-        if (UB) { MPC_UNROLL for (int i = 0; i < NU; i++) { one(slu[i], flu[i]); one(shu[i], fhu[i]); } }
-        MPC_UNROLL for (int i = 0; i < NS; i++) { one(slx[i], flx[i]); one(shx[i], fhx[i]); if (FREE0) { one(sl0[i], flx[i]); one(sh0[i], fhx[i]); } }
-    };
-    // ... and the iterate (it is not touched between the linearisation and the first trial point)
+    // The iterate itself is parked there across the sweeps (it is not touched between the linearisation and the first trial point).
     auto park_iter = [&](const bool store) {
-        int slot = 6 * NBV;
+        int slot = R_IT;
         auto one = [&](double &v) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; slot++; };
         MPC_UNROLL for (int i = 0; i < NU; i++) one(u[i]);
         MPC_UNROLL for (int i = 0; i < NS; i++) { one(xn[i]); one(pi[i]); if (FREE0) one(x0v[i]); }
@@ -377,7 +386,6 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NS; i++) xn[i] = push_in(xn[i], blx[i], bhx[i]);
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) x0v[i] = push_in(x0v[i], bl0[i], bh0[i]); }
     }
-    park_io(true);
     EC_IPM_STAMP(0);      // scaling, push
     bool first = true;      // (wave-uniform: every segment's first iteration starts with the least-squares multipliers)
     int it = 0;
@@ -392,7 +400,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         double fv, gv[NS], Hv[NS][NS];
         term(xn, fv, gv, Hv);
         EC_IPM_STAMP(1);      // linearisation
-        park_io(false);
+        EC_LDS_FENCE();
         // the scaled problem: df f.  (An entry the generated code knows to be zero stays a literal zero - 0 * df would be a run-time value to the compiler, and the
         // sweeps below would multiply and keep in registers what the estimator's structure - constant diagonal cost Hessian, no cross terms - lets them drop.)
         auto scaled = [&](double x_) { return (__builtin_constant_p(x_) && x_ == 0.0) ? 0.0 : x_ * df; };
@@ -446,7 +454,6 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         EC_IPM_STAMP(3);      // least-squares multipliers (first iteration)
         addpi(aux, pi, L);      // Hessian of the Lagrangian of the scaled problem: df (cost) + pi' F
         // ---- slacks (safe: a slack that rounding took below eps min(1, mu) is lifted, its bound moves) ------------------------------------------
-        double slu[NU], shu[NU], slx[NS], shx[NS], sl0[NS], sh0[NS];
         MPC_UNROLL for (int i = 0; i < NU; i++) { slu[i] = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0; shu[i] = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0; }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             slx[i] = flx[i] ? safe_slack(xn[i], blx[i], zlx[i], mu, true) : 1.0; shx[i] = fhx[i] ? safe_slack(xn[i], bhx[i], zhx[i], mu, false) : 1.0;
@@ -550,7 +557,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NU; i++) gu[i] = L.lu[i] + bu[i];
         MPC_UNROLL for (int i = 0; i < NS; i++) { gxk[i] = L.lx[i] + bxk[i]; pt[i] = gv[i] + bx[i]; p0a[i] = FREE0 ? ga0[i] + b0[i] : 0.0; }
         EC_IPM_STAMP(5);      // barrier parameter, barrier terms
-        park_io(true); park_slacks(true, slu, shu, slx, shx, sl0, sh0); park_iter(true);
+        park_iter(true); EC_LDS_FENCE();
         double delta = 0.0;
         bool failed = false;
         for (;;) {
@@ -573,7 +580,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         double du[NU], dxn[NS], dx0[NS], pin[NS];
         ric_forward<NS, NU, SEG, ST>(N, lane, k, L, Fc, Vc, c, du, dxn, pin);
         MPC_UNROLL for (int i = 0; i < NS; i++) dx0[i] = Vc.dx0[i];
-        park_io(false); park_slacks(false, slu, shu, slx, shx, sl0, sh0); park_iter(false);
+        EC_LDS_FENCE(); park_iter(false);
         EC_IPM_STAMP(7);      // forward sweep
         // fraction to the boundary of a step (du_, dxn_, dx0_)
         auto ratio = [&](double a, double v, double dv) { return dv < 0.0 ? dmin(a, -tau * v / dv) : a; };
@@ -613,7 +620,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             MPC_UNROLL for (int i = 0; i < NS; i++) xkt[i] = SG::up1(FREE0 ? x0t[i] : x0fix[i], xt[i], k);
             val(xkt, ut, Ft, lt);
             term(xt, fvt, gvt, Hvt);
-            park_io(false);      // (unchanged since they were parked: read again rather than kept alive across the integration)
+            EC_LDS_FENCE();      // (multipliers and bounds are read again rather than kept alive across the integration)
             double tht = 0.0, pht = 0.0;
             bool okl = finite_all(lt);
             MPC_UNROLL for (int i = 0; i < NS; i++) { ct[i] = xt[i] - Ft[i]; tht += fabs(ct[i]); okl = okl && finite_all(ct[i]); }
@@ -732,7 +739,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
         }
         EC_IPM_STAMP(10);
-        park_slacks(false, slu, shu, slx, shx, sl0, sh0);      // (likewise)
+        EC_LDS_FENCE();
         if (!done) {
             if (!accepted) {      // IPOPT enters its restoration phase here (not restated for this recursion): infeasible point -> failed; feasible to 1e-2 tol -> the point is kept
                 status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; done = true;
@@ -794,7 +801,6 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
             it++;
         }
-        park_io(true);
         EC_IPM_STAMP(12);      // filter, multiplier steps, the new iterate
     }
     return status;
