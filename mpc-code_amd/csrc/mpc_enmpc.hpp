@@ -155,12 +155,29 @@ __device__ __forceinline__ double safe_slack(double w, BoundRef &&bound, double 
     const double b = bound;
     double s = lower ? w - b : b - w;
     const double s_min = kEps * dmin(1.0, mu);
-    if (s < s_min) {
-        s = dmin(dmax(mu / z, s_min), dmax(s, 0.0) + kSlackMove * dmax(1.0, fabs(b)));
-        bound = lower ? w - s : w + s;
+    if (__builtin_expect(__any(s < s_min ? 1 : 0), 0)) {      // (no lane of the wave in almost every call: the division is not even issued)
+        if (s < s_min) {
+            s = dmin(dmax(mu / z, s_min), dmax(s, 0.0) + kSlackMove * dmax(1.0, fabs(b)));
+            bound = lower ? w - s : w + s;
+        }
     }
     return s;
 }
+// A sum of logarithms as the logarithm of a product: mantissas multiplied, exponents added, ONE logarithm at the end - the barrier function of a stage with 16
+// bounds costs one log instead of 16 (each some 60 instructions).  Mantissas are in [0.5, 1): a thousand factors stay clear of underflow.
+struct LogSum {
+    double m = 1.0; int e = 0;
+    __device__ __forceinline__ void mul(double s, bool use = true) { int ei; const double f = frexp(s, &ei); m *= use ? f : 1.0; e += use ? ei : 0; }
+    __device__ __forceinline__ double value() const { return log(m) + (double)e * 0.69314718055994530942; }
+};
+// min(1, min_i tau v_i / (-dv_i)) over the candidates with dv_i < 0 (fraction to the boundary) without a division per candidate: the smallest fraction is found by
+// cross-multiplication, one division at the end.  The result is the quotient the candidate-by-candidate minimum would have picked, except between fractions that
+// differ by rounding.
+struct MinRatio {
+    double n = 1.0, d = 1.0;
+    __device__ __forceinline__ void add(double v, double dv, double tau, bool use = true) { const double ni = tau * v, di = -dv; if (use && di > 0.0 && ni * d < n * di) { n = ni; d = di; } }
+    __device__ __forceinline__ double value() const { return n / d; }
+};
 // Per-lane arrays that live in LDS: row r of the wave's area is 64 doubles, one per lane.  REAL = false: the array does not exist (a variable class without
 // bounds) - reads give `dflt`, writes vanish; with the loops unrolled nothing of it is left.
 template <bool REAL>
@@ -528,29 +545,29 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         // ---- barrier terms; those of x_k come from the neighbour that holds x_k --------------------------------------------------------
         double Su[NU], bu[NU], Sx[NS], bx[NS], Sxk[NS], bxk[NS], S0[NS], b0[NS];
         double phl = 0.0;      // this lane's part of the barrier function
+        LogSum lgl, lg0;
         MPC_UNROLL for (int i = 0; i < NU; i++) {
             const double il = flu[i] ? 1.0 / slu[i] : 0.0, ih = fhu[i] ? 1.0 / shu[i] : 0.0, dm = damp(flu[i], fhu[i]);
             Su[i] = zlu[i] * il + zhu[i] * ih; bu[i] = -mu * il + mu * ih + kKappaD * mu * dm;
-            if (flu[i]) phl -= mu * log(slu[i]);
-            if (fhu[i]) phl -= mu * log(shu[i]);
+            lgl.mul(slu[i], flu[i]); lgl.mul(shu[i], fhu[i]);
             if (dm != 0.0) phl += kKappaD * mu * (dm > 0.0 ? slu[i] : shu[i]);
         }
         double ph0 = 0.0;
         MPC_UNROLL for (int i = 0; i < NS; i++) {
             const double il = flx[i] ? 1.0 / slx[i] : 0.0, ih = fhx[i] ? 1.0 / shx[i] : 0.0, dm = damp(flx[i], fhx[i]);
             Sx[i] = zlx[i] * il + zhx[i] * ih; bx[i] = -mu * il + mu * ih + kKappaD * mu * dm;
-            if (flx[i]) phl -= mu * log(slx[i]);
-            if (fhx[i]) phl -= mu * log(shx[i]);
+            lgl.mul(slx[i], flx[i]); lgl.mul(shx[i], fhx[i]);
             if (dm != 0.0) phl += kKappaD * mu * (dm > 0.0 ? slx[i] : shx[i]);
             Sxk[i] = SG::up1(0.0, Sx[i], k); bxk[i] = SG::up1(0.0, bx[i], k);
             const double jl = (FREE0 && flx[i]) ? 1.0 / sl0[i] : 0.0, jh = (FREE0 && fhx[i]) ? 1.0 / sh0[i] : 0.0;
             S0[i] = zl0[i] * jl + zh0[i] * jh; b0[i] = FREE0 ? (-mu * jl + mu * jh + kKappaD * mu * dm) : 0.0;
             if (FREE0) {
-                if (flx[i]) ph0 -= mu * log(sl0[i]);
-                if (fhx[i]) ph0 -= mu * log(sh0[i]);
+                lg0.mul(sl0[i], flx[i]); lg0.mul(sh0[i], fhx[i]);
                 if (dm != 0.0) ph0 += kKappaD * mu * (dm > 0.0 ? sl0[i] : sh0[i]);
             }
         }
+        phl -= mu * lgl.value();
+        if (FREE0) ph0 -= mu * lg0.value();
         const double phi = fobj + SG::sum(on ? phl : 0.0) + ph0;
         // ---- Newton direction: backward sweep (repeated with a larger shift while a stage lacks positive curvature), forward sweep -----------------
         double gu[NU], gxk[NS], pt[NS], p0a[NS];
@@ -583,13 +600,16 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         EC_LDS_FENCE(); park_iter(false);
         EC_IPM_STAMP(7);      // forward sweep
         // fraction to the boundary of a step (du_, dxn_, dx0_)
-        auto ratio = [&](double a, double v, double dv) { return dv < 0.0 ? dmin(a, -tau * v / dv) : a; };
         auto max_step = [&](const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
-            double a = 1.0;
-            MPC_UNROLL for (int i = 0; i < NU; i++) { if (flu[i]) a = ratio(a, slu[i], du_[i]); if (fhu[i]) a = ratio(a, shu[i], -du_[i]); }
-            MPC_UNROLL for (int i = 0; i < NS; i++) { if (flx[i]) a = ratio(a, slx[i], dxn_[i]); if (fhx[i]) a = ratio(a, shx[i], -dxn_[i]); }
-            a = SG::min(on ? a : 1.0);
-            if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { if (flx[i]) a = ratio(a, sl0[i], dx0_[i]); if (fhx[i]) a = ratio(a, sh0[i], -dx0_[i]); } }
+            MinRatio mr;
+            MPC_UNROLL for (int i = 0; i < NU; i++) { mr.add(slu[i], du_[i], tau, flu[i]); mr.add(shu[i], -du_[i], tau, fhu[i]); }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { mr.add(slx[i], dxn_[i], tau, flx[i]); mr.add(shx[i], -dxn_[i], tau, fhx[i]); }
+            double a = SG::min(on ? mr.value() : 1.0);
+            if (FREE0) {
+                MinRatio m0;
+                MPC_UNROLL for (int i = 0; i < NS; i++) { m0.add(sl0[i], dx0_[i], tau, flx[i]); m0.add(sh0[i], -dx0_[i], tau, fhx[i]); }
+                a = dmin(a, m0.value());
+            }
             return a;
         };
         const double a_max = max_step(du, dxn, dx0);
@@ -601,14 +621,14 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         drel = SG::max(on ? drel : 0.0); dym = SG::max(on ? dym : 0.0);
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { gbd += (lx0[i] + ga0[i] + b0[i]) * dx0[i]; drel = dmax(drel, fabs(dx0[i]) / (1.0 + fabs(x0v[i]))); } }
         // ---- filter line search (per segment, the wave in lockstep) -------------------------------------------------------------------------------
+        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);      // (the two powers of the switching condition, once)
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
             a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
-            if (theta <= theta_min) a_min = dmin(a_min, pow(theta, kSTheta) / pow(-gbd, kSPhi));
+            if (theta <= theta_min) a_min = dmin(a_min, pw_th / pw_gbd);
         }
         a_min *= kAlphaMinFrac;
         if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
-        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
         auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
         // a trial point u + a_ du_ ...: infeasibility, barrier function (safe slacks; their moved bounds are not kept), constraint values
         double theta_t = 0.0, phi_t = 0.0, ct[NS];
@@ -622,14 +642,14 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             term(xt, fvt, gvt, Hvt);
             EC_LDS_FENCE();      // (multipliers and bounds are read again rather than kept alive across the integration)
             double tht = 0.0, pht = 0.0;
+            LogSum lgt, lgt0;
             bool okl = finite_all(lt);
             MPC_UNROLL for (int i = 0; i < NS; i++) { ct[i] = xt[i] - Ft[i]; tht += fabs(ct[i]); okl = okl && finite_all(ct[i]); }
             MPC_UNROLL for (int i = 0; i < NU; i++) {
                 double bl_ = blu[i], bh_ = bhu[i];
                 const double dm = damp(flu[i], fhu[i]);
                 const double s1 = flu[i] ? safe_slack(ut[i], bl_, zlu[i], mu, true) : 1.0, s2 = fhu[i] ? safe_slack(ut[i], bh_, zhu[i], mu, false) : 1.0;
-                if (flu[i]) pht -= mu * log(s1);
-                if (fhu[i]) pht -= mu * log(s2);
+                lgt.mul(s1, flu[i]); lgt.mul(s2, fhu[i]);
                 if (dm != 0.0) pht += kKappaD * mu * (dm > 0.0 ? s1 : s2);
             }
             double pht0 = 0.0, farrt = 0.0;
@@ -637,20 +657,20 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                 double bl_ = blx[i], bh_ = bhx[i];
                 const double dm = damp(flx[i], fhx[i]);
                 const double s1 = flx[i] ? safe_slack(xt[i], bl_, zlx[i], mu, true) : 1.0, s2 = fhx[i] ? safe_slack(xt[i], bh_, zhx[i], mu, false) : 1.0;
-                if (flx[i]) pht -= mu * log(s1);
-                if (fhx[i]) pht -= mu * log(s2);
+                lgt.mul(s1, flx[i]); lgt.mul(s2, fhx[i]);
                 if (dm != 0.0) pht += kKappaD * mu * (dm > 0.0 ? s1 : s2);
                 if (FREE0) {
                     double cl_ = bl0[i], ch_ = bh0[i];
                     const double t1 = flx[i] ? safe_slack(x0t[i], cl_, zl0[i], mu, true) : 1.0, t2 = fhx[i] ? safe_slack(x0t[i], ch_, zh0[i], mu, false) : 1.0;
-                    if (flx[i]) pht0 -= mu * log(t1);
-                    if (fhx[i]) pht0 -= mu * log(t2);
+                    lgt0.mul(t1, flx[i]); lgt0.mul(t2, fhx[i]);
                     if (dm != 0.0) pht0 += kKappaD * mu * (dm > 0.0 ? t1 : t2);
                 }
             }
             if (FREE0) {
                 MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a += Pinv[i][j] * (x0t[j] - xbar[j]); farrt += 0.5 * (x0t[i] - xbar[i]) * a; }
             }
+            pht -= mu * lgt.value();
+            if (FREE0) pht0 -= mu * lgt0.value();
             const bool ok_t = !SG::any(on && !okl, lane);
             theta_t = SG::sum(on ? tht : 0.0);
             phi_t = df * (SG::sum(on ? lt + (k == N - 1 ? fvt : 0.0) : 0.0) + farrt) + SG::sum(on ? pht : 0.0) + pht0;
@@ -754,49 +774,42 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         // ---- the accepted point: multiplier steps of the direction that was taken, bounds moved with corrected slacks, multipliers within
         // kappa_Sigma of mu / slack ----------------------------------------------------------------------------------------------------------------
         double dzlu[NU], dzhu[NU], dzlx[NS], dzhx[NS], dzl0[NS], dzh0[NS];
-        double adu = 1.0;
+        // multiplier step of a bound with slack s_, multiplier z_, whose variable moves by dv_ towards the bound's side: mu / s - z - z / s dv, one division
+        auto dzstep = [&](bool f_, double s_, double z_, double dv_) { return f_ ? (mu - z_ * dv_) / s_ - z_ : 0.0; };
+        MinRatio mz;
         MPC_UNROLL for (int i = 0; i < NU; i++) {
-            dzlu[i] = flu[i] ? mu / slu[i] - zlu[i] - zlu[i] / slu[i] * du[i] : 0.0;
-            dzhu[i] = fhu[i] ? mu / shu[i] - zhu[i] + zhu[i] / shu[i] * du[i] : 0.0;
-            if (flu[i]) adu = ratio(adu, zlu[i], dzlu[i]);
-            if (fhu[i]) adu = ratio(adu, zhu[i], dzhu[i]);
+            dzlu[i] = dzstep(flu[i], slu[i], zlu[i], du[i]); dzhu[i] = dzstep(fhu[i], shu[i], zhu[i], -du[i]);
+            mz.add(zlu[i], dzlu[i], tau, flu[i]); mz.add(zhu[i], dzhu[i], tau, fhu[i]);
         }
         MPC_UNROLL for (int i = 0; i < NS; i++) {
-            dzlx[i] = flx[i] ? mu / slx[i] - zlx[i] - zlx[i] / slx[i] * dxn[i] : 0.0;
-            dzhx[i] = fhx[i] ? mu / shx[i] - zhx[i] + zhx[i] / shx[i] * dxn[i] : 0.0;
-            if (flx[i]) adu = ratio(adu, zlx[i], dzlx[i]);
-            if (fhx[i]) adu = ratio(adu, zhx[i], dzhx[i]);
+            dzlx[i] = dzstep(flx[i], slx[i], zlx[i], dxn[i]); dzhx[i] = dzstep(fhx[i], shx[i], zhx[i], -dxn[i]);
+            mz.add(zlx[i], dzlx[i], tau, flx[i]); mz.add(zhx[i], dzhx[i], tau, fhx[i]);
         }
-        adu = SG::min(on ? adu : 1.0);
+        double adu = SG::min(on ? mz.value() : 1.0);
         if (FREE0) {
+            MinRatio m0;
             MPC_UNROLL for (int i = 0; i < NS; i++) {
-                dzl0[i] = flx[i] ? mu / sl0[i] - zl0[i] - zl0[i] / sl0[i] * dx0[i] : 0.0;
-                dzh0[i] = fhx[i] ? mu / sh0[i] - zh0[i] + zh0[i] / sh0[i] * dx0[i] : 0.0;
-                if (flx[i]) adu = ratio(adu, zl0[i], dzl0[i]);
-                if (fhx[i]) adu = ratio(adu, zh0[i], dzh0[i]);
+                dzl0[i] = dzstep(flx[i], sl0[i], zl0[i], dx0[i]); dzh0[i] = dzstep(fhx[i], sh0[i], zh0[i], -dx0[i]);
+                m0.add(zl0[i], dzl0[i], tau, flx[i]); m0.add(zh0[i], dzh0[i], tau, fhx[i]);
             }
+            adu = dmin(adu, m0.value());
         }
-        auto clampz = [&](double z, double s_) { return dmin(dmax(z, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_); };
+        // the new multiplier of a bound: the step, then within [mu / (kappa_Sigma s), kappa_Sigma mu / s] of the new slack - one division
+        auto newz = [&](bool f_, double z_, double dz_, double s_) { const double q = mu / s_, zn_ = z_ + adu * dz_; return f_ ? dmin(dmax(zn_, q * (1.0 / kKappaSigma)), kKappaSigma * q) : zn_; };
         if (!done) {      // (a finished segment keeps its iterate)
             MPC_UNROLL for (int i = 0; i < NU; i++) {      // (the accepted trial point again, to the bit; its slacks with the multipliers of the old point, as the trial had them; the bounds move now)
                 u[i] = u[i] + a_pr * du[i];
                 const double s1 = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0, s2 = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0;
-                zlu[i] += adu * dzlu[i]; zhu[i] += adu * dzhu[i];
-                if (flu[i]) zlu[i] = clampz(zlu[i], s1);
-                if (fhu[i]) zhu[i] = clampz(zhu[i], s2);
+                zlu[i] = newz(flu[i], zlu[i], dzlu[i], s1); zhu[i] = newz(fhu[i], zhu[i], dzhu[i], s2);
             }
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 xn[i] = xn[i] + a_pr * dxn[i]; pi[i] += a_pr * (pin[i] - pi[i]);
                 const double s1 = flx[i] ? safe_slack(xn[i], blx[i], zlx[i], mu, true) : 1.0, s2 = fhx[i] ? safe_slack(xn[i], bhx[i], zhx[i], mu, false) : 1.0;
-                zlx[i] += adu * dzlx[i]; zhx[i] += adu * dzhx[i];
-                if (flx[i]) zlx[i] = clampz(zlx[i], s1);
-                if (fhx[i]) zhx[i] = clampz(zhx[i], s2);
+                zlx[i] = newz(flx[i], zlx[i], dzlx[i], s1); zhx[i] = newz(fhx[i], zhx[i], dzhx[i], s2);
                 if (FREE0) {
                     x0v[i] = x0v[i] + a_pr * dx0[i];
                     const double t1 = flx[i] ? safe_slack(x0v[i], bl0[i], zl0[i], mu, true) : 1.0, t2 = fhx[i] ? safe_slack(x0v[i], bh0[i], zh0[i], mu, false) : 1.0;
-                    zl0[i] += adu * dzl0[i]; zh0[i] += adu * dzh0[i];
-                    if (flx[i]) zl0[i] = clampz(zl0[i], t1);
-                    if (fhx[i]) zh0[i] = clampz(zh0[i], t2);
+                    zl0[i] = newz(flx[i], zl0[i], dzl0[i], t1); zh0[i] = newz(fhx[i], zh0[i], dzh0[i], t2);
                 }
             }
             it++;
@@ -881,15 +894,16 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
         MPC_UNROLL for (int i = 0; i < NY; i++) { double a = w[i] - w[NX + NU + i]; MPC_UNROLL for (int j = 0; j < ND; j++) a += Cd[i][j] * d[j]; th_t += fabs(a); ok_ = ok_ && finite_all(a); }
         if (!ok_ || th_t > kRestoKappa * io.theta) return false;
         double ph_t = f_;
+        LogSum lg;
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             double bl_ = io.lo[i], bh_ = io.hi[i];
             const bool fl_ = fin(bl_), fh_ = fin(bh_);
             const double s1 = fl_ ? safe_slack(w[i], bl_, io.zl[i], mu_o, true) : 1.0, s2 = fh_ ? safe_slack(w[i], bh_, io.zh[i], mu_o, false) : 1.0;
-            if (fl_) ph_t -= mu_o * log(s1);
-            if (fh_) ph_t -= mu_o * log(s2);
+            lg.mul(s1, fl_); lg.mul(s2, fh_);
             if (fl_ && !fh_) ph_t += kKappaD * mu_o * s1;
             if (fh_ && !fl_) ph_t += kKappaD * mu_o * s2;
         }
+        ph_t -= mu_o * lg.value();
         return !filter_rejects(io.filt, io.nfilt, ph_t, th_t) && (le_tol(th_t, (1.0 - kGammaTheta) * io.theta, io.theta) || le_tol(ph_t - io.phi, -kGammaPhi * io.theta, io.phi));
     };
     bool fl[NV], fh[NV];
@@ -933,19 +947,20 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
     };
     auto barrier = [&](const double (&w)[NV], const double (&n_)[MC], const double (&p_)[MC], double f_, double mu_) {      // with the safe slacks of a trial point
         double ph = f_;
+        LogSum lg;
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             double bl_ = lo[i], bh_ = hi[i];
             const double s1 = fl[i] ? safe_slack(w[i], bl_, zl[i], mu_, true) : 1.0, s2 = fh[i] ? safe_slack(w[i], bh_, zh[i], mu_, false) : 1.0;
-            if (fl[i]) ph -= mu_ * log(s1);
-            if (fh[i]) ph -= mu_ * log(s2);
+            lg.mul(s1, fl[i]); lg.mul(s2, fh[i]);
             if (dmp[i] != 0.0) ph += kKappaD * mu_ * (dmp[i] > 0.0 ? s1 : s2);
         }
         MPC_UNROLL for (int j = 0; j < MC; j++) {
             double b1 = nlo[j], b2 = plo[j];
             const double s1 = safe_slack(n_[j], b1, zn[j], mu_, true), s2 = safe_slack(p_[j], b2, zp[j], mu_, true);
-            ph += -mu_ * log(s1) - mu_ * log(s2) + kKappaD * mu_ * (s1 + s2);
+            lg.mul(s1); lg.mul(s2);
+            ph += kKappaD * mu_ * (s1 + s2);
         }
-        return ph;
+        return ph - mu_ * lg.value();
     };
     for (;;) {
         typename M::Ctx cx;
@@ -1018,18 +1033,20 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
         // gradient of the barrier function, diagonal terms, barrier function
         double Sg[NV], gx[NV], Sn[MC], Sp[MC], gn[MC], gp[MC];
         double phi = f;
+        LogSum lgp;
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             const double il = fl[i] ? 1.0 / sl[i] : 0.0, ih = fh[i] ? 1.0 / sh[i] : 0.0;
             Sg[i] = zl[i] * il + zh[i] * ih; gx[i] = eta * dr2[i] * (x[i] - xr[i]) - mu * il + mu * ih + kKappaD * mu * dmp[i];
-            if (fl[i]) phi -= mu * log(sl[i]);
-            if (fh[i]) phi -= mu * log(sh[i]);
+            lgp.mul(sl[i], fl[i]); lgp.mul(sh[i], fh[i]);
             if (dmp[i] != 0.0) phi += kKappaD * mu * (dmp[i] > 0.0 ? sl[i] : sh[i]);
         }
         MPC_UNROLL for (int j = 0; j < MC; j++) {
             Sn[j] = zn[j] / sn[j]; Sp[j] = zp[j] / sp[j];
             gn[j] = kRestoRho + kKappaD * mu - mu / sn[j]; gp[j] = kRestoRho + kKappaD * mu - mu / sp[j];
-            phi += -mu * log(sn[j]) - mu * log(sp[j]) + kKappaD * mu * (sn[j] + sp[j]);
+            lgp.mul(sn[j]); lgp.mul(sp[j]);
+            phi += kKappaD * mu * (sn[j] + sp[j]);
         }
+        phi -= mu * lgp.value();
         // Hessian of lam' c with respect to x (only the model's rows are non-linear) + the proximity term
         double H[NV][NV];
         MPC_UNROLL for (int i = 0; i < NV; i++) { MPC_UNROLL for (int j = 0; j < NV; j++) H[i][j] = (i == j) ? eta * dr2[i] : 0.0; }
@@ -1082,14 +1099,14 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
             gbd += gn[j] * dn[j] + gp[j] * dp[j];
             drel = dmax(drel, dmax(fabs(dn[j]) / (1.0 + fabs(nn[j])), fabs(dp[j]) / (1.0 + fabs(pp[j])))); dym = dmax(dym, fabs(yn[j] - lam[j]));
         }
+        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
             a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
-            if (theta <= theta_min) a_min = dmin(a_min, pow(theta, kSTheta) / pow(-gbd, kSPhi));
+            if (theta <= theta_min) a_min = dmin(a_min, pw_th / pw_gbd);
         }
         a_min *= kAlphaMinFrac;
         if (theta_max < 0.0) { theta_max = kRestoThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
-        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
         auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
         double xt[NV], nt[MC], pt[MC], ct[MC], theta_t = 0.0, phi_t = 0.0;
         bool ok_t = false;
@@ -1240,14 +1257,14 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
     };
     auto barrier = [&](const double (&w)[NV], double f_, double mu_) {      // with the safe slacks of a trial point (its moved bounds are not kept)
         double ph = f_;
+        LogSum lg;
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             double bl_ = lo[i], bh_ = hi[i];
             const double s1 = fl[i] ? safe_slack(w[i], bl_, zl[i], mu_, true) : 1.0, s2 = fh[i] ? safe_slack(w[i], bh_, zh[i], mu_, false) : 1.0;
-            if (fl[i]) ph -= mu_ * log(s1);
-            if (fh[i]) ph -= mu_ * log(s2);
+            lg.mul(s1, fl[i]); lg.mul(s2, fh[i]);
             if (dmp[i] != 0.0) ph += kKappaD * mu_ * (dmp[i] > 0.0 ? s1 : s2);
         }
-        return ph;
+        return ph - mu_ * lg.value();
     };
     int it = 0;
     for (;; it++) {
@@ -1347,13 +1364,14 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         }
         double Sg[NV], gt[NV];
         double phi = f;
+        LogSum lgp;
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             const double il = fl[i] ? 1.0 / sl[i] : 0.0, ih = fh[i] ? 1.0 / sh[i] : 0.0;
             Sg[i] = zl[i] * il + zh[i] * ih; gt[i] = g[i] - mu * il + mu * ih + kKappaD * mu * dmp[i];
-            if (fl[i]) phi -= mu * log(sl[i]);
-            if (fh[i]) phi -= mu * log(sh[i]);
+            lgp.mul(sl[i], fl[i]); lgp.mul(sh[i], fh[i]);
             if (dmp[i] != 0.0) phi += kKappaD * mu * (dmp[i] > 0.0 ? sl[i] : sh[i]);
         }
+        phi -= mu * lgp.value();
         // reduced Hessian with the shift delta while it lacks positive curvature
         double Hr[NU][NU];
         double delta = 0.0;
@@ -1382,7 +1400,7 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
             mults(Hd, l1n, l2n);
         };
         auto ratio = [&](double a, double vv, double dvv) { return dvv < 0.0 ? dmin(a, -tau * vv / dvv) : a; };
-        auto max_step = [&](const double (&dv_)[NV]) { double a = 1.0; MPC_UNROLL for (int i = 0; i < NV; i++) { if (fl[i]) a = ratio(a, sl[i], dv_[i]); if (fh[i]) a = ratio(a, sh[i], -dv_[i]); } return a; };
+        auto max_step = [&](const double (&dv_)[NV]) { MinRatio mr; MPC_UNROLL for (int i = 0; i < NV; i++) { mr.add(sl[i], dv_[i], tau, fl[i]); mr.add(sh[i], -dv_[i], tau, fh[i]); } return mr.value(); };
         double dv[NV], l1n[NX], l2n[NY];
         direction(c1, c2, dv, l1n, l2n);
         const double a_max = max_step(dv);
@@ -1391,14 +1409,14 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         MPC_UNROLL for (int i = 0; i < NX; i++) dym = dmax(dym, fabs(l1n[i] - lam1[i]));
         MPC_UNROLL for (int i = 0; i < NY; i++) dym = dmax(dym, fabs(l2n[i] - lam2[i]));
         // ---- filter line search ------------------------------------------------------------------------------------------------------------------
+        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);      // (the two powers of the switching condition, once)
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
             a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
-            if (theta <= theta_min) a_min = dmin(a_min, pow(theta, kSTheta) / pow(-gbd, kSPhi));
+            if (theta <= theta_min) a_min = dmin(a_min, pw_th / pw_gbd);
         }
         a_min *= kAlphaMinFrac;
         if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
-        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
         auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
         double vt[NV], c1t[NX], c2t[NY], theta_t = 0.0, phi_t = 0.0;
         bool ok_t = false;
@@ -1510,21 +1528,20 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         }
         // the accepted point vt: multiplier steps of the direction that was taken
         const double a_pr = soc_taken ? a_soc : alpha;
-        double adu = 1.0, dzl[NV], dzh[NV];
-        MPC_UNROLL for (int i = 0; i < NV; i++) {
+        double dzl[NV], dzh[NV];
+        MinRatio mz;
+        MPC_UNROLL for (int i = 0; i < NV; i++) {      // (as ipm_stage: one division per multiplier step, one per new multiplier, one for the step length)
             const double d_ = soc_taken ? ds[i] : dv[i];
-            dzl[i] = fl[i] ? mu / sl[i] - zl[i] - zl[i] / sl[i] * d_ : 0.0;
-            dzh[i] = fh[i] ? mu / sh[i] - zh[i] + zh[i] / sh[i] * d_ : 0.0;
-            if (fl[i]) adu = ratio(adu, zl[i], dzl[i]);
-            if (fh[i]) adu = ratio(adu, zh[i], dzh[i]);
+            dzl[i] = fl[i] ? (mu - zl[i] * d_) / sl[i] - zl[i] : 0.0;
+            dzh[i] = fh[i] ? (mu + zh[i] * d_) / sh[i] - zh[i] : 0.0;
+            mz.add(zl[i], dzl[i], tau, fl[i]); mz.add(zh[i], dzh[i], tau, fh[i]);
         }
-        auto clampz = [&](double z, double s_) { return dmin(dmax(z, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_); };
+        const double adu = mz.value();
+        auto newz = [&](bool f_, double z_, double dz_, double s_) { const double q = mu / s_, zn_ = z_ + adu * dz_; return f_ ? dmin(dmax(zn_, q * (1.0 / kKappaSigma)), kKappaSigma * q) : zn_; };
         MPC_UNROLL for (int i = 0; i < NV; i++) {
             v[i] = vt[i];
             const double s1 = fl[i] ? safe_slack(v[i], lo[i], zl[i], mu, true) : 1.0, s2 = fh[i] ? safe_slack(v[i], hi[i], zh[i], mu, false) : 1.0;
-            zl[i] += adu * dzl[i]; zh[i] += adu * dzh[i];
-            if (fl[i]) zl[i] = clampz(zl[i], s1);
-            if (fh[i]) zh[i] = clampz(zh[i], s2);
+            zl[i] = newz(fl[i], zl[i], dzl[i], s1); zh[i] = newz(fh[i], zh[i], dzh[i], s2);
         }
         MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] += a_pr * ((soc_taken ? l1s[i] : l1n[i]) - lam1[i]);
         MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] += a_pr * ((soc_taken ? l2s[i] : l2n[i]) - lam2[i]);
