@@ -621,15 +621,17 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         drel = SG::max(on ? drel : 0.0); dym = SG::max(on ? dym : 0.0);
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) { gbd += (lx0[i] + ga0[i] + b0[i]) * dx0[i]; drel = dmax(drel, fabs(dx0[i]) / (1.0 + fabs(x0v[i]))); } }
         // ---- filter line search (per segment, the wave in lockstep) -------------------------------------------------------------------------------
-        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);      // (the two powers of the switching condition, once)
+        // the switching condition [WB (19)] alpha (-gbd)^s_phi > theta^s_theta as alpha > sw = theta^s_theta / (-gbd)^s_phi, the quotient through two logarithms and an
+        // exponential (a third of two pow calls); theta = 0 gives 0, gbd -> 0 gives inf, both zero NaN: the comparisons below come out as with the powers
+        const double sw = gbd < 0.0 ? exp(kSTheta * log(theta) - kSPhi * log(-gbd)) : INFINITY;
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
             a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
-            if (theta <= theta_min) a_min = dmin(a_min, pw_th / pw_gbd);
+            if (theta <= theta_min) a_min = dmin(a_min, sw);
         }
         a_min *= kAlphaMinFrac;
         if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
-        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
+        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ > sw); };
         // a trial point u + a_ du_ ...: infeasibility, barrier function (safe slacks; their moved bounds are not kept), constraint values
         double theta_t = 0.0, phi_t = 0.0, ct[NS];
         bool fin_t = false;
@@ -1099,15 +1101,17 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
             gbd += gn[j] * dn[j] + gp[j] * dp[j];
             drel = dmax(drel, dmax(fabs(dn[j]) / (1.0 + fabs(nn[j])), fabs(dp[j]) / (1.0 + fabs(pp[j])))); dym = dmax(dym, fabs(yn[j] - lam[j]));
         }
-        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);
+        // the switching condition [WB (19)] alpha (-gbd)^s_phi > theta^s_theta as alpha > sw = theta^s_theta / (-gbd)^s_phi, the quotient through two logarithms and an
+        // exponential (a third of two pow calls); theta = 0 gives 0, gbd -> 0 gives inf, both zero NaN: the comparisons below come out as with the powers
+        const double sw = gbd < 0.0 ? exp(kSTheta * log(theta) - kSPhi * log(-gbd)) : INFINITY;
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
             a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
-            if (theta <= theta_min) a_min = dmin(a_min, pw_th / pw_gbd);
+            if (theta <= theta_min) a_min = dmin(a_min, sw);
         }
         a_min *= kAlphaMinFrac;
         if (theta_max < 0.0) { theta_max = kRestoThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
-        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
+        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ > sw); };
         double xt[NV], nt[MC], pt[MC], ct[MC], theta_t = 0.0, phi_t = 0.0;
         bool ok_t = false;
         auto trial = [&](double a_, const double (&dx_)[NV], const double (&dn_)[MC], const double (&dp_)[MC]) {
@@ -1409,15 +1413,17 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         MPC_UNROLL for (int i = 0; i < NX; i++) dym = dmax(dym, fabs(l1n[i] - lam1[i]));
         MPC_UNROLL for (int i = 0; i < NY; i++) dym = dmax(dym, fabs(l2n[i] - lam2[i]));
         // ---- filter line search ------------------------------------------------------------------------------------------------------------------
-        const double pw_gbd = gbd < 0.0 ? pow(-gbd, kSPhi) : 0.0, pw_th = pow(theta, kSTheta);      // (the two powers of the switching condition, once)
+        // the switching condition [WB (19)] alpha (-gbd)^s_phi > theta^s_theta as alpha > sw = theta^s_theta / (-gbd)^s_phi, the quotient through two logarithms and an
+        // exponential (a third of two pow calls); theta = 0 gives 0, gbd -> 0 gives inf, both zero NaN: the comparisons below come out as with the powers
+        const double sw = gbd < 0.0 ? exp(kSTheta * log(theta) - kSPhi * log(-gbd)) : INFINITY;
         double a_min = kGammaTheta;
         if (gbd < 0.0) {
             a_min = dmin(kGammaTheta, kGammaPhi * theta / (-gbd));
-            if (theta <= theta_min) a_min = dmin(a_min, pw_th / pw_gbd);
+            if (theta <= theta_min) a_min = dmin(a_min, sw);
         }
         a_min *= kAlphaMinFrac;
         if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
-        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ * pw_gbd > pw_th); };
+        auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ > sw); };
         double vt[NV], c1t[NX], c2t[NY], theta_t = 0.0, phi_t = 0.0;
         bool ok_t = false;
         auto trial = [&](double a_, const double (&d_)[NV]) {
