@@ -1217,16 +1217,19 @@ __device__ __forceinline__ int target_resto(TgtRestoIO<M> &io)
 template <class M, int FS>      // filt: this solve's filter list (FS: stride between its words, see filter_rejects)
 __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], const double *d, const double (*Bd)[M::ND > 0 ? M::ND : 1],
                                           const double (*Cd)[M::ND > 0 ? M::ND : 1], const double *lo_in, const double *hi_in, double t, double h,
-                                          const double tol, const int max_iter, int &iters, double *const filt)
+                                          const double tol, const int max_iter, int &iters, double *const filt, double *const tpk)
 {
     constexpr int NX = M::NX, NU = M::NU, NY = M::NY, ND = M::ND, NV = NX + NU + NY, NP = NX + NU, NPP = NP * (NP + 1) / 2;
     static_assert(NY == NX, "StateFeedback outputs");
     bool fl[NV], fh[NV];
-    double zl[NV], zh[NV], lo[NV], hi[NV], lam1[NX], lam2[NY], dmp[NV];
+    // bound multipliers, this solve's own bounds and the slacks live in LDS as in ipm_stage (tpk: this lane's column of 6 NV rows of 64 doubles) - kept in
+    // registers they were three quarters of this kernel's 840 scratch accesses per iteration
+    const LRows<true> zl{tpk, 0.0}, zh{tpk + 64 * NV, 0.0}, lo{tpk + 128 * NV, 0.0}, hi{tpk + 192 * NV, 0.0}, sl{tpk + 256 * NV, 1.0}, sh{tpk + 320 * NV, 1.0};
+    double lam1[NX], lam2[NY], dmp[NV];
     int nbi = 0;
     MPC_UNROLL for (int i = 0; i < NV; i++) {
         lo[i] = lo_in[i]; hi[i] = hi_in[i];
-        fl[i] = fin(lo[i]); fh[i] = fin(hi[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nbi += (fl[i] ? 1 : 0) + (fh[i] ? 1 : 0);
+        fl[i] = fin(lo_in[i]); fh[i] = fin(hi_in[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nbi += (fl[i] ? 1 : 0) + (fh[i] ? 1 : 0);
         dmp[i] = (fl[i] && !fh[i]) ? 1.0 : ((fh[i] && !fl[i]) ? -1.0 : 0.0);
     }
     // scaling of the objective at the caller's point, then the push into the box
@@ -1279,6 +1282,7 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         MPC_UNROLL for (int i = 0; i < NX; i++) cx.xs[i] = 0.0;
         double Fx[NX], S[NX][NP], T[NX][NPP];
         rk4_sens2<typename M::Mdl>(v, cx, t, true, h, M::MX, Fx, S, T);
+        EC_LDS_FENCE();
         double f, g[NV], Hc[NV][NV];
         M::fss(v, &f, g, Hc);
         f *= df;
@@ -1325,7 +1329,6 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         double H[NV][NV];
         MPC_UNROLL for (int i = 0; i < NV; i++) { MPC_UNROLL for (int j = 0; j < NV; j++) H[i][j] = Hc[i][j]; }
         MPC_UNROLL for (int a = 0; a < NP; a++) { MPC_UNROLL for (int b = 0; b < NP; b++) { double s = 0.0; MPC_UNROLL for (int i = 0; i < NX; i++) s += lam1[i] * T[i][pair_idx<NP>(a, b)]; H[a][b] += s; } }
-        double sl[NV], sh[NV];
         double e_st = 0.0, e_c = 0.0, s_l = 0.0, s_z = 0.0, cmax = -INFINITY, cmin = INFINITY, theta = 0.0;
         bool finite = finite_all(f);
         MPC_UNROLL for (int i = 0; i < NV; i++) {
@@ -1430,6 +1433,7 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
             MPC_UNROLL for (int i = 0; i < NV; i++) vt[i] = v[i] + a_ * d_[i];
             double ft;
             values(vt, ft, c1t, c2t);
+            EC_LDS_FENCE();
             ok_t = finite_all(ft); theta_t = 0.0;
             MPC_UNROLL for (int i = 0; i < NX; i++) { theta_t += fabs(c1t[i]); ok_t = ok_t && finite_all(c1t[i]); }
             MPC_UNROLL for (int i = 0; i < NY; i++) { theta_t += fabs(c2t[i]); ok_t = ok_t && finite_all(c2t[i]); }
