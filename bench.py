@@ -40,7 +40,8 @@ KERNEL_NAMES = {1: "loop_kernel (one instance per lane)", 2: "loop_kernel_tp (ho
 B_PER_GPU = 4096
 SEED = 20250614
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PROFILE_ROUND = "r04"      # the round whose PMC summaries (profiles/<round>_*pmc_summary.json) the traffic figures come from
+PMC_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_summary.json")
 
 
 def alg_bytes_per_step(p) -> int:
@@ -310,7 +311,7 @@ def main_enmpc(args):
             per_launch_s, units, launches = float(np.mean(kms)) * 1e-3, B * K, len(times)
         achieved = ab * units / per_launch_s / 1e9
         tflops = fl * units / per_launch_s / 1e12
-        traffic, traffic_src = measured_traffic(kname, units, os.path.join(ROOT, "profiles", "r03_%s_pmc_summary.json" % args.config))
+        traffic, traffic_src = measured_traffic(kname, units, os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PROFILE_ROUND, args.config)))
         out = {"metric": cfg["metric"], "value": B * world * K / dt, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "Ex_ENMPC (isothermal reactor, nx=2,nu=1,ny=2,nd=2; continuous-time economic cost integrated over every shooting interval, "
@@ -402,7 +403,7 @@ def main_nmpc(args):
     ne = p.nx + p.nd
     state = p.nxp + p.nx + p.nd + ne * ne + p.nu + p.nx + p.nu
     ab = (2 * state + 2 * p.nw + p.ny + p.nu) * 8              # state in + out, shifted trajectory in + out, set points
-    summary = os.path.join(ROOT, "profiles", "r03_nmpc_pmc_summary.json")
+    summary = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_nmpc_pmc_summary.json")
     if split:
         # the dominant kernel of the split pipeline: one launch = linearisation + QP of one step of every instance
         per_launch_s = float(np.mean(wms)) * 1e-3
