@@ -35,6 +35,8 @@ typedef struct enmpc_desc {
     int32_t quad_steps;              /* Runge-Kutta steps per shooting interval of the OCP (cost quadrature included) */
     int32_t device;
     int32_t mhe_update;              /* update of the arrival cost, mhe_up (Estimator.py:626-736): 0 = 'smooth', 1 = 'filter' */
+    int32_t estimator;               /* 0 = moving-horizon estimator (mhe = True), 1 = extended Kalman filter on [x; d] (ekf = True: the other position of the
+                                        example's switch, Ex_ENMPC.py:109-123; Estimator.py:313-386 through MPC_code.py:640-650) */
     double h;                        /* sampling interval */
     double tol, tol_mhe;             /* optimality tolerances: IPOPT's default 1e-8, 1e-10 for the estimator (MPC_code.py:383) */
     const double *umin, *umax, *xmin, *xmax;                                   /* OCP boxes; +-INFINITY = absent */
@@ -45,6 +47,7 @@ typedef struct enmpc_desc {
     const double *G_mhe;             /* [nx+nd][nw] */
     const double *P0;                /* [nx+nd]^2 initial arrival weight and Kalman covariance (MPC_code.py:421-422,455-458) */
     const double *x0_m, *u0;         /* the first guesses of target and OCP (MPC_code.py:696-700,740-756) */
+    const double *Q_kf, *R_kf;       /* estimator = 1: [nx+nd]^2 process and [ny]^2 measurement noise covariances; P0 is then P(0|-1).  NULL with estimator = 0 */
 } enmpc_desc;
 
 int enmpc_create(const enmpc_desc *desc, enmpc_handle **out);
@@ -109,7 +112,9 @@ int enmpc_allgather_log(enmpc_handle *h, const char *name, int32_t k0, int32_t n
  * (they give the estimator's prior and the first guesses); then, per step and in this order, enmpc_mhe_update, enmpc_target_solve,
  * enmpc_ocp_solve - a step of the closed loop is exactly one call of each (tests/test_enmpc.py: the three calls + enmpc_plant_step reproduce
  * enmpc_run bit for bit).  status words as everywhere: 0 solved, 1 accepted without convergence, 2 the reference's hold rule. */
-/* y [B][ny]: the measurement of this step (StateFeedback: the plant state); u_prev [B][nu]: the input applied over the step before (u0 at the first).
+/* The estimator call of the step - the moving-horizon estimator or, with estimator = 1, the extended Kalman filter (whose predicted state x(k|k-1) is what
+ * enmpc_ocp_solve left in the handle: the optimiser's next state, MPC_code.py:798-799, and whose covariance the handle keeps).
+ * y [B][ny]: the measurement of this step (StateFeedback: the plant state); u_prev [B][nu]: the input applied over the step before (u0 at the first).
  * Out: xhat [B][nx], dhat [B][nd] (saturated by dmin / dmax when given, MPC_code.py:657-664), xes [B][nx+nd] the estimator's corrected [x; d] (or NULL) */
 int enmpc_mhe_update(enmpc_handle *h, const double *y, const double *u_prev, double *xhat, double *dhat, double *xes, int32_t *status, int32_t *iters);
 /* cold-started from (x0_m, u0) as the reference's (MPC_code.py:696-700); a failed solve (status 2) returns the targets of the step before (:714-718) */

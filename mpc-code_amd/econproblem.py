@@ -73,6 +73,9 @@ class EconomicMPCProblem:
     x_bar: np.ndarray = None
     xmin_mhe: np.ndarray = None
     xmax_mhe: np.ndarray = None
+    estimator: str = "mhe"          # 'mhe' | 'ekf': the example's estimator switch (Ex_ENMPC.py:109-123, mhe_mod)
+    Q_kf: Optional[np.ndarray] = None      # extended Kalman filter on [x; d]: process / measurement noise covariances (Estimator.py:313-386); P0 is P(0|-1)
+    R_kf: Optional[np.ndarray] = None
     name: str = ""
     funcs: Dict[str, Any] = field(default_factory=dict)
 
@@ -117,7 +120,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
                 "r_w", "Q_mhe"):
         if has(bad):
             raise UnsupportedProblem(f"'{bad}' is outside the economic path built so far")
-    for flag in ("ssjacid", "Fp_nominal", "Adaptation", "Collocation", "slacks", "TermCons", "DUFormEcon", "kal", "kalss", "lue", "ekf", "estimating"):
+    for flag in ("ssjacid", "Fp_nominal", "Adaptation", "Collocation", "slacks", "TermCons", "DUFormEcon", "kal", "kalss", "lue", "estimating"):
         if ns.get(flag, False) is True:
             raise UnsupportedProblem(f"flag {flag}=True is outside the economic path built so far")
     if ns.get("LinPar", True) is not True:
@@ -127,24 +130,25 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
             raise UnsupportedProblem(f"'{req}' missing: not an economic example with continuous model, plant and cost")
     if ns.get("StateFeedback", False) is not True or ns.get("offree", "no") != "lin":
         raise UnsupportedProblem("the economic path needs StateFeedback = True and offree = 'lin' (outputs y = x + Cd d)")
-    if not ns.get("mhe", False):
-        raise UnsupportedProblem("the economic path needs the moving-horizon estimator (mhe = True)")
-    if ns.get("mhe_up", "smooth") not in ("smooth", "filter"):
+    use_mhe, use_ekf = bool(ns.get("mhe", False)), bool(ns.get("ekf", False))
+    if use_mhe == use_ekf:
+        raise UnsupportedProblem("the economic path needs one estimator: the moving-horizon estimator (mhe = True) or the extended Kalman filter (ekf = True)")
+    if use_mhe and ns.get("mhe_up", "smooth") not in ("smooth", "filter"):
         raise UnsupportedProblem("mhe_up: 'smooth' or 'filter' (Estimator.py:626-736)")
-    for req in ("N_mhe", "w", "User_fx_mhe_Cont", "User_fobj_mhe", "P0", "x_bar"):
+    for req in (("N_mhe", "w", "User_fx_mhe_Cont", "User_fobj_mhe", "P0", "x_bar") if use_mhe else ("Q_kf", "R_kf", "P0")):
         if not has(req):
-            raise UnsupportedProblem(f"'{req}' missing for the moving-horizon estimator")
+            raise UnsupportedProblem(f"'{req}' missing for the " + ("moving-horizon estimator" if use_mhe else "extended Kalman filter"))
     if (ns.get("dmin") is None) != (ns.get("dmax") is None):
         raise UnsupportedProblem("dmin and dmax have to come together")
     nx, nu, ny, nd, nxp = ns["x"].size1(), ns["u"].size1(), ns["y"].size1(), ns["d"].size1(), ns["xp"].size1()
-    n_w = ns["w"].size1()
+    n_w = ns["w"].size1() if use_mhe else nx + nd
     if ny != nx or nd != ny:
         raise UnsupportedProblem("StateFeedback with an output disturbance needs ny = nx = nd")
     if nxp != nx:
         raise UnsupportedProblem("StateFeedback: the measurement is the plant state, so the plant needs the model's state dimension (nxp = nx)")
     if has("dhat0") and np.any(np.asarray(ns["dhat0"], dtype=float) != 0.0):      # MPC_code.py:459-462 seeds dhat_k with it; this path starts from zero
         raise UnsupportedProblem("a non-zero dhat0 is outside the economic path built so far")
-    N_mhe = int(ns["N_mhe"])
+    N_mhe = int(ns["N_mhe"]) if use_mhe else 2      # (the filter has no window; the per-model library still carries the estimator kernels, with the defaults below)
     if N_mhe < 2 or N_mhe > 63 or int(ns["N"]) < 2 or int(ns["N"]) > 64:
         raise UnsupportedProblem("horizons: 2 <= N <= 64, 2 <= N_mhe <= 63 (one stage per lane of a wavefront)")
     if n_w != nx + nd:
@@ -156,11 +160,12 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     col, zero = st.SymMat.col, (lambda n: st.SymMat.zeros(n))
     f = _trace(ns["User_fxm_Cont"], (col(vx), col(vu), col(vd), vt, zero(nx)), "User_fxm_Cont")
     fp = _trace(ns["User_fxp_Cont"], (col(vxp), vt, col(vu), zero(nxp), zero(nxp)), "User_fxp_Cont")
-    f_mhe = _trace(ns["User_fx_mhe_Cont"], (col(vx), col(vu), col(vd), vt, zero(nx), col(vw)), "User_fx_mhe_Cont")
+    # without a moving-horizon estimator its model is the controller's and its cost the unit quadratic (never evaluated: the library's estimator kernels are not launched)
+    f_mhe = _trace(ns["User_fx_mhe_Cont"], (col(vx), col(vu), col(vd), vt, zero(nx), col(vw)), "User_fx_mhe_Cont") if use_mhe else f
     if len(f) != nx or len(fp) != nxp or len(f_mhe) != nx:
         raise UnsupportedProblem("a user function returns a vector of the wrong length")
     if _depends_on(f_mhe, ("w", "d")):
-        raise UnsupportedProblem("User_fx_mhe_Cont uses w or d inside the differential equation: only their linear entry (+ Bd d, + G w) is built")
+        raise UnsupportedProblem(("User_fx_mhe_Cont" if use_mhe else "User_fxm_Cont (the filter's state map)") + " uses w or d inside the differential equation: only their linear entry (+ Bd d, + G w) is built")
     # Fy_model with StateFeedback: x + Cd d (Utilities.py:200-204)
     fy = lambda xv: [xv[i] + sum((float(Cd[i, j]) * vd[j] for j in range(nd)), st.Sym.const(0.0)) for i in range(ny)]
     ell = _trace(ns["User_fobj_Cont"], (col(vx), col(vu), col(fy(vx)), col(vxs), col(vus), col(fy(vxs))), "User_fobj_Cont")
@@ -169,7 +174,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     vfin = [st.Sym.const(0.0)]
     if has("User_vfin"):
         vfin = _trace(ns["User_vfin"], (col(vx), col(vxs)), "User_vfin")
-    c_mhe = _trace(ns["User_fobj_mhe"], (col(vw), col(vv), vt), "User_fobj_mhe")
+    c_mhe = _trace(ns["User_fobj_mhe"], (col(vw), col(vv), vt), "User_fobj_mhe") if use_mhe else [sum((a * a for a in list(vw) + list(vv)), st.Sym.const(0.0)) * st.Sym.const(0.5)]
     if len(ell) != 1 or len(fss) != 1 or len(vfin) != 1 or len(c_mhe) != 1:
         raise UnsupportedProblem("a cost function does not return a scalar")
 
@@ -187,7 +192,10 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         ymin_ss=pick("ymin", "_ss", ny, -INF), ymax_ss=pick("ymax", "_ss", ny, INF),
         dmin=None if ns.get("dmin") is None else _vec(ns["dmin"], nd, -INF), dmax=None if ns.get("dmax") is None else _vec(ns["dmax"], nd, INF),
         x0_p=_vec(ns["x0_p"], nxp, 0.0), x0_m=_vec(ns["x0_m"], nx, 0.0), u0=_vec(ns["u0"], nu, 0.0), max_iter=int(ns.get("Sol_itmax", 100)),
-        N_mhe=N_mhe, mhe_up=str(ns.get("mhe_up", "smooth")), n_w=n_w, G_mhe=G, P0=_mat(ns["P0"], nx + nd, nx + nd, "P0"), x_bar=np.asarray(ns["x_bar"], dtype=np.float64).reshape(nx + nd),
+        N_mhe=N_mhe, mhe_up=str(ns.get("mhe_up", "smooth")), n_w=n_w, G_mhe=G, P0=_mat(ns["P0"], nx + nd, nx + nd, "P0"),
+        x_bar=(np.asarray(ns["x_bar"], dtype=np.float64).reshape(nx + nd) if use_mhe else np.concatenate([_vec(ns["x0_m"], nx, 0.0), np.zeros(nd)])),
+        estimator="mhe" if use_mhe else "ekf",
+        Q_kf=None if use_mhe else _mat(ns["Q_kf"], nx + nd, nx + nd, "Q_kf"), R_kf=None if use_mhe else _mat(ns["R_kf"], ny, ny, "R_kf"),
         xmin_mhe=np.concatenate([_vec(ns.get("xmin"), nx, -INF), _vec(ns.get("dmin"), nd, -INF)]),      # MPC_code.py:397-402
         xmax_mhe=np.concatenate([_vec(ns.get("xmax"), nx, INF), _vec(ns.get("dmax"), nd, INF)]),
         name=name or str(ns.get("__name__", "")),

@@ -26,10 +26,10 @@ _ip = ct.POINTER(ct.c_int32)
 
 
 class _EDesc(ct.Structure):
-    _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "nw", "N", "N_mhe", "max_iter", "quad_steps", "device", "mhe_update")]
+    _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "nw", "N", "N_mhe", "max_iter", "quad_steps", "device", "mhe_update", "estimator")]
                 + [(k, ct.c_double) for k in ("h", "tol", "tol_mhe")]
                 + [(k, _dp) for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe",
-                                      "dmin", "dmax", "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0")])
+                                      "dmin", "dmax", "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0", "Q_kf", "R_kf")])
 
 
 _libs: Dict[str, ct.CDLL] = {}
@@ -94,8 +94,9 @@ class EnmpcSolver:
         d.nx, d.nu, d.ny, d.nd, d.nxp, d.nw, d.N, d.N_mhe = p.nx, p.nu, p.ny, p.nd, p.nxp, p.n_w, p.N, p.N_mhe
         d.max_iter, d.quad_steps, d.device, d.h, d.tol, d.tol_mhe = int(p.max_iter), int(p.quad_steps), int(device), float(p.h), float(tol), float(tol_mhe)
         d.mhe_update = {"smooth": 0, "filter": 1}[p.mhe_up]
+        d.estimator = {"mhe": 0, "ekf": 1}[getattr(p, "estimator", "mhe")]
         for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe", "dmin", "dmax",
-                  "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0"):
+                  "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0", "Q_kf", "R_kf"):
             v = getattr(p, k, None)
             if v is None:
                 setattr(d, k, None)

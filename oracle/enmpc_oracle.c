@@ -36,6 +36,8 @@ typedef struct {
     double par[7];               /* cA0, V, k1, k2, alfa, beta, terminal weight */
     double umin[NU], umax[NU], xmin[NX], xmax[NX], tlo[NV], thi[NV], elo[NE], ehi[NE], dmin[ND], dmax[ND];
     double Bd[NX][ND], Cd[NY][ND], G[NE][NW], P0[NE][NE], x0m[NX], u0[NU];
+    int32_t est_ekf, pad_;       /* estimator: 0 the moving-horizon estimator, 1 the extended Kalman filter on [x; d] (Ex_ENMPC.py:109-123, mhe_mod = 'off') */
+    double Qkf[NE][NE], Rkf[NY][NY];
 } EProb;
 
 /* ---- the example's functions (hand-written; checked against the Ex-file by the Python wrapper) --------------------------------------- */
@@ -344,6 +346,30 @@ static void ekf_cov(const EProb *P, const double *Pin, const double *x, double u
     for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = T2[i * NE + j]; for (int l = 0; l < NW; l++) s += P->G[i][l] * P->G[j][l]; Pn[i * NE + j] = s; }      /* + G Q G' */
 }
 
+/* ekf() of Estimator.py:313-386 with Fx_es = [Fx_model(x, u, d); d], Fy_es = x + Cd d (MPC_code.py:546-561): Pk = P(k|k-1) in, P(k+1|k) out; xes = [x; d](k|k-1) in,
+   (k|k) out.  The state map is linearised at the corrected estimate (:371-379). */
+static void ekf_step(const EProb *P, double *Pk, double *xes, const double *y, double u)
+{
+    double Ca[NY * NE], K[NE * NY], Sm[NY * NY], Si[NY * NY], Pc[NE * NE], Ak[NE * NE], T1[NE * NE], T2[NE * NE], e[NY];
+    for (int r = 0; r < NY; r++) for (int i = 0; i < NE; i++) Ca[r * NE + i] = i < NX ? (r == i) : P->Cd[r][i - NX];
+    for (int r = 0; r < NY; r++) { double yh = 0.0; for (int i = 0; i < NE; i++) yh += Ca[r * NE + i] * xes[i]; e[r] = y[r] - yh; }
+    for (int r = 0; r < NY; r++) for (int q = 0; q < NY; q++) { double s = P->Rkf[r][q]; for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) s += Ca[r * NE + i] * Pk[i * NE + j] * Ca[q * NE + j]; Sm[r * NY + q] = s; }
+    inv_small(NY, Sm, Si);
+    for (int i = 0; i < NE; i++) for (int r = 0; r < NY; r++) { double s = 0.0; for (int j = 0; j < NE; j++) for (int q = 0; q < NY; q++) s += Pk[i * NE + j] * Ca[q * NE + j] * Si[q * NY + r]; K[i * NY + r] = s; }
+    for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) { double s = Pk[i * NE + j]; for (int r = 0; r < NY; r++) for (int l = 0; l < NE; l++) s -= K[i * NY + r] * Ca[r * NE + l] * Pk[l * NE + j]; Pc[i * NE + j] = s; }
+    for (int i = 0; i < NE; i++) { double s = xes[i]; for (int r = 0; r < NY; r++) s += K[i * NY + r] * e[r]; xes[i] = s; }
+    for (int j = 0; j < NE; j++) {      /* A = d [Fx_model(x, u, d); d] / d [x; d] by complex steps */
+        cplx zc[3] = {xes[0], xes[1], u}, dc[ND] = {xes[2], xes[3]}, oo[NX + 1];
+        if (j < NX) zc[j] += I * CS; else dc[j - NX] += I * CS;
+        double dr[ND] = {0.0, 0.0};
+        model_map(P, zc, dr, oo);      /* the flow without its Bd d; that term is added here with the complex d */
+        for (int r = 0; r < NX; r++) { cplx v = oo[r]; for (int l = 0; l < ND; l++) v += P->Bd[r][l] * dc[l]; Ak[r * NE + j] = cimag(v) / CS; }
+        for (int r = 0; r < ND; r++) Ak[(NX + r) * NE + j] = cimag(dc[r]) / CS;
+    }
+    mm4(Ak, Pc, T1, 0); mm4(T1, Ak, T2, 1);
+    for (int i = 0; i < NE; i++) for (int j = 0; j < NE; j++) Pk[i * NE + j] = T2[i * NE + j] + P->Qkf[i][j];
+}
+
 static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, double u, double *xes, int *iters)
 {
     const int Nm = P->N_mhe, N = ksim + 1 < Nm ? ksim + 1 : Nm;
@@ -433,7 +459,9 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
             if (XP) { XP[o * NX] = x[0]; XP[o * NX + 1] = x[1]; }
             double xes[NE];
             int itm, its, itd;
-            const int sm = mhe_step(P, S, k, x, u, xes, &itm);      /* y = x_p (StateFeedback plant output) */
+            int sm = 0;
+            if (P->est_ekf) { xes[0] = xh[0]; xes[1] = xh[1]; xes[2] = dh[0]; xes[3] = dh[1]; ekf_step(P, S->Pkal, xes, x, u); itm = 0; }      /* (P_k lives where the other estimator keeps its filter covariance) */
+            else sm = mhe_step(P, S, k, x, u, xes, &itm);      /* y = x_p (StateFeedback plant output) */
             xh[0] = xes[0]; xh[1] = xes[1]; dh[0] = xes[2]; dh[1] = xes[3];
             if (P->has_dsat) for (int i = 0; i < ND; i++) dh[i] = fmin(fmax(dh[i], P->dmin[i]), P->dmax[i]);
             const double xs_prev[NX] = {xs[0], xs[1]}, us_prev = us;

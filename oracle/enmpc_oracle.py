@@ -90,6 +90,12 @@ def load_problem(path, overrides=None, quad_steps=20):
         for k in ("wmin", "wmax", "vmin", "vmax"):
             assert ns.get(k) is None, "noise bounds are not restated here"
         assert p.G_mhe.shape == (ne, p.n_w)
+    p.ekf = bool(ns.get("ekf", False))
+    if not p.mhe:      # the example's other estimator (Ex_ENMPC.py:109-123, mhe_mod = 'off'): the extended Kalman filter on [x; d]
+        assert p.ekf, "estimator: the moving-horizon estimator (mhe = True) or the extended Kalman filter (ekf = True)"
+        ne = p.nx + p.nd
+        p.Q_kf, p.R_kf, p.P0 = (np.asarray(ns[k], dtype=float) for k in ("Q_kf", "R_kf", "P0"))
+        assert p.Q_kf.shape == (ne, ne) and p.R_kf.shape == (p.ny, p.ny) and p.P0.shape == (ne, ne)
     return p
 
 
@@ -791,6 +797,23 @@ def target_solve(p, d, t=0.0, usp=None, ysp=None, xsp=None, max_iter=None, tol=1
 
 
 # ---------------------------------------------------------------------------------------------------
+# extended Kalman filter on the augmented state (Estimator.py:313-386 with the Fx_es / Fy_es of MPC_code.py:546-561)
+# ---------------------------------------------------------------------------------------------------
+def ekf_step(p, P_min, x_es, y_k, u_k, t_k=0.0):
+    """ekf(Fx_es, Fy_es, y, u, Q, R, P_min, xhat_min, h, t): returns P(k+1|k), P(k|k), [x; d](k|k).  Fy_es(csi) = x + Cd d, so C = [I, Cd];
+    Fx_es(csi, u) = [Fx_model(x, u, d); d], linearised at the CORRECTED estimate (:371-379)."""
+    n, nd = p.nx, p.nd
+    C = np.hstack([np.eye(p.ny, n), p.Cd])                                   # jac Fy_x (:343-350; StateFeedback: ny = nx)
+    yhat = x_es[:n] + p.Cd @ x_es[n:]                                        # :339
+    K = P_min @ C.T @ np.linalg.inv(C @ P_min @ C.T + p.R_kf)                # :356-357
+    P_corr = P_min - K @ C @ P_min                                           # :360
+    x_corr = x_es + K @ (y_k - yhat)                                         # :363-369
+    _, A = jac_cs(lambda Zc: np.vstack([fx_model(p, Zc[:n], np.asarray(u_k, dtype=float).reshape(-1, 1), Zc[n:], t_k), Zc[n:]]), x_corr)      # :372-379
+    P_plus = A @ P_corr @ A.T + p.Q_kf                                       # :382
+    return P_plus, P_corr, x_corr
+
+
+# ---------------------------------------------------------------------------------------------------
 # MHE (mhe_opt's NLP + mhe()'s bookkeeping)
 # ---------------------------------------------------------------------------------------------------
 def mhe_eval(p, N, Us, Ys, x_bar, Pinv, t=0.0):
@@ -938,6 +961,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
     x0_m = (p.x0_m if x0_m is None else np.asarray(x0_m, dtype=float)).copy()
     xhat = x0_m.copy(); dhat = np.zeros(nd); u_k = p.u0.copy()
     S = MheState(p) if p.mhe else None
+    P_k = None if p.mhe else p.P0.copy()                    # MPC_code.py:455-458
     if S is not None and x0_m is not None:
         S.x_bar[:n] = x0_m                                   # Ex-file: x_bar = [x0_m; 0]
     xs_k, us_k = x0_m.copy(), u_k.copy()                     # MPC_code.py:682-684
@@ -954,8 +978,9 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
             if certify:
                 log["KKT_MHE"].append(max(kkt_nlp(S.last["evalf"], S.last, S.last["lo"], S.last["hi"]).values()))
             log["P_K"].append(S.P_k.copy())
-        else:
-            raise NotImplementedError("only the moving-horizon estimator of the shipped example is restated")
+        else:                                                # MPC_code.py:640-650: estype 'ekf', P_k <- P_plus
+            P_k, _, x_es = ekf_step(p, P_k, np.concatenate([xhat, dhat]), y_k, u_k, t_k)
+            log["ITERS_MHE"].append(0); log["STATUS_MHE"].append(0); log["P_K"].append(P_k.copy())
         xhat, dhat = x_es[:n].copy(), x_es[n:].copy()
         if p.dmin is not None:
             dhat = np.minimum(np.maximum(dhat, p.dmin), p.dmax)

@@ -26,7 +26,7 @@ class _EProb(ct.Structure):
                 + [("par", ct.c_double * 7), ("umin", ct.c_double * NU), ("umax", ct.c_double * NU), ("xmin", ct.c_double * NX), ("xmax", ct.c_double * NX),
                    ("tlo", ct.c_double * NV), ("thi", ct.c_double * NV), ("elo", ct.c_double * NE), ("ehi", ct.c_double * NE), ("dmin", ct.c_double * ND), ("dmax", ct.c_double * ND),
                    ("Bd", ct.c_double * (NX * ND)), ("Cd", ct.c_double * (NY * ND)), ("G", ct.c_double * (NE * NW)), ("P0", ct.c_double * (NE * NE)),
-                   ("x0m", ct.c_double * NX), ("u0", ct.c_double * NU)])
+                   ("x0m", ct.c_double * NX), ("u0", ct.c_double * NU), ("est_ekf", ct.c_int32), ("pad_", ct.c_int32), ("Qkf", ct.c_double * (NE * NE)), ("Rkf", ct.c_double * (NY * NY))])
 
 
 def build(fast=False):
@@ -48,20 +48,24 @@ def _params(p):
 
 class OracleEC:
     def __init__(self, p, fast=False):
-        assert (p.nx, p.nu, p.ny, p.nd, p.nxp) == (2, 1, 2, 2, 2) and p.mhe and p.n_w == 4, "the C restatement is written for the example family of Ex_ENMPC.py"
+        assert (p.nx, p.nu, p.ny, p.nd, p.nxp) == (2, 1, 2, 2, 2) and ((p.mhe and p.n_w == 4) or p.ekf), "the C restatement is written for the example family of Ex_ENMPC.py"
         self.p = p
         self.lib = ct.CDLL(build(fast))
         s = _EProb()
-        s.N, s.N_mhe, s.Mx, s.quad, s.max_iter, s.has_dsat = p.N, p.N_mhe, p.Mx, p.quad_steps, p.max_iter, int(p.dmin is not None)
+        s.N, s.N_mhe, s.Mx, s.quad, s.max_iter, s.has_dsat = p.N, (p.N_mhe if p.mhe else 2), p.Mx, p.quad_steps, p.max_iter, int(p.dmin is not None)
+        s.est_ekf = int(not p.mhe)
         s.mhe_filter = int(getattr(p, "mhe_up", "smooth") == "filter")
         s.h, s.tol, s.tol_mhe = p.h, 1e-8, 1e-10
         fill = lambda field, v: field.__setitem__(slice(0, len(field)), [float(a) for a in np.ravel(v)])
         fill(s.par, _params(p))
         for k in ("umin", "umax", "xmin", "xmax", "Bd", "Cd", "P0"):
             fill(getattr(s, k), getattr(p, k))
-        fill(s.G, p.G_mhe); fill(s.x0m, p.x0_m); fill(s.u0, p.u0)
+        fill(s.G, p.G_mhe if p.mhe else np.eye(NE)); fill(s.x0m, p.x0_m); fill(s.u0, p.u0)
+        if not p.mhe:
+            fill(s.Qkf, p.Q_kf); fill(s.Rkf, p.R_kf)
         fill(s.tlo, np.concatenate([p.xmin_ss, p.umin_ss, p.ymin_ss])); fill(s.thi, np.concatenate([p.xmax_ss, p.umax_ss, p.ymax_ss]))
-        fill(s.elo, p.xmin_mhe); fill(s.ehi, p.xmax_mhe)
+        if p.mhe:
+            fill(s.elo, p.xmin_mhe); fill(s.ehi, p.xmax_mhe)
         fill(s.dmin, p.dmin if p.dmin is not None else [-np.inf] * ND); fill(s.dmax, p.dmax if p.dmax is not None else [np.inf] * ND)
         self.s = s
         self._check_functions()
@@ -75,9 +79,9 @@ class OracleEC:
             self.lib.eorc_functions(ct.byref(self.s), x.ctypes.data_as(_dp), ct.c_double(u[0]), d.ctypes.data_as(_dp), xs.ctypes.data_as(_dp), wv.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
             f = np.asarray(p.fxm(x, u, d, 0.0, np.zeros(2)), dtype=float)
             fp = np.asarray(p.fxp(x, 0.0, u, np.zeros(2), np.zeros(2)), dtype=float)
-            fm = np.asarray(p.fx_mhe(x, u, d, 0.0, np.zeros(2), wv[:4]), dtype=float)
+            fm = np.asarray(p.fx_mhe(x, u, d, 0.0, np.zeros(2), wv[:4]), dtype=float) if p.mhe else f
             y = x + p.Cd @ d
-            ref = [f[0], f[1], float(p.fobj(x, u, y, xs, u, y)), float(np.real(p.vfin(x, xs))) if p.vfin is not None else 0.0, float(p.fobj_mhe(wv[:4], wv[4:], 0.0))]
+            ref = [f[0], f[1], float(p.fobj(x, u, y, xs, u, y)), float(np.real(p.vfin(x, xs))) if p.vfin is not None else 0.0, float(p.fobj_mhe(wv[:4], wv[4:], 0.0)) if p.mhe else 0.5 * float(wv @ wv)]
             assert np.allclose(out, ref, rtol=1e-13, atol=1e-13), "the C restatement's functions are not this example's"
             assert np.allclose(fp, f, rtol=1e-13) and np.allclose(fm, f, rtol=1e-13), "plant / estimator model differ from the model: not restated in C"
             assert abs(float(p.fssobj(xs, u, y, None, None, None)) - float(p.fobj(x, u, y, xs, u, y))) < 1e-13, "target cost is not the stage cost rate"

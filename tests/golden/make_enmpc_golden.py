@@ -11,6 +11,11 @@ terminates on.
   c4_*     BASELINE configs[3]: N = 40, 10 steps, 3 starts of the benchmark box x0_p ~ U([0.5, 1] x [0, 0.5])
   c5_*     BASELINE configs[4]: N_mhe = 20, 24 steps (the window fills at step 19: growing window, then the smoothing update), 2 starts
   flt_*    the example with mhe_up = 'filter' (Estimator.py:627-649,740-748) and N_mhe = 6, 16 steps, 2 starts
+
+``make_enmpc_golden.py ekf`` writes tests/golden/enmpc_reactor_ekf.npz instead (half a minute): the example with the other position of its estimator switch
+(mpc-code_amd/examples/reactor_enmpc_ekf.py: extended Kalman filter on [x; d], Ex_ENMPC.py:109-123)
+  ekf_*    21 steps from the shipped start and two starts of the benchmark box
+  sat_*    the same with the disturbance estimate saturated (dmin / dmax, MPC_code.py:657-664), 12 steps, 2 starts
 """
 import os
 import sys
@@ -33,7 +38,7 @@ def box(n, seed=20250614):
 
 def run(p, nsteps, x0s):
     logs = [eo.closed_loop(p, nsteps, x0_p=x0, certify=True) for x0 in x0s]
-    return {k: np.stack([lg[k] for lg in logs], axis=1) for k in KEYS}
+    return {k: np.stack([lg[k] for lg in logs], axis=1) for k in KEYS if k in logs[0]}
 
 
 def main():
@@ -60,5 +65,22 @@ def main():
     np.savez_compressed(os.path.join(HERE, "enmpc_reactor.npz"), **out)
 
 
+def main_ekf():
+    ex = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc_ekf.py")
+    out = {}
+    p = eo.load_problem(ex)
+    x0 = np.vstack([p.x0_p[None], box(2, seed=5)])
+    out.update({"ekf_" + k: v for k, v in run(p, p.Nsim, x0).items()}); out["ekf_x0"] = x0
+    over = {"dmin": np.array([-0.05, -0.02]), "dmax": np.array([0.03, 0.05])}
+    ps = eo.load_problem(ex, overrides=over)
+    xs = box(2, seed=9)
+    out.update({"sat_" + k: v for k, v in run(ps, 12, xs).items()}); out["sat_x0"] = xs; out["sat_dmin"], out["sat_dmax"] = over["dmin"], over["dmax"]
+    for pre in ("ekf_", "sat_"):
+        worst = max(float(out[pre + k].max()) for k in ("KKT_DYN", "KKT_SS"))
+        print(pre, "largest KKT residual", worst, "all solved", int(out[pre + "STATUS_DYN"].max()) == 0 and int(out[pre + "STATUS_SS"].max()) == 0,
+              "dhat in", float(out[pre + "D_HAT"].min()), float(out[pre + "D_HAT"].max()))
+    np.savez_compressed(os.path.join(HERE, "enmpc_reactor_ekf.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    main_ekf() if sys.argv[1:] == ["ekf"] else main()

@@ -20,6 +20,8 @@ import enmpc_oracle as eo
 
 EX = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc.py")
 GOLD = os.path.join(ROOT, "tests", "golden", "enmpc_reactor.npz")
+EX_EKF = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc_ekf.py")      # the example with the other position of its estimator switch
+GOLD_EKF = os.path.join(ROOT, "tests", "golden", "enmpc_reactor_ekf.npz")
 TOL_U = 1e-7          # GPU against the oracle on u*, xs, us, [x; d]: both stop at a scaled KKT error of 1e-8 (measured: 1e-13)
 
 
@@ -200,6 +202,45 @@ def test_repo_example_is_the_reference_example(oprob, pkg):
     assert (q.N, q.N_mhe, q.nx, q.nu, q.n_w, q.max_iter) == (40, 20, 2, 1, 4, 200)
 
 
+def test_extended_kalman_filter_variant_restatements_agree_and_reproduce_their_vectors():
+    """The example's other estimator (Ex_ENMPC.py:109-123, mhe_mod = 'off': ekf() of Estimator.py:313-386 on [x; d], driven as MPC_code.py:640-650): the golden loops
+    certify themselves, NumPy and C restatement agree to rounding, the saturation of the disturbance estimate (MPC_code.py:657-664) is active in the second set."""
+    import enmpc_oracle_c as ec
+    g = np.load(GOLD_EKF)
+    for pre in ("ekf_", "sat_"):
+        assert int(g[pre + "STATUS_DYN"].max()) == 0 and int(g[pre + "STATUS_SS"].max()) == 0
+        assert float(g[pre + "KKT_DYN"].max()) < 2e-7 and float(g[pre + "KKT_SS"].max()) < 1e-8
+    assert float(g["sat_D_HAT"].min()) == -0.05 and float(g["ekf_D_HAT"].min()) < -0.2      # the filter moves the disturbance, the box holds it
+    assert abs(g["ekf_U"][-1, 0, 0] - 1.04297536) < 1e-6      # the same economic steady state as with the moving-horizon estimator
+    for pre, over, n in (("ekf_", None, 8), ("sat_", {"dmin": g["sat_dmin"], "dmax": g["sat_dmax"]}, 12)):
+        q = eo.load_problem(EX_EKF, overrides=over)
+        assert q.ekf and not q.mhe
+        r = eo.closed_loop(q, n, x0_p=g[pre + "x0"][1])
+        c = ec.OracleEC(q).closed_loop(n, g[pre + "x0"], nthreads=0)
+        for k in ("U", "XS", "US", "X_ES", "Xp"):
+            assert np.abs(r[k] - g[pre + k][:n, 1]).max() < 1e-12, (pre, k)
+            assert np.abs(c[k] - g[pre + k][:n]).max() < 1e-9, (pre, k)
+        for k in ("STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+            assert np.array_equal(c[k], g[pre + k][:n]), (pre, k)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "Ex_ENMPC.py")), reason="reference tree not present")
+def test_reference_example_with_its_estimator_switch_off_is_the_filter_variant(pkg, tmp_path):
+    """The switch is a source line of the reference's file (mhe_mod = 'on', Ex_ENMPC.py:109), evaluated while the file runs: a copy with that one line changed
+    loads in both loaders as the extended-Kalman-filter problem and gives the loops of mpc-code_amd/examples/reactor_enmpc_ekf.py to the bit."""
+    src = open(os.path.join(REF, "Ex_ENMPC.py")).read()
+    assert src.count("mhe_mod = 'on'") == 1
+    f = tmp_path / "Ex_ENMPC_ekf.py"
+    f.write_text(src.replace("mhe_mod = 'on'", "mhe_mod = 'off'"))
+    ref, own = eo.load_problem(str(f)), eo.load_problem(EX_EKF)
+    assert ref.ekf and not ref.mhe and np.array_equal(ref.Q_kf, own.Q_kf) and np.array_equal(ref.R_kf, own.R_kf) and np.array_equal(ref.P0, own.P0)
+    a, b = eo.closed_loop(own, 3), eo.closed_loop(ref, 3)
+    for k in ("U", "XS", "US", "X_ES", "P_K"):
+        assert np.array_equal(a[k], b[k]), k
+    q = pkg.load_problem(str(f), overrides={"N": 40})
+    assert (q.estimator, q.N, q.nx, q.nu) == ("ekf", 40, 2, 1) and np.array_equal(q.Q_kf, own.Q_kf) and np.array_equal(q.R_kf, own.R_kf)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # product, host side
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -208,9 +249,13 @@ def test_loader_classifies_and_refuses(pkg, prob):
     assert isinstance(prob, EconomicMPCProblem) and (prob.N, prob.N_mhe, prob.quad_steps, prob.max_iter) == (25, 10, 20, 200)
     assert np.array_equal(prob.xmax_mhe, [1.0, 1.0, np.inf, np.inf]) and np.array_equal(prob.x_bar, [1.2, 0.5, 0.0, 0.0])
     assert pkg.load_problem(EX, overrides={"mhe_up": "filter"}).mhe_up == "filter" and prob.mhe_up == "smooth"
-    for over in ({"mhe_up": "window"}, {"slacks": True}, {"N": 80}, {"N_mhe": 64}, {"StateFeedback": False}, {"TermCons": True}):
-        with pytest.raises(UnsupportedProblem):
+    for over in ({"mhe_up": "window"}, {"slacks": True}, {"N": 80}, {"N_mhe": 64}, {"StateFeedback": False}, {"TermCons": True}, {"ekf": True}, {"mhe": False}):
+        with pytest.raises(UnsupportedProblem):      # (the last two: both estimators, none)
             pkg.load_problem(EX, overrides=over)
+    pe = pkg.load_problem(EX_EKF)
+    assert prob.estimator == "mhe" and pe.estimator == "ekf" and np.array_equal(np.diag(pe.Q_kf), [1e-8, 1e-8, 1.0, 1.0]) and np.array_equal(pe.P0, 1e-8 * np.eye(4))
+    with pytest.raises(UnsupportedProblem):
+        pkg.load_problem(EX_EKF, overrides={"Q_kf": None})
 
 
 @pytest.fixture(scope="module")
@@ -348,6 +393,38 @@ def test_gpu_filter_update_of_the_arrival_cost_follows_the_golden_loop(pkg, gold
     _check(r, gold, "flt_", 16)
     p, q = _gpu_loop(pkg, {"mhe_up": "filter", "N_mhe": 6}, gold["flt_x0"], 16, kernel=kernel, steps_per_launch=5)      # the lists through HBM between launches
     assert np.array_equal(q["U"], r["U"]) and np.array_equal(q["X_ES"], r["X_ES"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pre", ["ekf_", "sat_"])
+def test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restatement(pkg, pre):
+    """The example with its estimator switch in the other position (Ex_ENMPC.py:109-123): the extended Kalman filter on [x; d] in the estimator's place
+    (enmpc_ekf_kernel / phase_ekf; Estimator.py:313-386 through MPC_code.py:640-664), both launch styles against the golden loops, a larger batch against the C
+    restatement, and the per-call seam (whose estimator call is then the filter) against the resident loop bit for bit."""
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc
+    g = np.load(GOLD_EKF)
+    over = {"dmin": g["sat_dmin"], "dmax": g["sat_dmax"]} if pre == "sat_" else None
+    p = pkg.load_problem(EX_EKF, overrides=over)
+    n = g[pre + "U"].shape[0]
+    s = enmpc.EnmpcSolver(p)
+    try:
+        for kernel in (1, 2):
+            r = enmpc.run_enmpc_closed_loop(p, g[pre + "x0"], n, solver=s, kernel=kernel)
+            _check(r, g, pre, n)
+            assert int(r["STATUS_MHE"].max()) == 0 and int(r["ITERS_MHE"].max()) == 0
+        x0 = np.random.default_rng(3).uniform([0.5, 0.0], [1.0, 0.5], size=(200, 2))
+        c = ec.OracleEC(eo.load_problem(EX_EKF, overrides=over)).closed_loop(10, x0, nthreads=0)
+        a = enmpc.run_enmpc_closed_loop(p, x0, 10, solver=s, kernel=2)
+        for k in ("U", "XS", "US", "X_ES", "Xp"):
+            assert np.abs(a[k] - c[k]).max() < TOL_U, (k, np.abs(a[k] - c[k]).max())
+        for k in ("STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"):
+            assert np.array_equal(a[k], c[k]), k
+        b = enmpc.run_enmpc_stepwise(p, x0, 10, solver=s)
+        for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "X_ES", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"):
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        s.close()
 
 
 @pytest.mark.gpu
