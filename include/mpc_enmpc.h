@@ -48,6 +48,8 @@ typedef struct enmpc_desc {
     const double *P0;                /* [nx+nd]^2 initial arrival weight and Kalman covariance (MPC_code.py:421-422,455-458) */
     const double *x0_m, *u0;         /* the first guesses of target and OCP (MPC_code.py:696-700,740-756) */
     const double *Q_kf, *R_kf;       /* estimator = 1: [nx+nd]^2 process and [ny]^2 measurement noise covariances; P0 is then P(0|-1).  NULL with estimator = 0 */
+    const double *wmin, *wmax;       /* [nw] bounds of the estimator's state noise (Utilities.py:881-884,974-977), +-INFINITY = absent; NULL = none.  A library generated
+                                        for a problem without them (build info "wb=0") refuses finite ones */
 } enmpc_desc;
 
 int enmpc_create(const enmpc_desc *desc, enmpc_handle **out);

@@ -21,6 +21,8 @@ import os
 import subprocess
 from typing import Dict, List, Sequence
 
+import numpy as np
+
 from . import PKG_DIR
 from . import symtrace as st
 
@@ -168,6 +170,7 @@ def emit_econ_header(p) -> str:
 #pragma once
 struct EcModel {{
     static constexpr int NX = {nx}, NU = {nu}, NY = {ny}, ND = {nd}, NXP = {nxp}, NW = {nw}, MX = {p.Mx};
+    static constexpr bool W_BOUNDS = {"true" if (np.isfinite(p.wmin).any() or np.isfinite(p.wmax).any()) else "false"};      // the estimator's state noise has bounds (wmin / wmax): its solver then carries them
     // disturbance model and noise input of the example (offree = 'lin': Bd, Cd, Utilities.py:174-177,202-204; G_mhe, MPC_code.py:387): part of the problem
     // definition, compiled in so that the estimator's recursions skip their zeros and ones; enmpc_create checks the descriptor against them
 {consts}    struct Ctx {{ double u[NU], d[ND], xs[NX], us[NU]; }};      // what a right-hand side reads besides its state

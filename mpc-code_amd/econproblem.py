@@ -73,6 +73,8 @@ class EconomicMPCProblem:
     x_bar: np.ndarray = None
     xmin_mhe: np.ndarray = None
     xmax_mhe: np.ndarray = None
+    wmin: np.ndarray = None         # bounds of the estimator's state noise (Utilities.py:881-884,974-977); +-inf = absent
+    wmax: np.ndarray = None
     estimator: str = "mhe"          # 'mhe' | 'ekf': the example's estimator switch (Ex_ENMPC.py:109-123, mhe_mod)
     Q_kf: Optional[np.ndarray] = None      # extended Kalman filter on [x; d]: process / measurement noise covariances (Estimator.py:313-386); P0 is P(0|-1)
     R_kf: Optional[np.ndarray] = None
@@ -116,7 +118,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     has = lambda k: k in ns and ns[k] is not None and not k.startswith("__")
     for bad in ("User_fobj_Dis", "User_fobj_Coll", "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "Q", "Qss",
                 "def_px", "def_py", "def_pxmp", "def_pymp", "def_pxp", "def_pyp", "A", "User_fxm_Dis", "User_fxp_Dis", "User_fym", "User_fyp",
-                "R_wn", "G_wn", "defSP", "ymin", "ymax", "ymin_dyn", "ymax_dyn", "Dumin", "Dumax", "wmin", "wmax", "vmin", "vmax", "User_fx_mhe_Dis",
+                "R_wn", "G_wn", "defSP", "ymin", "ymax", "ymin_dyn", "ymax_dyn", "Dumin", "Dumax", "vmin", "vmax", "User_fx_mhe_Dis",
                 "r_w", "Q_mhe"):
         if has(bad):
             raise UnsupportedProblem(f"'{bad}' is outside the economic path built so far")
@@ -194,6 +196,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         x0_p=_vec(ns["x0_p"], nxp, 0.0), x0_m=_vec(ns["x0_m"], nx, 0.0), u0=_vec(ns["u0"], nu, 0.0), max_iter=int(ns.get("Sol_itmax", 100)),
         N_mhe=N_mhe, mhe_up=str(ns.get("mhe_up", "smooth")), n_w=n_w, G_mhe=G, P0=_mat(ns["P0"], nx + nd, nx + nd, "P0"),
         x_bar=(np.asarray(ns["x_bar"], dtype=np.float64).reshape(nx + nd) if use_mhe else np.concatenate([_vec(ns["x0_m"], nx, 0.0), np.zeros(nd)])),
+        wmin=_vec(ns.get("wmin") if use_mhe else None, n_w, -INF), wmax=_vec(ns.get("wmax") if use_mhe else None, n_w, INF),
         estimator="mhe" if use_mhe else "ekf",
         Q_kf=None if use_mhe else _mat(ns["Q_kf"], nx + nd, nx + nd, "Q_kf"), R_kf=None if use_mhe else _mat(ns["R_kf"], ny, ny, "R_kf"),
         xmin_mhe=np.concatenate([_vec(ns.get("xmin"), nx, -INF), _vec(ns.get("dmin"), nd, -INF)]),      # MPC_code.py:397-402

@@ -29,7 +29,7 @@ class _EDesc(ct.Structure):
     _fields_ = ([(k, ct.c_int32) for k in ("nx", "nu", "ny", "nd", "nxp", "nw", "N", "N_mhe", "max_iter", "quad_steps", "device", "mhe_update", "estimator")]
                 + [(k, ct.c_double) for k in ("h", "tol", "tol_mhe")]
                 + [(k, _dp) for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe",
-                                      "dmin", "dmax", "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0", "Q_kf", "R_kf")])
+                                      "dmin", "dmax", "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0", "Q_kf", "R_kf", "wmin", "wmax")])
 
 
 _libs: Dict[str, ct.CDLL] = {}
@@ -96,7 +96,7 @@ class EnmpcSolver:
         d.mhe_update = {"smooth": 0, "filter": 1}[p.mhe_up]
         d.estimator = {"mhe": 0, "ekf": 1}[getattr(p, "estimator", "mhe")]
         for k in ("umin", "umax", "xmin", "xmax", "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss", "xmin_mhe", "xmax_mhe", "dmin", "dmax",
-                  "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0", "Q_kf", "R_kf"):
+                  "Bd", "Cd", "G_mhe", "P0", "x0_m", "u0", "Q_kf", "R_kf", "wmin", "wmax"):
             v = getattr(p, k, None)
             if v is None:
                 setattr(d, k, None)

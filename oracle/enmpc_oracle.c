@@ -38,6 +38,7 @@ typedef struct {
     double Bd[NX][ND], Cd[NY][ND], G[NE][NW], P0[NE][NE], x0m[NX], u0[NU];
     int32_t est_ekf, pad_;       /* estimator: 0 the moving-horizon estimator, 1 the extended Kalman filter on [x; d] (Ex_ENMPC.py:109-123, mhe_mod = 'off') */
     double Qkf[NE][NE], Rkf[NY][NY];
+    double wlo[NW], whi[NW];     /* bounds of the estimator's state noise (Utilities.py:881-884,974-977); +-INFINITY = absent */
 } EProb;
 
 /* ---- the example's functions (hand-written; checked against the Ex-file by the Python wrapper) --------------------------------------- */
@@ -384,7 +385,7 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
     for (int k = 0; k <= N; k++) {
         for (int i = 0; i < NE; i++) { w[NB * k + i] = creal(xc[i]); lo[NB * k + i] = P->elo[i]; hi[NB * k + i] = P->ehi[i]; }
         if (k < N) {
-            for (int i = NE; i < NB; i++) { lo[NB * k + i] = -INFINITY; hi[NB * k + i] = INFINITY; }
+            for (int i = NE; i < NB; i++) { lo[NB * k + i] = i < NE + NY ? -INFINITY : P->wlo[i - NE - NY]; hi[NB * k + i] = i < NE + NY ? INFINITY : P->whi[i - NE - NY]; }
             mhe_map(P, xc, S->U[k], wz, xo);
             for (int i = 0; i < NE; i++) xc[i] = xo[i];
         }

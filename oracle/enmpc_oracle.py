@@ -87,8 +87,9 @@ def load_problem(path, overrides=None, quad_steps=20):
         ne = p.nx + p.nd
         p.xmin_mhe = np.concatenate([_vec(ns.get("xmin"), p.nx, -INF), _vec(ns.get("dmin"), p.nd, -INF)])      # MPC_code.py:397-402
         p.xmax_mhe = np.concatenate([_vec(ns.get("xmax"), p.nx, INF), _vec(ns.get("dmax"), p.nd, INF)])
-        for k in ("wmin", "wmax", "vmin", "vmax"):
-            assert ns.get(k) is None, "noise bounds are not restated here"
+        p.wmin, p.wmax = _vec(ns.get("wmin"), p.n_w, -INF), _vec(ns.get("wmax"), p.n_w, INF)      # bounds of the state noise (Utilities.py:881-884,974-977)
+        for k in ("vmin", "vmax"):
+            assert ns.get(k) is None, "bounds of the output noise are not restated here"
         assert p.G_mhe.shape == (ne, p.n_w)
     p.ekf = bool(ns.get("ekf", False))
     if not p.mhe:      # the example's other estimator (Ex_ENMPC.py:109-123, mhe_mod = 'off'): the extended Kalman filter on [x; d]
@@ -858,6 +859,8 @@ def mhe_eval(p, N, Us, Ys, x_bar, Pinv, t=0.0):
     lo = np.full(nopt, -INF); hi = np.full(nopt, INF)
     for k in range(N + 1):                                   # Utilities.py:956-966: the state boxes on every X_k
         lo[nb * k: nb * k + ne], hi[nb * k: nb * k + ne] = p.xmin_mhe, p.xmax_mhe
+    for k in range(N):                                       # :968-977: the boxes of the state noise
+        lo[nb * k + ne + q: nb * (k + 1)], hi[nb * k + ne + q: nb * (k + 1)] = p.wmin, p.wmax
     return evalf, lo, hi
 
 

@@ -26,7 +26,8 @@ class _EProb(ct.Structure):
                 + [("par", ct.c_double * 7), ("umin", ct.c_double * NU), ("umax", ct.c_double * NU), ("xmin", ct.c_double * NX), ("xmax", ct.c_double * NX),
                    ("tlo", ct.c_double * NV), ("thi", ct.c_double * NV), ("elo", ct.c_double * NE), ("ehi", ct.c_double * NE), ("dmin", ct.c_double * ND), ("dmax", ct.c_double * ND),
                    ("Bd", ct.c_double * (NX * ND)), ("Cd", ct.c_double * (NY * ND)), ("G", ct.c_double * (NE * NW)), ("P0", ct.c_double * (NE * NE)),
-                   ("x0m", ct.c_double * NX), ("u0", ct.c_double * NU), ("est_ekf", ct.c_int32), ("pad_", ct.c_int32), ("Qkf", ct.c_double * (NE * NE)), ("Rkf", ct.c_double * (NY * NY))])
+                   ("x0m", ct.c_double * NX), ("u0", ct.c_double * NU), ("est_ekf", ct.c_int32), ("pad_", ct.c_int32), ("Qkf", ct.c_double * (NE * NE)), ("Rkf", ct.c_double * (NY * NY)),
+                   ("wlo", ct.c_double * NW), ("whi", ct.c_double * NW)])
 
 
 def build(fast=False):
@@ -64,8 +65,9 @@ class OracleEC:
         if not p.mhe:
             fill(s.Qkf, p.Q_kf); fill(s.Rkf, p.R_kf)
         fill(s.tlo, np.concatenate([p.xmin_ss, p.umin_ss, p.ymin_ss])); fill(s.thi, np.concatenate([p.xmax_ss, p.umax_ss, p.ymax_ss]))
+        fill(s.wlo, [-np.inf] * NW); fill(s.whi, [np.inf] * NW)
         if p.mhe:
-            fill(s.elo, p.xmin_mhe); fill(s.ehi, p.xmax_mhe)
+            fill(s.elo, p.xmin_mhe); fill(s.ehi, p.xmax_mhe); fill(s.wlo, p.wmin); fill(s.whi, p.wmax)
         fill(s.dmin, p.dmin if p.dmin is not None else [-np.inf] * ND); fill(s.dmax, p.dmax if p.dmax is not None else [np.inf] * ND)
         self.s = s
         self._check_functions()

@@ -224,6 +224,23 @@ def test_extended_kalman_filter_variant_restatements_agree_and_reproduce_their_v
             assert np.array_equal(c[k], g[pre + k][:n]), (pre, k)
 
 
+W_BOUNDS = {"wmin": np.array([-1e-3, -1e-3, -0.02, -0.02]), "wmax": np.array([1e-3, 1e-3, 0.02, 0.02]), "N": 12, "N_mhe": 6}
+
+
+def test_estimator_with_bounded_state_noise_restatements_agree():
+    """mhe_opt's boxes on the state noise (wmin / wmax, Utilities.py:881-884,974-977): both restatements solve the estimator's NLP with them - the same loop to
+    rounding - and the boxes matter (the estimate moves by 0.08 against the unbounded estimator's)."""
+    import enmpc_oracle_c as ec
+    q, q0 = eo.load_problem(EX, overrides=W_BOUNDS), eo.load_problem(EX, overrides={"N": 12, "N_mhe": 6})
+    r, r0 = eo.closed_loop(q, 8), eo.closed_loop(q0, 8)
+    c = ec.OracleEC(q).closed_loop(8, q.x0_p[None], nthreads=1)
+    for k in ("U", "XS", "US", "X_ES", "Xp"):
+        assert np.abs(r[k] - c[k][:, 0]).max() < 1e-9, k
+    for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+        assert np.array_equal(r[k], c[k][:, 0]), k
+    assert int(r["STATUS_MHE"].max()) == 0 and np.abs(r["X_ES"] - r0["X_ES"]).max() > 0.05
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "Ex_ENMPC.py")), reason="reference tree not present")
 def test_reference_example_with_its_estimator_switch_off_is_the_filter_variant(pkg, tmp_path):
     """The switch is a source line of the reference's file (mhe_mod = 'on', Ex_ENMPC.py:109), evaluated while the file runs: a copy with that one line changed
@@ -252,6 +269,10 @@ def test_loader_classifies_and_refuses(pkg, prob):
     for over in ({"mhe_up": "window"}, {"slacks": True}, {"N": 80}, {"N_mhe": 64}, {"StateFeedback": False}, {"TermCons": True}, {"ekf": True}, {"mhe": False}):
         with pytest.raises(UnsupportedProblem):      # (the last two: both estimators, none)
             pkg.load_problem(EX, overrides=over)
+    pw = pkg.load_problem(EX, overrides=W_BOUNDS)
+    assert np.array_equal(pw.wmax, W_BOUNDS["wmax"]) and np.all(np.isinf(prob.wmin)) and np.all(np.isinf(prob.wmax))
+    with pytest.raises(UnsupportedProblem):      # the output noise is eliminated from the estimator's NLP here: no boxes on it
+        pkg.load_problem(EX, overrides={"vmax": np.array([0.1, 0.1])})
     pe = pkg.load_problem(EX_EKF)
     assert prob.estimator == "mhe" and pe.estimator == "ekf" and np.array_equal(np.diag(pe.Q_kf), [1e-8, 1e-8, 1.0, 1.0]) and np.array_equal(pe.P0, 1e-8 * np.eye(4))
     with pytest.raises(UnsupportedProblem):
@@ -425,6 +446,44 @@ def test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restateme
             assert np.array_equal(a[k], b[k]), k
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("more", [{}, {"mhe_up": "filter", "N_mhe": 18}])
+def test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, more):
+    """wmin / wmax (Utilities.py:881-884,974-977): the library generated for such a problem (build info wb=1) carries the boxes of the noise in the estimator's
+    solver - every launch style against the C restatement on 70 starts, the seam against the resident loop; a library generated without them refuses them."""
+    import warnings
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc, econcodegen
+    from mpc_code_amd.capi import MpcAmdError
+    over = dict(W_BOUNDS, **more)
+    K = 24 if more else 12
+    x0 = np.random.default_rng(3).uniform([0.5, 0.0], [1.0, 0.5], size=(70, 2))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = pkg.load_problem(EX, overrides=over)
+        c = ec.OracleEC(eo.load_problem(EX, overrides=over)).closed_loop(K, x0, nthreads=0)
+    assert int(c["STATUS_MHE"].max()) == 0
+    s = enmpc.EnmpcSolver(p)
+    try:
+        assert s.lib.enmpc_build_info().decode().endswith("wb=1")
+        for kernel in (1, 2, 64):
+            r = enmpc.run_enmpc_closed_loop(p, x0, K, solver=s, kernel=kernel)
+            for k in ("U", "XS", "US", "X_ES", "Xp"):
+                assert np.abs(r[k] - c[k]).max() < TOL_U, (kernel, k, np.abs(r[k] - c[k]).max())
+            for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS"):
+                assert np.array_equal(r[k], c[k]), (kernel, k)
+            d = np.abs(r["ITERS_MHE"].astype(int) - c["ITERS_MHE"])      # (tol 1e-10: 'E_0 <= tol' an iteration apart in a few per cent of the solves, as in the randomised models)
+            assert d.max() <= 1 and (d != 0).mean() < 0.05, (kernel, int((d != 0).sum()))
+        a, b = enmpc.run_enmpc_closed_loop(p, x0, K, solver=s, kernel=2), enmpc.run_enmpc_stepwise(p, x0, K, solver=s)
+        for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "X_ES", "STATUS_MHE", "ITERS_MHE", "ITERS_DYN"):
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        s.close()
+    if not more:
+        with pytest.raises(MpcAmdError):      # the shipped example's library has no rows for them
+            enmpc.EnmpcSolver(p, lib_path=econcodegen.build_enmpc_library(pkg.load_problem(EX)))
 
 
 @pytest.mark.gpu
