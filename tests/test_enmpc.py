@@ -224,6 +224,22 @@ def test_extended_kalman_filter_variant_restatements_agree_and_reproduce_their_v
             assert np.array_equal(c[k], g[pre + k][:n]), (pre, k)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "tests", "golden", "ipopt_enmpc.npz")), reason="no IPOPT vectors (tools/make_ipopt_vectors.py econ needs CasADi)")
+def test_ipopt_vectors_if_present(oprob):
+    """Where a machine with CasADi has written tests/golden/ipopt_enmpc.npz: the restated interior point against IPOPT itself on the same discretised NLPs from the
+    same guesses - solutions to 1e-6, return status, and the iteration counts side by side (equal where the restatement is faithful; reported, and required within 2)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ipopt_enmpc.npz"), allow_pickle=True)
+    n, m, N = oprob.nx, oprob.nu, oprob.N
+    w0 = np.concatenate([np.concatenate([oprob.x0_m, oprob.u0])] * N + [oprob.x0_m])
+    for i in range(len(g["D"])):
+        ts = eo.target_solve(oprob, g["D"][i])
+        assert (ts["status"] == 0) == (str(g["STATUS_T"][i]) == "Solve_Succeeded") and np.abs(ts["w"] - g["WT"][i]).max() < 1e-6
+        assert abs(int(ts["iters"]) - int(g["ITERS_T"][i])) <= 2, (i, ts["iters"], g["ITERS_T"][i])
+        sol = eo.ocp_solve(oprob, g["XHAT"][i], g["WT"][i][:n], g["WT"][i][n:n + m], g["D"][i], w0)
+        assert (sol["status"] == 0) == (str(g["STATUS"][i]) == "Solve_Succeeded") and np.abs(sol["w"] - g["W"][i]).max() < 1e-6
+        assert abs(int(sol["iters"]) - int(g["ITERS"][i])) <= 2, (i, sol["iters"], g["ITERS"][i])
+
+
 W_BOUNDS = {"wmin": np.array([-1e-3, -1e-3, -0.02, -0.02]), "wmax": np.array([1e-3, 1e-3, 0.02, 0.02]), "N": 12, "N_mhe": 6}
 
 

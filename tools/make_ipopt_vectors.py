@@ -5,6 +5,7 @@ The build container has no CasADi, so parity with IPOPT is pinned by mathematics
 machine where ``import casadi`` succeeds this script adds true IPOPT vectors:
 
     python3 tools/make_ipopt_vectors.py            # writes tests/golden/ipopt_*.npz
+    python3 tools/make_ipopt_vectors.py econ /path/to/MPC-code      # the economic example's target NLP and OCP: tests/golden/ipopt_enmpc.npz (see econ_vectors)
 
 It poses the NLP of ``opt_dyn`` (Control_Calc.py:20-260) in its own variable / constraint layout - built here from the
 dense matrices of oracle/mpc_oracle.py:ocp_qp, which restates Control_Calc.py:126-252 row by row - hands it to
@@ -39,12 +40,83 @@ def ipopt_qp(ca, H, g, E, e, G, lo, hi, w0, max_iter):
     return np.array(sol["x"]).ravel(), float(sol["f"]), solver.stats()["return_status"]
 
 
+def econ_vectors(ca, ref_dir):
+    """The economic example's target NLP and OCP (mpc-code_amd/examples/reactor_enmpc.py, which needs CasADi and the reference's ``Utilities.py`` to run as it is)
+    as THIS project discretises them - Mx resp. quad_steps classical Runge-Kutta steps per interval, cost quadrature in the integrator state (oracle/enmpc_oracle.py:
+    fx_model, ocp_stage; the reference integrates the interval with IDAS) - solved by IPOPT at its defaults + max_iter = Sol_itmax (MPC_code.py:262-263).  What the vectors
+    pin is the restated interior point: solution, objective, ITERATION COUNT and return status of the same NLP from the same guess.
+    Written without a CasADi to run it against (the build container has none): treat a failure in here as a bug of this script, not of the library."""
+    import runpy
+    sys.path.insert(0, ref_dir)      # the Ex-file does `from Utilities import *`
+    ns = runpy.run_path(os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc.py"))
+    nx, nu, ny, nd = (ns[k].size1() for k in ("x", "u", "y", "d"))
+    N, h, Mx, quad = int(ns["N"]), float(ns["h"]), int(ns.get("Mx", 10)), 20
+    Bd, Cd = ca.DM(np.asarray(ns["Bd"], dtype=float)), ca.DM(np.asarray(ns["Cd"], dtype=float))
+    fxm, fobj, fss, vfin = ns["User_fxm_Cont"], ns["User_fobj_Cont"], ns["User_fssobj"], ns.get("User_vfin")
+    vec = lambda v, n_, fill: np.full(n_, fill) if v is None else np.asarray(v, dtype=float).reshape(n_)
+    opts = {"ipopt.max_iter": int(ns.get("Sol_itmax", 100)), "ipopt.print_level": 0, "ipopt.sb": "yes", "print_time": 0}
+
+    def rk4(rhs, z, steps):
+        dt = h / steps
+        for _ in range(steps):
+            k1 = rhs(z); k2 = rhs(z + 0.5 * dt * k1); k3 = rhs(z + 0.5 * dt * k2); k4 = rhs(z + dt * k3)
+            z = z + dt / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        return z
+    zero_x = ca.DM.zeros(nx)
+    dpar = ca.SX.sym("dpar", nd)
+    # ---- target: w = [xs; us; ys], g = [Fx_model(xs, us, d) - xs; xs + Cd d - ys] (Target_Calc.py:73-81), cold start (MPC_code.py:696-700)
+    wt = ca.SX.sym("wt", nx + nu + ny)
+    xs_, us_, ys_ = wt[:nx], wt[nx:nx + nu], wt[nx + nu:]
+    Fx = rk4(lambda z: fxm(z, us_, dpar, 0.0, zero_x), xs_, Mx) + ca.mtimes(Bd, dpar)
+    gt = ca.vertcat(Fx - xs_, xs_ + ca.mtimes(Cd, dpar) - ys_)
+    ft = fss(xs_, us_, ys_, ca.DM.zeros(nx), ca.DM.zeros(nu), ca.DM.zeros(ny))
+    st = ca.nlpsol("target", "ipopt", {"x": wt, "p": dpar, "f": ft, "g": gt}, opts)
+    pick = lambda b, sfx, n_, fill: vec(ns.get(b + sfx) if ns.get(b + sfx) is not None else ns.get(b), n_, fill)
+    lot = np.concatenate([pick("xmin", "_ss", nx, -np.inf), pick("umin", "_ss", nu, -np.inf), pick("ymin", "_ss", ny, -np.inf)])
+    hit = np.concatenate([pick("xmax", "_ss", nx, np.inf), pick("umax", "_ss", nu, np.inf), pick("ymax", "_ss", ny, np.inf)])
+    # ---- OCP: w = [x0, u0, x1, ..., x_N] (Control_Calc.py:31-37), x0 fixed by equal bounds (MPC_code.py:734), g_k = x_{k+1} - X_k(h), f = sum q_k + Vfin
+    nz = nx + nu
+    wd = ca.SX.sym("wd", nz * N + nx)
+    par = ca.SX.sym("par", nx + nu + nd)      # xs, us, d
+    pxs, pus, pd = par[:nx], par[nx:nx + nu], par[nx + nu:]
+    pys = pxs + ca.mtimes(Cd, pd)
+    g, f = [], 0
+    for k in range(N):
+        xk, uk, xn = wd[nz * k: nz * k + nx], wd[nz * k + nx: nz * (k + 1)], wd[nz * (k + 1): nz * (k + 1) + nx]
+        zk = rk4(lambda z: ca.vertcat(fxm(z[:nx], uk, pd, 0.0, zero_x), fobj(z[:nx], uk, z[:nx] + ca.mtimes(Cd, pd), pxs, pus, pys)), ca.vertcat(xk, 0), quad)
+        g.append(xn - zk[:nx]); f = f + zk[nx]
+    if vfin is not None:
+        f = f + vfin(wd[nz * N:], pxs)
+    sd = ca.nlpsol("ocp", "ipopt", {"x": wd, "p": par, "f": f, "g": ca.vertcat(*g)}, opts)
+    umin, umax, xmin, xmax = pick("umin", "_dyn", nu, -np.inf), pick("umax", "_dyn", nu, np.inf), pick("xmin", "_dyn", nx, -np.inf), pick("xmax", "_dyn", nx, np.inf)
+    x0_m, u0 = vec(ns["x0_m"], nx, 0.0), vec(ns["u0"], nu, 0.0)
+    rng = np.random.default_rng(20250614)
+    rec = {k: [] for k in ("D", "XHAT", "WT", "FT", "ITERS_T", "STATUS_T", "W", "F", "ITERS", "STATUS")}
+    for _ in range(24):
+        d = rng.uniform(-0.05, 0.05, nd); xhat = rng.uniform([0.5, 0.0], [1.0, 0.5])
+        w0t = np.concatenate([x0_m, u0, x0_m + np.asarray(ns["Cd"], dtype=float) @ d])
+        sol = st(x0=w0t, p=d, lbx=lot, ubx=hit, lbg=0, ubg=0)
+        wts = np.array(sol["x"]).ravel()
+        rec["D"].append(d); rec["XHAT"].append(xhat); rec["WT"].append(wts); rec["FT"].append(float(sol["f"]))
+        rec["ITERS_T"].append(int(st.stats()["iter_count"])); rec["STATUS_T"].append(st.stats()["return_status"])
+        lo = np.concatenate([np.concatenate([xmin, umin])] * N + [xmin]); hi = np.concatenate([np.concatenate([xmax, umax])] * N + [xmax])
+        lo[:nx] = hi[:nx] = xhat
+        w0 = np.concatenate([np.concatenate([x0_m, u0])] * N + [x0_m]); w0[:nx] = xhat      # MPC_code.py:740-756
+        sol = sd(x0=w0, p=np.concatenate([wts[:nx], wts[nx:nx + nu], d]), lbx=lo, ubx=hi, lbg=0, ubg=0)
+        rec["W"].append(np.array(sol["x"]).ravel()); rec["F"].append(float(sol["f"]))
+        rec["ITERS"].append(int(sd.stats()["iter_count"])); rec["STATUS"].append(sd.stats()["return_status"])
+    np.savez_compressed(os.path.join(GOLD, "ipopt_enmpc.npz"), **{k: np.array(v) for k, v in rec.items()})
+    print("enmpc written: 24 target + OCP solves, iterations", rec["ITERS_T"][:6], rec["ITERS"][:6])
+
+
 def main():
     try:
         import casadi as ca
     except ImportError:
         print("casadi is not importable here: no IPOPT vectors written (the mathematical pinning of tests/golden/ stands)")
         return 0
+    if len(sys.argv) > 2 and sys.argv[1] == "econ":      # python3 tools/make_ipopt_vectors.py econ /path/to/MPC-code   (the reference tree: its Utilities.py)
+        return econ_vectors(ca, sys.argv[2]) or 0
     import mpc_code_amd as m
     import mpc_oracle as o
     rng = np.random.default_rng(20250614)
