@@ -68,6 +68,7 @@ class NonlinearMPCProblem:
     dhat0: np.ndarray = None
     max_iter: int = 100
     defSP: Optional[Callable] = None
+    R_wn: Optional[np.ndarray] = None      # covariance of the white noise the reference adds to every measurement (MPC_code.py:538-541): run_nmpc_stepwise(noise_seed=...)
     name: str = ""
     ycols: List[int] = None         # output row i is state ycols[i] (bounded outputs are boxes on states)
     discrete: bool = False          # f is the discrete map Fx (User_fxm_Dis, Utilities.py:186-198), not a right-hand side to integrate
@@ -165,9 +166,10 @@ def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMP
             raise UnsupportedProblem(f"'{bad}' is outside the non-linear path built so far")
     if has("R_wn"):
         # the reference adds UNSEEDED Gaussian noise to every measurement (MPC_code.py:538-541): a run is not reproducible even there.
-        # The batched loop is deterministic and runs noise-free - said out loud, not silently (Ex_NMPC.py ships R_wn)
+        # The resident batched loop is deterministic and runs noise-free - said out loud, not silently (Ex_NMPC.py ships R_wn); the loop through the per-call seam
+        # (nmpc.run_nmpc_stepwise, where the measurement is the caller's) adds seeded noise of this covariance when asked to
         import warnings
-        warnings.warn("R_wn: the measurement noise of the example (unseeded in the reference, MPC_code.py:538-541) is not simulated; the loop runs noise-free", UserWarning, stacklevel=3)
+        warnings.warn("R_wn: the measurement noise of the example (unseeded in the reference, MPC_code.py:538-541) is not simulated in the resident loop, which runs noise-free; nmpc.run_nmpc_stepwise(noise_seed=...) adds it", UserWarning, stacklevel=3)
     for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks", "TermCons", "mhe", "ContForm",
                  "DUFormEcon", "kal", "kalss", "estimating"):
         if ns.get(flag, False) is True:
@@ -274,7 +276,7 @@ def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMP
         Q_kf=_mat(ns["Q_kf"], nx + nd, nx + nd, "Q_kf") if est == "ekf" else None, R_kf=_mat(ns["R_kf"], ny, ny, "R_kf") if est == "ekf" else None, P0=P0,
         x0_p=_vec(ns["x0_p"], nxp, 0.0), x0_m=_vec(ns["x0_m"], nx, 0.0), u0=_vec(ns["u0"], nu, 0.0),
         dhat0=_vec(ns.get("dhat0"), nd, 0.0) if has("dhat0") else np.zeros(nd),
-        max_iter=int(ns.get("Sol_itmax", 100)), defSP=ns.get("defSP"), name=name or str(ns.get("__name__", "")), ycols=ycols,
+        max_iter=int(ns.get("Sol_itmax", 100)), defSP=ns.get("defSP"), R_wn=(_mat(ns["R_wn"], ny, ny, "R_wn") if has("R_wn") else None), name=name or str(ns.get("__name__", "")), ycols=ycols,
         funcs={k: ns[k] for k in ("User_fxm_Cont", "User_fxm_Dis", "User_fym", "User_fxp_Cont", "User_fxp_Dis", "User_fyp") if has(k)},
         discrete=discrete, plant_discrete=plant_discrete, offree=offree, Bd=Bd, Cd=Cd, estimator=est,
         K=_mat(ns["K"], nx + nd, ny, "K") if est == "lue" else None, DUForm=DUForm, DUssForm=DUssForm,

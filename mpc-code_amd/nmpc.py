@@ -224,10 +224,12 @@ class NmpcSolver:
 
 
 def run_nmpc_stepwise(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[NmpcSolver] = None, max_sqp: int = 1, sqp_tol: float = 1e-9,
-                      device: int = 0, plant=None) -> Dict[str, np.ndarray]:
+                      device: int = 0, plant=None, noise_seed: Optional[int] = None) -> Dict[str, np.ndarray]:
     """The reference's loop body call by call (MPC_code.py:485-827): per step the measurement (the Ex-file's plant output on the host), ``ekf_update``
     (defEstimator), ``target_solve`` (solver_ss), ``ocp_solve`` (solver) and the plant - ``plant(x_p [B, nxp], u [B, nu], t) -> x_p+`` of the caller, or the
-    device's.  With the device's plant: :func:`run_nmpc_closed_loop` on the instance-per-lane kernel to the bit (when the plant output is exact on the host)."""
+    device's.  With the device's plant: :func:`run_nmpc_closed_loop` on the instance-per-lane kernel to the bit (when the plant output is exact on the host).
+    ``noise_seed``: the white noise of the example's ``R_wn`` on every measurement, ``y_k += sqrtm(R_wn) N(0, I)`` (MPC_code.py:538-541; unseeded there), one draw per
+    step and instance from ``numpy.random.default_rng(noise_seed)``; the draws come back as ``V_WN`` [nsteps, B, ny]."""
     p = problem
     nsteps = p.Nsim if nsteps is None else int(nsteps)
     x_p = (p.x0_p[None] if x0_p is None else np.atleast_2d(np.asarray(x0_p, dtype=np.float64))).copy()
@@ -245,10 +247,20 @@ def run_nmpc_stepwise(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = Non
         u, xs, us = _rows(p.u0, B, p.nu).copy(), xhat.copy(), _rows(p.u0, B, p.nu).copy()
         keys = ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "SQP_DYN", "SQP_SS")
         out = {k: [] for k in keys}
+        Rv = rng = None
+        if noise_seed is not None:
+            if getattr(p, "R_wn", None) is None:
+                raise ValueError("noise_seed: the example defines no R_wn")
+            ev, evec = np.linalg.eigh(0.5 * (p.R_wn + p.R_wn.T))      # the symmetric square root scipy.linalg.sqrtm returns for a covariance
+            Rv, rng = (evec * np.sqrt(np.maximum(ev, 0.0))) @ evec.T, np.random.default_rng(noise_seed)
+            out["V_WN"] = []
         for k in range(nsteps):
             t = k * p.h
             out["Xp"].append(x_p.copy()); out["X_HAT"].append(xhat.copy())
             y = p.plant_output(x_p, u, t) + sch["pyp"][k]                    # MPC_code.py:531-534
+            if rng is not None:                                              # :537-541
+                v = rng.standard_normal((B, p.ny)) @ Rv.T
+                y = y + v; out["V_WN"].append(v)
             xhat, dhat, P = s.ekf_update(y, u, xhat, dhat, P)
             xs, us, st_s, sq_s = s.target_solve(dhat, sch["ysp"][k], sch["usp"][k], xs, us)
             u, xhat, st_d, it_d, sq_d = s.ocp_solve(xhat, dhat, xs, us, u, max_sqp, sqp_tol)

@@ -215,7 +215,7 @@ static void ekf(const NProb *P, double *xi, double *Pk /* [NE][NE] */, const dou
 /* ---- closed loop of B instances (MPC_code.py:485-827); schedules [step][dim], logs [step][B][dim] -------------------------------------- */
 int norc_closed_loop(const NProb *P, int B, int nsteps, const double *x0_p, const double *x0_m, const double *ysp, const double *usp, const double *pxp, const double *pyp,
                      int max_sqp, double sqp_tol, double *U, double *XHAT, double *XS, double *US, double *XP, double *DHAT,
-                     int32_t *st_dyn, int32_t *st_ss, int32_t *sqp_dyn, int nthreads)
+                     int32_t *st_dyn, int32_t *st_ss, int32_t *sqp_dyn, int nthreads, const double *v_wn /* [nsteps][B][NY] white noise on the measurement (MPC_code.py:537-541), or NULL */)
 {
     const int N = P->N;
 #ifdef _OPENMP
@@ -237,7 +237,7 @@ int norc_closed_loop(const NProb *P, int B, int nsteps, const double *x0_p, cons
             if (XP) for (int i = 0; i < NX; i++) XP[o * NX + i] = x[i];
             if (XHAT) for (int i = 0; i < NX; i++) XHAT[o * NX + i] = xi[i];
             double y[NY];
-            for (int r = 0; r < NY; r++) y[r] = x[YCOL[r]] + pyp[NY * k + r];
+            for (int r = 0; r < NY; r++) y[r] = x[YCOL[r]] + pyp[NY * k + r] + (v_wn ? v_wn[o * NY + r] : 0.0);
             ekf(P, xi, Pk, y, u);
             if (P->has_dsat) for (int i = 0; i < ND; i++) xi[NX + i] = fmin(fmax(xi[NX + i], P->dmin[i]), P->dmax[i]);
             if (DHAT) for (int i = 0; i < ND; i++) DHAT[o * ND + i] = xi[NX + i];

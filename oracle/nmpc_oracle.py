@@ -358,7 +358,7 @@ def kkt_nlp(p, w, xhat, xs, us, d, t=0.0, u_prev=None):
 # ---------------------------------------------------------------------------------------------------
 # the closed loop, one instance: MPC_code.py:485-827
 # ---------------------------------------------------------------------------------------------------
-def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certify=False):
+def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certify=False, v_wn=None):
     n, m, N = p.nx, p.nu, p.N
     nxu = n + m
     x = np.array(p.x0_p if x0_p is None else x0_p, dtype=np.float64)
@@ -374,6 +374,8 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, max_sqp=50, sqp_tol=1e-9, certi
         t = k * p.h
         L["Xp"].append(x.copy()); L["X_HAT"].append(xhat.copy())
         y = plant_fy(p, x, u, t, sched["pyp"][k])                              # :531-534
+        if v_wn is not None:                                                   # :537-541: white noise on the measurement (v_wn [nsteps, ny]: the draws, sqrtm(R_wn) applied)
+            y = y + v_wn[k]
         L["Yp"].append(y.copy())
         if lue:                                                               # xi+ = xi + K (y - yhat), Estimator.py:231-261
             xi = np.concatenate([xhat, dhat]) + p.K @ (y - model_fy(p, xhat, u, dhat, t))

@@ -70,7 +70,7 @@ class OracleNC:
     def max_threads(self):
         return int(self.lib.norc_max_threads())
 
-    def closed_loop(self, nsteps, x0_p, x0_m=None, max_sqp=1, sqp_tol=1e-9, nthreads=0, logs=True):
+    def closed_loop(self, nsteps, x0_p, x0_m=None, max_sqp=1, sqp_tol=1e-9, nthreads=0, logs=True, v_wn=None):
         p = self.p
         x0 = np.ascontiguousarray(np.atleast_2d(x0_p), dtype=np.float64)
         xm = x0 if x0_m is None else np.ascontiguousarray(np.atleast_2d(x0_m), dtype=np.float64)
@@ -82,6 +82,7 @@ class OracleNC:
         il = {k: np.zeros((nsteps, B), dtype=np.int32) for k in ("STATUS_DYN", "STATUS_SS", "SQP_DYN")} if logs else {}
         ptr = lambda a, t=_dp: a.ctypes.data_as(t) if a is not None else None
         rc = self.lib.norc_closed_loop(ct.byref(self.s), B, int(nsteps), ptr(x0), ptr(xm), ptr(ysp), ptr(usp), ptr(pxp), ptr(pyp), int(max_sqp), ct.c_double(sqp_tol),
-                                       *[ptr(dl.get(k)) for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT")], *[ptr(il.get(k), _ip) for k in ("STATUS_DYN", "STATUS_SS", "SQP_DYN")], int(nthreads))
+                                       *[ptr(dl.get(k)) for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT")], *[ptr(il.get(k), _ip) for k in ("STATUS_DYN", "STATUS_SS", "SQP_DYN")], int(nthreads),
+                                       ptr(None if v_wn is None else c(np.asarray(v_wn).reshape(nsteps, B, NY))))
         assert rc == 0
         return {**dl, **il}

@@ -150,6 +150,22 @@ def test_c_restatement_follows_the_golden_loops(onl, gold):
     assert np.max(np.abs(r["U"] - gold["sqp_U"]) / (1 + np.abs(gold["sqp_U"]))) < 1e-8 and int(r["STATUS_DYN"].max()) == 0
 
 
+def test_restatements_agree_with_white_noise_on_the_measurement(nl, onl):
+    """R_wn of the shipped example (Ex_NMPC.py:108; MPC_code.py:537-541: y_k += sqrtm(R_wn) N(0, I), unseeded there): with the same draws handed to both, the NumPy
+    and the C restatement give the same loop; the noise is in the loop (the estimate moves) and the loader keeps the covariance."""
+    import nmpc_oracle as no
+    import nmpc_oracle_c as nc
+    assert nl.R_wn is not None and np.array_equal(nl.R_wn, 1e-7 * np.eye(2))
+    K = 8
+    v = np.random.default_rng(11).standard_normal((K, 1, 2)) * np.sqrt(1e-7)
+    a = no.closed_loop(onl, K, max_sqp=1, v_wn=v[:, 0])
+    o = nc.OracleNC(onl)
+    c, c0 = o.closed_loop(K, onl.x0_p[None], max_sqp=1, v_wn=v), o.closed_loop(K, onl.x0_p[None], max_sqp=1)
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        assert np.max(np.abs(np.asarray(a[k]).reshape(c[k][:, 0].shape) - c[k][:, 0]) / (1 + np.abs(c[k][:, 0]))) < 1e-7, k
+    assert np.abs(c["D_HAT"] - c0["D_HAT"]).max() > 1e-6
+
+
 def test_golden_converged_rows_satisfy_the_nlp_kkt_conditions(nl, onl, gold):
     """Re-verify the certificate without trusting any solver: dynamics defect, stationarity and bounds of the NLP
     (Control_Calc.py:20-260) at the stored trajectories."""
@@ -395,6 +411,24 @@ def test_gpu_the_three_solver_calls_of_a_step_reproduce_the_fused_loop(nl, solve
     c = nmpc.run_nmpc_stepwise(nl, x0[:8], x0[:8], nsteps=ns, solver=solver, max_sqp=max_sqp, sqp_tol=1e-9, plant=lambda x, u, t: nl.plant_step(x, u, t))
     assert np.max(np.abs(c["U"] - a["U"][:, :8]) / (1 + np.abs(c["U"]))) < 1e-8 and np.array_equal(c["STATUS_DYN"], a["STATUS_DYN"][:, :8])
     solver.set_kernel(0)
+
+
+@pytest.mark.gpu
+def test_gpu_white_noise_on_the_measurement_through_the_per_call_seam(nl, onl, solver):
+    """The shipped example's R_wn (Ex_NMPC.py:108; MPC_code.py:537-541): in the loop through the per-call seam the measurement is the caller's, and
+    run_nmpc_stepwise(noise_seed=...) adds sqrtm(R_wn) N(0, I) to it - the C restatement, handed the same draws, gives the same loop."""
+    import nmpc_oracle_c as nc
+    from mpc_code_amd import nmpc
+    B, ns = 40, 25
+    rng = np.random.default_rng(4)
+    x0 = np.tile(nl.x0_p, (B, 1)) * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, 3)))
+    r = nmpc.run_nmpc_stepwise(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9, noise_seed=7)
+    r0 = nmpc.run_nmpc_stepwise(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9)
+    assert r["V_WN"].shape == (ns, B, 2) and abs(r["V_WN"].std() - np.sqrt(1e-7)) < 0.1 * np.sqrt(1e-7) and np.abs(r["D_HAT"] - r0["D_HAT"]).max() > 1e-6
+    c = nc.OracleNC(onl).closed_loop(ns, x0, x0, max_sqp=1, nthreads=0, v_wn=r["V_WN"])
+    assert np.array_equal(r["STATUS_DYN"], c["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], c["STATUS_SS"])
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+        assert np.max(np.abs(r[k] - c[k]) / (1 + np.abs(c[k]))) < 1e-6, (k, float(np.max(np.abs(r[k] - c[k]) / (1 + np.abs(c[k])))))
 
 
 @pytest.mark.gpu
