@@ -420,12 +420,12 @@ def test_gpu_white_noise_on_the_measurement_through_the_per_call_seam(nl, onl, s
     import nmpc_oracle_c as nc
     from mpc_code_amd import nmpc
     B, ns = 40, 25
-    rng = np.random.default_rng(4)
-    x0 = np.tile(nl.x0_p, (B, 1)) * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, 3)))
-    r = nmpc.run_nmpc_stepwise(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9, noise_seed=7)
-    r0 = nmpc.run_nmpc_stepwise(nl, x0, x0, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9)
+    x0, xm = np.tile(nl.x0_p, (B, 1)), np.tile(nl.x0_m, (B, 1))      # the shipped start, forty noise histories
+    r = nmpc.run_nmpc_stepwise(nl, x0, xm, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9, noise_seed=7)
+    r0 = nmpc.run_nmpc_stepwise(nl, x0, xm, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9)
+    assert int(r["STATUS_DYN"].max()) == 0 and np.isfinite(r["U"]).all() and np.abs(r["U"][:, 0] - r["U"][:, 1]).max() > 0      # the histories differ
     assert r["V_WN"].shape == (ns, B, 2) and abs(r["V_WN"].std() - np.sqrt(1e-7)) < 0.1 * np.sqrt(1e-7) and np.abs(r["D_HAT"] - r0["D_HAT"]).max() > 1e-6
-    c = nc.OracleNC(onl).closed_loop(ns, x0, x0, max_sqp=1, nthreads=0, v_wn=r["V_WN"])
+    c = nc.OracleNC(onl).closed_loop(ns, x0, xm, max_sqp=1, nthreads=0, v_wn=r["V_WN"])
     assert np.array_equal(r["STATUS_DYN"], c["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], c["STATUS_SS"])
     for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
         assert np.max(np.abs(r[k] - c[k]) / (1 + np.abs(c[k]))) < 1e-6, (k, float(np.max(np.abs(r[k] - c[k]) / (1 + np.abs(c[k])))))
