@@ -30,7 +30,7 @@ for a in MODE:
     out = []
     for b in PERT:
         try:
-            o = subprocess.run([sys.executable, __file__, a, b], capture_output=True, text=True, timeout=25).stdout.strip().split("\n")[-1]
+            o = subprocess.run([sys.executable, __file__, a, b], capture_output=True, text=True, timeout=25, env=dict(os.environ, ENMPC_NO_SELFTEST="1")).stdout.strip().split("\n")[-1]
         except subprocess.TimeoutExpired:
             o = "T"
         out.append(f"{b}:{o}")
