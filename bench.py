@@ -477,7 +477,8 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0, help="closed-loop steps per kernel launch (0: library default)")
     ap.add_argument("--loop-kernel", type=int, default=0, help="0: library default, 1: instance per lane, 2: horizon-parallel, 3: wave-autonomous")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions (0: as many as fill --min-seconds)")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="GPU time to spend in timed regions")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="GPU time to spend in timed regions (of this workload and of each of the other configs' child runs: "
+                                                                   "twelve seconds of busy GPU in the default run, which a utilisation sampler can see between the CPU baselines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="create the RCCL communicator even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--config", default="lmpc", choices=["lmpc", "nmpc", "enmpc", "mhe"], help="lmpc: the metric workload (BASELINE configs[1]); nmpc: "
