@@ -59,6 +59,9 @@ int nmpc_set_state(nmpc_handle *h, const double *x_p, const double *xhat, const 
 /* pxp [nsteps][nxp], pyp [nsteps][ny]: the plant's disturbances def_pxp(t), def_pyp(t) (MPC_code.py:512-515), or NULL */
 int nmpc_set_schedule(nmpc_handle *h, int32_t nsteps, const double *ysp /* [nsteps][ny] */, const double *usp /* [nsteps][nu] */,
                       const double *pxp, const double *pyp);
+/* white noise on the measurements of the resident loop: v [nsteps][B][ny] is added to y_k before the estimator - the reference's sqrtm(R_wn) N(0, I) of
+ * MPC_code.py:537-541 (unseeded there; the draws are the caller's here: nmpc.py makes them from a seed).  NULL: none.  After nmpc_alloc */
+int nmpc_set_noise(nmpc_handle *h, int32_t nsteps, const double *v);
 /* steps [k0, k0+nsteps); asynchronous.  max_sqp SQP iterations per OCP (1 = real-time iteration), stopped early when the
  * trajectory moves less than sqp_tol */
 int nmpc_run(nmpc_handle *h, int32_t k0, int32_t nsteps, int32_t max_sqp, double sqp_tol);

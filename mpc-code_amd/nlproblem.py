@@ -166,10 +166,10 @@ def nl_problem_from_namespace(ns: Dict[str, Any], name: str = "") -> NonlinearMP
             raise UnsupportedProblem(f"'{bad}' is outside the non-linear path built so far")
     if has("R_wn"):
         # the reference adds UNSEEDED Gaussian noise to every measurement (MPC_code.py:538-541): a run is not reproducible even there.
-        # The resident batched loop is deterministic and runs noise-free - said out loud, not silently (Ex_NMPC.py ships R_wn); the loop through the per-call seam
-        # (nmpc.run_nmpc_stepwise, where the measurement is the caller's) adds seeded noise of this covariance when asked to
+        # The batched loops are deterministic and run noise-free unless asked otherwise - said out loud, not silently (Ex_NMPC.py ships R_wn): with noise_seed = s
+        # nmpc.run_nmpc_closed_loop (draws on the device, nmpc_set_noise) and nmpc.run_nmpc_stepwise (the measurement is the caller's) add seeded noise of this covariance
         import warnings
-        warnings.warn("R_wn: the measurement noise of the example (unseeded in the reference, MPC_code.py:538-541) is not simulated in the resident loop, which runs noise-free; nmpc.run_nmpc_stepwise(noise_seed=...) adds it", UserWarning, stacklevel=3)
+        warnings.warn("R_wn: the measurement noise of the example (unseeded in the reference, MPC_code.py:538-541) is simulated only on request: the loops run noise-free unless called with noise_seed=...", UserWarning, stacklevel=3)
     for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks", "TermCons", "mhe", "ContForm",
                  "DUFormEcon", "kal", "kalss", "estimating"):
         if ns.get(flag, False) is True:

@@ -17,7 +17,7 @@ from .capi import MpcAmdError
 
 NMPC_EXPORTS = ("nmpc_create", "nmpc_destroy", "nmpc_last_error", "nmpc_build_info", "nmpc_alloc", "nmpc_set_state", "nmpc_set_schedule",
                 "nmpc_run", "nmpc_sync", "nmpc_get_log", "nmpc_last_kernel_ms", "nmpc_set_kernel", "nmpc_set_groups", "nmpc_get_kernel", "nmpc_time_kernels",
-                "nmpc_wave_kernel_ms", "nmpc_ekf_update", "nmpc_target_solve", "nmpc_ocp_solve", "nmpc_plant_step")
+                "nmpc_wave_kernel_ms", "nmpc_ekf_update", "nmpc_target_solve", "nmpc_ocp_solve", "nmpc_plant_step", "nmpc_set_noise")
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)
@@ -45,6 +45,7 @@ def load_nmpc_library(path: str) -> ct.CDLL:
     lib.nmpc_alloc.argtypes = [vp, ct.c_int32, ct.c_int32]
     lib.nmpc_set_state.argtypes = [vp] + [_dp] * 7
     lib.nmpc_set_schedule.argtypes = [vp, ct.c_int32, _dp, _dp, _dp, _dp]
+    lib.nmpc_set_noise.argtypes = [vp, ct.c_int32, _dp]
     lib.nmpc_run.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double]
     lib.nmpc_sync.argtypes = [vp]
     lib.nmpc_set_kernel.argtypes = [vp, ct.c_int32]
@@ -141,6 +142,16 @@ class NmpcSolver:
                                              None if pxp is None else pxp.ctypes.data_as(_dp), None if pyp is None else pyp.ctypes.data_as(_dp)), "nmpc_set_schedule")
         self.steps = ysp.shape[0]
 
+    def set_noise(self, v: Optional[np.ndarray]):
+        """white noise on the measurements of the resident loop, v [nsteps, B, ny] (MPC_code.py:537-541), or None"""
+        if v is None:
+            self._chk(self.lib.nmpc_set_noise(self.h, 0, None), "nmpc_set_noise")
+            return
+        v = _c(np.asarray(v, dtype=np.float64))
+        if v.ndim != 3 or v.shape[1:] != (self.B, self.p.ny):
+            raise ValueError(f"noise: [nsteps, {self.B}, {self.p.ny}] expected, got {v.shape}")
+        self._chk(self.lib.nmpc_set_noise(self.h, v.shape[0], v.ctypes.data_as(_dp)), "nmpc_set_noise")
+
     # ---- per-call seam: the reference's three solver calls of a step (include/mpc_nmpc.h) --------------------------------------------------
     def ekf_update(self, y, u_prev, xhat, dhat, P):
         """defEstimator(..., 'ekf' | 'lue') for the batch (MPC_code.py:577-650); returns the posterior ``xhat, dhat, P``"""
@@ -223,6 +234,16 @@ class NmpcSolver:
         return out
 
 
+def measurement_noise(problem, nsteps: int, B: int, seed: int) -> np.ndarray:
+    """The draws ``sqrtm(R_wn) N(0, I)`` of MPC_code.py:537-541 for nsteps x B measurements from ``numpy.random.default_rng(seed)`` (step by step, instance by
+    instance: the same numbers in the resident loop and in the loop through the per-call seam)."""
+    if getattr(problem, "R_wn", None) is None:
+        raise ValueError("noise_seed: the example defines no R_wn")
+    ev, evec = np.linalg.eigh(0.5 * (problem.R_wn + problem.R_wn.T))      # the symmetric square root scipy.linalg.sqrtm returns for a covariance
+    Rv, rng = (evec * np.sqrt(np.maximum(ev, 0.0))) @ evec.T, np.random.default_rng(seed)
+    return np.stack([rng.standard_normal((B, problem.ny)) @ Rv.T for _ in range(nsteps)])
+
+
 def run_nmpc_stepwise(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[NmpcSolver] = None, max_sqp: int = 1, sqp_tol: float = 1e-9,
                       device: int = 0, plant=None, noise_seed: Optional[int] = None) -> Dict[str, np.ndarray]:
     """The reference's loop body call by call (MPC_code.py:485-827): per step the measurement (the Ex-file's plant output on the host), ``ekf_update``
@@ -247,35 +268,32 @@ def run_nmpc_stepwise(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = Non
         u, xs, us = _rows(p.u0, B, p.nu).copy(), xhat.copy(), _rows(p.u0, B, p.nu).copy()
         keys = ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "SQP_DYN", "SQP_SS")
         out = {k: [] for k in keys}
-        Rv = rng = None
-        if noise_seed is not None:
-            if getattr(p, "R_wn", None) is None:
-                raise ValueError("noise_seed: the example defines no R_wn")
-            ev, evec = np.linalg.eigh(0.5 * (p.R_wn + p.R_wn.T))      # the symmetric square root scipy.linalg.sqrtm returns for a covariance
-            Rv, rng = (evec * np.sqrt(np.maximum(ev, 0.0))) @ evec.T, np.random.default_rng(noise_seed)
-            out["V_WN"] = []
+        vn = measurement_noise(p, nsteps, B, noise_seed) if noise_seed is not None else None
         for k in range(nsteps):
             t = k * p.h
             out["Xp"].append(x_p.copy()); out["X_HAT"].append(xhat.copy())
             y = p.plant_output(x_p, u, t) + sch["pyp"][k]                    # MPC_code.py:531-534
-            if rng is not None:                                              # :537-541
-                v = rng.standard_normal((B, p.ny)) @ Rv.T
-                y = y + v; out["V_WN"].append(v)
+            if vn is not None:                                               # :537-541
+                y = y + vn[k]
             xhat, dhat, P = s.ekf_update(y, u, xhat, dhat, P)
             xs, us, st_s, sq_s = s.target_solve(dhat, sch["ysp"][k], sch["usp"][k], xs, us)
             u, xhat, st_d, it_d, sq_d = s.ocp_solve(xhat, dhat, xs, us, u, max_sqp, sqp_tol)
             x_p = s.plant_step(u, x_p, sch["pxp"][k]) if plant is None else np.asarray(plant(x_p, u, t), dtype=np.float64) + sch["pxp"][k]
             for kk, v in (("U", u), ("XS", xs), ("US", us), ("D_HAT", dhat[:, :p.nd]), ("STATUS_DYN", st_d), ("STATUS_SS", st_s), ("ITERS_DYN", it_d), ("SQP_DYN", sq_d), ("SQP_SS", sq_s)):
                 out[kk].append(np.array(v))
-        return {k: np.stack(v) for k, v in out.items() if not (k == "D_HAT" and p.nd == 0)}
+        res = {k: np.stack(v) for k, v in out.items() if not (k == "D_HAT" and p.nd == 0)}
+        if vn is not None:
+            res["V_WN"] = vn
+        return res
     finally:
         if own:
             s.close()
 
 
 def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None, solver: Optional[NmpcSolver] = None,
-                         max_sqp: int = 1, sqp_tol: float = 1e-9, device: int = 0) -> Dict[str, np.ndarray]:
-    """``max_sqp = 1``: one real-time iteration per step (one linearisation along the shifted previous trajectory, one QP);
+                         max_sqp: int = 1, sqp_tol: float = 1e-9, device: int = 0, noise_seed: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """``noise_seed``: white noise of the example's ``R_wn`` on every measurement (:func:`measurement_noise`; returned as ``V_WN``); None: the deterministic loop.
+    ``max_sqp = 1``: one real-time iteration per step (one linearisation along the shifted previous trajectory, one QP);
     larger: iterate each OCP to the NLP's KKT point, what the reference's IPOPT call returns (``MPC_code.py:775-783``).
     Result arrays carry the reference's names (``MPC_code.py:877-895``), shaped [nsteps, B, dim]."""
     p = problem
@@ -289,9 +307,13 @@ def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = 
         s.alloc(B, nsteps)
         s.set_state(x0_p, x0_m)
         s.set_schedule(p.schedules(nsteps))
+        vn = measurement_noise(p, nsteps, B, noise_seed) if noise_seed is not None else None
+        s.set_noise(vn)
         s.run(0, nsteps, max_sqp, sqp_tol)
         s.sync()
         out = {k: s.get_log(k) for k in list(s.LOGS) + list(s.ILOGS) if not (k == "D_HAT" and p.nd == 0)}
+        if vn is not None:
+            out["V_WN"] = vn; s.set_noise(None)
         ms = s.last_kernel_ms()
         out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
         u_prev = np.concatenate([_rows(p.u0, B, p.nu)[None], out["U"][:-1]]) if nsteps else out["U"]

@@ -429,6 +429,21 @@ def test_gpu_white_noise_on_the_measurement_through_the_per_call_seam(nl, onl, s
     assert np.array_equal(r["STATUS_DYN"], c["STATUS_DYN"]) and np.array_equal(r["STATUS_SS"], c["STATUS_SS"])
     for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
         assert np.max(np.abs(r[k] - c[k]) / (1 + np.abs(c[k]))) < 1e-6, (k, float(np.max(np.abs(r[k] - c[k]) / (1 + np.abs(c[k])))))
+    # ... and in the RESIDENT loop (nmpc_set_noise: the draws live on the device, one row per step): the instance-per-lane kernel is the seam's loop to the bit, the
+    # wave-autonomous kernel and the split pipeline follow the C restatement; switched off again, the loop is the deterministic one
+    for kernel in (1, 3, 4):
+        solver.set_kernel(kernel)
+        a = nmpc.run_nmpc_closed_loop(nl, x0, xm, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9, noise_seed=7)
+        assert np.array_equal(a["V_WN"], r["V_WN"])
+        for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT"):
+            if kernel == 1:
+                assert np.array_equal(a[k], r[k]), k
+            assert np.max(np.abs(a[k] - c[k]) / (1 + np.abs(c[k]))) < 1e-6, (kernel, k)
+        assert np.array_equal(a["STATUS_DYN"], c["STATUS_DYN"])
+    solver.set_kernel(1)
+    b = nmpc.run_nmpc_closed_loop(nl, x0, xm, nsteps=ns, solver=solver, max_sqp=1, sqp_tol=1e-9)
+    assert np.array_equal(b["U"], r0["U"])
+    solver.set_kernel(0)
 
 
 @pytest.mark.gpu
