@@ -30,6 +30,8 @@ def main(argv=None):
     ap.add_argument("-o", "--override", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--out", default=None, help="write the result arrays to this .npz")
     ap.add_argument("--load-only", action="store_true", help="load and classify the file, then stop (no GPU needed)")
+    ap.add_argument("--plots", default=None, metavar="DIR", help="write the reference's figures (State / Input / Output / Disturbance Estimate, MPC_code.py:897-935) of one instance as PDFs under DIR")
+    ap.add_argument("--instance", type=int, default=0, help="the instance --plots draws")
     a = ap.parse_args(argv)
     import mpc_code_amd as m
     over = {}
@@ -56,6 +58,10 @@ def main(argv=None):
             print(f"  {k:10s} {str(v.shape):18s} last step, instance 0: {np.array2string(v[-1, 0], precision=6)}")
         elif v.ndim >= 2:
             print(f"  {k:10s} {str(v.shape):18s} values {np.unique(v).tolist()[:8]}")
+    if a.plots:
+        from mpc_code_amd.plots import make_plots
+        files = make_plots(out, float(p.h), a.plots, instance=a.instance)
+        print(f"wrote {len(files)} figures under {a.plots}")
     if a.out:
         np.savez_compressed(a.out, **{k: np.asarray(v) for k, v in out.items()})
         print("wrote", a.out)

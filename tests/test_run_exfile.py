@@ -13,6 +13,18 @@ EXAMPLES = ["cstr_lmpc.py", "wood_berry_lmpc.py", "cstr_nlplant_lmpc.py", "cstr_
 
 
 @pytest.mark.parametrize("ex", EXAMPLES)
+def test_figures_of_the_reference_from_result_arrays(tmp_path):
+    """mpc_code_amd.plots.make_plots on the golden economic loop (no GPU): State / Input / Output / Disturbance Estimate, one PDF per component (Utilities.py:422-496)"""
+    from mpc_code_amd.plots import make_plots
+    g = np.load(os.path.join(ROOT, "tests", "golden", "enmpc_reactor.npz"))
+    out = {k: g["ship_" + k] for k in ("U", "X_HAT", "XS", "US", "D_HAT", "Xp")}
+    out["Yp"], out["YS"] = out["Xp"], out["XS"] + out["D_HAT"]
+    files = make_plots(out, 2.0, str(tmp_path / "fig"))
+    assert [os.path.basename(f) for f in files] == ["State 1.pdf", "State 2.pdf", "Input 1.pdf", "Output 1.pdf", "Output 2.pdf", "Disturbance Estimate 1.pdf", "Disturbance Estimate 2.pdf"]
+    assert all(open(f, "rb").read(5) == b"%PDF-" for f in files)
+
+
+@pytest.mark.parametrize("ex", EXAMPLES)
 def test_cli_loads_and_classifies_every_example(pkg, ex, capsys):
     import run_exfile
     assert run_exfile.main([pkg.example_path(ex), "--load-only", "-o", "N=12"]) == 0
@@ -30,8 +42,11 @@ def test_gpu_every_example_runs_through_the_one_entry_point(pkg, ex, tmp_path, c
     out = str(tmp_path / "r.npz")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        assert run_exfile.main([pkg.example_path(ex), "--batch", "5", "--spread", "0.001", "--nsteps", "4", "--out", out]) == 0
+        assert run_exfile.main([pkg.example_path(ex), "--batch", "5", "--spread", "0.001", "--nsteps", "4", "--out", out, "--plots", str(tmp_path / "fig"), "--instance", "2"]) == 0
         p = pkg.load_problem(pkg.example_path(ex))
+    figs = sorted(os.listdir(tmp_path / "fig"))      # the reference's figures (MPC_code.py:897-935), one PDF per component
+    assert figs.count("Input 1.pdf") == 1 and len([f for f in figs if f.startswith("State ")]) == p.nx and len([f for f in figs if f.startswith("Input ")]) == p.nu, figs
+    assert len([f for f in figs if f.startswith("Output ")]) == p.ny and all(os.path.getsize(tmp_path / "fig" / f) > 1000 for f in figs)
     r = np.load(out)
     for k, d in (("U", p.nu), ("X_HAT", p.nx), ("XS", p.nx), ("US", p.nu), ("Xp", len(p.x0_p))):
         assert r[k].shape == (4, 5, d) and np.isfinite(r[k]).all(), (ex, k)
