@@ -12,7 +12,6 @@ EXAMPLES = ["cstr_lmpc.py", "wood_berry_lmpc.py", "cstr_nlplant_lmpc.py", "cstr_
             "reactor_enmpc.py"]
 
 
-@pytest.mark.parametrize("ex", EXAMPLES)
 def test_figures_of_the_reference_from_result_arrays(tmp_path):
     """mpc_code_amd.plots.make_plots on the golden economic loop (no GPU): State / Input / Output / Disturbance Estimate, one PDF per component (Utilities.py:422-496)"""
     from mpc_code_amd.plots import make_plots
