@@ -76,6 +76,9 @@ class EconomicMPCProblem:
     wmin: np.ndarray = None         # bounds of the estimator's state noise (Utilities.py:881-884,974-977); +-inf = absent
     wmax: np.ndarray = None
     estimator: str = "mhe"          # 'mhe' | 'ekf': the example's estimator switch (Ex_ENMPC.py:109-123, mhe_mod)
+    R_wn: Optional[np.ndarray] = None      # white noise of the loop (MPC_code.py:537-541, 822-827; Ex_ENMPC.py:68-69 carries the state noise commented out): covariance of the
+    G_wn: Optional[np.ndarray] = None      # measurement noise, input matrix and covariance of the state noise - enmpc.run_enmpc_stepwise(noise_seed=...) draws them
+    Q_wn: Optional[np.ndarray] = None
     Q_kf: Optional[np.ndarray] = None      # extended Kalman filter on [x; d]: process / measurement noise covariances (Estimator.py:313-386); P0 is P(0|-1)
     R_kf: Optional[np.ndarray] = None
     name: str = ""
@@ -118,7 +121,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     has = lambda k: k in ns and ns[k] is not None and not k.startswith("__")
     for bad in ("User_fobj_Dis", "User_fobj_Coll", "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "Q", "Qss",
                 "def_px", "def_py", "def_pxmp", "def_pymp", "def_pxp", "def_pyp", "A", "User_fxm_Dis", "User_fxp_Dis", "User_fym", "User_fyp",
-                "R_wn", "G_wn", "defSP", "ymin", "ymax", "ymin_dyn", "ymax_dyn", "Dumin", "Dumax", "vmin", "vmax", "User_fx_mhe_Dis",
+                "defSP", "ymin", "ymax", "ymin_dyn", "ymax_dyn", "Dumin", "Dumax", "vmin", "vmax", "User_fx_mhe_Dis",
                 "r_w", "Q_mhe"):
         if has(bad):
             raise UnsupportedProblem(f"'{bad}' is outside the economic path built so far")
@@ -140,6 +143,12 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     for req in (("N_mhe", "w", "User_fx_mhe_Cont", "User_fobj_mhe", "P0", "x_bar") if use_mhe else ("Q_kf", "R_kf", "P0")):
         if not has(req):
             raise UnsupportedProblem(f"'{req}' missing for the " + ("moving-horizon estimator" if use_mhe else "extended Kalman filter"))
+    if has("G_wn") != has("Q_wn"):
+        raise UnsupportedProblem("G_wn and Q_wn (the state noise, MPC_code.py:822-827) have to come together")
+    if has("R_wn") or has("G_wn"):
+        import warnings
+        warnings.warn("R_wn / G_wn: the white noise of the example (unseeded in the reference, MPC_code.py:537-541, 822-827) is simulated only on request: the resident loop runs "
+                      "noise-free, enmpc.run_enmpc_stepwise(noise_seed=...) draws it", UserWarning, stacklevel=3)
     if (ns.get("dmin") is None) != (ns.get("dmax") is None):
         raise UnsupportedProblem("dmin and dmax have to come together")
     nx, nu, ny, nd, nxp = ns["x"].size1(), ns["u"].size1(), ns["y"].size1(), ns["d"].size1(), ns["xp"].size1()
@@ -197,6 +206,8 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         N_mhe=N_mhe, mhe_up=str(ns.get("mhe_up", "smooth")), n_w=n_w, G_mhe=G, P0=_mat(ns["P0"], nx + nd, nx + nd, "P0"),
         x_bar=(np.asarray(ns["x_bar"], dtype=np.float64).reshape(nx + nd) if use_mhe else np.concatenate([_vec(ns["x0_m"], nx, 0.0), np.zeros(nd)])),
         wmin=_vec(ns.get("wmin") if use_mhe else None, n_w, -INF), wmax=_vec(ns.get("wmax") if use_mhe else None, n_w, INF),
+        R_wn=_mat(ns["R_wn"], ny, ny, "R_wn") if has("R_wn") else None,
+        G_wn=_mat(ns["G_wn"], nxp, nxp, "G_wn") if has("G_wn") else None, Q_wn=_mat(ns["Q_wn"], nxp, nxp, "Q_wn") if has("Q_wn") else None,
         estimator="mhe" if use_mhe else "ekf",
         Q_kf=None if use_mhe else _mat(ns["Q_kf"], nx + nd, nx + nd, "Q_kf"), R_kf=None if use_mhe else _mat(ns["R_kf"], ny, ny, "R_kf"),
         xmin_mhe=np.concatenate([_vec(ns.get("xmin"), nx, -INF), _vec(ns.get("dmin"), nd, -INF)]),      # MPC_code.py:397-402

@@ -258,10 +258,32 @@ class EnmpcSolver:
         return out
 
 
-def run_enmpc_stepwise(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, solver: Optional[EnmpcSolver] = None, plant=None):
+def loop_noise(problem, nsteps: int, B: int, seed: int):
+    """The draws of the reference's white noises for nsteps x B instances from ``numpy.random.default_rng(seed)``: ``V_WN`` = sqrtm(R_wn) N(0, I) on the measurement
+    (MPC_code.py:537-541) and ``W_WN`` = G_wn sqrtm(Q_wn) N(0, I) on the plant state after its step (:822-827) - None where the example does not define them.  Per step
+    first the measurement's draws, then the state's."""
+    def root(S):
+        ev, evec = np.linalg.eigh(0.5 * (S + S.T))      # the symmetric square root scipy.linalg.sqrtm returns for a covariance
+        return (evec * np.sqrt(np.maximum(ev, 0.0))) @ evec.T
+    p, rng = problem, np.random.default_rng(seed)
+    if getattr(p, "R_wn", None) is None and getattr(p, "G_wn", None) is None:
+        raise ValueError("noise_seed: the example defines neither R_wn nor G_wn / Q_wn")
+    Rv = None if p.R_wn is None else root(p.R_wn)
+    Gw = None if p.G_wn is None else p.G_wn @ root(p.Q_wn)
+    V, W = [], []
+    for _ in range(nsteps):
+        if Rv is not None:
+            V.append(rng.standard_normal((B, p.ny)) @ Rv.T)
+        if Gw is not None:
+            W.append(rng.standard_normal((B, p.nxp)) @ Gw.T)
+    return (np.stack(V) if V else None), (np.stack(W) if W else None)
+
+
+def run_enmpc_stepwise(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, solver: Optional[EnmpcSolver] = None, plant=None, noise_seed: Optional[int] = None):
     """The reference's loop body call by call (MPC_code.py:485-827): per step the measurement, ``mhe_update`` (defEstimator), ``target_solve`` (solver_ss),
     ``ocp_solve`` (solver) and the plant - ``plant(x_p [B, nxp], u [B, nu]) -> x_p+`` of the caller, or the device's.  Same result arrays as
-    :func:`run_enmpc_closed_loop`; with the device's plant, the same numbers to the bit."""
+    :func:`run_enmpc_closed_loop`; with the device's plant, the same numbers to the bit.  ``noise_seed``: the example's white noises on the measurement and on the plant
+    state (:func:`loop_noise`; returned as ``V_WN`` / ``W_WN``) - the measurement and the plant are the caller's side of the seam."""
     p = problem
     nsteps = p.Nsim if nsteps is None else int(nsteps)
     x_p = np.atleast_2d(np.asarray(x0_p, dtype=np.float64)).copy()
@@ -273,17 +295,27 @@ def run_enmpc_stepwise(problem, x0_p, nsteps: Optional[int] = None, device: int 
         u = _rows(p.u0, B, p.nu)
         xhat = _rows(p.x0_m, B, p.nx)
         out = {k: [] for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "X_ES", "STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")}
-        for _ in range(nsteps):
+        vn, wn = loop_noise(p, nsteps, B, noise_seed) if noise_seed is not None else (None, None)
+        for k_ in range(nsteps):
             out["Xp"].append(x_p.copy()); out["X_HAT"].append(xhat.copy())
             y = x_p                                        # Fy_p with StateFeedback (Utilities.py:84-86)
+            if vn is not None:
+                y = y + vn[k_]                             # MPC_code.py:537-541
             xhat, dhat, xes, st_m, it_m = s.mhe_update(y, u)
             xs, us, st_s, it_s = s.target_solve(dhat)
             u, xhat, st_d, it_d = s.ocp_solve(xhat, dhat, xs, us)
             x_p = s.plant_step(u, x_p) if plant is None else np.asarray(plant(x_p, u), dtype=np.float64)
+            if wn is not None:
+                x_p = x_p + wn[k_]                         # :822-827
             for k, v in (("U", u), ("XS", xs), ("US", us), ("D_HAT", dhat), ("X_ES", xes), ("STATUS_DYN", st_d), ("STATUS_SS", st_s), ("STATUS_MHE", st_m),
                          ("ITERS_DYN", it_d), ("ITERS_SS", it_s), ("ITERS_MHE", it_m)):
                 out[k].append(np.array(v))
-        return {k: np.stack(v) for k, v in out.items()}
+        res = {k: np.stack(v) for k, v in out.items()}
+        if vn is not None:
+            res["V_WN"] = vn
+        if wn is not None:
+            res["W_WN"] = wn
+        return res
     finally:
         if solver is None:
             s.close()

@@ -440,7 +440,8 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
 
 /* ---- closed loop of B instances (MPC_code.py:485-827); logs [step][B][dim] ----------------------------------------------------------- */
 int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, const double *x_bar0, double *U, double *XS, double *US, double *XES, double *XP,
-                     int32_t *st_dyn, int32_t *st_ss, int32_t *st_mhe, int32_t *it_dyn, int32_t *it_ss, int32_t *it_mhe, int nthreads)
+                     int32_t *st_dyn, int32_t *st_ss, int32_t *st_mhe, int32_t *it_dyn, int32_t *it_ss, int32_t *it_mhe, int nthreads,
+                     const double *v_wn /* [nsteps][B][NY] white noise on the measurement (MPC_code.py:537-541), or NULL */, const double *w_wn /* [nsteps][B][NX] on the plant state (:822-827), or NULL */)
 {
     const int N = P->N;
     if (N > 64 || P->N_mhe > 63) return -1;
@@ -458,11 +459,12 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
         for (int k = 0; k < nsteps; k++) {
             const size_t o = (size_t)k * B + b;
             if (XP) { XP[o * NX] = x[0]; XP[o * NX + 1] = x[1]; }
-            double xes[NE];
+            double xes[NE], ym[NY] = {x[0], x[1]};      /* y = x_p (StateFeedback plant output) + its white noise */
+            if (v_wn) { ym[0] += v_wn[o * NY]; ym[1] += v_wn[o * NY + 1]; }
             int itm, its, itd;
             int sm = 0;
-            if (P->est_ekf) { xes[0] = xh[0]; xes[1] = xh[1]; xes[2] = dh[0]; xes[3] = dh[1]; ekf_step(P, S->Pkal, xes, x, u); itm = 0; }      /* (P_k lives where the other estimator keeps its filter covariance) */
-            else sm = mhe_step(P, S, k, x, u, xes, &itm);      /* y = x_p (StateFeedback plant output) */
+            if (P->est_ekf) { xes[0] = xh[0]; xes[1] = xh[1]; xes[2] = dh[0]; xes[3] = dh[1]; ekf_step(P, S->Pkal, xes, ym, u); itm = 0; }      /* (P_k lives where the other estimator keeps its filter covariance) */
+            else sm = mhe_step(P, S, k, ym, u, xes, &itm);
             xh[0] = xes[0]; xh[1] = xes[1]; dh[0] = xes[2]; dh[1] = xes[3];
             if (P->has_dsat) for (int i = 0; i < ND; i++) dh[i] = fmin(fmax(dh[i], P->dmin[i]), P->dmax[i]);
             const double xs_prev[NX] = {xs[0], xs[1]}, us_prev = us;
@@ -485,6 +487,7 @@ int eorc_closed_loop(const EProb *P, int B, int nsteps, const double *x0_p, cons
             cplx xc[2] = {x[0], x[1]}, xo[2];
             rk4(P, xc, u, NULL, P->Mx, 0, xo, NULL);      /* plant: the same balances (Ex_ENMPC.py:42-49) */
             x[0] = creal(xo[0]); x[1] = creal(xo[1]);
+            if (w_wn) { x[0] += w_wn[o * NX]; x[1] += w_wn[o * NX + 1]; }
         }
         arena_release(mark_b); free(S);
     }

@@ -957,7 +957,7 @@ def mhe_step(p, S, ksim, y_act, u_k, t_k=0.0, max_iter=None, tol=1e-10):
 # ---------------------------------------------------------------------------------------------------
 # closed loop (MPC_code.py:485-827)
 # ---------------------------------------------------------------------------------------------------
-def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
+def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False, v_wn=None, w_wn=None):
     n, m, nd, N = p.nx, p.nu, p.nd, p.N
     nz = n + m
     x_k = (p.x0_p if x0_p is None else np.asarray(x0_p, dtype=float)).copy()
@@ -974,6 +974,8 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
         t_k = ksim * p.h
         log["Xp"].append(x_k.copy()); log["X_HAT"].append(xhat.copy())
         y_k = x_k.copy()                                     # Fy_p with StateFeedback (Utilities.py:84-86)
+        if v_wn is not None:
+            y_k = y_k + v_wn[ksim]                           # white noise on the measurement, MPC_code.py:537-541 (the draws, sqrtm(R_wn) applied)
         log["Yp"].append(y_k.copy())
         if p.mhe:
             x_es = mhe_step(p, S, ksim, y_k, u_k, t_k)
@@ -1018,4 +1020,6 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False):
         if verbose:
             print(f"step {ksim}: u {u_k}, xs {xs_k}, us {us_k}, iters {sol['iters']} / {ts['iters']} / {log['ITERS_MHE'][-1] if p.mhe else 0}, status {sol['status']}")
         x_k = fx_plant(p, x_k.reshape(-1, 1), u_k.reshape(-1, 1), t_k)[:, 0]      # :813-816
+        if w_wn is not None:
+            x_k = x_k + w_wn[ksim]                           # white noise on the state, :822-827 (G_wn sqrtm(Q_wn) applied)
     return {k: np.array(v) for k, v in log.items() if len(v)}

@@ -91,7 +91,7 @@ class OracleEC:
     def max_threads(self):
         return int(self.lib.eorc_max_threads())
 
-    def closed_loop(self, nsteps, x0_p, x_bar=None, nthreads=0, logs=True):
+    def closed_loop(self, nsteps, x0_p, x_bar=None, nthreads=0, logs=True, v_wn=None, w_wn=None):
         x0 = np.ascontiguousarray(np.atleast_2d(x0_p), dtype=np.float64)
         B = len(x0)
         xb = None if x_bar is None else np.ascontiguousarray(np.broadcast_to(x_bar, (B, NE)), dtype=np.float64)
@@ -99,6 +99,8 @@ class OracleEC:
         il = {k: np.zeros((nsteps, B), dtype=np.int32) for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")} if logs else {}
         ptr = lambda a, t=_dp: a.ctypes.data_as(t) if a is not None else None
         rc = self.lib.eorc_closed_loop(ct.byref(self.s), B, int(nsteps), ptr(x0), ptr(xb), *[ptr(dl.get(k)) for k in ("U", "XS", "US", "X_ES", "Xp")],
-                                       *[ptr(il.get(k), _ip) for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")], int(nthreads))
+                                       *[ptr(il.get(k), _ip) for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE")], int(nthreads),
+                                       ptr(None if v_wn is None else np.ascontiguousarray(np.asarray(v_wn, dtype=np.float64).reshape(nsteps, B, NY))),
+                                       ptr(None if w_wn is None else np.ascontiguousarray(np.asarray(w_wn, dtype=np.float64).reshape(nsteps, B, NX))))
         assert rc == 0
         return {**dl, **il}

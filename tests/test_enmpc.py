@@ -240,6 +240,29 @@ def test_ipopt_vectors_if_present(oprob):
         assert abs(int(sol["iters"]) - int(g["ITERS"][i])) <= 2, (i, sol["iters"], g["ITERS"][i])
 
 
+WHITE_NOISE = {"R_wn": 1e-6 * np.eye(2), "G_wn": 1e-2 * np.eye(2), "Q_wn": 1e-3 * np.eye(2), "N": 12, "N_mhe": 6}      # (Ex_ENMPC.py:68-69 carries G_wn / Q_wn commented out)
+
+
+def test_white_noise_on_measurement_and_state_restatements_agree(pkg):
+    """The reference's white noises of the loop (MPC_code.py:537-541 on the measurement, :822-827 on the plant state; unseeded there): handed the same draws, the NumPy and the C
+    restatement give the same loop, the noise is in it, and the loader keeps the covariances (and says that the resident loop runs without them)."""
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc
+    with pytest.warns(UserWarning, match="simulated only on request"):
+        p = pkg.load_problem(EX, overrides=WHITE_NOISE)
+    assert np.array_equal(p.R_wn, WHITE_NOISE["R_wn"]) and np.array_equal(p.G_wn, WHITE_NOISE["G_wn"])
+    V, W = enmpc.loop_noise(p, 8, 1, seed=5)
+    assert V.shape == (8, 1, 2) and W.shape == (8, 1, 2) and abs(V.std() - 1e-3) < 5e-4 and abs(W.std() - 1e-2 * np.sqrt(1e-3)) < 2e-4
+    q = eo.load_problem(EX, overrides={"N": 12, "N_mhe": 6})
+    r, r0 = eo.closed_loop(q, 8, v_wn=V[:, 0], w_wn=W[:, 0]), eo.closed_loop(q, 8)
+    c = ec.OracleEC(q).closed_loop(8, q.x0_p[None], nthreads=1, v_wn=V, w_wn=W)
+    for k in ("U", "XS", "US", "X_ES", "Xp"):
+        assert np.abs(r[k] - c[k][:, 0]).max() < 1e-9, k
+    assert np.array_equal(r["STATUS_DYN"], c["STATUS_DYN"][:, 0]) and np.abs(r["X_ES"] - r0["X_ES"]).max() > 1e-4
+    with pytest.raises(pkg.UnsupportedProblem):
+        pkg.load_problem(EX, overrides={"G_wn": np.eye(2)})      # the state noise needs its covariance
+
+
 W_BOUNDS = {"wmin": np.array([-1e-3, -1e-3, -0.02, -0.02]), "wmax": np.array([1e-3, 1e-3, 0.02, 0.02]), "N": 12, "N_mhe": 6}
 
 
@@ -500,6 +523,28 @@ def test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, m
     if not more:
         with pytest.raises(MpcAmdError):      # the shipped example's library has no rows for them
             enmpc.EnmpcSolver(p, lib_path=econcodegen.build_enmpc_library(pkg.load_problem(EX)))
+
+
+@pytest.mark.gpu
+def test_gpu_white_noise_through_the_per_call_seam_follows_the_c_restatement(pkg):
+    """Measurement and state noise of the loop (MPC_code.py:537-541, :822-827) are the caller's side of the per-call seam: run_enmpc_stepwise(noise_seed=...) draws them, the C
+    restatement handed the same draws gives the same loop - forty histories from the shipped start."""
+    import warnings
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = pkg.load_problem(EX, overrides=WHITE_NOISE)
+    B, K = 40, 14
+    x0 = np.tile(p.x0_p, (B, 1))
+    r = enmpc.run_enmpc_stepwise(p, x0, K, noise_seed=3)
+    assert r["V_WN"].shape == (K, B, 2) and r["W_WN"].shape == (K, B, 2) and np.abs(r["U"][:, 0] - r["U"][:, 1]).max() > 0
+    c = ec.OracleEC(eo.load_problem(EX, overrides={"N": 12, "N_mhe": 6})).closed_loop(K, x0, nthreads=0, v_wn=r["V_WN"], w_wn=r["W_WN"])
+    for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE"):
+        assert np.array_equal(r[k], c[k]), k
+    tied = any((r[k] != c[k]).any() for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"))
+    for k in ("U", "XS", "US", "X_ES", "Xp"):
+        assert np.abs(r[k] - c[k]).max() < (2e-6 if tied else TOL_U), (k, tied, np.abs(r[k] - c[k]).max())
 
 
 @pytest.mark.gpu
