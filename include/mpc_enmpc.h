@@ -62,6 +62,10 @@ int enmpc_alloc(enmpc_handle *h, int32_t B, int32_t max_steps);
 /* plant state, model state, disturbance estimate, applied input, the estimator's prior mean x_bar [B][nx+nd]; resets the estimator
  * (window, covariances = P0) and the OCP's warm start; the first target guess is (x0_m, u0) */
 int enmpc_set_state(enmpc_handle *h, const double *x_p, const double *xhat, const double *dhat, const double *u, const double *x_bar);
+/* white noise of the resident loop: v [nsteps][B][ny] on the measurement of every step before the estimator (the reference's sqrtm(R_wn) N(0, I), MPC_code.py:537-541),
+ * w [nsteps][B][nxp] on the plant state after its step (G_wn sqrtm(Q_wn) N(0, I), :822-827) - unseeded there, the caller's draws here (enmpc.py makes them from a seed).
+ * Either may be NULL; both NULL: none.  After enmpc_alloc */
+int enmpc_set_noise(enmpc_handle *h, int32_t nsteps, const double *v, const double *w);
 /* steps [k0, k0+nsteps) of every instance in one launch; k0 must continue where the last run ended (0 after enmpc_set_state); asynchronous */
 int enmpc_run(enmpc_handle *h, int32_t k0, int32_t nsteps);
 int enmpc_sync(enmpc_handle *h);

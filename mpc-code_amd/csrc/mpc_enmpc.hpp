@@ -1,7 +1,9 @@
 // Economic NMPC with a moving-horizon estimator on the GPU (BASELINE configs 4 and 5): device side.
 //
-// Mapping: ONE WAVEFRONT = ONE INSTANCE, LANE = STAGE of the horizon (N <= 64).  Everything an interior-point iteration touches lives in
-// registers; stages talk to their neighbours through DPP wave shifts and v_readlane broadcasts - no LDS, no HBM workspace.
+// Mapping: ONE WAVEFRONT = ONE INSTANCE (or two / four side by side in segments of 32 / 16 lanes), LANE = STAGE of the horizon (N <= 64).  The iterate, the
+// linearised stage and the factors of the Newton system live in registers; the solver's bound data - multipliers, moved bounds, slacks - in rows of the wave's LDS
+// area (since round 4: in registers they were what spilled); stages talk to their neighbours through DPP wave shifts and v_readlane / ds_bpermute broadcasts; no HBM
+// workspace.
 //
 // The three NLPs of a closed-loop step (reference MPC_code.py:485-827 with Ex_ENMPC.py) are solved by one primal-dual interior point
 // method whose outer algorithm is the reference solver's (IPOPT at the defaults MPC_code.py:262-263 leaves it at [ext]; restated and

@@ -147,8 +147,8 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         raise UnsupportedProblem("G_wn and Q_wn (the state noise, MPC_code.py:822-827) have to come together")
     if has("R_wn") or has("G_wn"):
         import warnings
-        warnings.warn("R_wn / G_wn: the white noise of the example (unseeded in the reference, MPC_code.py:537-541, 822-827) is simulated only on request: the resident loop runs "
-                      "noise-free, enmpc.run_enmpc_stepwise(noise_seed=...) draws it", UserWarning, stacklevel=3)
+        warnings.warn("R_wn / G_wn: the white noise of the example (unseeded in the reference, MPC_code.py:537-541, 822-827) is simulated only on request: the loops run "
+                      "noise-free unless called with noise_seed=...", UserWarning, stacklevel=3)
     if (ns.get("dmin") is None) != (ns.get("dmax") is None):
         raise UnsupportedProblem("dmin and dmax have to come together")
     nx, nu, ny, nd, nxp = ns["x"].size1(), ns["u"].size1(), ns["y"].size1(), ns["d"].size1(), ns["xp"].size1()

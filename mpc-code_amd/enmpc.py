@@ -19,7 +19,7 @@ ENMPC_EXPORTS = ("enmpc_create", "enmpc_destroy", "enmpc_last_error", "enmpc_bui
                  "enmpc_sync", "enmpc_get_log", "enmpc_last_kernel_ms", "enmpc_set_kernel", "enmpc_get_kernel", "enmpc_time_kernels",
                  "enmpc_phase_ms", "enmpc_set_groups", "enmpc_comm_unique_id", "enmpc_comm_init", "enmpc_comm_destroy", "enmpc_comm_rank",
                  "enmpc_comm_allgather", "enmpc_comm_allreduce_max", "enmpc_comm_barrier", "enmpc_allgather_log", "enmpc_mhe_update",
-                 "enmpc_target_solve", "enmpc_ocp_solve", "enmpc_plant_step")
+                 "enmpc_target_solve", "enmpc_ocp_solve", "enmpc_plant_step", "enmpc_set_noise")
 
 _dp = ct.POINTER(ct.c_double)
 _ip = ct.POINTER(ct.c_int32)
@@ -56,6 +56,7 @@ def load_enmpc_library(path: str) -> ct.CDLL:
     lib.enmpc_time_kernels.argtypes = [vp, ct.c_int32]
     lib.enmpc_phase_ms.argtypes = [vp, ct.POINTER(ct.c_float), ct.POINTER(ct.c_int32)]
     lib.enmpc_mhe_update.argtypes = [vp] + [_dp] * 5 + [_ip] * 2
+    lib.enmpc_set_noise.argtypes = [vp, ct.c_int32, _dp, _dp]
     lib.enmpc_comm_unique_id.argtypes = [ct.c_char_p]
     lib.enmpc_comm_init.argtypes = [vp, ct.c_int32, ct.c_int32, ct.c_char_p]
     lib.enmpc_comm_destroy.argtypes = [vp]
@@ -209,6 +210,15 @@ class EnmpcSolver:
         return out
 
     # ---- per-call seam: the reference's three solver calls of a step (include/mpc_enmpc.h) -------------------------------------------------
+    def set_noise(self, v=None, w=None):
+        """white noise of the resident loop: v [nsteps, B, ny] on the measurements, w [nsteps, B, nxp] on the plant state after its step (MPC_code.py:537-541, 822-827); None: none"""
+        arrs = [None if a is None else _c(np.asarray(a, dtype=np.float64)) for a in (v, w)]
+        for a, d in zip(arrs, (self.p.ny, self.p.nxp)):
+            if a is not None and (a.ndim != 3 or a.shape[1:] != (self.B, d)):
+                raise ValueError(f"noise: [nsteps, {self.B}, {d}] expected, got {a.shape}")
+        n = next((a.shape[0] for a in arrs if a is not None), 0)
+        self._chk(self.lib.enmpc_set_noise(self.h, n, *[None if a is None else a.ctypes.data_as(_dp) for a in arrs]), "enmpc_set_noise")
+
     def mhe_update(self, y, u_prev):
         """defEstimator(..., 'mhe') for the batch (MPC_code.py:577-650): measurement ``y [B, ny]``, the input applied over the step before ``[B, nu]``;
         returns ``xhat, dhat, xes, status, iters``"""
@@ -322,9 +332,10 @@ def run_enmpc_stepwise(problem, x0_p, nsteps: Optional[int] = None, device: int 
 
 
 def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: int = 0, steps_per_launch: int = 0, solver: Optional[EnmpcSolver] = None,
-                          kernel: Optional[int] = None, groups: Optional[int] = None):
+                          kernel: Optional[int] = None, groups: Optional[int] = None, noise_seed: Optional[int] = None):
     """The closed loop of the reference for B instances (rows of ``x0_p``); model state, input and the estimator's prior start from the
-    Ex-file's ``x0_m``, ``u0``, ``x_bar``.  Returns the reference's result arrays ``[nsteps, B, dim]`` plus status / iteration words."""
+    Ex-file's ``x0_m``, ``u0``, ``x_bar``.  Returns the reference's result arrays ``[nsteps, B, dim]`` plus status / iteration words.
+    ``noise_seed``: the example's white noises on measurement and plant state (:func:`loop_noise`; on the device: ``enmpc_set_noise``), returned as ``V_WN`` / ``W_WN``."""
     p = problem
     nsteps = p.Nsim if nsteps is None else int(nsteps)
     x0_p = np.atleast_2d(np.asarray(x0_p, dtype=np.float64))
@@ -336,6 +347,8 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
         if groups is not None:
             s.set_groups(groups)
         s.set_state(x0_p)
+        vn, wn = loop_noise(p, nsteps, len(x0_p), noise_seed) if noise_seed is not None else (None, None)
+        s.set_noise(vn, wn)
         spl = steps_per_launch if steps_per_launch > 0 else nsteps
         for k0 in range(0, nsteps, spl):
             s.run(k0, min(spl, nsteps - k0))
@@ -346,7 +359,13 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
         # (Utilities.py:84-86), yhat_k = Fy_model(xhat_k, dhat_k) with the disturbance estimate of the step before (:524), ys_k = Fy_model(xs_k, dhat_k) (:730)
         B = len(x0_p)
         d_prior = np.zeros((nsteps, B, p.nd)); d_prior[1:] = out["D_HAT"][:-1]
-        out["Yp"] = out["Xp"].copy()
+        out["Yp"] = out["Xp"].copy() if vn is None else out["Xp"] + vn      # (the measurement: StateFeedback, + its white noise)
+        if vn is not None:
+            out["V_WN"] = vn
+        if wn is not None:
+            out["W_WN"] = wn
+        if noise_seed is not None:
+            s.set_noise(None, None)
         out["Y_HAT"] = out["X_HAT"] + d_prior @ p.Cd.T
         out["YS"] = out["XS"] + out["D_HAT"] @ p.Cd.T
         out["TIME_DYN"] = np.full(nsteps, out["kernel_ms"] * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)      # (one device time for the whole step)

@@ -545,6 +545,19 @@ def test_gpu_white_noise_through_the_per_call_seam_follows_the_c_restatement(pkg
     tied = any((r[k] != c[k]).any() for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"))
     for k in ("U", "XS", "US", "X_ES", "Xp"):
         assert np.abs(r[k] - c[k]).max() < (2e-6 if tied else TOL_U), (k, tied, np.abs(r[k] - c[k]).max())
+    # ... and in the RESIDENT loop (enmpc_set_noise: the draws on the device, one row per step and instance): the split pipeline is the seam's noisy loop to the bit (the same
+    # kernels), the one-launch kernel follows the C restatement; switched off again the loop is the deterministic one
+    for kernel in (2, 1):
+        a = enmpc.run_enmpc_closed_loop(p, x0, K, kernel=kernel, noise_seed=3)
+        assert np.array_equal(a["V_WN"], r["V_WN"]) and np.array_equal(a["W_WN"], r["W_WN"]) and np.array_equal(a["Yp"], a["Xp"] + a["V_WN"])
+        for k in ("U", "XS", "US", "X_ES", "Xp", "D_HAT", "X_HAT"):
+            if kernel == 2:
+                assert np.array_equal(a[k], r[k]), k
+            elif k in c:
+                assert np.abs(a[k] - c[k]).max() < 2e-6, (k, np.abs(a[k] - c[k]).max())
+        assert np.array_equal(a["STATUS_DYN"], c["STATUS_DYN"]) and np.array_equal(a["STATUS_MHE"], c["STATUS_MHE"])
+    b0, b1 = enmpc.run_enmpc_closed_loop(p, x0[:3], K, kernel=2), enmpc.run_enmpc_stepwise(p, x0[:3], K)
+    assert np.array_equal(b0["U"], b1["U"]) and np.abs(b0["U"][:, 0] - b0["U"][:, 1]).max() == 0.0
 
 
 @pytest.mark.gpu
