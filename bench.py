@@ -83,6 +83,22 @@ def measured_traffic(kernel_name: str, instance_steps_per_launch: float, summary
     return per * instance_steps_per_launch, src
 
 
+ISSUE_PEAK_WINST = 256 * 4 * 2.4e9 / 4.0      # wave-instructions per second the chip issues in fp64 (or unpacked 32-bit) VALU: 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 instruction
+                                               # takes four cycles on a 16-lane SIMD (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def issue_roofline(summary: str, launch_s: float, scale: float = 1.0):
+    """What 'bound: issue' is priced against: the vector instructions the priced kernel issues per launch (SQ_INSTS_VALU of the committed counter summary - the counters cannot be
+    read from inside this process -, scaled to this run's launch size) over the LIVE launch time, against the rate at which the chip's SIMDs issue them."""
+    try:
+        d = json.load(open(summary))
+        valu = float(d["SQ_INSTS_VALU"]["mean_per_launch"]) * scale
+    except Exception:
+        return None
+    return {"valu_insts_per_launch": valu, "achieved_winst_per_s": valu / launch_s, "peak_winst_per_s": ISSUE_PEAK_WINST, "frac": valu / launch_s / ISSUE_PEAK_WINST,
+            "wait_fraction": d.get("wait_fraction"), "source": os.path.relpath(summary, ROOT) + ": SQ_INSTS_VALU per launch of " + str(d.get("kernel"))}
+
+
 def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     """Time the oracle's C restatement on the host cores: the same closed loop (same instances, same steps, from
     t=0), on all cores and on one, each a bounded sample."""
@@ -193,7 +209,8 @@ def other_configs(args):
                      "batch_per_gpu": d["config"]["batch_per_gpu"], "repeats": d["config"]["repeats"], "workload": d["config"]["workload"],
                      "roofline": {"bound": rf["bound"], "priced_against": rf.get("priced_against"), "kernel": rf["kernel"].split(" (")[0], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
                                   "frac": rf["frac"], "traffic": rf["traffic"], "avg_launch_ms": rf["avg_launch_ms"], "alg_bytes_per_step": rf["alg_bytes_per_step"],
-                                  "instance_steps_per_launch": rf["instance_steps_per_launch"], "fp64_frac": (rf.get("fp64") or {}).get("frac")},
+                                  "instance_steps_per_launch": rf["instance_steps_per_launch"], "fp64_frac": (rf.get("fp64") or {}).get("frac"),
+                                  "issue_frac": (rf.get("issue") or {}).get("frac")},
                      "solver": d.get("solver"), "cpu_baseline": ({k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "single_core_value", "sample")} if "cpu_baseline" in d else None),
                      "command": " ".join(["python", "bench.py"] + cmd[2:]), "wall_s": time.perf_counter() - t0}
     return out
@@ -323,6 +340,7 @@ def main_enmpc(args):
                           "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
                "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                             "kernel": kdesc, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
+                            "issue": issue_roofline(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PROFILE_ROUND, args.config)), per_launch_s, units / float(cfg["batch"])),
                             "launch_timing": ("HIP events around every launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
                                               "groups on streams of their own)" % (len(pms), K)) if kern == 2 else "HIP events around the timed regions' launches",
                             "alg_bytes_per_step": ab, "instance_steps_per_launch": units, "device_ms_per_run": float(np.mean(kms)),
@@ -436,6 +454,7 @@ def main_nmpc(args):
                       "device_ms_per_run": float(np.mean(kms))},
            "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": kdesc, "launches": (wn * len(wms)) if split else len(times), "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
+                        "issue": issue_roofline(summary, per_launch_s, units / 16384.0) if split else None,
                         "launch_timing": ("HIP events around every wave-style launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
                                           "groups on streams of their own)" % (len(wms), K)) if split else "HIP events around the timed regions' launches",
                         "instance_steps_per_launch": units, "note": note},
@@ -591,6 +610,7 @@ def main():
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab, "carried_bytes_per_step": carried_bytes_per_step(prob),
                          "issue_bound": True,
+                         "issue": issue_roofline(PMC_SUMMARY, per_launch_s, inst_steps_per_launch / 81920.0),
                          "fp64": (lambda fl: {"achieved_tflops": fl * inst_steps_per_launch / per_launch_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                                               "frac": fl * inst_steps_per_launch / per_launch_s / 1e12 / FP64_PEAK_TFLOPS, "alg_flops_per_step": fl,
                                               "formula": "BASELINE.md section 3 / SURVEY.md 8d: 31 kflop per interior-point iteration x mean iterations per instance-step of this run"})(
