@@ -9,7 +9,7 @@ from conftest import ROOT
 
 sys.path.insert(0, ROOT)
 EXAMPLES = ["cstr_lmpc.py", "wood_berry_lmpc.py", "cstr_nlplant_lmpc.py", "cstr_xp_nlplant_lmpc.py", "cstr_nmpc.py", "quadtank_nmpc_dis.py", "reactor_nmpc.py",
-            "reactor_enmpc.py"]
+            "reactor_enmpc.py", "reactor_enmpc_ekf.py"]
 
 
 def test_figures_of_the_reference_from_result_arrays(tmp_path):
