@@ -10,6 +10,21 @@ import mpc_code_amd as m
 from mpc_code_amd import capi, nmpc
 
 out = {"lmpc_cstr": [], "lmpc_wb": [], "nmpc_cstr": []}
+# (the non-linear workload first: after the linear sweeps' allocations and frees, round 4's first recordings of its 16384 row came out at 27 ms against 16.6 ms in a fresh process)
+p = m.load_problem(m.example_path("cstr_nmpc.py"))
+s = nmpc.NmpcSolver(p)
+rng = np.random.default_rng(20250615)      # (starts of its own: continuing the linear part's stream, round 4's first recording drew a 16384 batch whose slowest wave took 27 ms against the 16.6 ms of every other draw)
+for B in (1024, 4096, 16384, 65536, 131072):
+    x0 = p.x0_p * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, 3)))
+    K = 20
+    s.alloc(B, K); s.set_schedule(p.schedules(K))
+    ts = []
+    for r in range(6):      # (the first run after a re-allocation or a change of launch style is discarded; the median of the rest - two were too few: one slow run of three made round 4's first recording of the 16384 row wrong)
+        s.set_state(x0, x0); s.run(0, K, 1); s.sync(); ts.append(s.last_kernel_ms())
+    ms = float(np.median(ts[1:]))
+    out["nmpc_cstr"].append(dict(B=B, K=K, kernel_ms=ms, msteps_per_s=B * K / ms / 1e3, runs_ms=[round(t, 2) for t in ts], kernel=s.get_kernel()))
+    print("nmpc", out["nmpc_cstr"][-1], flush=True)
+s.close()
 rng = np.random.default_rng(20250614)
 for ex, key, Bs in (("cstr_lmpc.py", "lmpc_cstr", (256, 1024, 4096, 16384, 65536)), ("wood_berry_lmpc.py", "lmpc_wb", (1024, 4096, 16384))):
     p = m.load_problem(m.example_path(ex))
@@ -33,18 +48,5 @@ for ex, key, Bs in (("cstr_lmpc.py", "lmpc_cstr", (256, 1024, 4096, 16384, 65536
                 out[key].append(dict(B=B, K=K, loop_kernel=lk, kernel_ms=ms, msteps_per_s=B * K / ms / 1e3))
                 print(key, out[key][-1], flush=True)
     s.close()
-p = m.load_problem(m.example_path("cstr_nmpc.py"))
-s = nmpc.NmpcSolver(p)
-for B in (1024, 4096, 16384, 65536, 131072):
-    x0 = p.x0_p * (1.0 + 0.02 * rng.uniform(-1, 1, size=(B, 3)))
-    K = 20
-    s.alloc(B, K); s.set_schedule(p.schedules(K))
-    ts = []
-    for r in range(3):
-        s.set_state(x0, x0); s.run(0, K, 1); s.sync(); ts.append(s.last_kernel_ms())
-    ms = float(np.median(ts[1:]))
-    out["nmpc_cstr"].append(dict(B=B, K=K, kernel_ms=ms, msteps_per_s=B * K / ms / 1e3))
-    print("nmpc", out["nmpc_cstr"][-1], flush=True)
-s.close()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "batch_sweep.json"), "w"), indent=1)
