@@ -19,6 +19,7 @@
 #ifndef MPC_ENMPC_H
 #define MPC_ENMPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

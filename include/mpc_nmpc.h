@@ -16,6 +16,7 @@
 #ifndef MPC_NMPC_H
 #define MPC_NMPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -59,7 +59,7 @@ def build_library(force: bool = False, verbose: bool = False, dims=None, plant_h
     ``dims = (nx, nu, ny, nd, nxp, du_form, general_output_rows)``: a library holding the kernels of exactly that
     dimension set (every kernel is a template on the problem dimensions; the default library carries the sets of the
     shipped examples, ``mpc_build_info()``), written to ``csrc/jit/`` and reused while the sources are unchanged."""
-    srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp", "mpc_tp.hpp", "mpc_wave.hpp")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("mpc_amd.hip", "mpc_device.hpp", "mpc_sym.hpp", "mpc_tp.hpp", "mpc_wave.hpp")] + \
            [os.path.join(os.path.dirname(PKG_DIR), "include", "mpc_amd.h")]
     out = LIB_PATH if dims is None else jit_library_path(dims)
     hdr = None

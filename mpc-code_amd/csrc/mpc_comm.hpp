@@ -63,6 +63,7 @@ struct Buf {
 struct State {
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     Buf send, recv;
+    size_t agreed_n = 0;      // the per-rank count of allgather_dev every rank was last seen to agree on
 };
 
 static int unique_id(char *out128)
@@ -135,6 +136,15 @@ static int barrier(State &c, int device, hipStream_t stream)
 static int allgather_dev(State &c, int device, hipStream_t stream, const double *src, size_t n)
 {
     HIP_TRY(hipSetDevice(device));
+    if (c.comm && c.world > 1 && c.agreed_n != n) {
+        // ncclAllGather wants the same count on every rank (unequal shards hang or corrupt the gather): checked once per count with a small gather of its own
+        unsigned long long mine = n, all[64];
+        if (c.world > 64) return fail(-1, "more than 64 ranks");
+        if (int rc = allgather_host(c, device, stream, &mine, sizeof(mine), all)) return rc;
+        for (int r = 0; r < c.world; r++)
+            if (all[r] != mine) return fail(-1, "all-gather of a log: rank %d holds %llu doubles per rank, rank %d holds %llu - every rank must allocate the same batch and step count (pad the shards: shard.py)", c.rank, mine, r, all[r]);
+        c.agreed_n = n;
+    }
     if (c.recv.ensure(n * sizeof(double) * c.world)) return -10;
     if (c.comm) MPC_RCCL_TRY(g_rccl.AllGather(src, c.recv.p, n, ncclDouble, c.comm, stream));
     else HIP_TRY(hipMemcpyAsync(c.recv.p, src, n * sizeof(double), hipMemcpyDeviceToDevice, stream));

@@ -20,7 +20,18 @@
 //   * target (opt_ss, Target_Calc.py:20-161): nx + nu + ny variables; the model's fixed-point equation is eliminated with an LU of
 //     (A - I) and the reduced Hessian is nu x nu; computed redundantly by every lane (wave-uniform).
 #pragma once
+#ifdef EC_WAVE_EMU      // CPU test suite only (tests/wave_emu): the wave primitives on host fibers, so that this source runs - lane by lane - next to the oracle without a GPU
+#include "wave_emu.hpp"
+#define EC_VGPR_PIN(r) do { } while (0)
+#define EC_ANY_HINT(p) ((p) != 0)      // (the fibers cannot vote inside a per-segment branch; the hint's answer for the lane itself is all its user needs)
+#else
 #include "mpc_tp.hpp"
+#define EC_VGPR_PIN(r) asm("" : "+v"(r))
+#define EC_LANE_INDEPENDENT_KERNEL
+// a vote that only gates work every lane would decide for itself anyway ("does any lane of the wave need the rare path?"): the one cross-lane operation that may sit
+// under a per-segment branch
+#define EC_ANY_HINT(p) __any(p)
+#endif
 #define EC_UNI(x) mpc::uni(x)
 #include "mpc_rk4s2.hpp"
 
@@ -67,7 +78,7 @@ struct Seg {
             // recursion); with the move, or with ds_bpermute broadcasts instead, all of them are right (round 3, tools/enmpc_bcast_matrix.py).
             double r = lane_of(v, kk);
 #ifndef EC_BCAST_IN_SGPRS      // (the matrix's failing leg)
-            asm("" : "+v"(r));
+            EC_VGPR_PIN(r);
 #endif
             return r;
         }
@@ -157,7 +168,7 @@ __device__ __forceinline__ double safe_slack(double w, BoundRef &&bound, double 
     const double b = bound;
     double s = lower ? w - b : b - w;
     const double s_min = kEps * dmin(1.0, mu);
-    if (__builtin_expect(__any(s < s_min ? 1 : 0), 0)) {      // (no lane of the wave in almost every call: the division is not even issued)
+    if (__builtin_expect(EC_ANY_HINT(s < s_min ? 1 : 0), 0)) {      // (no lane of the wave in almost every call: the division is not even issued)
         if (s < s_min) {
             s = dmin(dmax(mu / z, s_min), dmax(s, 0.0) + kSlackMove * dmax(1.0, fabs(b)));
             bound = lower ? w - s : w + s;

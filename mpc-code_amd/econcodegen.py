@@ -194,7 +194,7 @@ struct EcModel {{
 
 def enmpc_library_path(header_text: str) -> str:
     inc = os.path.join(os.path.dirname(PKG_DIR), "include")
-    srcs = [os.path.join(CSRC, f) for f in ("mpc_enmpc.hip", "mpc_enmpc.hpp", "mpc_rk4s2.hpp", "mpc_device.hpp", "mpc_tp.hpp", "mpc_comm.hpp")] + [os.path.join(inc, "mpc_enmpc.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mpc_enmpc.hip", "mpc_enmpc.hpp", "mpc_rk4s2.hpp", "mpc_device.hpp", "mpc_sym.hpp", "mpc_tp.hpp", "mpc_comm.hpp")] + [os.path.join(inc, "mpc_enmpc.h")]
     hsh = hashlib.sha256(header_text.encode())
     hsh.update(" ".join(ENMPC_FLAGS).encode())
     for s in srcs:

@@ -217,6 +217,8 @@ class EnmpcSolver:
             if a is not None and (a.ndim != 3 or a.shape[1:] != (self.B, d)):
                 raise ValueError(f"noise: [nsteps, {self.B}, {d}] expected, got {a.shape}")
         n = next((a.shape[0] for a in arrs if a is not None), 0)
+        if any(a is not None and a.shape[0] != n for a in arrs):
+            raise ValueError("noise: v and w cover the same number of steps")
         self._chk(self.lib.enmpc_set_noise(self.h, n, *[None if a is None else a.ctypes.data_as(_dp) for a in arrs]), "enmpc_set_noise")
 
     def mhe_update(self, y, u_prev):
@@ -348,7 +350,8 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
             s.set_groups(groups)
         s.set_state(x0_p)
         vn, wn = loop_noise(p, nsteps, len(x0_p), noise_seed) if noise_seed is not None else (None, None)
-        s.set_noise(vn, wn)
+        if noise_seed is not None:      # (a caller-owned solver keeps the noise its caller installed)
+            s.set_noise(vn, wn)
         spl = steps_per_launch if steps_per_launch > 0 else nsteps
         for k0 in range(0, nsteps, spl):
             s.run(k0, min(spl, nsteps - k0))
@@ -364,8 +367,6 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
             out["V_WN"] = vn
         if wn is not None:
             out["W_WN"] = wn
-        if noise_seed is not None:
-            s.set_noise(None, None)
         out["Y_HAT"] = out["X_HAT"] + d_prior @ p.Cd.T
         out["YS"] = out["XS"] + out["D_HAT"] @ p.Cd.T
         out["TIME_DYN"] = np.full(nsteps, out["kernel_ms"] * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)      # (one device time for the whole step)
@@ -373,3 +374,5 @@ def run_enmpc_closed_loop(problem, x0_p, nsteps: Optional[int] = None, device: i
     finally:
         if solver is None:
             s.close()
+        elif noise_seed is not None:      # (also after an exception: a caller-owned solver does not keep this run's draws)
+            s.set_noise(None, None)

@@ -308,12 +308,13 @@ def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = 
         s.set_state(x0_p, x0_m)
         s.set_schedule(p.schedules(nsteps))
         vn = measurement_noise(p, nsteps, B, noise_seed) if noise_seed is not None else None
-        s.set_noise(vn)
+        if vn is not None:      # (a caller-owned solver keeps the noise its caller installed)
+            s.set_noise(vn)
         s.run(0, nsteps, max_sqp, sqp_tol)
         s.sync()
         out = {k: s.get_log(k) for k in list(s.LOGS) + list(s.ILOGS) if not (k == "D_HAT" and p.nd == 0)}
         if vn is not None:
-            out["V_WN"] = vn; s.set_noise(None)
+            out["V_WN"] = vn
         ms = s.last_kernel_ms()
         out["TIME_DYN"] = np.full(nsteps, ms * 1e-3 / nsteps); out["TIME_SS"] = np.zeros(nsteps)
         u_prev = np.concatenate([_rows(p.u0, B, p.nu)[None], out["U"][:-1]]) if nsteps else out["U"]
@@ -326,4 +327,6 @@ def run_nmpc_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = 
     finally:
         if own:
             s.close()
+        elif noise_seed is not None:      # (also after an exception)
+            s.set_noise(None)
     return out

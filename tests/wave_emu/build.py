@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE: builds ``mpc-code_amd/csrc/mpc_enmpc.hip`` - kernels and host side, as they are - for the CPU with g++ against the wave emulator of
+``tests/wave_emu/include/hip/hip_runtime.h`` (64 host fibers in lockstep stand for a wavefront; the HIP runtime's names are host stubs).  The resulting
+library exports the C-ABI of ``include/mpc_enmpc.h`` and is opened through the product's own ctypes binding (``EnmpcSolver(p, lib_path=...)``), so the CPU test
+suite runs the KERNEL SOURCE next to the oracle.  The product never calls this: its loader builds with hipcc for gfx950 and fails without a GPU."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build")
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-march=native", "-fPIC", "-shared", "-DEC_WAVE_EMU", "-w"]
+
+
+def build(p, extra_flags=(), verbose=False) -> str:
+    """the emulated library of the economic problem ``p`` (cached by the hash of every source it is made of)"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from mpc_code_amd import econcodegen
+    text = econcodegen.emit_econ_header(p)
+    csrc = econcodegen.CSRC
+    srcs = [os.path.join(csrc, f) for f in ("mpc_enmpc.hip", "mpc_enmpc.hpp", "mpc_rk4s2.hpp", "mpc_sym.hpp", "mpc_comm.hpp")] + \
+           [os.path.join(ROOT, "include", "mpc_enmpc.h"), os.path.join(HERE, "wave_emu.hpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+    hsh = hashlib.sha256((text + " ".join(FLAGS) + " ".join(extra_flags)).encode())
+    for s in srcs:
+        hsh.update(open(s, "rb").read())
+    out = os.path.join(OUT, f"libemu_enmpc_{hsh.hexdigest()[:16]}.so")
+    if os.path.exists(out):
+        return out
+    os.makedirs(OUT, exist_ok=True)
+    hdr = out[:-3] + "_model.hpp"
+    with open(hdr, "w") as fh:
+        fh.write(text)
+    tmp = out + f".{os.getpid()}.tmp"
+    cmd = ["g++", *FLAGS, *extra_flags, f'-DMPC_EC_MODEL_HEADER="{hdr}"', "-I", os.path.join(HERE, "include"), "-I", HERE, "-I", csrc, "-o", tmp, srcs[0], "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, out)
+    return out

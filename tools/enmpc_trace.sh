@@ -6,7 +6,7 @@ TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for c in enmpc mhe; do
-  rm -rf $R/gpurun_out/tr_$TAG_$c
+  rm -rf "$R/gpurun_out/tr_${TAG}_$c"
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tr_${TAG}_$c -- python3 $R/bench.py --config $c --steps 20 --warmup 2 --no-cpu-baseline --groups 1 --repeats 3 > /dev/null 2>&1
   f=$(find $R/gpurun_out/tr_${TAG}_$c -name "*kernel_stats.csv" | head -1)
   echo "== $c"; head -4 $f | cut -d, -f1-4
