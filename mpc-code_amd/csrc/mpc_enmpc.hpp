@@ -39,6 +39,7 @@ namespace enm {
 using namespace mpc;
 
 // ---- the outer algorithm's constants (the checker carries the same) ----------------------------------------------------
+constexpr double kBoundRelax = 1e-8;      // bound_relax_factor: every finite bound is relaxed by this times max(1, |bound|) before the solve, the final point projected back (honor_original_bounds)
 constexpr double kPush = 1e-2, kMuInit = 0.1, kKappaEps = 10.0, kKappaMu = 0.2, kTauMin = 0.99, kKappaSigma = 1e10, kSMax = 100.0,
                  kDeltaFirst = 1e-4, kDeltaMax = 1e40;
 enum : int { kStSolved = 0, kStMaxIter = 1, kStFailed = 2 };
@@ -46,6 +47,8 @@ enum : int { kStSolved = 0, kStMaxIter = 1, kStFailed = 2 };
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 __device__ __forceinline__ bool finite_all(double v) { return fabs(v) < 1.0e300; }      // false for inf and NaN
 
+__device__ __forceinline__ double relax_lo(double b) { return fin(b) ? b - kBoundRelax * dmax(1.0, fabs(b)) : b; }
+__device__ __forceinline__ double relax_hi(double b) { return fin(b) ? b + kBoundRelax * dmax(1.0, fabs(b)) : b; }
 __device__ __forceinline__ double push_in(double v, double lo, double hi)
 {
     const bool fl = fin(lo), fh = fin(hi);
@@ -191,19 +194,23 @@ struct MinRatio {
     __device__ __forceinline__ void add(double v, double dv, double tau, bool use = true) { const double ni = tau * v, di = -dv; if (use && di > 0.0 && ni * d < n * di) { n = ni; d = di; } }
     __device__ __forceinline__ double value() const { return n / d; }
 };
-// Per-lane arrays that live in LDS: row r of the wave's area is 64 doubles, one per lane.  REAL = false: the array does not exist (a variable class without
-// bounds) - reads give `dflt`, writes vanish; with the loops unrolled nothing of it is left.
+// Per-lane arrays that live outside the register file: row r of the wave's LDS area is 64 doubles, one per lane (PS = 64) - or, in the rare-path solves that run with
+// everything in private memory (restoration phase: ipm_stage MODE 1 / 2), a lane's own array (PS = 1).  REAL = false: the array does not exist (a variable class
+// without bounds) - reads give `dflt`, writes vanish; with the loops unrolled nothing of it is left.
 template <bool REAL>
 struct LRow {
     double *p; double dflt;
     __device__ __forceinline__ operator double() const { return REAL ? *p : dflt; }
     __device__ __forceinline__ void operator=(double v) const { if (REAL) *p = v; }
+    __device__ __forceinline__ void operator=(const LRow &o) const { if (REAL) *p = (double)o; }      // (row = row copies the VALUE, not the handle)
     __device__ __forceinline__ void operator+=(double v) const { if (REAL) *p = *p + v; }
+    __device__ __forceinline__ LRow(double *p_, double d_) : p(p_), dflt(d_) {}
+    LRow(const LRow &) = default;
 };
-template <bool REAL>
+template <bool REAL, int PS = 64>
 struct LRows {
     double *base; double dflt;
-    __device__ __forceinline__ LRow<REAL> operator[](int i) const { return LRow<REAL>{base + i * 64, dflt}; }
+    __device__ __forceinline__ LRow<REAL> operator[](int i) const { return LRow<REAL>(base + i * PS, dflt); }
 };
 // the compiler forgets what it knows of memory: values read from LDS before this point are read again after it instead of being kept in registers
 #define EC_LDS_FENCE() asm volatile("" ::: "memory")
@@ -340,12 +347,43 @@ __device__ __forceinline__ void ric_forward(const int N, const int lane, const i
 }
 
 //   grd(xk, u, L)          cost value / gradient only (L.l, L.lx, L.lu): the caller's point, where IPOPT takes the scaling of the objective from
-template <int NS, int NU, bool FREE0, bool UB, int SEG, class ST, class AUX, class GrdF, class LinF, class AddPiF, class ValF, class TermF>
+// (every functor takes the barrier parameter as its last argument: the restoration problem's objective depends on it, the callers' problems ignore it)
+//
+// MODE 0: the solve without the restoration phase - the form the hot kernels carry.  A line search that runs out of step lengths at an infeasible point returns
+//         kStNeedResto: the caller hands the instance, untouched, to the rare path (MODE 1) - some solves in 1e5 on the benchmark workloads.
+// MODE 1: the complete algorithm: such a line search enters IPOPT's RESTORATION PHASE [WB 3.3; IpRestoMinC_1Nrm, IpRestoIpoptNLP, IpRestoFilterConvCheck]:
+//             min  rho sum(n + p) + sqrt(mu) / 2 |D_R (w - w_R)|^2   s.t.  x_{k+1} = F_k(x_k, u_k) - n_k + p_k,  the boxes,  n, p >= 0
+//         which is a problem of THIS function's own form with the defects as 2 NS more inputs per stage - solved by MODE 2 (same iteration, same recursion over
+//         the lanes, inputs [u; n; p], B~ = [B, -I, I]) until the point is enough less infeasible and acceptable to this solve's filter and iterate.
+//         Bound data lives in the lane's private memory (PS = 1): nothing here is sized for the hot path.
+// MODE 2: the restoration problem's iteration: first iterate, multipliers and barrier parameter given (ext.mu0, rows of `park` filled by the caller), no scaling,
+//         the caller's test (xt.hook) ends it, its objective is recomposed after every change of mu (xt.recost); returns kRs*.
+enum : int { kStNeedResto = 3 };
+struct IpmNoExtra {};
+struct IpmRestoWs { double *park_r, *filt_r; };      // MODE 1: private areas of the inner solve (ipm_park_rows<NS, NU + 2 NS, FREE0, true>() doubles; 2 kFilterCap doubles)
+template <class HookF, class RecostF> struct IpmRestoIn { double mu0; int it0; HookF hook; RecostF recost; };      // MODE 2
+// the rows of the bound data (multipliers Z, bounds B, slacks S; L / H lower / upper; U inputs, X states x_{k+1}, 0 the free initial state)
+template <int NS, int NU, bool FREE0, bool UB>
+struct ParkRows {
+    static constexpr int NUB = UB ? NU : 0, N0 = FREE0 ? NS : 0, NBV = NUB + NS + N0;
+    static constexpr int ZLU = 0, BLU = ZLU + NUB, ZHU = BLU + NUB, BHU = ZHU + NUB, ZLX = BHU + NUB, BLX = ZLX + NS, ZHX = BLX + NS, BHX = ZHX + NS,
+                         ZL0 = BHX + NS, BL0 = ZL0 + N0, ZH0 = BL0 + N0, BH0 = ZH0 + N0, SLU = BH0 + N0, SHU = SLU + NUB, SLX = SHU + NUB, SHX = SLX + NS,
+                         SL0 = SHX + NS, SH0 = SL0 + N0, IT = SH0 + N0;
+    static_assert(IT == 6 * NBV, "rows of the bound data");
+};
+constexpr double kRestoRho = 1000.0, kRestoKappa = 0.9, kRestoThetaMaxFact = 1e8, kRestoBoundMultReset = 1e3, kRestoFeasFact = 1e2;
+enum : int { kRsRestored = 0, kRsConverged = 1, kRsLimit = 2, kRsFailed = 3 };
+
+template <int NS, int NU, bool FREE0, bool UB, int SEG, class ST, class AUX, int MODE = 0, int PS = 64, class GrdF, class LinF, class AddPiF, class ValF, class TermF, class XT = IpmNoExtra>
 __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
                                          double (&pi)[NS], const double (&ulo_in)[NU], const double (&uhi_in)[NU], const double (&xlo_in)[NS],
                                          const double (&xhi_in)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
-                                         const int max_iter, GrdF grd, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt, double *const park)
+                                         const int max_iter, GrdF grd, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt, double *const park, XT ext = XT())
 {
+    static_assert(MODE == 0 || PS == 1, "the rare-path solves keep their bound data in private memory");
+    // what the solve's events are called: a status word of the caller's (kSt*), or - restoration problem - what its caller makes of it (kRs*)
+    constexpr int S_FAIL = MODE == 2 ? (int)kRsFailed : (int)kStFailed, S_CONV = MODE == 2 ? (int)kRsConverged : (int)kStSolved, S_LIMIT = MODE == 2 ? (int)kRsLimit : (int)kStMaxIter,
+                  S_TINY = MODE == 2 ? (int)kRsConverged : (int)kStMaxIter;
     using SG = Seg<SEG>;
     // Large stages (the estimator: 4 + 4 here) do not keep the factors of the Newton system across the line search - with the trial point's integration they
     // would not fit the register file, and what the compiler then moves to scratch memory is paid for in every iteration.  The second-order correction, which
@@ -358,24 +396,28 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
     // lane's column; ipm_park_rows), for the inputs (u; UB), the states x_{k+1} (x) and the free initial state (0; FREE0).  They are read where they are used:
     // kept in registers (round 3; then parked across the linearisation and the sweeps) they were what the compiler moved to scratch memory around every
     // larger piece of an iteration - 400 scratch accesses per iteration of the estimator at one wave per SIMD, each waited for.
-    constexpr int NUB = UB ? NU : 0, N0 = FREE0 ? NS : 0, NBV = NUB + NS + N0;
-    constexpr int R_ZLU = 0, R_BLU = R_ZLU + NUB, R_ZHU = R_BLU + NUB, R_BHU = R_ZHU + NUB, R_ZLX = R_BHU + NUB, R_BLX = R_ZLX + NS, R_ZHX = R_BLX + NS, R_BHX = R_ZHX + NS,
-                  R_ZL0 = R_BHX + NS, R_BL0 = R_ZL0 + N0, R_ZH0 = R_BL0 + N0, R_BH0 = R_ZH0 + N0, R_SLU = R_BH0 + N0, R_SHU = R_SLU + NUB, R_SLX = R_SHU + NUB, R_SHX = R_SLX + NS,
-                  R_SL0 = R_SHX + NS, R_SH0 = R_SL0 + N0, R_IT = R_SH0 + N0;
-    static_assert(R_IT == 6 * NBV, "rows of the LDS area");
-    double *const pk = park + lane;
-    const LRows<UB> zlu{pk + 64 * R_ZLU, 0.0}, blu{pk + 64 * R_BLU, -INFINITY}, zhu{pk + 64 * R_ZHU, 0.0}, bhu{pk + 64 * R_BHU, INFINITY}, slu{pk + 64 * R_SLU, 1.0}, shu{pk + 64 * R_SHU, 1.0};
-    const LRows<true> zlx{pk + 64 * R_ZLX, 0.0}, blx{pk + 64 * R_BLX, -INFINITY}, zhx{pk + 64 * R_ZHX, 0.0}, bhx{pk + 64 * R_BHX, INFINITY}, slx{pk + 64 * R_SLX, 1.0}, shx{pk + 64 * R_SHX, 1.0};
-    const LRows<FREE0> zl0{pk + 64 * R_ZL0, 0.0}, bl0{pk + 64 * R_BL0, -INFINITY}, zh0{pk + 64 * R_ZH0, 0.0}, bh0{pk + 64 * R_BH0, INFINITY}, sl0{pk + 64 * R_SL0, 1.0}, sh0{pk + 64 * R_SH0, 1.0};
+    using PR = ParkRows<NS, NU, FREE0, UB>;
+    constexpr int R_IT = PR::IT;
+    double *const pk = park + (PS == 64 ? lane : 0);
+    const LRows<UB, PS> zlu{pk + PS * PR::ZLU, 0.0}, blu{pk + PS * PR::BLU, -INFINITY}, zhu{pk + PS * PR::ZHU, 0.0}, bhu{pk + PS * PR::BHU, INFINITY}, slu{pk + PS * PR::SLU, 1.0}, shu{pk + PS * PR::SHU, 1.0};
+    const LRows<true, PS> zlx{pk + PS * PR::ZLX, 0.0}, blx{pk + PS * PR::BLX, -INFINITY}, zhx{pk + PS * PR::ZHX, 0.0}, bhx{pk + PS * PR::BHX, INFINITY}, slx{pk + PS * PR::SLX, 1.0}, shx{pk + PS * PR::SHX, 1.0};
+    const LRows<FREE0, PS> zl0{pk + PS * PR::ZL0, 0.0}, bl0{pk + PS * PR::BL0, -INFINITY}, zh0{pk + PS * PR::ZH0, 0.0}, bh0{pk + PS * PR::BH0, INFINITY}, sl0{pk + PS * PR::SL0, 1.0}, sh0{pk + PS * PR::SH0, 1.0};
     int nbl = 0, nbx = 0;
-    MPC_UNROLL for (int i = 0; i < NU; i++) { blu[i] = ulo_in[i]; bhu[i] = uhi_in[i]; flu[i] = UB && fin(ulo_in[i]); fhu[i] = UB && fin(uhi_in[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0); }
+    MPC_UNROLL for (int i = 0; i < NU; i++) {
+        flu[i] = UB && fin(ulo_in[i]); fhu[i] = UB && fin(uhi_in[i]); nbl += (flu[i] ? 1 : 0) + (fhu[i] ? 1 : 0);
+        if (MODE != 2) { blu[i] = relax_lo(ulo_in[i]); bhu[i] = relax_hi(uhi_in[i]); zlu[i] = flu[i] ? 1.0 : 0.0; zhu[i] = fhu[i] ? 1.0 : 0.0; }      // (MODE 2: the caller has filled the rows of bounds and multipliers)
+    }
     MPC_UNROLL for (int i = 0; i < NS; i++) {
-        blx[i] = xlo_in[i]; bhx[i] = xhi_in[i]; bl0[i] = xlo_in[i]; bh0[i] = xhi_in[i];
-        flx[i] = fin(xlo_in[i]); fhx[i] = fin(xhi_in[i]); zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0; nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
-        zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0;
+        flx[i] = fin(xlo_in[i]); fhx[i] = fin(xhi_in[i]); nbx += (flx[i] ? 1 : 0) + (fhx[i] ? 1 : 0); pi[i] = 0.0;
+        if (MODE != 2) {
+            blx[i] = relax_lo(xlo_in[i]); bhx[i] = relax_hi(xhi_in[i]); bl0[i] = relax_lo(xlo_in[i]); bh0[i] = relax_hi(xhi_in[i]);
+            zlx[i] = flx[i] ? 1.0 : 0.0; zhx[i] = fhx[i] ? 1.0 : 0.0;
+            zl0[i] = (FREE0 && flx[i]) ? 1.0 : 0.0; zh0[i] = (FREE0 && fhx[i]) ? 1.0 : 0.0;
+        }
     }
     // The iterate itself is parked there across the sweeps (it is not touched between the linearisation and the first trial point).
     auto park_iter = [&](const bool store) {
+        if (PS != 64) return;      // (private memory: nothing to gain)
         int slot = R_IT;
         auto one = [&](double &v) { if (store) park[slot * 64 + lane] = v; else v = park[slot * 64 + lane]; slot++; };
         MPC_UNROLL for (int i = 0; i < NU; i++) one(u[i]);
@@ -388,19 +430,20 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
     // count.  A segment that has finished (done) keeps computing with its frozen iterate while its wave neighbours go on; `live` = false marks a
     // segment without an instance (ragged batch).  Cross-lane operations (shifts, broadcasts, reductions) are never under a per-segment branch.
     double mu = kMuInit, tau = dmax(kTauMin, 1.0 - kMuInit), delta_last = 0.0, df = 1.0, theta_max = -1.0, theta_min = -1.0;
+    if constexpr (MODE == 2) { mu = ext.mu0; tau = dmax(kTauMin, 1.0 - mu); }
     const double mu_min = dmin(tol, kComplInfTol) / (kKappaEps + 1.0);
-    int status = kStMaxIter, nfilt = 0, acc_count = 0;
+    int status = S_LIMIT, nfilt = 0, acc_count = 0;
     bool done = !live, tiny_last = false, tiny_flag = false;
     iters = 0;
     EC_IPM_STAMP_INIT
     // ---- scaling of the objective at the caller's point (IpGradientScaling), then the push into the box --------------------------------------------
-    {
+    if constexpr (MODE != 2) {
         double xk[NS];
         MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
         StageLin<NS, NU> L;
-        grd(xk, u, L);
+        grd(xk, u, L, mu);
         double fv, gv[NS], Hv[NS][NS], gm = 0.0;
-        term(xn, fv, gv, Hv);
+        term(xn, fv, gv, Hv, mu);
         MPC_UNROLL for (int i = 0; i < NU; i++) gm = dmax(gm, fabs(L.lu[i]));
         MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, L.lx[i], k); gm = dmax(gm, fabs(k == N - 1 ? gv[i] : sh)); }
         gm = SG::max(on ? gm : 0.0);
@@ -417,8 +460,9 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) x0v[i] = push_in(x0v[i], bl0[i], bh0[i]); }
     }
     EC_IPM_STAMP(0);      // scaling, push
-    bool first = true;      // (wave-uniform: every segment's first iteration starts with the least-squares multipliers)
+    bool first = MODE != 2;      // (wave-uniform: every segment's first iteration starts with the least-squares multipliers)
     int it = 0;
+    if constexpr (MODE == 2) it = ext.it0;
     for (;;) {
         if (!done) iters = it;
         // ---- linearise this lane's stage at (x_k, u_k); x_k is the neighbour's x_{k+1} ------------------------------------------------
@@ -426,20 +470,22 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NS; i++) xk[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
         StageLin<NS, NU> L;
         AUX aux;
-        lin(xk, u, L, aux);
+        lin(xk, u, L, aux, mu);
         double fv, gv[NS], Hv[NS][NS];
-        term(xn, fv, gv, Hv);
+        term(xn, fv, gv, Hv, mu);
         EC_IPM_STAMP(1);      // linearisation
         EC_LDS_FENCE();
         // the scaled problem: df f.  (An entry the generated code knows to be zero stays a literal zero - 0 * df would be a run-time value to the compiler, and the
         // sweeps below would multiply and keep in registers what the estimator's structure - constant diagonal cost Hessian, no cross terms - lets them drop.)
         auto scaled = [&](double x_) { return (__builtin_constant_p(x_) && x_ == 0.0) ? 0.0 : x_ * df; };
-        L.l *= df; fv *= df;
-        MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] = scaled(L.lu[i]); MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] = scaled(L.R[i][j]); }
-        MPC_UNROLL for (int i = 0; i < NS; i++) {
-            L.lx[i] = scaled(L.lx[i]); gv[i] = scaled(gv[i]);
-            MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] = scaled(L.Q[i][j]); Hv[i][j] = scaled(Hv[i][j]); }
-            MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] = scaled(L.M[i][j]);
+        if constexpr (MODE != 2) {      // (the restoration problem is not scaled)
+            L.l *= df; fv *= df;
+            MPC_UNROLL for (int i = 0; i < NU; i++) { L.lu[i] = scaled(L.lu[i]); MPC_UNROLL for (int j = 0; j < NU; j++) L.R[i][j] = scaled(L.R[i][j]); }
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                L.lx[i] = scaled(L.lx[i]); gv[i] = scaled(gv[i]);
+                MPC_UNROLL for (int j = 0; j < NS; j++) { L.Q[i][j] = scaled(L.Q[i][j]); Hv[i][j] = scaled(Hv[i][j]); }
+                MPC_UNROLL for (int j = 0; j < NU; j++) L.M[i][j] = scaled(L.M[i][j]);
+            }
         }
         // gradient of the objective with respect to this lane's x_{k+1}: the next stage's cost gradient, the terminal cost's at the end; with respect to the
         // free initial state: stage 0's cost gradient + the arrival cost's (ga0)
@@ -513,7 +559,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         e_st = SG::max(on ? e_st : 0.0); e_c = SG::max(on ? e_c : 0.0); s_pi = SG::sum(on ? s_pi : 0.0); s_z = SG::sum(on ? s_z : 0.0);
         cmax = SG::max(on ? cmax : -INFINITY); cmin = SG::min(on ? cmin : INFINITY);
         const double theta = SG::sum(on ? th_l : 0.0);
-        const double fobj = SG::sum(on ? L.l + (k == N - 1 ? fv : 0.0) : 0.0) + farr;
+        double fobj = SG::sum(on ? L.l + (k == N - 1 ? fv : 0.0) : 0.0) + farr;
         if (FREE0) {
             MPC_UNROLL for (int i = 0; i < NS; i++) {
                 const double r0 = SG::bcast(gxA[i], 0, lane) + ga0[i] - zl0[i] + zh0[i];      // stage 0's part of the gradient with respect to the free initial state + arrival cost
@@ -527,12 +573,21 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         const double s_d = dmax(kSMax, (s_pi + s_z) / dmax(meq + nb, 1.0)) / kSMax, s_c = dmax(kSMax, s_z / dmax(nb, 1.0)) / kSMax;
         auto compl_ = [&](double m_) { return nb > 0.0 ? dmax(cmax - m_, m_ - cmin) : 0.0; };
         auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
+#ifdef EC_EMU_TRACE
+        if (MODE == 2 && lane == 14 && getenv("EC_EMU_TRACE")) fprintf(stderr, "   lane14 u=%g blu=%g bhu=%g zlu=%g zhu=%g slu=%g shu=%g flu=%d fhu=%d cmax=%g\n", u[0], (double)blu[0], (double)bhu[0], (double)zlu[0], (double)zhu[0], (double)slu[0], (double)shu[0], (int)flu[0], (int)fhu[0], cmax);
+#endif
+#ifdef EC_EMU_TRACE      /* diagnostic build of the CPU test suite's emulator only: the iterations of the first lane's segment */
+        if (lane == 0 && getenv("EC_EMU_TRACE")) fprintf(stderr, "%c it=%3d mu=%.3e E0=%.6e e_st=%.3e e_c=%.3e compl=%.3e theta=%.6e f=%.9e done=%d\n", MODE == 2 ? 'R' : (MODE == 1 ? '1' : ' '), it, mu, err(0.0), e_st, e_c, compl_(0.0), theta, fobj / df, (int)done);
+#endif
+        bool hooked = false;      // restoration problem: the test of the solve that called (it holds cross-lane sums: taken by every lane, used per segment)
+        if constexpr (MODE == 2) hooked = ext.hook(u, xn, x0v);
         if (!done) {
             const double e0_ = err(0.0), c0_ = compl_(0.0);
-            if (nonfinite) { status = kStFailed; done = true; }
-            else if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = kStSolved; done = true; }
+            if (nonfinite) { status = S_FAIL; done = true; }
+            else if (MODE == 2 && hooked) { status = kRsRestored; done = true; }
+            else if (e0_ <= tol && e_st <= kDualInfTol && e_c <= kConstrViolTol && c0_ <= kComplInfTol) { status = S_CONV; done = true; }
             else {
-                if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = kStSolved; done = true; } }
+                if (e0_ <= kAccTol && e_st <= kAccDualInfTol && e_c <= kAccConstrViolTol && c0_ <= kAccComplInfTol) { if (++acc_count >= kAccIter) { status = S_CONV; done = true; } }
                 else acc_count = 0;
                 if (!done && it >= max_iter) done = true;
             }
@@ -551,9 +606,16 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
                     else { mu = new_mu; mu_changed = true; tiny_flag = false; }
                 }
             }
-            if (!done && stop_tiny) { status = kStMaxIter; done = true; }      // 'Search_Direction_Becomes_Too_Small': the reference accepts the point
+            if (!done && stop_tiny) { status = S_TINY; done = true; }      // 'Search_Direction_Becomes_Too_Small': the reference accepts the point
             tiny_flag = false;
             if (mu_changed) { nfilt = 0; tau = dmax(kTauMin, 1.0 - mu); }
+        }
+        if constexpr (MODE == 2) {      // the restoration problem's objective changes with mu: cost terms, Hessian of the Lagrangian, the gradients taken from them, the objective's value
+            ext.recost(xk, u, L, mu);
+            addpi(aux, pi, L);
+            term(xn, fv, gv, Hv, mu);
+            MPC_UNROLL for (int i = 0; i < NS; i++) { const double sh = SG::dn1(0.0, L.lx[i], k); gfx[i] = k == N - 1 ? gv[i] : sh; if (FREE0) lx0[i] = SG::bcast(L.lx[i], 0, lane); }
+            fobj = SG::sum(on ? L.l + (k == N - 1 ? fv : 0.0) : 0.0) + farr;
         }
         // ---- barrier terms; those of x_k come from the neighbour that holds x_k --------------------------------------------------------
         double Su[NU], bu[NU], Sx[NS], bx[NS], Sxk[NS], bxk[NS], S0[NS], b0[NS];
@@ -604,7 +666,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             }
             if (__builtin_expect(!__any((retry && !failed) ? 1 : 0), 1)) break;      // (segments that were fine recompute the same numbers with their own shift)
         }
-        if (!done && failed) { status = kStFailed; done = true; }
+        if (!done && failed) { status = S_FAIL; done = true; }
         if (!done && delta > 0.0) delta_last = delta;
         EC_IPM_STAMP(6);      // backward sweep(s)
         double du[NU], dxn[NS], dx0[NS], pin[NS];
@@ -643,18 +705,16 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             if (theta <= theta_min) a_min = dmin(a_min, sw);
         }
         a_min *= kAlphaMinFrac;
-        if (theta_max < 0.0) { theta_max = kThetaMaxFact * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
+        if (theta_max < 0.0) { theta_max = (MODE == 2 ? kRestoThetaMaxFact : kThetaMaxFact) * dmax(1.0, theta); theta_min = kThetaMinFact * dmax(1.0, theta); }
         auto ftype = [&](double alpha_) { return (theta == 0.0 && gbd > 0.0 && gbd < 100.0 * kEps) || (gbd < 0.0 && alpha_ > sw); };
         // a trial point u + a_ du_ ...: infeasibility, barrier function (safe slacks; their moved bounds are not kept), constraint values
         double theta_t = 0.0, phi_t = 0.0, ct[NS];
         bool fin_t = false;
-        auto trial = [&](const double a_, const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
-            double ut[NU], xt[NS], x0t[NS], xkt[NS], Ft[NS], lt, fvt, gvt[NS], Hvt[NS][NS];
-            MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i] + a_ * du_[i];
-            MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i] + a_ * dxn_[i]; x0t[i] = FREE0 ? x0v[i] + a_ * dx0_[i] : 0.0; }
+        auto eval_point = [&](const double (&ut)[NU], const double (&xt)[NS], const double (&x0t)[NS]) {
+            double xkt[NS], Ft[NS], lt, fvt, gvt[NS], Hvt[NS][NS];
             MPC_UNROLL for (int i = 0; i < NS; i++) xkt[i] = SG::up1(FREE0 ? x0t[i] : x0fix[i], xt[i], k);
-            val(xkt, ut, Ft, lt);
-            term(xt, fvt, gvt, Hvt);
+            val(xkt, ut, Ft, lt, mu);
+            term(xt, fvt, gvt, Hvt, mu);
             EC_LDS_FENCE();      // (multipliers and bounds are read again rather than kept alive across the integration)
             double tht = 0.0, pht = 0.0;
             LogSum lgt, lgt0;
@@ -691,6 +751,12 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             phi_t = df * (SG::sum(on ? lt + (k == N - 1 ? fvt : 0.0) : 0.0) + farrt) + SG::sum(on ? pht : 0.0) + pht0;
             fin_t = ok_t && finite_all(phi_t);
             if (!fin_t) { theta_t = INFINITY; phi_t = INFINITY; }
+        };
+        auto trial = [&](const double a_, const double (&du_)[NU], const double (&dxn_)[NS], const double (&dx0_)[NS]) {
+            double ut[NU], xt[NS], x0t[NS];
+            MPC_UNROLL for (int i = 0; i < NU; i++) ut[i] = u[i] + a_ * du_[i];
+            MPC_UNROLL for (int i = 0; i < NS; i++) { xt[i] = xn[i] + a_ * dxn_[i]; x0t[i] = FREE0 ? x0v[i] + a_ * dx0_[i] : 0.0; }
+            eval_point(ut, xt, x0t);
         };
         // acceptable to the current iterate and to the filter?  (alpha_: the step length of the Newton step, also for a corrected step)
         auto acceptable = [&](double alpha_) {
@@ -775,9 +841,169 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         EC_IPM_STAMP(10);
         EC_LDS_FENCE();
-        if (!done) {
-            if (!accepted) {      // IPOPT enters its restoration phase here (not restated for this recursion): infeasible point -> failed; feasible to 1e-2 tol -> the point is kept
-                status = theta <= 1e-2 * tol ? kStMaxIter : kStFailed; done = true;
+        bool restored = false;      // (MODE 1) this segment comes back from the restoration phase with a new point: no step of this iteration's direction is taken
+        if constexpr (MODE == 1) {
+            // ---- IPOPT's restoration phase (the comment above this function; the checker restates it with dense linear algebra) --------------------------------
+            const bool need = !done && !accepted && !(theta <= 1e-2 * tol);
+            if (__builtin_expect(__any(need ? 1 : 0), 0)) {
+                constexpr int NUR = NU + 2 * NS;
+                using PRr = ParkRows<NS, NUR, FREE0, true>;
+                if (need) nfilt = filter_add(filt, nfilt, phi - kGammaPhi * theta, (1.0 - kGammaTheta) * theta);      // the point the restoration starts from is never returned to
+                // reference point, its scaling D_R, the defects' first values [WB (32), (33)] at mu_R = max(mu, |c|_inf)
+                double cm_ = 0.0;
+                MPC_UNROLL for (int i = 0; i < NS; i++) cm_ = dmax(cm_, fabs(c[i]));
+                const double mu_r = dmax(mu, SG::max(on ? cm_ : 0.0));
+                double uR[NU], xR[NS], x0R[NS], xkR[NS], du2[NU], dx2[NS], dxk2[NS];
+                double ur[NUR], xr[NS], x0r[NS], pir[NS], ulo_r[NUR], uhi_r[NUR], xlo_r[NS], xhi_r[NS];
+                double *const pr = ext.park_r;
+                const LRows<true, 1> rzlu{pr + PRr::ZLU, 0.0}, rblu{pr + PRr::BLU, 0.0}, rzhu{pr + PRr::ZHU, 0.0}, rbhu{pr + PRr::BHU, 0.0}, rzlx{pr + PRr::ZLX, 0.0}, rblx{pr + PRr::BLX, 0.0},
+                                     rzhx{pr + PRr::ZHX, 0.0}, rbhx{pr + PRr::BHX, 0.0};
+                const LRows<FREE0, 1> rzl0{pr + PRr::ZL0, 0.0}, rbl0{pr + PRr::BL0, 0.0}, rzh0{pr + PRr::ZH0, 0.0}, rbh0{pr + PRr::BH0, 0.0};
+                MPC_UNROLL for (int i = 0; i < NU; i++) {
+                    uR[i] = u[i]; ur[i] = u[i]; const double d_ = 1.0 / dmax(1.0, fabs(u[i])); du2[i] = d_ * d_;
+                    ulo_r[i] = blu[i]; uhi_r[i] = bhu[i];      // (this solve's bounds as they are now: relaxed, moved)
+                    rblu[i] = blu[i]; rbhu[i] = bhu[i]; rzlu[i] = flu[i] ? dmin(kRestoRho, zlu[i]) : 0.0; rzhu[i] = fhu[i] ? dmin(kRestoRho, zhu[i]) : 0.0;
+                }
+                MPC_UNROLL for (int i = 0; i < NS; i++) {
+                    xR[i] = xn[i]; xr[i] = xn[i]; x0R[i] = FREE0 ? x0v[i] : 0.0; x0r[i] = x0R[i]; pir[i] = 0.0;
+                    const double d_ = 1.0 / dmax(1.0, fabs(xn[i])); dx2[i] = d_ * d_;
+                    const double d0_ = 1.0 / dmax(1.0, fabs(x0R[i]));
+                    xkR[i] = SG::up1(x0R[i], xR[i], k); dxk2[i] = SG::up1(FREE0 ? d0_ * d0_ : 0.0, dx2[i], k);      // x_k's term sits in stage k's cost; a given x_0 has none
+                    xlo_r[i] = blx[i]; xhi_r[i] = bhx[i];
+                    rblx[i] = blx[i]; rbhx[i] = bhx[i]; rzlx[i] = flx[i] ? dmin(kRestoRho, zlx[i]) : 0.0; rzhx[i] = fhx[i] ? dmin(kRestoRho, zhx[i]) : 0.0;
+                    rbl0[i] = bl0[i]; rbh0[i] = bh0[i]; rzl0[i] = (FREE0 && flx[i]) ? dmin(kRestoRho, zl0[i]) : 0.0; rzh0[i] = (FREE0 && fhx[i]) ? dmin(kRestoRho, zh0[i]) : 0.0;
+                    const double a_ = mu_r / (2.0 * kRestoRho) - 0.5 * c[i], n_ = a_ + sqrt(a_ * a_ + mu_r * c[i] / (2.0 * kRestoRho)), p_ = c[i] + n_;
+                    ur[NU + i] = n_; ur[NU + NS + i] = p_;
+                    ulo_r[NU + i] = 0.0; ulo_r[NU + NS + i] = 0.0; uhi_r[NU + i] = INFINITY; uhi_r[NU + NS + i] = INFINITY;
+                    rblu[NU + i] = 0.0; rblu[NU + NS + i] = 0.0; rbhu[NU + i] = INFINITY; rbhu[NU + NS + i] = INFINITY;
+                    rzlu[NU + i] = mu_r / n_; rzlu[NU + NS + i] = mu_r / p_; rzhu[NU + i] = 0.0; rzhu[NU + NS + i] = 0.0;
+                }
+                struct AuxR { AUX a; };
+                // the restoration problem's cost of this lane's stage: rho (n + p) + eta / 2 (|D (u - u_R)|^2 + |D (x_k - x_kR)|^2)
+                auto cost_r = [&](const double (&xk_)[NS], const double (&ur_)[NUR], StageLin<NS, NUR> &Lr, const double mu_) {
+                    const double eta = sqrt(mu_);
+                    double l_ = 0.0, q_ = 0.0;
+                    MPC_UNROLL for (int i = 0; i < NUR; i++) { MPC_UNROLL for (int j = 0; j < NUR; j++) Lr.R[i][j] = 0.0; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { const double e_ = ur_[i] - uR[i]; q_ += du2[i] * e_ * e_; Lr.lu[i] = eta * du2[i] * e_; Lr.R[i][i] = eta * du2[i]; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) {
+                        const double e_ = xk_[i] - xkR[i]; q_ += dxk2[i] * e_ * e_; Lr.lx[i] = eta * dxk2[i] * e_;
+                        MPC_UNROLL for (int j = 0; j < NS; j++) Lr.Q[i][j] = i == j ? eta * dxk2[i] : 0.0;
+                        MPC_UNROLL for (int j = 0; j < NUR; j++) Lr.M[i][j] = 0.0;
+                        l_ += ur_[NU + i] + ur_[NU + NS + i]; Lr.lu[NU + i] = kRestoRho; Lr.lu[NU + NS + i] = kRestoRho;
+                    }
+                    Lr.l = kRestoRho * l_ + 0.5 * eta * q_;
+                };
+                auto lin_r = [&](const double (&xk_)[NS], const double (&ur_)[NUR], StageLin<NS, NUR> &Lr, AuxR &ax, const double mu_) {
+                    double uo[NU];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) uo[i] = ur_[i];
+                    StageLin<NS, NU> Lo;
+                    lin(xk_, uo, Lo, ax.a, mu_);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) {
+                        Lr.F[i] = Lo.F[i] - ur_[NU + i] + ur_[NU + NS + i];
+                        MPC_UNROLL for (int j = 0; j < NS; j++) { Lr.A[i][j] = Lo.A[i][j]; Lr.B[i][NU + j] = i == j ? -1.0 : 0.0; Lr.B[i][NU + NS + j] = i == j ? 1.0 : 0.0; }
+                        MPC_UNROLL for (int j = 0; j < NU; j++) Lr.B[i][j] = Lo.B[i][j];
+                    }
+                    cost_r(xk_, ur_, Lr, mu_);
+                };
+                auto addpi_r = [&](const AuxR &ax, const double (&pi_)[NS], StageLin<NS, NUR> &Lr) {      // + sum pi_i Hessian(F_i): the defects enter linearly
+                    StageLin<NS, NU> Lt;
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Lt.Q[i][j] = 0.0; MPC_UNROLL for (int j = 0; j < NU; j++) Lt.M[i][j] = 0.0; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Lt.R[i][j] = 0.0; }
+                    addpi(ax.a, pi_, Lt);
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Lr.Q[i][j] += Lt.Q[i][j]; MPC_UNROLL for (int j = 0; j < NU; j++) Lr.M[i][j] += Lt.M[i][j]; }
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Lr.R[i][j] += Lt.R[i][j]; }
+                };
+                auto val_r = [&](const double (&xk_)[NS], const double (&ur_)[NUR], double (&F_)[NS], double &l_, const double mu_) {
+                    double uo[NU], lo_;
+                    MPC_UNROLL for (int i = 0; i < NU; i++) uo[i] = ur_[i];
+                    val(xk_, uo, F_, lo_, mu_);
+                    const double eta = sqrt(mu_);
+                    double s_ = 0.0, q_ = 0.0;
+                    MPC_UNROLL for (int i = 0; i < NU; i++) { const double e_ = ur_[i] - uR[i]; q_ += du2[i] * e_ * e_; }
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double e_ = xk_[i] - xkR[i]; q_ += dxk2[i] * e_ * e_; s_ += ur_[NU + i] + ur_[NU + NS + i]; F_[i] += -ur_[NU + i] + ur_[NU + NS + i]; }
+                    l_ = kRestoRho * s_ + 0.5 * eta * q_;
+                };
+                auto term_r = [&](const double (&xe_)[NS], double &fv_, double (&gv_)[NS], double (&Hv_)[NS][NS], const double mu_) {      // x_N's term (used from lane N - 1)
+                    const double eta = sqrt(mu_);
+                    double q_ = 0.0;
+                    MPC_UNROLL for (int i = 0; i < NS; i++) { const double e_ = xe_[i] - xR[i]; q_ += dx2[i] * e_ * e_; gv_[i] = eta * dx2[i] * e_; MPC_UNROLL for (int j = 0; j < NS; j++) Hv_[i][j] = i == j ? eta * dx2[i] : 0.0; }
+                    fv_ = 0.5 * eta * q_;
+                };
+                auto grd_r = [&](const double (&)[NS], const double (&)[NUR], StageLin<NS, NUR> &, const double) {};      // (no scaling of the restoration problem)
+                // the test of this solve [IpRestoFilterConvCheck]: enough less infeasible, acceptable to the filter and to the iterate that was left - with this solve's
+                // mu, multipliers and bounds as they were on entry
+                auto hook = [&](const double (&ur_)[NUR], const double (&xr_)[NS], const double (&x0r_)[NS]) {
+                    double uo[NU];
+                    MPC_UNROLL for (int i = 0; i < NU; i++) uo[i] = ur_[i];
+                    eval_point(uo, xr_, x0r_);
+                    if (!fin_t || theta_t > kRestoKappa * theta) return false;
+                    return !filter_rejects(filt, nfilt, phi_t, theta_t) && (le_tol(theta_t, (1.0 - kGammaTheta) * theta, theta) || le_tol(phi_t - phi, -kGammaPhi * theta, phi));
+                };
+                double zeroP[NS][NS], zerob[NS];
+                MPC_UNROLL for (int i = 0; i < NS; i++) { zerob[i] = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) zeroP[i][j] = 0.0; }
+                int it_r = 0;
+                IpmRestoIn<decltype(hook), decltype(cost_r)> rin{mu_r, it + 1, hook, cost_r};
+                const int rs = ipm_stage<NS, NUR, FREE0, true, SEG, DenseStage, AuxR, 2, 1>(N, lane, need, x0fix, x0r, ur, xr, pir, ulo_r, uhi_r, xlo_r, xhi_r, zeroP, zerob, tol, max_iter,
+                                                                                         grd_r, lin_r, addpi_r, val_r, term_r, it_r, ext.filt_r, ext.park_r, rin);
+                // the point it ends at, seen by this solve (constraint values: is a converged restoration feasible?)
+                double un_[NU];
+                MPC_UNROLL for (int i = 0; i < NU; i++) un_[i] = ur[i];
+                eval_point(un_, xr, x0r);
+                double cx_ = 0.0;
+                MPC_UNROLL for (int i = 0; i < NS; i++) cx_ = dmax(cx_, fabs(ct[i]));
+                cx_ = SG::max(on ? cx_ : 0.0);
+                // back from the restoration: bound multipliers as if the whole move had been one Newton step, reset to 1 beyond 1e3; the bounds it moved stay moved
+                double s1u[NU], s2u[NU], s1x[NS], s2x[NS], s10[NS], s20[NS], dzl_u[NU], dzh_u[NU], dzl_x[NS], dzh_x[NS], dzl_0[NS], dzh_0[NS];
+                double bl_u[NU], bh_u[NU], bl_x[NS], bh_x[NS], bl_0[NS], bh_0[NS];
+                MinRatio mzr;
+                double zmx = 0.0;
+                auto dzr = [&](bool f_, double so_, double z_, double sn_) { return f_ ? mu / so_ - z_ - z_ / so_ * (sn_ - so_) : 0.0; };
+                MPC_UNROLL for (int i = 0; i < NU; i++) {
+                    bl_u[i] = rblu[i]; bh_u[i] = rbhu[i];
+                    s1u[i] = flu[i] ? safe_slack(un_[i], bl_u[i], zlu[i], mu, true) : 1.0; s2u[i] = fhu[i] ? safe_slack(un_[i], bh_u[i], zhu[i], mu, false) : 1.0;
+                    dzl_u[i] = dzr(flu[i], slu[i], zlu[i], s1u[i]); dzh_u[i] = dzr(fhu[i], shu[i], zhu[i], s2u[i]);
+                    mzr.add(zlu[i], dzl_u[i], tau, flu[i]); mzr.add(zhu[i], dzh_u[i], tau, fhu[i]);
+                }
+                MinRatio mz0;
+                MPC_UNROLL for (int i = 0; i < NS; i++) {
+                    bl_x[i] = rblx[i]; bh_x[i] = rbhx[i]; bl_0[i] = rbl0[i]; bh_0[i] = rbh0[i];
+                    s1x[i] = flx[i] ? safe_slack(xr[i], bl_x[i], zlx[i], mu, true) : 1.0; s2x[i] = fhx[i] ? safe_slack(xr[i], bh_x[i], zhx[i], mu, false) : 1.0;
+                    dzl_x[i] = dzr(flx[i], slx[i], zlx[i], s1x[i]); dzh_x[i] = dzr(fhx[i], shx[i], zhx[i], s2x[i]);
+                    mzr.add(zlx[i], dzl_x[i], tau, flx[i]); mzr.add(zhx[i], dzh_x[i], tau, fhx[i]);
+                    s10[i] = (FREE0 && flx[i]) ? safe_slack(x0r[i], bl_0[i], zl0[i], mu, true) : 1.0; s20[i] = (FREE0 && fhx[i]) ? safe_slack(x0r[i], bh_0[i], zh0[i], mu, false) : 1.0;
+                    dzl_0[i] = dzr(FREE0 && flx[i], sl0[i], zl0[i], s10[i]); dzh_0[i] = dzr(FREE0 && fhx[i], sh0[i], zh0[i], s20[i]);
+                    mz0.add(zl0[i], dzl_0[i], tau, FREE0 && flx[i]); mz0.add(zh0[i], dzh_0[i], tau, FREE0 && fhx[i]);
+                }
+                double adr = SG::min(on ? mzr.value() : 1.0);
+                if (FREE0) adr = dmin(adr, mz0.value());
+                MPC_UNROLL for (int i = 0; i < NU; i++) zmx = dmax(zmx, dmax(zlu[i] + adr * dzl_u[i], zhu[i] + adr * dzh_u[i]));
+                MPC_UNROLL for (int i = 0; i < NS; i++) zmx = dmax(zmx, dmax(zlx[i] + adr * dzl_x[i], zhx[i] + adr * dzh_x[i]));
+                zmx = SG::max(on ? zmx : 0.0);
+                if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) zmx = dmax(zmx, dmax(zl0[i] + adr * dzl_0[i], zh0[i] + adr * dzh_0[i])); }
+                if (need) {
+                    if (rs != kRsRestored) {
+                        if (rs == kRsLimit) status = kStMaxIter;
+                        else if (rs == kRsConverged) status = cx_ <= kRestoFeasFact * tol ? kStMaxIter : kStFailed;      // the restoration problem has a minimiser here: infeasible, or feasible and not acceptable
+                        else status = kStMaxIter;      // 'Restoration_Failed': the reference accepts the point
+                        done = true; iters = it_r - 1;
+                    } else {
+                        const bool reset = zmx > kRestoBoundMultReset;
+                        auto zfin = [&](bool f_, double z_, double dz_, double s_) { const double zn_ = reset ? 1.0 : z_ + adr * dz_; return f_ ? dmin(dmax(zn_, mu / (kKappaSigma * s_)), kKappaSigma * mu / s_) : 0.0; };
+                        MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = un_[i]; blu[i] = bl_u[i]; bhu[i] = bh_u[i]; zlu[i] = zfin(flu[i], zlu[i], dzl_u[i], s1u[i]); zhu[i] = zfin(fhu[i], zhu[i], dzh_u[i], s2u[i]); }
+                        MPC_UNROLL for (int i = 0; i < NS; i++) {
+                            xn[i] = xr[i]; pi[i] = 0.0; blx[i] = bl_x[i]; bhx[i] = bh_x[i]; zlx[i] = zfin(flx[i], zlx[i], dzl_x[i], s1x[i]); zhx[i] = zfin(fhx[i], zhx[i], dzh_x[i], s2x[i]);
+                            if (FREE0) { x0v[i] = x0r[i]; bl0[i] = bl_0[i]; bh0[i] = bh_0[i]; zl0[i] = zfin(flx[i], zl0[i], dzl_0[i], s10[i]); zh0[i] = zfin(fhx[i], zh0[i], dzh_0[i], s20[i]); }
+                        }
+                        tiny_last = false;
+                        it = it_r;      // (the restoration's return counts as an iteration: its own counter went on from it + 1)
+                        restored = true;
+                    }
+                }
+            }
+        }
+        if (!done && !restored) {
+            if (!accepted) {      // MODE 0: IPOPT enters its restoration phase here - the caller's rare path (kStNeedResto); feasible to 1e-2 tol: the point is kept ('Restoration_Failed'); MODE 2: no restoration inside the restoration
+                status = MODE == 2 ? (int)kRsFailed : (theta <= 1e-2 * tol ? (int)kStMaxIter : (int)(MODE == 0 ? kStNeedResto : kStFailed)); done = true;
             } else if (tiny) { tiny_flag = tiny_last; tiny_last = dym < kTinyStepYTol; }
             else {
                 tiny_last = false;
@@ -811,7 +1037,7 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         }
         // the new multiplier of a bound: the step, then within [mu / (kappa_Sigma s), kappa_Sigma mu / s] of the new slack - one division
         auto newz = [&](bool f_, double z_, double dz_, double s_) { const double q = mu / s_, zn_ = z_ + adu * dz_; return f_ ? dmin(dmax(zn_, q * (1.0 / kKappaSigma)), kKappaSigma * q) : zn_; };
-        if (!done) {      // (a finished segment keeps its iterate)
+        if (!done && !restored) {      // (a finished segment keeps its iterate)
             MPC_UNROLL for (int i = 0; i < NU; i++) {      // (the accepted trial point again, to the bit; its slacks with the multipliers of the old point, as the trial had them; the bounds move now)
                 u[i] = u[i] + a_pr * du[i];
                 const double s1 = flu[i] ? safe_slack(u[i], blu[i], zlu[i], mu, true) : 1.0, s2 = fhu[i] ? safe_slack(u[i], bhu[i], zhu[i], mu, false) : 1.0;
@@ -830,6 +1056,10 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
             it++;
         }
         EC_IPM_STAMP(12);      // filter, multiplier steps, the new iterate
+    }
+    if constexpr (MODE != 2) {      // the final point goes back into the caller's bounds (honor_original_bounds)
+        MPC_UNROLL for (int i = 0; i < NU; i++) { if (UB) u[i] = dmin(dmax(u[i], ulo_in[i]), uhi_in[i]); }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { xn[i] = dmin(dmax(xn[i], xlo_in[i]), xhi_in[i]); if (FREE0) x0v[i] = dmin(dmax(x0v[i], xlo_in[i]), xhi_in[i]); }
     }
     return status;
 }
@@ -863,9 +1093,6 @@ __device__ __forceinline__ bool gj_inverse(const double (&a_in)[n][n], double (&
     }
     return ok;
 }
-
-constexpr double kRestoRho = 1000.0, kRestoKappa = 0.9, kRestoThetaMaxFact = 1e8, kRestoBoundMultReset = 1e3, kRestoFeasFact = 1e2;
-enum : int { kRsRestored = 0, kRsConverged = 1, kRsLimit = 2, kRsFailed = 3 };
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // IPOPT's restoration phase for the target problem ([WB 3.3]): the same interior point iteration on
@@ -1241,7 +1468,7 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
     double lam1[NX], lam2[NY], dmp[NV];
     int nbi = 0;
     MPC_UNROLL for (int i = 0; i < NV; i++) {
-        lo[i] = lo_in[i]; hi[i] = hi_in[i];
+        lo[i] = relax_lo(lo_in[i]); hi[i] = relax_hi(hi_in[i]);
         fl[i] = fin(lo_in[i]); fh[i] = fin(hi_in[i]); zl[i] = fl[i] ? 1.0 : 0.0; zh[i] = fh[i] ? 1.0 : 0.0; nbi += (fl[i] ? 1 : 0) + (fh[i] ? 1 : 0);
         dmp[i] = (fl[i] && !fh[i]) ? 1.0 : ((fh[i] && !fl[i]) ? -1.0 : 0.0);
     }
@@ -1569,6 +1796,7 @@ __device__ __forceinline__ int target_ipm(double (&v)[M::NX + M::NU + M::NY], co
         MPC_UNROLL for (int i = 0; i < NX; i++) lam1[i] += a_pr * ((soc_taken ? l1s[i] : l1n[i]) - lam1[i]);
         MPC_UNROLL for (int i = 0; i < NY; i++) lam2[i] += a_pr * ((soc_taken ? l2s[i] : l2n[i]) - lam2[i]);
     }
+    MPC_UNROLL for (int i = 0; i < NV; i++) v[i] = dmin(dmax(v[i], lo_in[i]), hi_in[i]);      // honor_original_bounds
     return status;
 }
 

@@ -29,6 +29,9 @@ typedef double complex cplx;
 enum { NX = 2, NU = 1, NY = 2, ND = 2, NE = 4, NW = 4, NZ = NX + NU, NV = NX + NU + NY };
 #define CS 1e-30
 #include "orc_dense.h"
+/* EORC_RESTO=0 (a test switch): the OCP and the estimator without the restoration phase, as the kernels of round 4 were - a failed line search at an infeasible point then ends the solve */
+static int resto_on(void) { const char *e = getenv("EORC_RESTO"); return !(e && e[0] == '0'); }
+
 
 typedef struct {
     int32_t N, N_mhe, Mx, quad, max_iter, has_dsat, mhe_filter;      /* mhe_filter: mhe_up = 'filter' (else 'smooth') */
@@ -168,7 +171,7 @@ static int ocp_solve(const EProb *P, const double *xhat, const double *xs, const
     double *lo = vec(n), *hi = vec(n);
     for (int k = 0; k < N; k++) { lo[NZ * k] = P->umin[0]; hi[NZ * k] = P->umax[0]; for (int r = 0; r < NX; r++) { lo[NZ * k + 1 + r] = P->xmin[r]; hi[NZ * k + 1 + r] = P->xmax[r]; } }
     OcpCtx c = {P, xhat, xs, us, d};
-    const int st = ipm_ipopt(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, 0, iters, NULL, NULL);
+    const int st = ipm_ipopt(n, m, ocp_evalf, &c, w, lo, hi, P->tol, P->max_iter, resto_on(), iters, NULL, NULL);      /* (with the restoration phase, as every NLP of the reference's solver) */
     arena_release(mark_);
     return st;
 }
@@ -393,7 +396,7 @@ static int mhe_step(const EProb *P, MheState *S, int ksim, const double *y, doub
     double Pinv[NE * NE];
     int ok = inv_small(NE, S->Pk, Pinv);
     MheCtx c = {P, N, S->U, S->Y, S->xbar, Pinv};
-    int st = ipm_ipopt(n, N * (NY + NE), mhe_evalf, &c, w, lo, hi, P->tol_mhe, P->max_iter, 0, iters, NULL, NULL);
+    int st = ipm_ipopt(n, N * (NY + NE), mhe_evalf, &c, w, lo, hi, P->tol_mhe, P->max_iter, resto_on(), iters, NULL, NULL);
     if (!ok) st = ST_FAILED;
     const double *Xl = w + NB * (N - 1);
     for (int i = 0; i < NE; i++) xes[i] = Xl[i];

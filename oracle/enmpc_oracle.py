@@ -225,13 +225,17 @@ def hess_fd(fun, z, rel=1e-5):
 #     (|dw| / (1 + |w|) < 10 eps with theta <= 1e-4) accepted unchecked, two in a row force mu down or end the solve;
 #   * slacks: IpIpoptCalculatedQuantities::CalculateSafeSlack - a slack below eps min(1, mu) becomes min(max(mu / z, eps min(1, mu)), max(s, 0) +
 #     eps^(3/4) max(1, |bound|)) and the bound of THIS solve moves along; bound multipliers kept within kappa_Sigma = 1e10 of mu / s [WB (16)];
+#   * bounds: every finite bound relaxed by bound_relax_factor max(1, |bound|) = 1e-8 ... before the first iterate is pushed (OrigIpoptNLP::relax_bounds), the final
+#     point projected back into the caller's bounds (honor_original_bounds = yes: the 3.12 series' default, the series CasADi 3.4 / 3.5 bundle [ext]);
+#   * RESTORATION PHASE [WB 3.3; IpRestoMinC_1Nrm, IpRestoIpoptNLP, IpRestoFilterConvCheck] for every NLP (``resto``; since round 5 also the OCP and the estimator): _restore;
 #   * stop [WB (5), (6); IpOptErrorConvCheck]: scaled error E_0 <= tol with the unscaled side conditions dual_inf_tol 1, constr_viol_tol 1e-4,
 #     compl_inf_tol 1e-4; "acceptable" stop after 15 iterations in a row within 1e-6 (1e10, 1e-2, 1e-2); iteration limit.
-# Not restated: the restoration phase - a line search that falls below alpha_min ends the solve: STATUS_INFEASIBLE when the point is infeasible
-# (IPOPT would enter restoration there; the reference holds the input on 'Infeasible_Problem_Detected' only, MPC_code.py:786), STATUS_MAXITER when it
-# is feasible to 1e-2 tol (IPOPT: 'Restoration_Failed' at an almost feasible point, accepted by the reference) -; the watchdog; constraint scaling (no
-# row of the Jacobian exceeds 100 on the models here: asserted by the tests through ``scale_rows``); the filter's reset heuristic; delta_c.
+# NOT RESTATED (the one list of it; DESIGN.md section 14 repeats it): the watchdog procedure (watchdog_shortened_iter_trigger 10: a relaxed acceptance after ten
+# shortened steps in a row); scaling of the CONSTRAINTS (no row of the Jacobian exceeds 100 on the models here: asserted by the tests through ``scale_rows``);
+# the filter's reset heuristic (max_filter_resets 5); delta_c (the regularisation of a rank-deficient Jacobian: the dynamics' Jacobian has full row rank by
+# construction); mu_target, the quality function and every non-default branch; the restoration phase's own restoration ('Restoration_Failed' there).
 # The product runs the SAME algorithm on a Riccati factorisation of the same Newton system (csrc/mpc_enmpc.hpp).
+BOUND_RELAX_FACTOR = 1e-8
 KAPPA_PUSH, MU_INIT, KAPPA_EPS, KAPPA_MU, THETA_MU, TAU_MIN, KAPPA_SIGMA, S_MAX = 1e-2, 0.1, 10.0, 0.2, 1.5, 0.99, 1e10, 100.0
 DELTA_FIRST, DELTA_MAX = 1e-4, 1e40
 EPS = float(np.finfo(float).eps)
@@ -287,7 +291,7 @@ def _le(lhs, rhs, bas):
     return lhs - rhs <= 10.0 * EPS * abs(bas)
 
 
-def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None, resto=False):
+def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None, resto=True):
     """evalf(w, lam) -> f, grad f [n], g [m], dg/dw [m, n], Hessian of f + lam'g [n, n] (``lam`` of length 0: no Hessian wanted).  Variables with
     lo == hi are PARAMETERS, as IPOPT treats them (fixed_variable_treatment = make_parameter, its default [ext]): the initial state of the OCP
     (MPC_code.py:734) drops out of the variables, and the rows that only restate it (Control_Calc.py:126) drop out of the constraints."""
@@ -322,7 +326,12 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None, 
         r.update(w=wfull, lam=lfull, z_lo=zl, z_hi=zh)
         return r
     n = len(w0)
-    lo, hi = np.array(lo, dtype=float), np.array(hi, dtype=float)      # this solve's own bounds: the safe slack moves them
+    lo_user, hi_user = np.array(lo, dtype=float), np.array(hi, dtype=float)
+    # IPOPT relaxes every finite bound by bound_relax_factor max(1, |bound|) before it starts (OrigIpoptNLP::relax_bounds [ext]; default 1e-8, left there by
+    # MPC_code.py:262-263) and projects the final point back into the caller's bounds (honor_original_bounds = yes, the default of the 3.12 series [ext])
+    with np.errstate(invalid="ignore"):
+        lo = np.where(np.isfinite(lo_user), lo_user - BOUND_RELAX_FACTOR * np.maximum(1.0, np.abs(lo_user)), lo_user)      # this solve's own bounds: the safe slack moves them
+        hi = np.where(np.isfinite(hi_user), hi_user + BOUND_RELAX_FACTOR * np.maximum(1.0, np.abs(hi_user)), hi_user)
     fl, fh = np.isfinite(lo), np.isfinite(hi)
     # ---- scaling of the objective at the caller's point (IpGradientScaling) ------------------------------------------------------------
     w0 = np.asarray(w0, dtype=float)
@@ -355,6 +364,7 @@ def ipm_dense(evalf, w0, lo, hi, tol=1e-8, max_iter=200, trace=None, info=None, 
     r = _ipm_core(ev, w, lo, hi, zl, zh, lam, MU_INIT, tol, max_iter, 0, THETA_MAX_FACT, None, resto, stats, trace, df)
     if info is not None:
         info.update(stats)
+    r["w"] = np.minimum(np.maximum(r["w"], lo_user), hi_user)      # honor_original_bounds
     return dict(w=r["w"], lam=r["lam"] / df, z_lo=r["zl"] / df, z_hi=r["zh"] / df, status=r["status"], iters=r["it"], mu=r["mu"], df=df, stop=stats["stop"])      # (multipliers of the unscaled problem)
 
 

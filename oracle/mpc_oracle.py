@@ -91,10 +91,17 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False, px=None, py=No
     output rows (Control_Calc.py:43-57,130,161).
     ``drop_stage0_rows`` leaves out the k=0 rows: they constrain the given x_0, i.e. they are a feasibility
     test that :func:`ocp_solve` makes up front with IPOPT's bound relaxation.
+
+    ``p.slacks`` (soft constraints, Control_Calc.py:39-40,186-192,228-239; ``Default_Values.py:128``): ONE vector ``Sl = [sl_ub (ny), sl_lb (ny)] >= 0`` appended to
+    ``w`` (:31,39-40), shared by all stages, penalised ``Sl' Ws Sl`` in EVERY stage's cost (:186-188: N times) and widening every stage's output rows,
+    ``ymin - Y_k - sl_lb <= 0``, ``-ymax + Y_k - sl_ub <= 0`` (:231-239; k = 0 included: there the row only bounds the slack from below).  A missing side of
+    the output box is +-1e12 with slacks on (:64-72).  The state and input bounds stay hard (:213-252).
     """
     n, m, N = p.nx, p.nu, p.N
     nxu = n + m
-    nw = nxu * N + n
+    soft = bool(getattr(p, "slacks", False))
+    ns = 2 * p.ny if soft else 0
+    nw = nxu * N + n + ns
     H = np.zeros((nw, nw))
     g = np.zeros(nw)
     ix = lambda k: slice(nxu * k, nxu * k + n)
@@ -117,6 +124,9 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False, px=None, py=No
                 H[iu(k - 1), iu(k)] -= R
     H[ix(N), ix(N)] += P                       # Vfin(dx) = 1/2 dx'P dx (Control_Calc.py:194-210)
     g[ix(N)] += -P @ xs
+    if soft:
+        Ws = np.asarray(p.Ws, dtype=float).reshape(ns, ns)
+        H[nw - ns:, nw - ns:] += N * (Ws + Ws.T)  # + Sl' Ws Sl in each of the N stage costs (Control_Calc.py:186-188)
     # equalities
     E = np.zeros((n * (N + 1), nw))
     e = np.zeros(n * (N + 1))
@@ -144,7 +154,17 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False, px=None, py=No
             if np.isfinite(p.umin[i]) or np.isfinite(p.umax[i]):
                 row = np.zeros(nw); row[nxu * k + n + i] = 1.0
                 rows.append(row); lo.append(p.umin[i]); hi.append(p.umax[i])
-    if p.y_bounded:
+    if p.y_bounded and soft:
+        yc = p.fy_const + (p.Cd @ dhat if p.nd else 0.0)
+        ymin = np.where(np.isfinite(p.ymin), p.ymin, -1e12); ymax = np.where(np.isfinite(p.ymax), p.ymax, 1e12)      # Control_Calc.py:64-72
+        for k in range(N):                     # (k = 0 stays: it bounds the slack)
+            for i in range(p.ny):
+                yk = yc[i] + (py[k][i] if py is not None else 0.0)
+                row = np.zeros(nw); row[ix(k)] = p.C[i]; row[nw - ns + p.ny + i] = 1.0      # ymin - Y_k - sl_lb <= 0
+                rows.append(row); lo.append(ymin[i] - yk); hi.append(np.inf)
+                row = np.zeros(nw); row[ix(k)] = p.C[i]; row[nw - ns + i] = -1.0            # -ymax + Y_k - sl_ub <= 0
+                rows.append(row); lo.append(-np.inf); hi.append(ymax[i] - yk)
+    elif p.y_bounded:
         yc = p.fy_const + (p.Cd @ dhat if p.nd else 0.0)
         for k in range(1 if drop_stage0_rows else 0, N):
             for i in range(p.ny):
@@ -163,6 +183,9 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False, px=None, py=No
                     if k > 0:
                         row[nxu * (k - 1) + n + i] = -1.0
                     rows.append(row); lo.append(dlo[i] + off); hi.append(dhi[i] + off)
+    for j in range(ns):                        # w_lb[nw-ns:nw] = 0 (Control_Calc.py:217)
+        row = np.zeros(nw); row[nw - ns + j] = 1.0
+        rows.append(row); lo.append(0.0); hi.append(np.inf)
     G = np.array(rows) if rows else np.zeros((0, nw))
     return H, g, E, e, G, np.array(lo, dtype=float), np.array(hi, dtype=float)
 
@@ -336,15 +359,18 @@ def ocp_solve(p, xhat, xs, us, dhat, u_prev, tol=1e-11, px=None, py=None):
     """
     H, g, E, e, G, lo, hi = ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=True, px=px, py=py)
     n, m = p.nx, p.nu
-    if p.y_bounded:
+    if p.y_bounded and not getattr(p, "slacks", False):
         y0 = model_fy(p, xhat, dhat, None if py is None else py[0])
         rl = BOUND_RELAX * np.maximum(1.0, np.abs(p.ymin)); rh = BOUND_RELAX * np.maximum(1.0, np.abs(p.ymax))
         if np.any(y0 < p.ymin - rl) or np.any(y0 > p.ymax + rh):
             return dict(u0=None, x1=None, w=None, status=STATUS_INFEASIBLE, iters=0, res=None)
     r = qp_ipm_dense(H, g, E, e, G, lo, hi, tol=tol)
     w = r["w"]
-    return dict(u0=w[n:n + m].copy(), x1=w[n + m:2 * n + m].copy(), w=w, status=r["status"],
-                iters=r["iters"], res=r["res"], nu=r["nu"], z_lo=r["z_lo"], z_hi=r["z_hi"])
+    out = dict(u0=w[n:n + m].copy(), x1=w[n + m:2 * n + m].copy(), w=w, status=r["status"],
+               iters=r["iters"], res=r["res"], nu=r["nu"], z_lo=r["z_lo"], z_hi=r["z_hi"])
+    if getattr(p, "slacks", False):
+        out["sl"] = w[-2 * p.ny:].copy()      # sl_k = w_opt[nw-ns:nw], MPC_code.py:800
+    return out
 
 
 def target_solve(p, usp, ysp, xsp, dhat, us_prev, tol=1e-11, px0=None, py0=None):

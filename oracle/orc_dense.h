@@ -15,6 +15,7 @@
 
 enum { ST_SOLVED = 0, ST_MAXITER = 1, ST_FAILED = 2 };
 #define KAPPA_PUSH 1e-2
+#define BOUND_RELAX_FACTOR 1e-8
 #define MU_INIT 0.1
 #define KAPPA_EPS 10.0
 #define KAPPA_MU 0.2
@@ -681,7 +682,12 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
 {
     const size_t mark_ = arena_mark();
     double *lo = vec(n), *hi = vec(n), *zl = vec(n), *zh = vec(n), *lam = vec(m), *lamn = vec(m), *gf = vec(n), *g = vec(m), *J = vec((size_t)m * n), *H = vec((size_t)n * n), *Jt = vec((size_t)n * m), *tau = vec(2 * m + 2), *tmp = vec(n);
-    memcpy(lo, lo_in, sizeof(double) * n); memcpy(hi, hi_in, sizeof(double) * n);
+    /* IPOPT relaxes every finite bound by bound_relax_factor max(1, |bound|) before it starts (OrigIpoptNLP::relax_bounds [ext], default 1e-8, left there by
+       MPC_code.py:262-263) and projects the final point back into the caller's bounds (honor_original_bounds = yes, the default of the 3.12 series [ext]) */
+    for (int i = 0; i < n; i++) {
+        lo[i] = isfinite(lo_in[i]) ? lo_in[i] - BOUND_RELAX_FACTOR * fmax(1.0, fabs(lo_in[i])) : lo_in[i];
+        hi[i] = isfinite(hi_in[i]) ? hi_in[i] + BOUND_RELAX_FACTOR * fmax(1.0, fabs(hi_in[i])) : hi_in[i];
+    }
     IpmInfo inf = {0, 0, 0, 0, 2, 0, 0, 1.0};
     double f;
     /* scaling of the objective at the caller's point */
@@ -707,6 +713,7 @@ static int ipm_ipopt(int n, int m, evalf2_t evalf, void *ctx, double *w, const d
     MainCtx C = {evalf, ctx, df, vec(m), m};
     IpmProb P = {n, m, main_ev, NULL, &C};
     const int status = ipm_core(&P, w, lo, hi, zl, zh, lam, MU_INIT, tol, max_iter, 0, THETA_MAX_FACT, resto, iters, &inf);
+    for (int i = 0; i < n; i++) w[i] = fmin(fmax(w[i], lo_in[i]), hi_in[i]);      /* honor_original_bounds */
     if (lam_out) for (int j = 0; j < m; j++) lam_out[j] = lam[j] / df;
     if (info) *info = inf;
     arena_release(mark_);

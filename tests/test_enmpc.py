@@ -48,7 +48,9 @@ def test_golden_vectors_certify_themselves(gold):
         assert int(gold[pre + "STATUS_DYN"].max()) == 0 and int(gold[pre + "STATUS_SS"].max()) == 0
         for k in ("KKT_DYN", "KKT_SS", "KKT_MHE"):      # every NLP's own first-order conditions: what IPOPT terminates on (tol 1e-8) - on the problem as IPOPT
             # scales it: the OCP's cost is multiplied by df = 100 / |grad f(w0)|_inf (0.07 - 0.2 on the cold steps), so its unscaled residual may reach 1e-8 / df
-            assert float(gold[pre + k].max()) < (2e-7 if k == "KKT_DYN" else 1e-8), (pre, k)
+            # ... and at the point IPOPT RETURNS: the solve runs on bounds relaxed by 1e-8 max(1, |b|) and the final point is projected back into the caller's bounds
+            # (honor_original_bounds), so a variable on a bound moves by that much and the equality rows it enters see it through the model's sensitivities
+            assert float(gold[pre + k].max()) < 2e-7, (pre, k)
     # the economics: the loop settles at the profit-optimal steady state of the reactor (u = 1.0430, cB = 0.4671)
     assert abs(gold["ship_U"][-1, 0, 0] - 1.04297536) < 1e-7 and abs(gold["ship_XS"][-1, 0, 1] - 0.46708998) < 1e-7
 
@@ -607,11 +609,9 @@ def test_gpu_full_size_batches(pkg):
     r = enmpc.run_enmpc_closed_loop(p, x0, 4, solver=s)
     for k in ("STATUS_SS", "STATUS_MHE"):
         assert int(r[k].max()) == 0, k
-    # The OCP of the cold step - far from its guess - is the one NLP here whose line search can run out of step lengths: IPOPT then enters its restoration
-    # phase, which is restated for the target problem only (oracle/enmpc_oracle.py: with it these OCPs solve in 25 iterations).  The stage kernel ends such a
-    # solve with status 2 - the reference's hold rule - as both restatements do: a few per hundred thousand solves, at step 0 only; all else solved.
-    bad = r["STATUS_DYN"] != 0
-    assert bad.mean() < 1e-4 and not bad[1:].any() and set(np.unique(r["STATUS_DYN"])) <= {0, 2}, (float(bad.mean()), np.unique(r["STATUS_DYN"]))
+    # The OCP of the cold step - far from its guess - is the one NLP here whose line search can run out of step lengths (17 of the 131072 cold solves): IPOPT then
+    # enters its restoration phase, and so do the kernels since round 5 (the rare path: enmpc_ocp_resto_kernel behind every OCP launch) - these OCPs solve in 25 iterations.
+    assert int(r["STATUS_DYN"].max()) == 0, np.unique(r["STATUS_DYN"], return_counts=True)
     assert r["U"].min() >= 0.0 and r["U"].max() <= 2.0 and np.isfinite(r["X_ES"]).all()
     assert r["XS"].min() >= 0.0 and r["XS"].max() <= 1.0 and r["X_ES"][..., :2].min() >= -1e-9 and r["X_ES"][..., :2].max() <= 1.0 + 1e-9
     sub = x0[:16384]
@@ -620,7 +620,8 @@ def test_gpu_full_size_batches(pkg):
     perm = rng.permutation(16384)
     b = enmpc.run_enmpc_closed_loop(p, sub[perm], 12, solver=s)
     assert np.array_equal(b["U"], a["U"][:, perm]) and np.array_equal(b["ITERS_DYN"], a["ITERS_DYN"][:, perm])
-    assert (a["STATUS_DYN"] != 0).mean() < 1e-4 and not (a["STATUS_DYN"][1:] != 0).any() and int(a["STATUS_MHE"].max()) == 0      # (cold OCPs that would need the restoration phase: above)
+    assert int(a["STATUS_DYN"].max()) == 0 and int(a["STATUS_MHE"].max()) == 0 and int(a["STATUS_SS"].max()) == 0
+    assert int(a["ITERS_DYN"][0, 6907]) == 25 and int(a["ITERS_DYN"][0, 9079]) == 25      # the two cold OCPs of this share that go through the restoration phase (test_wave_emu.py has them on the CPU)
     # economics: after 12 steps every loop is heading to the profit-optimal feed rate, the targets already sit there
     assert np.abs(a["US"][-1] - 1.0430).max() < 0.05 and np.abs(a["U"][-1] - 1.0430).max() < 0.2
     s.close()
@@ -656,7 +657,7 @@ def test_gpu_full_size_batches(pkg):
     r5 = enmpc.run_enmpc_closed_loop(p5, x0[:32768], 23)
     for k in ("STATUS_SS", "STATUS_MHE"):
         assert int(r5[k].max()) == 0, k
-    assert (r5["STATUS_DYN"] != 0).mean() < 1e-4 and not (r5["STATUS_DYN"][1:] != 0).any()
+    assert int(r5["STATUS_DYN"].max()) == 0
     q5 = eo.load_problem(EX, overrides={"N_mhe": 20})
     o = eo.closed_loop(q5, 23, x0_p=x0[31000])
     for k in ("U", "X_ES"):
@@ -695,8 +696,8 @@ def test_gpu_the_three_solver_calls_of_a_step_reproduce_the_fused_loop(pkg, over
 def test_gpu_unreachable_boxes_take_the_hold_branches(pkg, over, what):
     """Boxes no trajectory / no steady state of the reactor can reach (cA + cB <= cA0 = 1; both >= 0.8 asked for).  The reference's IPOPT answers
     'Infeasible_Problem_Detected' and the driver holds the input and propagates the model (MPC_code.py:786-805) or keeps the previous targets (:714-718).
-    Here the line search runs out of step lengths at an infeasible point (OCP: status 2) or the target's restoration phase ends at a minimiser of the
-    infeasibility (status 2) - after some twenty iterations, not at the iteration limit with an unconverged iterate applied (round 3) - and the loop goes on:
+    Here the restoration phase - the OCP's (since round 5: the kernels' rare path) or the target's - ends at a minimiser of the infeasibility (status 2:
+    'Infeasible_Problem_Detected') after some twenty to fifty iterations, not at the iteration limit with an unconverged iterate applied (round 3) - and the loop goes on:
     every status word, iteration count and value as in the C restatement."""
     import warnings
     import enmpc_oracle_c as ec
@@ -706,7 +707,7 @@ def test_gpu_unreachable_boxes_take_the_hold_branches(pkg, over, what):
         warnings.simplefilter("ignore")
         p = pkg.load_problem(EX, overrides=over)
         c = ec.OracleEC(eo.load_problem(EX, overrides=over)).closed_loop(5, x0, nthreads=3)
-    assert (c["STATUS_SS"] == 2).all() and int(c["ITERS_SS"].max()) < 40 and int(c["ITERS_DYN"].max()) < 40
+    assert (c["STATUS_SS"] == 2).all() and int(c["ITERS_SS"].max()) < 40 and int(c["ITERS_DYN"].max()) < (70 if what == "ocp" else 40)      # (the OCP's restoration phase converges to a minimiser of the infeasibility: some fifty iterations)
     if what == "ocp":
         assert (c["STATUS_DYN"] == 2).all() and np.all(c["U"] == p.u0[0])      # the input is held at u0
     else:
@@ -716,6 +717,13 @@ def test_gpu_unreachable_boxes_take_the_hold_branches(pkg, over, what):
         for kernel in (1, 2):
             r = enmpc.run_enmpc_closed_loop(p, x0, 5, solver=s, kernel=kernel)
             for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+                if k == "ITERS_DYN" and what == "ocp":
+                    # fifty iterations of a restoration phase that creeps to a minimiser of the infeasibility: its stopping test (E_0 <= tol on a problem with
+                    # multipliers of 1e3) sits within rounding of its threshold for several iterations - the recursion over the lanes and the dense factorisation
+                    # leave it a few iterations apart on some solves (measured: 2 of 15, by 1 and 7); same verdict, same held input
+                    d = np.abs(r[k].astype(int) - c[k].astype(int))
+                    assert (d != 0).mean() <= 0.2 and d.max() <= 10, (kernel, k, r[k].T.tolist(), c[k].T.tolist())
+                    continue
                 assert np.array_equal(r[k], c[k]), (kernel, k, r[k].T.tolist(), c[k].T.tolist())
             for k in ("U", "XS", "US", "X_ES", "Xp"):
                 assert np.abs(r[k] - c[k]).max() < TOL_U, (kernel, k)

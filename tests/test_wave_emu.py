@@ -107,6 +107,37 @@ def test_kernel_source_launch_styles_and_lane_counts_agree(emulated, pkg):
             assert np.array_equal(r[k][nm], r[1][nm]), (k, nm)
 
 
+def test_kernel_source_restoration_phase_of_the_ocp(emulated, pkg):
+    """The two cold OCPs of BASELINE configs[3]'s per-GPU share (instances 6907 and 9079 of 16384, N = 40) whose line search runs out of step lengths at an infeasible
+    point: IPOPT enters its restoration phase there.  The kernels' rare path (ipm_stage MODE 1 / 2: the restoration problem as a stage problem with the defects as
+    inputs, enmpc_ocp_resto_kernel behind the OCP launch; the one-launch kernel's non-inlined redo) against the C restatement (dense, orc_dense.h:ipm_restore):
+    one restoration iteration, 25 iterations in all, the same point - and the restatement without the phase (EORC_RESTO=0: round 4's kernels) holds the input."""
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc
+    x0 = np.array([[0.82282676, 0.01523584], [0.73551569, 0.01499672], [0.9, 0.2]])
+    over = {"N": 40}
+    p = pkg.load_problem(te.EX, overrides=over)
+    q = te.eo.load_problem(te.EX, overrides=over)
+    c = ec.OracleEC(q).closed_loop(3, x0, nthreads=3)
+    assert c["ITERS_DYN"][0].tolist() == [25, 25, 23] and int(c["STATUS_DYN"].max()) == 0
+    os.environ["EORC_RESTO"] = "0"
+    try:
+        c0 = ec.OracleEC(q).closed_loop(1, x0, nthreads=3)
+    finally:
+        del os.environ["EORC_RESTO"]
+    assert c0["STATUS_DYN"][0].tolist() == [2, 2, 0] and c0["ITERS_DYN"][0].tolist() == [8, 8, 23]
+    s = enmpc.EnmpcSolver(p)
+    try:
+        for kernel in (1, 2):
+            r = enmpc.run_enmpc_closed_loop(p, x0, 3, solver=s, kernel=kernel)
+            for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+                assert np.array_equal(r[k], c[k]), (kernel, k, r[k].T.tolist(), c[k].T.tolist())
+            for k in ("U", "XS", "US", "X_ES", "Xp"):
+                assert np.abs(r[k] - c[k]).max() < te.TOL_U, (kernel, k)
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("seed", [1, 7, 13, 24])
 def test_kernel_source_randomised_reactor_models(emulated, pkg, seed):
     te.test_gpu_randomised_reactor_models_follow_the_c_restatement(pkg, seed)
