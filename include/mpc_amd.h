@@ -75,6 +75,13 @@ typedef struct mpc_lin_desc {
      * Ex-file function (one library per plant; capi.Solver builds it); Ap, Bp are ignored then */
     int32_t nl_plant;
     double h_sample;             /* sampling interval h (the time a user plant integrates over); 0 = 1 */
+    /* soft output constraints (`slacks = True`, Control_Calc.py:39-40,186-192,228-239; Default_Values.py:128): ONE slack vector Sl = [sl_ub (ny); sl_lb (ny)] >= 0
+     * shared by all stages widens every stage's output rows, ymin - sl_lb <= y_k <= ymax + sl_ub (k = 0..N-1), and is penalised Sl' Ws Sl in every stage's cost;
+     * Ws [2 ny][2 ny] (MPC_code.py:55-57).  Input and state bounds stay hard.  Solved by mpc_ocp_solve on the arrowhead solver (csrc/mpc_soft.hpp: one Riccati
+     * factorisation with 1 + 2 ny right-hand sides, a dense Schur complement for Sl); the optimal slacks of the last call: mpc_get_slacks.  The fused closed loops
+     * (mpc_loop_run) do not carry it: step by step through the three solver calls. */
+    int32_t slacks;
+    const double *Ws;
 } mpc_lin_desc;
 
 /* Replaces the construction nlpsol('solver','ipopt',...) of Control_Calc.py:256-258 and
@@ -103,6 +110,9 @@ int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const double *xs
                   const double *dhat, const double *u_prev, const double *px, const double *py,
                   double *w_inout, double *u_out, double *xnext_out, int32_t *status, int32_t *iters,
                   double *kkt_res);
+
+/* The optimal slack vectors Sl = w_opt[nw-ns:nw] of the last mpc_ocp_solve call of a problem with soft constraints (MPC_code.py:800), [B][2 ny] */
+int mpc_get_slacks(mpc_handle *h, int32_t B, double *sl_out);
 
 /* One solver_ss(...) call per instance, MPC_code.py:693-718 (par_ss = usp,ysp,xsp,dhat,us_prev, :693). */
 int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, const double *ysp, const double *xsp,

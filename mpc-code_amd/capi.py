@@ -41,7 +41,8 @@ class _Desc(ct.Structure):
                [(k, _dp) for k in ("A", "B", "C", "Bd", "Cd", "fx_const", "fy_const", "Ap", "Bp", "Cp",
                                    "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax",
                                    "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss",
-                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")] + [("term_cons", ct.c_int32), ("nl_plant", ct.c_int32), ("h_sample", ct.c_double)]
+                                   "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")] + [("term_cons", ct.c_int32), ("nl_plant", ct.c_int32), ("h_sample", ct.c_double),
+                                                                                             ("slacks", ct.c_int32), ("Ws", _dp)]
 
 
 def jit_library_path(dims) -> str:
@@ -149,6 +150,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     lib.mpc_ocp_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 7 + [_dp, _dp, _dp, _ip, _ip, _dp]
     lib.mpc_target_solve.argtypes = [ct.c_void_p, ct.c_int32] + [_dp] * 5 + [_dp, _dp, _dp, _ip, _ip]
     lib.mpc_kf_update.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp, _dp]
+    lib.mpc_get_slacks.argtypes = [ct.c_void_p, ct.c_int32, _dp]
     lib.mpc_set_model_offsets.argtypes = [ct.c_void_p, ct.c_int32, _dp, _dp]
     lib.mpc_closed_loop.argtypes = [ct.c_void_p, ct.c_int32, ct.c_int32] + [_dp] * 13
     lib.mpc_comm_unique_id.argtypes = [ct.c_char_p]
@@ -166,7 +168,7 @@ def load_library(path: Optional[str] = None) -> ct.CDLL:
     return lib
 
 
-EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_target_solve", "mpc_kf_update", "mpc_set_model_offsets",
+EXPORTS = ("mpc_lin_create", "mpc_destroy", "mpc_last_error", "mpc_ocp_solve", "mpc_get_slacks", "mpc_target_solve", "mpc_kf_update", "mpc_set_model_offsets",
            "mpc_loop_alloc", "mpc_loop_set_state", "mpc_loop_get_state", "mpc_loop_set_schedule", "mpc_loop_set_model_schedule", "mpc_loop_run",
            "mpc_loop_sync", "mpc_loop_get_log", "mpc_closed_loop", "mpc_last_kernel_ms", "mpc_stream", "mpc_dev_ptr",
            "mpc_pack_u", "mpc_pack_log", "mpc_set_option", "mpc_get_option", "mpc_build_info",
@@ -202,6 +204,9 @@ class Solver:
         d.estimator, d.max_iter, d.device = _EST[p.estimator], int(p.max_iter), int(device)
         d.term_cons = int(bool(getattr(p, "TermCons", False)))
         d.h_sample = float(p.h)
+        d.slacks = int(bool(getattr(p, "slacks", False)))
+        if d.slacks:
+            self._keep["Ws"] = _c(p.Ws); d.Ws = _p(self._keep["Ws"])
         self.fused_plant = False
         if lib_path is None and not p.plant_is_linear and jit and not os.environ.get("MPC_AMD_NO_JIT"):
             # the Ex-file's plant function, traced and compiled into a library of this problem's own (cached under csrc/jit/)
@@ -211,7 +216,7 @@ class Solver:
             except Exception:      # noqa: BLE001 - a plant the tracer cannot follow stays on the host (call-by-call mode)
                 hdr = None
             if hdr is not None:
-                ng = sum(1 for i in range(p.ny) if p.y_bounded and (np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i])) and np.count_nonzero(p.C[i]) != 1)
+                ng = 0 if getattr(p, "slacks", False) else sum(1 for i in range(p.ny) if p.y_bounded and (np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i])) and np.count_nonzero(p.C[i]) != 1)
                 dims = (p.nx, p.nu, p.ny, p.nd, p.nxp, int(p.DUForm or p.Dumin is not None or p.Dumax is not None), ng)
                 self.lib = load_library(build_library(dims=dims, plant_header=hdr))
                 d.nl_plant = 1
@@ -358,7 +363,12 @@ class Solver:
         pya = None if py is None else np.ascontiguousarray(np.broadcast_to(np.asarray(py, dtype=np.float64), (B, p.N, p.ny)))
         self._chk(self.lib.mpc_ocp_solve(self.h, B, _p(xhat), _p(xs), _p(us), _p(dhat) if p.nd else None, _p(u_prev),
                                          _p(pxa), _p(pya), _p(w), _p(u0), _p(x1), _pi(st), _pi(it), _p(res)), "mpc_ocp_solve")
-        return dict(u0=u0, x1=x1, status=st, iters=it, res=res, w=w)
+        out = dict(u0=u0, x1=x1, status=st, iters=it, res=res, w=w)
+        if getattr(p, "slacks", False):      # sl_k = w_opt[nw-ns:nw], MPC_code.py:800
+            sl = np.zeros((B, 2 * p.ny))
+            self._chk(self.lib.mpc_get_slacks(self.h, B, _p(sl)), "mpc_get_slacks")
+            out["sl"] = sl
+        return out
 
     def target_solve(self, usp, ysp, xsp, dhat, us_prev):
         """``solver_ss(...)`` of MPC_code.py:704-709 for a batch; returns dict(xs, us, ys, status, iters)."""

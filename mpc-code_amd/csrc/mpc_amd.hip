@@ -8,6 +8,7 @@
 #include "mpc_device.hpp"
 #include "mpc_tp.hpp"
 #include "mpc_wave.hpp"
+#include "mpc_soft.hpp"
 #ifdef MPC_NL_PLANT_HEADER
 // A non-linear plant for the fused closed loop (Ex_LMPC_nlplant.py, Ex_LMPCxp_nlplant.py: linear controller, User_fxp_Cont as the
 // simulated process): struct NlPlant { NXP, NU, MX; __device__ static void f(x, u, t, xdot); } generated from the traced Ex-file
@@ -122,6 +123,54 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
     if (st != kInfeasible) {
         MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * a.Bs + b] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];      // input v = u - u_prev: u is the u_prev part of z_1
+        MPC_UNROLL for (int i = 0; i < NX; i++) a.xnext_out[i * a.Bs + b] = z1[i];
+    }
+}
+
+// The same call for a problem with SOFT output constraints (`slacks = True`, Control_Calc.py:39-40,186-192,228-239): one slack vector shared by all stages - the
+// arrowhead solver of mpc_soft.hpp, one instance per lane, workspace [wave][block][field][64 lanes] in HBM.  sl_out [2 NY][Bs]: the optimal slacks (MPC_code.py:800).
+struct OcpSoftArgs { OcpArgs o; double *sl_out; };
+
+template <int NX, int NU, int NY, int ND, bool DU, int NG>
+__global__ __launch_bounds__(64) void ocp_kernel_soft(const DevProblem *__restrict__ Pp, OcpSoftArgs w)
+{
+    constexpr int NS = NX + (DU ? NU : 0) + NG;
+    const OcpArgs &a = w.o;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    double xhat[NX], xs[NX], us[NU], up[NU], dh[ND > 0 ? ND : 1];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { xhat[i] = a.xhat[i * a.Bs + b]; xs[i] = a.xs[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { us[i] = a.us[i * a.Bs + b]; up[i] = a.u_prev[i * a.Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * a.Bs + b];
+    OcpInst<NS, NU> q;
+    build_inst<NX, NU, NY, ND, DU, NG>(P, xhat, xs, us, dh, up, q);      // (y_bounded = 0 in a soft problem: the stage boxes are the state bounds alone)
+    SoftProb<NS, NU, NY> S;
+    S.N = P.N; S.max_iter = P.max_iter;
+    for (int i = 0; i < NS; i++) {
+        for (int j = 0; j < NS; j++) { S.A[i][j] = P.A[i][j]; S.Q[i][j] = P.Q[i][j]; S.Pf[i][j] = P.Pf[i][j]; }
+        for (int j = 0; j < NU; j++) { S.B[i][j] = P.B[i][j]; S.M[i][j] = DU ? P.M[i][j] : 0.0; }
+        S.c[i] = q.c[i]; S.z0[i] = q.z0[i]; S.zr[i] = q.zr[i]; S.zrN[i] = q.zrN[i];
+        S.zlo[i] = q.zlo_m[i]; S.zhi[i] = q.zhi_m[i]; S.zlo_e[i] = P.zlo_e[i]; S.zhi_e[i] = P.zhi_e[i];
+    }
+    for (int i = 0; i < NU; i++) { for (int j = 0; j < NU; j++) S.R[i][j] = P.R[i][j]; S.ur[i] = q.ur[i]; S.us[i] = q.us[i]; S.ulo[i] = P.ulo[i]; S.uhi[i] = P.uhi[i]; }
+    for (int i = 0; i < NY; i++) {
+        double e = P.fyc[i];
+        for (int j = 0; j < ND; j++) e += P.Cd[i][j] * dh[j];
+        S.cy[i] = e; S.ymin[i] = P.ymin[i]; S.ymax[i] = P.ymax[i];
+        for (int j = 0; j < NS; j++) S.Cy[i][j] = j < NX ? P.Cm[i][j < NX ? j : 0] : 0.0;      // outputs read the model states (not the u_prev part of the stage state)
+    }
+    for (int i = 0; i < 2 * NY; i++) for (int j = 0; j < 2 * NY; j++) S.Ws[i][j] = P.Ws[i][j];
+    using LY = SoftLayout<NS, NU, NY>;
+    double *const ws = a.ws + (size_t)blockIdx.x * LY::FIELDS * P.N * 64 + threadIdx.x;
+    double u0[NU], z1[NS], sl[2 * NY], res[3];
+    int it;
+    const int st = soft_solve<NS, NU, NY, 64>(S, ws, u0, z1, sl, res, it);
+    a.status[b] = st; a.iters[b] = it;
+    MPC_UNROLL for (int i = 0; i < 3; i++) a.res[i * a.Bs + b] = res[i];
+    for (int i = 0; i < 2 * NY; i++) w.sl_out[i * a.Bs + b] = sl[i];
+    if (st != kInfeasible) {
+        MPC_UNROLL for (int i = 0; i < NU; i++) a.u_out[i * a.Bs + b] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];
         MPC_UNROLL for (int i = 0; i < NX; i++) a.xnext_out[i * a.Bs + b] = z1[i];
     }
 }
@@ -1224,6 +1273,8 @@ __global__ void pack_u_kernel(const double *__restrict__ u, double *__restrict__
 struct Launchers {
     void (*ocp)(const DevProblem *, OcpArgs, hipStream_t);
     void (*ocp_pxy)(const DevProblem *, OcpPxyArgs, hipStream_t);      // time-varying px / py: one variant (all bounds maskable)
+    void (*ocp_soft)(const DevProblem *, OcpSoftArgs, hipStream_t);    // soft output constraints (mpc_soft.hpp)
+    int soft_fields;                                                   // doubles per block and lane of its workspace
     void (*loop_pxy)(const DevProblem *, LoopArgs, hipStream_t);       // the closed loop with def_px / def_py schedules (instance per lane)
     int pxy_ws_rows, pxy_nc, pxy_lin;                                  // its workspace rows / bounded variables / slab entries per block
     void (*target)(const DevProblem *, TargetArgs, hipStream_t);
@@ -1268,6 +1319,8 @@ static Launchers make_launchers_mode()
         l.ocp_pxy = [](const DevProblem *p, OcpPxyArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel_pxy<NX, NU, NY, ND, DU, NG>), dim3((a.o.B + 63) / 64), dim3(64), 0, s, p, a); };
         l.loop_pxy = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel_pxy<NX, NU, NY, ND, NXP, DU, NG>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
         l.pxy_ws_rows = 2 * BlkLayout<NSZ, NU, NSZ + NU>::SLOTS; l.pxy_nc = NSZ + NU; l.pxy_lin = NSZ * (NSZ + NU + 1) + 2 * NSZ;
+        l.ocp_soft = [](const DevProblem *p, OcpSoftArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel_soft<NX, NU, NY, ND, DU, NG>), dim3((a.o.B + 63) / 64), dim3(64), 0, s, p, a); };
+        l.soft_fields = SoftLayout<NSZ, NU, NY>::FIELDS;
     }
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
@@ -1420,6 +1473,7 @@ struct mpc_handle {
     DevBuf pc_prev, pc_valid, pc_guess, pc_traj;
     // time-varying model parameters: horizon values of one mpc_ocp_solve call, its slab and workspace; this step's p_x_k / p_y_k for
     // mpc_target_solve / mpc_kf_update (mpc_set_model_offsets)
+    DevBuf soft_ws, soft_sl; int soft_B = 0;      // soft output constraints: the arrowhead solver's workspace, the last call's optimal slacks
     DevBuf pxy_in, pxy_lin, pxy_ws, off_px, off_py; int off_B = 0; bool off_has_px = false, off_has_py = false;
     DevBuf msch; int msch_steps = 0; bool msch_px = false, msch_py = false;      // def_px / def_py over the horizon for every step of the fused loop
     DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
@@ -1452,7 +1506,7 @@ static void from_soa(const double *src, int B, int d, size_t Bs, double *dst)
 static int general_output_rows(const mpc_lin_desc *d, int *rows)
 {
     int ng = 0;
-    if (!d->y_bounded) return 0;
+    if (!d->y_bounded || d->slacks) return 0;      // (soft output rows are rows of their own solver, not stage states)
     for (int i = 0; i < d->ny; i++) {
         int cnt = 0;
         for (int j = 0; j < d->nx; j++) if (d->C[i * d->nx + j] != 0.0) cnt++;
@@ -1535,7 +1589,14 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
     std::memset(&P, 0, sizeof(P));
     const int n0 = d->nx, m = d->nu, q = d->ny, nd = d->nd, nxp = d->nxp;
     P.nx = n0; P.nu = m; P.ny = q; P.nd = nd; P.nxp = nxp; P.N = d->N;
-    P.du_form = d->du_form; P.duss_form = d->duss_form; P.y_bounded = d->y_bounded; P.estimator = d->estimator;
+    P.du_form = d->du_form; P.duss_form = d->duss_form; P.y_bounded = d->slacks ? 0 : d->y_bounded; P.estimator = d->estimator;
+    if (d->slacks) {
+        if (!d->Ws) return fail(-1, "slacks = 1 needs the slack weight Ws [2 ny][2 ny]");
+        if (!d->y_bounded) return fail(-2, "slacks = 1 without output bounds");
+        if (d->term_cons) return fail(-8, "soft constraints together with a terminal equality are not carried");
+        P.soft = 1;
+        for (int i = 0; i < 2 * q; i++) for (int j = 0; j < 2 * q; j++) P.Ws[i][j] = d->Ws[i * 2 * q + j];
+    }
     P.max_iter = d->max_iter > 0 ? d->max_iter : 100;
     for (int i = 0; i < n0; i++) {
         for (int j = 0; j < n0; j++) { P.A[i][j] = P.Am[i][j] = d->A[i * n0 + j]; P.Q[i][j] = d->Q[i * n0 + j]; P.Pf[i][j] = d->P[i * n0 + j]; }
@@ -1593,7 +1654,7 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
     // Any other row i gets a stage state of its own, w = C_i x, carried by w+ = C_i (A x + B u + c): the row becomes a box on w
     // at k = 1..N-1 (the terminal state has no output row); no cost on w.
     P.ng = general_output_rows(d, P.yg_row);
-    if (d->y_bounded) {
+    if (d->y_bounded && !d->slacks) {
         const int nb = n0 + (stage_has_uprev(d) ? m : 0);
         for (int i = 0; i < q; i++) {
             P.ymap_idx[i] = -1;       // unbounded rows and rows that are identically zero: nothing to map
@@ -1644,7 +1705,7 @@ static int bound_mode(const mpc_lin_desc *d)
         x_all = x_all && lo && hi; x_none = x_none && !lo && !hi;
     }
     bool y_any = false;
-    if (d->y_bounded) for (int i = 0; i < d->ny; i++) y_any = y_any || std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]);
+    if (d->y_bounded && !d->slacks) for (int i = 0; i < d->ny; i++) y_any = y_any || std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]);
     if (du_bounded(d)) return kBoundsGeneric;
     if (u_all && x_all && !d->du_form) return kBoundsAllFinite;        // Delta-u form carries unbounded u_prev states
     if (u_all && x_none && !y_any) return kBoundsInputsOnly;
@@ -1713,6 +1774,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     (void)mpc_comm_destroy(h);
     h->coll_send.release(); h->coll_recv.release();
     h->pc_prev.release(); h->pc_valid.release(); h->pc_guess.release(); h->pc_traj.release();
+    h->soft_ws.release(); h->soft_sl.release();
     h->pxy_in.release(); h->pxy_lin.release(); h->pxy_ws.release(); h->off_px.release(); h->off_py.release(); h->msch.release();
     for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
@@ -1855,6 +1917,34 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     a.ws = (double *)h->ws.p; a.B = B; a.Bs = Bs;
     HIP_TRY(hipMemsetAsync(a.u_out, 0, n_out * sizeof(double), h->stream));
     const bool pxy = px || py;
+    if (P.soft) {
+        // soft output constraints: the arrowhead solver, one instance per lane (mpc_soft.hpp)
+        if (pxy) return fail(-8, "soft constraints with horizon parameters (px / py) are not carried");
+        const int ny = P.ny;
+        if (h->soft_ws.ensure((size_t)(Bs / 64) * h->L.soft_fields * P.N * 64 * sizeof(double)) || h->soft_sl.ensure((size_t)2 * ny * Bs * sizeof(double))) return -10;
+        OcpSoftArgs sa;
+        sa.o = a; sa.o.ws = (double *)h->soft_ws.p; sa.sl_out = (double *)h->soft_sl.p;
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        h->L.ocp_soft(h->dp, sa, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev1, h->stream));
+        h->timed = true; h->n_launches = 1; h->soft_B = B;
+        HIP_TRY(hipMemcpyAsync(sp + n_in, a.u_out, n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        std::vector<int32_t> sti(2 * Bs);
+        HIP_TRY(hipMemcpyAsync(sti.data(), a.status, 2 * Bs * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const double *uo = sp + n_in, *xo = uo + (size_t)nu * Bs, *ro = xo + (size_t)nx * Bs;
+        for (int b = 0; b < B; b++) {
+            status[b] = sti[b];
+            if (iters) iters[b] = sti[Bs + b];
+            if (sti[b] != MPC_STATUS_INFEASIBLE) {
+                for (int i = 0; i < nu; i++) u_out[(size_t)b * nu + i] = uo[(size_t)i * Bs + b];
+                for (int i = 0; i < nx; i++) xnext_out[(size_t)b * nx + i] = xo[(size_t)i * Bs + b];
+            }
+            if (kkt_res) for (int i = 0; i < 3; i++) kkt_res[(size_t)b * 3 + i] = ro[(size_t)i * Bs + b];
+        }
+        return 0;
+    }
     const bool wave = !pxy && ocp_uses_wave(h);
     const int ns_w = h->L.wv_ns, N = P.N;
     std::vector<double> guess;
@@ -1969,6 +2059,20 @@ extern "C" int mpc_ocp_solve(mpc_handle *h, int32_t B, const double *xhat, const
     return 0;
 }
 
+extern "C" int mpc_get_slacks(mpc_handle *h, int32_t B, double *sl_out)
+{
+    if (!h || !sl_out) return fail(-1, "null argument");
+    if (!h->hp.soft) return fail(-8, "this problem has no soft constraints");
+    if (B != h->soft_B || B < 1) return fail(-1, "mpc_get_slacks: the last mpc_ocp_solve call had %d instances, not %d", h->soft_B, B);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t Bs = pad64(B);
+    const int ns = 2 * h->hp.ny;
+    std::vector<double> st((size_t)ns * Bs);
+    HIP_TRY(hipMemcpy(st.data(), h->soft_sl.p, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++) for (int i = 0; i < ns; i++) sl_out[(size_t)b * ns + i] = st[(size_t)i * Bs + b];
+    return 0;
+}
+
 extern "C" int mpc_target_solve(mpc_handle *h, int32_t B, const double *usp, const double *ysp, const double *xsp,
                                 const double *dhat, const double *us_prev, double *xs, double *us, double *ys,
                                 int32_t *status, int32_t *iters)
@@ -2073,6 +2177,7 @@ static const char *kLogI[] = {"STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"
 
 extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32_t log_level)
 {
+    if (h && h->hp.soft) return fail(-8, "soft output constraints (slacks) are solved call by call (mpc_kf_update, mpc_target_solve, mpc_ocp_solve): the fused closed loops do not carry the shared slack vector");
     if (!h || B < 1 || max_steps < 1) return fail(-1, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const DevProblem &P = h->hp;

@@ -66,6 +66,10 @@ struct DevProblem {
     double Aa[kMaxE][kMaxE], Ca[kMaxY][kMaxE], Qkf[kMaxE][kMaxE], Rkf[kMaxY][kMaxY], Kfix[kMaxE][kMaxY];
     // A^(2^j), j = 0..5, of the stage form: the adjoint recursion as a parallel scan over the horizon (mpc_tp.hpp)
     double Apow[6][kMaxN][kMaxN];
+    // soft output constraints (`slacks`, Control_Calc.py:39-40,186-192,228-239): the output rows are then NOT boxes of the stage problem (y_bounded = 0 above) but rows
+    // widened by one shared slack vector [sl_ub; sl_lb] with weight Ws in every stage's cost - mpc_soft.hpp
+    int soft;
+    double Ws[2 * kMaxY][2 * kMaxY];
 };
 
 typedef __attribute__((address_space(4))) DevProblem ConstProblem;

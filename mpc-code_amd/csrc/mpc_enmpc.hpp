@@ -20,6 +20,7 @@
 //   * target (opt_ss, Target_Calc.py:20-161): nx + nu + ny variables; the model's fixed-point equation is eliminated with an LU of
 //     (A - I) and the reduced Hessian is nu x nu; computed redundantly by every lane (wave-uniform).
 #pragma once
+#include <type_traits>
 #ifdef EC_WAVE_EMU      // CPU test suite only (tests/wave_emu): the wave primitives on host fibers, so that this source runs - lane by lane - next to the oracle without a GPU
 #include "wave_emu.hpp"
 #define EC_VGPR_PIN(r) do { } while (0)
@@ -360,6 +361,7 @@ __device__ __forceinline__ void ric_forward(const int N, const int lane, const i
 //         the caller's test (xt.hook) ends it, its objective is recomposed after every change of mu (xt.recost); returns kRs*.
 enum : int { kStNeedResto = 3 };
 struct IpmNoExtra {};
+struct IpmNoAux0 {};      // aux0(xk, u, xn): states that are FUNCTIONS of the first iterate (the slack states of user rows) get their first values from the pushed point
 struct IpmRestoWs { double *park_r, *filt_r; };      // MODE 1: private areas of the inner solve (ipm_park_rows<NS, NU + 2 NS, FREE0, true>() doubles; 2 kFilterCap doubles)
 template <class HookF, class RecostF> struct IpmRestoIn { double mu0; int it0; HookF hook; RecostF recost; };      // MODE 2
 // the rows of the bound data (multipliers Z, bounds B, slacks S; L / H lower / upper; U inputs, X states x_{k+1}, 0 the free initial state)
@@ -374,11 +376,11 @@ struct ParkRows {
 constexpr double kRestoRho = 1000.0, kRestoKappa = 0.9, kRestoThetaMaxFact = 1e8, kRestoBoundMultReset = 1e3, kRestoFeasFact = 1e2;
 enum : int { kRsRestored = 0, kRsConverged = 1, kRsLimit = 2, kRsFailed = 3 };
 
-template <int NS, int NU, bool FREE0, bool UB, int SEG, class ST, class AUX, int MODE = 0, int PS = 64, class GrdF, class LinF, class AddPiF, class ValF, class TermF, class XT = IpmNoExtra>
+template <int NS, int NU, bool FREE0, bool UB, int SEG, class ST, class AUX, int MODE = 0, int PS = 64, class GrdF, class LinF, class AddPiF, class ValF, class TermF, class XT = IpmNoExtra, class Aux0F = IpmNoAux0>
 __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool live, const double (&x0fix)[NS], double (&x0v)[NS], double (&u)[NU], double (&xn)[NS],
                                          double (&pi)[NS], const double (&ulo_in)[NU], const double (&uhi_in)[NU], const double (&xlo_in)[NS],
                                          const double (&xhi_in)[NS], const double (*Pinv)[NS], const double *xbar, const double tol,
-                                         const int max_iter, GrdF grd, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt, double *const park, XT ext = XT())
+                                         const int max_iter, GrdF grd, LinF lin, AddPiF addpi, ValF val, TermF term, int &iters, double *const filt, double *const park, XT ext = XT(), Aux0F aux0 = Aux0F())
 {
     static_assert(MODE == 0 || PS == 1, "the rare-path solves keep their bound data in private memory");
     // what the solve's events are called: a status word of the caller's (kSt*), or - restoration problem - what its caller makes of it (kRs*)
@@ -458,6 +460,14 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = push_in(u[i], blu[i], bhu[i]);
         MPC_UNROLL for (int i = 0; i < NS; i++) xn[i] = push_in(xn[i], blx[i], bhx[i]);
         if (FREE0) { MPC_UNROLL for (int i = 0; i < NS; i++) x0v[i] = push_in(x0v[i], bl0[i], bh0[i]); }
+        if constexpr (!std::is_same<Aux0F, IpmNoAux0>::value) {
+            // IPOPT's own slacks (of inequality rows) start from the rows' values at the PUSHED first iterate and are then pushed into their bound themselves
+            // (IpDefaultIterateInitializer [ext]): the states that stand for them here
+            double xkp[NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) xkp[i] = SG::up1(FREE0 ? x0v[i] : x0fix[i], xn[i], k);
+            aux0(xkp, u, xn);
+            MPC_UNROLL for (int i = 0; i < NS; i++) xn[i] = push_in(xn[i], blx[i], bhx[i]);
+        }
     }
     EC_IPM_STAMP(0);      // scaling, push
     bool first = MODE != 2;      // (wave-uniform: every segment's first iteration starts with the least-squares multipliers)
@@ -573,9 +583,6 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
         const double s_d = dmax(kSMax, (s_pi + s_z) / dmax(meq + nb, 1.0)) / kSMax, s_c = dmax(kSMax, s_z / dmax(nb, 1.0)) / kSMax;
         auto compl_ = [&](double m_) { return nb > 0.0 ? dmax(cmax - m_, m_ - cmin) : 0.0; };
         auto err = [&](double m_) { return dmax(dmax(e_st / s_d, e_c), compl_(m_) / s_c); };
-#ifdef EC_EMU_TRACE
-        if (MODE == 2 && lane == 14 && getenv("EC_EMU_TRACE")) fprintf(stderr, "   lane14 u=%g blu=%g bhu=%g zlu=%g zhu=%g slu=%g shu=%g flu=%d fhu=%d cmax=%g\n", u[0], (double)blu[0], (double)bhu[0], (double)zlu[0], (double)zhu[0], (double)slu[0], (double)shu[0], (int)flu[0], (int)fhu[0], cmax);
-#endif
 #ifdef EC_EMU_TRACE      /* diagnostic build of the CPU test suite's emulator only: the iterations of the first lane's segment */
         if (lane == 0 && getenv("EC_EMU_TRACE")) fprintf(stderr, "%c it=%3d mu=%.3e E0=%.6e e_st=%.3e e_c=%.3e compl=%.3e theta=%.6e f=%.9e done=%d\n", MODE == 2 ? 'R' : (MODE == 1 ? '1' : ' '), it, mu, err(0.0), e_st, e_c, compl_(0.0), theta, fobj / df, (int)done);
 #endif

@@ -15,6 +15,11 @@
 #ifndef MPC_UNROLL
 #define MPC_UNROLL
 #endif
+#ifdef __HIPCC__
+#define MPC_SOFT_FN __host__ __device__ inline
+#else
+#define MPC_SOFT_FN inline
+#endif
 
 namespace mpc {
 
@@ -39,11 +44,11 @@ struct SoftLayout {
 };
 
 namespace soft_detail {
-inline double smax(double a, double b) { return a > b ? a : b; }
-inline double smin(double a, double b) { return a < b ? a : b; }
-inline bool sfin(double a) { return (a < 0 ? -a : a) < 1.0e300; }
+MPC_SOFT_FN double smax(double a, double b) { return a > b ? a : b; }
+MPC_SOFT_FN double smin(double a, double b) { return a < b ? a : b; }
+MPC_SOFT_FN bool sfin(double a) { return (a < 0 ? -a : a) < 1.0e300; }
 // symmetric positive definite inverse by LDL' (n small); false when a pivot is not positive
-template <int n> inline bool spd_inverse(double (&a)[n][n])
+template <int n> MPC_SOFT_FN bool spd_inverse(double (&a)[n][n])
 {
     double l[n][n], d[n];
     bool ok = true;
@@ -67,10 +72,7 @@ template <int n> inline bool spd_inverse(double (&a)[n][n])
 // u0 / z1: first input and next state of the final iterate; sl: the optimal slack vector [sl_ub; sl_lb] (the reference's Sl, MPC_code.py:800);
 // res: stationarity, bound residual, mean complementarity.
 template <int NS, int NU, int NY, int WST>
-#ifdef __HIPCC__
-__device__
-#endif
-inline int soft_solve(const SoftProb<NS, NU, NY> &P, double *const ws, double (&u0)[NU], double (&z1)[NS], double (&sl)[2 * NY], double (&res)[3], int &iters)
+MPC_SOFT_FN int soft_solve(const SoftProb<NS, NU, NY> &P, double *const ws, double (&u0)[NU], double (&z1)[NS], double (&sl)[2 * NY], double (&res)[3], int &iters)
 {
     using namespace soft_detail;
     using LY = SoftLayout<NS, NU, NY>;

@@ -44,6 +44,8 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
     s = capi.Solver(p, device=device) if own else solver
     try:
         sched = p.schedules(nsteps)
+        if getattr(p, "slacks", False):
+            fused = False      # soft constraints: the shared slack vector is carried by mpc_ocp_solve (csrc/mpc_soft.hpp), the loop runs call by call
         if fused and not p.plant_is_linear and not getattr(s, "fused_plant", False):
             raise ValueError("this solver's library has no compiled plant function (User_fxp_Cont): the plant is simulated on the host, "
                              "call run_closed_loop(..., fused=False)")
@@ -92,7 +94,8 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched, warm_start=False):
     Pk = np.broadcast_to(p.P0, (B,) + p.P0.shape).copy() if p.estimator == "kal" else None
     us_k, xs_k = u.copy(), x0_m.copy()                                   # :682-684
     import time
-    keys = ("U", "X_HAT", "Y_HAT", "XS", "US", "YS", "Xp", "Yp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "TIME_SS", "TIME_DYN")
+    keys = ("U", "X_HAT", "Y_HAT", "XS", "US", "YS", "Xp", "Yp", "D_HAT", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS", "TIME_SS", "TIME_DYN") + (("Sl",) if getattr(p, "slacks", False) else ())
+    sl_k = np.zeros((B, 2 * p.ny))
     log = {k: [] for k in keys}
     s.set_option("ocp_warm_start", 1 if warm_start else 0)
     # The reference builds x0= for IPOPT itself (first guess (x0_m, u0) tiled :740-756, then the previous optimum shifted by one
@@ -128,6 +131,8 @@ def _stepwise(p, s, x0_p, x0_m, nsteps, sched, warm_start=False):
         hold = xhat @ p.A.T + u @ p.B.T + p.fx_const + (dhat @ p.Bd.T if p.nd else 0.0) + px0      # :804-805
         u = np.where(ok, o["u0"], u); xhat = np.where(ok, o["x1"], hold)                     # :798-799
         log["U"].append(u.copy())
+        if "sl" in o:                                                                        # :800,808-809: Sl.append(sl_k), the last accepted one
+            sl_k = np.where(ok, o["sl"], sl_k); log["Sl"].append(sl_k.copy())
         log["STATUS_DYN"].append(o["status"]); log["STATUS_SS"].append(t["status"])
         log["ITERS_DYN"].append(o["iters"]); log["ITERS_SS"].append(t["iters"])
         x = p.plant_step(x, u, k * p.h, sched["pxp"][k] + (px0 if p.has_model_params else 0.0))                               # :813-816 (p_xmp = p_x_k, :502-505)

@@ -131,6 +131,33 @@ def emit_scalar(name: str, expr: st.Sym, zv: Sequence[st.Sym], vm: Dict[str, str
 """
 
 
+def emit_rows(name: str, exprs: Sequence[st.Sym], zv: Sequence[st.Sym], vm: Dict[str, str]) -> str:
+    """``struct name``: values, Jacobian and (packed, per row) Hessian of the vector function ``exprs`` of ``zv`` = (x, u): the user rows of the OCP"""
+    n, NP = len(exprs), len(zv)
+    NPP = NP * (NP + 1) // 2
+    if n == 0:
+        return ""
+    J = st.jacobian(exprs, zv)
+    outs, names = [], []
+    for r in range(n):
+        outs.append(exprs[r]); names.append(f"g[{r}]")
+        for c in range(NP):
+            outs.append(J[r][c]); names.append(f"J[{r}][{c}]")
+        Hr = st.jacobian(J[r], zv)
+        for c in range(NP):
+            for e in range(c, NP):
+                outs.append(Hr[c][e]); names.append(f"H[{r}][{_pp(c, e, NP)}]")
+    return f"""    struct {name} {{
+        static constexpr int NG = {n}, NP = {NP}, NPP = {NPP};
+        __device__ static __forceinline__ void eval(const double *X, const Ctx &c, double t, double *g, double (*J)[NP], double (*H)[NPP])
+        {{
+            (void)X; (void)c; (void)t;
+{_ind(st.emit_cpp(outs, names, vm), 12)}
+        }}
+    }};
+"""
+
+
 def emit_econ_header(p) -> str:
     nx, nu, ny, nd, nxp, nw = p.nx, p.nu, p.ny, p.nd, p.nxp, p.n_w
     vx, vu = st.symvec("x", nx), st.symvec("u", nu)
@@ -161,6 +188,9 @@ def emit_econ_header(p) -> str:
     vmw.update({f"v[{i}]": f"wv[{nw + i}]" for i in range(ny)})
     vmw["t"] = "t"
     cmhe = emit_scalar("cmhe", p.c_mhe, vwv, vmw, "const double *wv, double t")
+    gin = emit_rows("Gin", list(getattr(p, "g_ineq", []) or []), list(vx) + list(vu), vm)
+    if gin:      # (a model without user rows keeps the header it always had)
+        gin = "    // User_g_ineq(x, u, y, d, t, px, py) <= 0, the OCP's user rows at every stage   (Control_Calc.py:94-100,132-147)\n#define MPC_EC_HAS_GIN 1\n" + gin
     def cmat(name, a):      # a constant matrix as a constexpr function of its indices: zeros and ones are known to the compiler where the loops unroll
         a = [[float(v) for v in row] for row in a]
         terms = "".join(f"(i == {i} && j == {j}) ? {v!r} : " for i, row in enumerate(a) for j, v in enumerate(row) if v != 0.0)
@@ -187,8 +217,7 @@ struct EcModel {{
     // User_vfin(x, xs)   (Control_Calc.py:194-210)
 {vfin}
     // User_fobj_mhe(w, v, t) in wv = [w; v]   (Utilities.py:928-932)
-{cmhe}
-}};
+{cmhe}{gin}}};
 """
 
 

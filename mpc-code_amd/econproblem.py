@@ -47,6 +47,7 @@ class EconomicMPCProblem:
     vfin: st.Sym = None             # terminal cost in x[i], xs[i]
     f_mhe: List[st.Sym] = None      # estimator model dx/dt in x[i], u[i], t
     c_mhe: st.Sym = None            # estimator stage cost in w[i], v[i], t
+    g_ineq: List[st.Sym] = field(default_factory=list)      # user inequality rows of the OCP, each <= 0, in x[i], u[i], d[i], t (User_g_ineq)
     Bd: np.ndarray = None
     Cd: np.ndarray = None
     umin: np.ndarray = None
@@ -119,7 +120,7 @@ def is_economic(ns: Dict[str, Any]) -> bool:
 def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: int = 20) -> EconomicMPCProblem:
     """Classify an economic Ex-file namespace (reference MPC_code.py:84-257,368-438 probes) and trace its functions."""
     has = lambda k: k in ns and ns[k] is not None and not k.startswith("__")
-    for bad in ("User_fobj_Dis", "User_fobj_Coll", "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "Q", "Qss",
+    for bad in ("User_fobj_Dis", "User_fobj_Coll", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y", "Q", "Qss",
                 "def_px", "def_py", "def_pxmp", "def_pymp", "def_pxp", "def_pyp", "A", "User_fxm_Dis", "User_fxp_Dis", "User_fym", "User_fyp",
                 "defSP", "ymin", "ymax", "ymin_dyn", "ymax_dyn", "Dumin", "Dumax", "vmin", "vmax", "User_fx_mhe_Dis",
                 "r_w", "Q_mhe"):
@@ -185,6 +186,16 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     vfin = [st.Sym.const(0.0)]
     if has("User_vfin"):
         vfin = _trace(ns["User_vfin"], (col(vx), col(vxs)), "User_vfin")
+    # user inequality rows of the OCP, G(x_k, u_k, y_k, d, t, px_k, py_k) <= 0 for k = 0..N-1 (Control_Calc.py:94-100,132-147,g4; MPC_code.py:306-314), with
+    # y = Fy_model(x, u, d) substituted as in the cost and px = py = 0 (LinPar).  The reference's solver turns every such row into an equality with a slack
+    # variable, g - s = 0, s <= 0 [ext]: here that slack is one more stage state (csrc/mpc_enmpc.hip:phase_ocp).  Slack variables of the Ex-file (`slacks`) stay refused.
+    g_ineq = []
+    if has("User_g_ineq"):
+        g_ineq = _trace(ns["User_g_ineq"], (col(vx), col(vu), col(fy(vx)), col(vd), vt, zero(nx), zero(ny)), "User_g_ineq")
+        if not g_ineq or len(g_ineq) > 4:
+            raise UnsupportedProblem("User_g_ineq: between one and four rows are carried")
+        if nx + len(g_ineq) > 8:
+            raise UnsupportedProblem("User_g_ineq: the stage state (nx + rows) exceeds 8")
     c_mhe = _trace(ns["User_fobj_mhe"], (col(vw), col(vv), vt), "User_fobj_mhe") if use_mhe else [sum((a * a for a in list(vw) + list(vv)), st.Sym.const(0.0)) * st.Sym.const(0.5)]
     if len(ell) != 1 or len(fss) != 1 or len(vfin) != 1 or len(c_mhe) != 1:
         raise UnsupportedProblem("a cost function does not return a scalar")
@@ -197,7 +208,7 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
     G = np.eye(nx + nd) if not has("G_mhe") else _mat(ns["G_mhe"], nx + nd, n_w, "G_mhe")      # MPC_code.py:387
     return EconomicMPCProblem(
         nx=nx, nu=nu, ny=ny, nd=nd, nxp=nxp, N=int(ns["N"]), h=float(ns["h"]), Nsim=int(ns["Nsim"]), Mx=int(ns.get("Mx", 10)), quad_steps=int(quad_steps),
-        f=f, fp=fp, ell=ell[0], fss=fss[0], vfin=vfin[0], f_mhe=f_mhe, c_mhe=c_mhe[0], Bd=Bd, Cd=Cd,
+        f=f, fp=fp, ell=ell[0], fss=fss[0], vfin=vfin[0], f_mhe=f_mhe, c_mhe=c_mhe[0], g_ineq=g_ineq, Bd=Bd, Cd=Cd,
         umin=pick("umin", "_dyn", nu, -INF), umax=pick("umax", "_dyn", nu, INF), xmin=pick("xmin", "_dyn", nx, -INF), xmax=pick("xmax", "_dyn", nx, INF),
         umin_ss=pick("umin", "_ss", nu, -INF), umax_ss=pick("umax", "_ss", nu, INF), xmin_ss=pick("xmin", "_ss", nx, -INF), xmax_ss=pick("xmax", "_ss", nx, INF),
         ymin_ss=pick("ymin", "_ss", ny, -INF), ymax_ss=pick("ymax", "_ss", ny, INF),
@@ -213,5 +224,5 @@ def econ_problem_from_namespace(ns: Dict[str, Any], name: str = "", quad_steps: 
         xmin_mhe=np.concatenate([_vec(ns.get("xmin"), nx, -INF), _vec(ns.get("dmin"), nd, -INF)]),      # MPC_code.py:397-402
         xmax_mhe=np.concatenate([_vec(ns.get("xmax"), nx, INF), _vec(ns.get("dmax"), nd, INF)]),
         name=name or str(ns.get("__name__", "")),
-        funcs={k: ns[k] for k in ("User_fxm_Cont", "User_fxp_Cont", "User_fobj_Cont", "User_fssobj", "User_vfin", "User_fx_mhe_Cont", "User_fobj_mhe") if has(k)},
+        funcs={k: ns[k] for k in ("User_fxm_Cont", "User_fxp_Cont", "User_fobj_Cont", "User_fssobj", "User_vfin", "User_fx_mhe_Cont", "User_fobj_mhe", "User_g_ineq") if has(k)},
     )

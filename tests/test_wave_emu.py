@@ -138,6 +138,10 @@ def test_kernel_source_restoration_phase_of_the_ocp(emulated, pkg):
         s.close()
 
 
-@pytest.mark.parametrize("seed", [1, 7, 13, 24])
+def test_kernel_source_user_inequality_rows(emulated, pkg):
+    te.test_gpu_user_inequality_rows_follow_the_oracle(pkg, 3, 6)
+
+
+@pytest.mark.parametrize("seed", [7, 24])
 def test_kernel_source_randomised_reactor_models(emulated, pkg, seed):
     te.test_gpu_randomised_reactor_models_follow_the_c_restatement(pkg, seed)
