@@ -80,6 +80,17 @@ def measured_traffic(kernel_name: str, instance_steps_per_launch: float, summary
            f"separate rocprofv3 --pmc passes of `{d.get('command')}` / its instance-steps; scaled to this run's {instance_steps_per_launch:.0f} instance-steps per launch")
     if d.get("kernel_short") and d["kernel_short"] not in kernel_name:
         src += f" (NOTE: summary is for {d['kernel_short']}, this run used {kernel_name})"
+    # a figure measured on other kernel sources than the ones this run was built from is STALE: said so in the line (roofline.traffic_stale)
+    stale = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        now = pmc_summary.sources_sha16(d.get("kernel_short") or kernel_name)
+        stale = (d.get("sources_sha16") != now) if d.get("sources_sha16") else None
+        src += f"; kernel sources then {d.get('sources_sha16', 'not recorded')}, now {now}"
+    except Exception as e:      # noqa: BLE001
+        src += f"; source fingerprint unavailable ({e})"
+    measured_traffic.stale = stale
     return per * instance_steps_per_launch, src
 
 
@@ -118,13 +129,22 @@ def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     rate1 = 256 * min(nsteps, 10) / max(t1, 1e-6)                       # one core, rough: only to size the samples
     nb1 = int(min(len(x0), max(16, 4.0 * rate1 / nsteps)))              # about 4 s on one core
     v1, r1, s1 = run(nb1, 1, 4.0)
-    nbn = int(min(len(x0), max(64, max_seconds * rate1 * nthr * 0.5 / nsteps)))
-    # the fastest thread count, not the largest: all hardware threads, one per physical core (SMT off), a quarter - each a bounded sample
+    # Every thread count gets a sample that keeps each of its threads busy for a good part of a second: the benchmark batch (4096 instances) is 16 instances per thread
+    # on a 256-thread host - a parallel region of some ten milliseconds, which measures thread wake-up and the spread of the cold starts' iteration counts, not the
+    # solver (round 4: 'peaks at 32 of 256 threads').  Instances are independent: the sample is the batch tiled.  Threads are pinned (OMP_PROC_BIND / OMP_PLACES, set
+    # before the OpenMP runtime starts: main()).
     tried = {}
     for th in sorted({nthr, max(1, nthr // 2), max(1, nthr // 4), max(1, nthr // 8)}, reverse=True):
-        tried[th] = run(nbn, th, target_seconds / 2.0)      # explicit: orc_closed_loop's thread count is sticky (omp_set_num_threads)
+        nb_th = int(max(len(x0), min(128 * th, max_seconds * rate1 * th * 0.25 / nsteps)))
+        xs_ = np.ascontiguousarray(np.tile(x0, (-(-nb_th // len(x0)), 1))[:nb_th])
+        reps, spent = 0, 0.0
+        while reps == 0 or (spent < target_seconds / 2.0 and spent * (reps + 1) / reps < max_seconds):
+            t0 = time.perf_counter(); oc.closed_loop(nsteps, xs_, xs_, logs=False, nthreads=th); spent += time.perf_counter() - t0      # explicit: orc_closed_loop's thread count is sticky (omp_set_num_threads)
+            reps += 1
+        tried[th] = (reps * nb_th * nsteps / spent, reps, spent, nb_th)
+    nbn = tried[max(tried, key=lambda th: tried[th][0])][3]
     best = max(tried, key=lambda th: tried[th][0])
-    vn, rn, sn = tried[best]
+    vn, rn, sn = tried[best][:3]
     return dict(value=vn, unit="steps/s", cores=best, kind="port", single_core_value=v1, threads_tried={str(th): tried[th][0] for th in tried},
                 sample=f"{nbn} instances x {nsteps} closed-loop steps from t=0 of the same workload, {rn} repetitions, {sn:.1f} s wall on {best} threads, the fastest of "
                        f"{sorted(tried)} tried ({nthr} hardware threads) "
@@ -338,7 +358,7 @@ def main_enmpc(args):
                           "parallelism": "instances sharded over %d GPU(s), one process each; RCCL all-gather of U inside the timed region" % world,
                           "rccl_ranks": (s.comm_rank()[1] if comm is not None else 1),
                           "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
-               "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+               "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": getattr(measured_traffic, "stale", None),
                             "kernel": kdesc, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
                             "issue": issue_roofline(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PROFILE_ROUND, args.config)), per_launch_s, units / float(cfg["batch"])),
                             "launch_timing": ("HIP events around every launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
@@ -367,8 +387,9 @@ def main_enmpc(args):
                                    "threads_tried": {str(th): tried[th][0] for th in tried},
                                    "sample": "%d instances x %d closed-loop steps from t=0 of the same workload on %d threads, the fastest of %s tried (%d hardware threads): "
                                              "oracle/enmpc_oracle.c - the same three NLPs per step solved by the same outer interior point method with complex-step "
-                                             "derivatives and null-space (QR + Cholesky) Newton steps, gcc -O3 -march=native -fopenmp built on this host; the reference's "
-                                             "CasADi/IPOPT/IDAS path is not installable here" % (tried[best][1], K, best, sorted(tried), nthr)}
+                                             "derivatives and DENSE null-space (QR + Cholesky) Newton steps, gcc -O3 -march=native -fopenmp built on this host - the CHECKER, which makes no use of the "
+                                             "stage structure: a structure-exploiting host build would be one to two orders faster, the GPU / CPU ratio of this line is no statement about either; "
+                                             "the reference's CasADi/IPOPT/IDAS path is not installable here" % (tried[best][1], K, best, sorted(tried), nthr)}
         import ctypes
         sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
@@ -452,7 +473,7 @@ def main_nmpc(args):
                       "batch_per_gpu": B, "horizon": p.N, "steps_per_run": K, "kernel": kern, "stream_groups": args.groups, "max_sqp": args.max_sqp, "repeats": len(times),
                       "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3},
                       "device_ms_per_run": float(np.mean(kms))},
-           "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+           "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": getattr(measured_traffic, "stale", None),
                         "kernel": kdesc, "launches": (wn * len(wms)) if split else len(times), "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab,
                         "issue": issue_roofline(summary, per_launch_s, units / 16384.0) if split else None,
                         "launch_timing": ("HIP events around every wave-style launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
@@ -606,7 +627,7 @@ def main():
                        "rccl_ranks": (solver.comm_rank()[1] if use_dist else 1),
                        "repeats": len(times), "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
             "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": getattr(measured_traffic, "stale", None),
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab, "carried_bytes_per_step": carried_bytes_per_step(prob),
                          "issue_bound": True,
@@ -640,4 +661,6 @@ def main():
 
 
 if __name__ == "__main__":
+    # the CPU baseline's threads stay where they start (before any OpenMP runtime is loaded): without it a 256-thread host migrates them between the samples
+    os.environ.setdefault("OMP_PROC_BIND", "spread"); os.environ.setdefault("OMP_PLACES", "threads")
     main()
