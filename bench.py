@@ -40,7 +40,7 @@ KERNEL_NAMES = {1: "loop_kernel (one instance per lane)", 2: "loop_kernel_tp (ho
 B_PER_GPU = 4096
 SEED = 20250614
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r04"      # the round whose PMC summaries (profiles/<round>_*pmc_summary.json) the traffic figures come from
+PROFILE_ROUND = "r05"      # the round whose PMC summaries (profiles/<round>_*pmc_summary.json) the traffic figures come from
 PMC_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_summary.json")
 
 
