@@ -241,6 +241,13 @@ def test_ipopt_vectors_if_present(oprob):
         sol = eo.ocp_solve(oprob, g["XHAT"][i], g["WT"][i][:n], g["WT"][i][n:n + m], g["D"][i], w0)
         assert (sol["status"] == 0) == (str(g["STATUS"][i]) == "Solve_Succeeded") and np.abs(sol["w"] - g["W"][i]).max() < 1e-6
         assert abs(int(sol["iters"]) - int(g["ITERS"][i])) <= 2, (i, sol["iters"], g["ITERS"][i])
+    for i in range(len(g["MHE_N"]) if "MHE_N" in g.files else 0):      # the estimator's NLP (mhe_opt), windows of 1 .. N_mhe stages
+        Nw = int(g["MHE_N"][i])
+        Us, Ys = [np.asarray(r, dtype=float) for r in g["MHE_U"][i]], [np.asarray(r, dtype=float) for r in g["MHE_Y"][i]]
+        evalf, lo, hi = eo.mhe_eval(oprob, Nw, Us, Ys, np.asarray(g["MHE_XBAR"][i], dtype=float), np.linalg.inv(np.asarray(g["MHE_P"][i], dtype=float)))
+        sol = eo.ipm_dense(evalf, np.asarray(g["MHE_W0"][i], dtype=float), lo, hi, tol=1e-10, max_iter=oprob.max_iter)
+        assert (sol["status"] == 0) == (str(g["MHE_STATUS"][i]) == "Solve_Succeeded") and np.abs(sol["w"] - np.asarray(g["MHE_W"][i], dtype=float)).max() < 1e-6, i
+        assert abs(int(sol["iters"]) - int(g["MHE_ITERS"][i])) <= 2, (i, sol["iters"], g["MHE_ITERS"][i])
 
 
 WHITE_NOISE = {"R_wn": 1e-6 * np.eye(2), "G_wn": 1e-2 * np.eye(2), "Q_wn": 1e-3 * np.eye(2), "N": 12, "N_mhe": 6}      # (Ex_ENMPC.py:68-69 carries G_wn / Q_wn commented out)

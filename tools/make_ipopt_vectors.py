@@ -5,7 +5,7 @@ The build container has no CasADi, so parity with IPOPT is pinned by mathematics
 machine where ``import casadi`` succeeds this script adds true IPOPT vectors:
 
     python3 tools/make_ipopt_vectors.py            # writes tests/golden/ipopt_*.npz
-    python3 tools/make_ipopt_vectors.py econ /path/to/MPC-code      # the economic example's target NLP and OCP: tests/golden/ipopt_enmpc.npz (see econ_vectors)
+    python3 tools/make_ipopt_vectors.py econ /path/to/MPC-code      # the economic example's target NLP, OCP and estimator NLP: tests/golden/ipopt_enmpc.npz (see econ_vectors)
 
 It poses the NLP of ``opt_dyn`` (Control_Calc.py:20-260) in its own variable / constraint layout - built here from the
 dense matrices of oracle/mpc_oracle.py:ocp_qp, which restates Control_Calc.py:126-252 row by row - hands it to
@@ -105,8 +105,49 @@ def econ_vectors(ca, ref_dir):
         sol = sd(x0=w0, p=np.concatenate([wts[:nx], wts[nx:nx + nu], d]), lbx=lo, ubx=hi, lbg=0, ubg=0)
         rec["W"].append(np.array(sol["x"]).ravel()); rec["F"].append(float(sol["f"]))
         rec["ITERS"].append(int(sd.stats()["iter_count"])); rec["STATUS"].append(sd.stats()["return_status"])
-    np.savez_compressed(os.path.join(GOLD, "ipopt_enmpc.npz"), **{k: np.array(v) for k, v in rec.items()})
-    print("enmpc written: 24 target + OCP solves, iterations", rec["ITERS_T"][:6], rec["ITERS"][:6])
+    # ---- estimator: mhe_opt's NLP for a window of Nw stages in its own layout w = [x0, v0, w0, x1, ..., x_Nw] with [x; d] for x (Utilities.py:831-846),
+    # g = [Fy(X_k) + V_k - Y_k; Fx_mhe(X_k, U_k, W_k) - X_{k+1}] (:909-926), f = sum F_obj_mhe(W_k, V_k) + 1/2 (x0 - x_bar)' P^-1 (x0 - x_bar) (:928-945), boxes on every X_k
+    # (:956-966); IPOPT at the estimator's options (MPC_code.py:383: tol 1e-10), first guess = x_bar propagated without noise (Estimator.py:503-512)
+    if ns.get("mhe", False):
+        ne, nwv = nx + nd, ns["w"].size1()
+        fmhe, cmhe = ns["User_fx_mhe_Cont"], ns["User_fobj_mhe"]
+        G = ca.DM(np.eye(ne) if ns.get("G_mhe") is None else np.asarray(ns["G_mhe"], dtype=float))
+        P0, xbar0 = np.asarray(ns["P0"], dtype=float), vec(ns["x_bar"], ne, 0.0)
+        lo_e = np.concatenate([vec(ns.get("xmin_mhe", ns.get("xmin")), nx, -np.inf), vec(ns.get("dmin"), nd, -np.inf)])
+        hi_e = np.concatenate([vec(ns.get("xmax_mhe", ns.get("xmax")), nx, np.inf), vec(ns.get("dmax"), nd, np.inf)])
+        opts_mhe = dict(opts); opts_mhe["ipopt.tol"] = 1e-10
+        nb = ne + ny + nwv
+
+        def fx_mhe(X, U, W):
+            xn = rk4(lambda z: fmhe(z, U, X[nx:], 0.0, zero_x, W), X[:nx], Mx) + ca.mtimes(Bd, X[nx:])
+            return ca.vertcat(xn, X[nx:]) + ca.mtimes(G, W)
+        rec.update({k: [] for k in ("MHE_N", "MHE_U", "MHE_Y", "MHE_XBAR", "MHE_P", "MHE_W0", "MHE_W", "MHE_F", "MHE_ITERS", "MHE_STATUS")})
+        for Nw in (1, 2, 3, 5, 8, 12, 20, 20):
+            Us, Ys = rng.uniform(0.2, 1.2, (Nw, nu)), rng.uniform([0.5, 0.0], [1.0, 0.5], (Nw, ny))
+            xb = xbar0 + np.concatenate([rng.uniform(-0.1, 0.1, nx), np.zeros(nd)]); Pk = P0 * rng.uniform(0.5, 2.0)
+            wm = ca.SX.sym("wm", Nw * nb + ne)
+            g, f = [], 0
+            for k in range(Nw):
+                X, V, W, Xn = wm[nb * k: nb * k + ne], wm[nb * k + ne: nb * k + ne + ny], wm[nb * k + ne + ny: nb * (k + 1)], wm[nb * (k + 1): nb * (k + 1) + ne]
+                g += [X[:nx] + ca.mtimes(Cd, X[nx:]) + V - ca.DM(Ys[k]), fx_mhe(X, ca.DM(Us[k]), W) - Xn]
+                f = f + cmhe(W, V, 0.0)
+            e0 = wm[:ne] - ca.DM(xb)
+            f = f + 0.5 * ca.mtimes([e0.T, ca.DM(np.linalg.inv(Pk)), e0])
+            sm = ca.nlpsol("mhe", "ipopt", {"x": wm, "f": f, "g": ca.vertcat(*g)}, opts_mhe)
+            lo, hi = np.full(Nw * nb + ne, -np.inf), np.full(Nw * nb + ne, np.inf)
+            w0, xg = np.zeros(Nw * nb + ne), xb.copy()
+            prop = ca.Function("prop", [wm[:ne], wm[ne:ne + nu]], [fx_mhe(wm[:ne], wm[ne:ne + nu], ca.DM.zeros(nwv))])
+            for k in range(Nw + 1):
+                lo[nb * k: nb * k + ne], hi[nb * k: nb * k + ne] = lo_e, hi_e
+                w0[nb * k: nb * k + ne] = xg
+                if k < Nw:
+                    xg = np.array(prop(xg, Us[k])).ravel()
+            sol = sm(x0=w0, lbx=lo, ubx=hi, lbg=0, ubg=0)
+            for k_, v_ in (("MHE_N", Nw), ("MHE_U", Us), ("MHE_Y", Ys), ("MHE_XBAR", xb), ("MHE_P", Pk), ("MHE_W0", w0), ("MHE_W", np.array(sol["x"]).ravel()), ("MHE_F", float(sol["f"])),
+                           ("MHE_ITERS", int(sm.stats()["iter_count"])), ("MHE_STATUS", sm.stats()["return_status"])):
+                rec[k_].append(v_)
+    np.savez_compressed(os.path.join(GOLD, "ipopt_enmpc.npz"), **{k: (np.array(v, dtype=object) if k.startswith("MHE_") and k not in ("MHE_N", "MHE_F", "MHE_ITERS", "MHE_STATUS") else np.array(v)) for k, v in rec.items()})
+    print("enmpc written: 24 target + OCP solves, iterations", rec["ITERS_T"][:6], rec["ITERS"][:6], "; estimator windows", rec.get("MHE_N"), "iterations", rec.get("MHE_ITERS"))
 
 
 def main():
