@@ -336,7 +336,7 @@ class Solver:
     def allgather_log(self, name: str, k0: int, nsteps: int, to_host: bool = True):
         """Steps [k0, k0+nsteps) of a float64 log of every rank, [world, nsteps, B, dim]; None when left on the device."""
         p = self.p
-        dims = dict(U=p.nu, X_HAT=p.nx, XS=p.nx, US=p.nu, YS=p.ny, Xp=p.nxp, D_HAT=p.nd)
+        dims = dict(U=p.nu, X_HAT=p.nx, XS=p.nx, US=p.nu, YS=p.ny, Xp=p.nxp, D_HAT=p.nd, SL=2 * p.ny)      # SL: the slacks of a problem with soft output constraints
         _, world = self.comm_rank()
         out = np.empty((world, int(nsteps), self._loop_B, dims[name])) if to_host else None
         self._chk(self.lib.mpc_allgather_log(self.h, name.encode(), int(k0), int(nsteps), _p(out)), "mpc_allgather_log")
@@ -453,7 +453,7 @@ class Solver:
 
     def loop_get_log(self, name: str):
         p, B, ns = self.p, self._loop_B, self._sched_n
-        dims = dict(U=p.nu, X_HAT=p.nx, XS=p.nx, US=p.nu, YS=p.ny, Xp=p.nxp, D_HAT=p.nd)
+        dims = dict(U=p.nu, X_HAT=p.nx, XS=p.nx, US=p.nu, YS=p.ny, Xp=p.nxp, D_HAT=p.nd, SL=2 * p.ny)      # SL: the slacks of a problem with soft output constraints
         if name in dims:
             out = np.zeros((ns, B, dims[name]))
         else:

@@ -127,6 +127,27 @@ __global__ __launch_bounds__(64) void ocp_kernel(const DevProblem *__restrict__ 
     }
 }
 
+// the soft problem of one instance: stage data of the hard problem (build_inst with y_bounded = 0: the stage boxes are the state bounds alone) + the output rows and their weight
+template <int NX, int NU, int NY, int ND, bool DU, int NS>
+__device__ __forceinline__ void soft_prob_fill(const DevProblem &P, const OcpInst<NS, NU> &q, const double *dh, SoftProb<NS, NU, NY> &S)
+{
+    S.N = P.N; S.max_iter = P.max_iter;
+    for (int i = 0; i < NS; i++) {
+        for (int j = 0; j < NS; j++) { S.A[i][j] = P.A[i][j]; S.Q[i][j] = P.Q[i][j]; S.Pf[i][j] = P.Pf[i][j]; }
+        for (int j = 0; j < NU; j++) { S.B[i][j] = P.B[i][j]; S.M[i][j] = DU ? P.M[i][j] : 0.0; }
+        S.c[i] = q.c[i]; S.z0[i] = q.z0[i]; S.zr[i] = q.zr[i]; S.zrN[i] = q.zrN[i];
+        S.zlo[i] = q.zlo_m[i]; S.zhi[i] = q.zhi_m[i]; S.zlo_e[i] = P.zlo_e[i]; S.zhi_e[i] = P.zhi_e[i];
+    }
+    for (int i = 0; i < NU; i++) { for (int j = 0; j < NU; j++) S.R[i][j] = P.R[i][j]; S.ur[i] = q.ur[i]; S.us[i] = q.us[i]; S.ulo[i] = P.ulo[i]; S.uhi[i] = P.uhi[i]; }
+    for (int i = 0; i < NY; i++) {
+        double e = P.fyc[i];
+        for (int j = 0; j < ND; j++) e += P.Cd[i][j] * dh[j];
+        S.cy[i] = e; S.ymin[i] = P.ymin[i]; S.ymax[i] = P.ymax[i];
+        for (int j = 0; j < NS; j++) S.Cy[i][j] = j < NX ? P.Cm[i][j < NX ? j : 0] : 0.0;      // outputs read the model states (not the u_prev part of the stage state)
+    }
+    for (int i = 0; i < 2 * NY; i++) for (int j = 0; j < 2 * NY; j++) S.Ws[i][j] = P.Ws[i][j];
+}
+
 // The same call for a problem with SOFT output constraints (`slacks = True`, Control_Calc.py:39-40,186-192,228-239): one slack vector shared by all stages - the
 // arrowhead solver of mpc_soft.hpp, one instance per lane, workspace [wave][block][field][64 lanes] in HBM.  sl_out [2 NY][Bs]: the optimal slacks (MPC_code.py:800).
 struct OcpSoftArgs { OcpArgs o; double *sl_out; };
@@ -146,21 +167,7 @@ __global__ __launch_bounds__(64) void ocp_kernel_soft(const DevProblem *__restri
     OcpInst<NS, NU> q;
     build_inst<NX, NU, NY, ND, DU, NG>(P, xhat, xs, us, dh, up, q);      // (y_bounded = 0 in a soft problem: the stage boxes are the state bounds alone)
     SoftProb<NS, NU, NY> S;
-    S.N = P.N; S.max_iter = P.max_iter;
-    for (int i = 0; i < NS; i++) {
-        for (int j = 0; j < NS; j++) { S.A[i][j] = P.A[i][j]; S.Q[i][j] = P.Q[i][j]; S.Pf[i][j] = P.Pf[i][j]; }
-        for (int j = 0; j < NU; j++) { S.B[i][j] = P.B[i][j]; S.M[i][j] = DU ? P.M[i][j] : 0.0; }
-        S.c[i] = q.c[i]; S.z0[i] = q.z0[i]; S.zr[i] = q.zr[i]; S.zrN[i] = q.zrN[i];
-        S.zlo[i] = q.zlo_m[i]; S.zhi[i] = q.zhi_m[i]; S.zlo_e[i] = P.zlo_e[i]; S.zhi_e[i] = P.zhi_e[i];
-    }
-    for (int i = 0; i < NU; i++) { for (int j = 0; j < NU; j++) S.R[i][j] = P.R[i][j]; S.ur[i] = q.ur[i]; S.us[i] = q.us[i]; S.ulo[i] = P.ulo[i]; S.uhi[i] = P.uhi[i]; }
-    for (int i = 0; i < NY; i++) {
-        double e = P.fyc[i];
-        for (int j = 0; j < ND; j++) e += P.Cd[i][j] * dh[j];
-        S.cy[i] = e; S.ymin[i] = P.ymin[i]; S.ymax[i] = P.ymax[i];
-        for (int j = 0; j < NS; j++) S.Cy[i][j] = j < NX ? P.Cm[i][j < NX ? j : 0] : 0.0;      // outputs read the model states (not the u_prev part of the stage state)
-    }
-    for (int i = 0; i < 2 * NY; i++) for (int j = 0; j < 2 * NY; j++) S.Ws[i][j] = P.Ws[i][j];
+    soft_prob_fill<NX, NU, NY, ND, DU, NS>(P, q, dh, S);
     using LY = SoftLayout<NS, NU, NY>;
     double *const ws = a.ws + (size_t)blockIdx.x * LY::FIELDS * P.N * 64 + threadIdx.x;
     double u0[NU], z1[NS], sl[2 * NY], res[3];
@@ -335,6 +342,7 @@ struct LoopArgs {
     int wv_ni;                                       // wave-autonomous kernel: instances per wave (0 = by batch size; option "wave_instances")
     const double *px_h, *py_h;                       // def_px / def_py over the horizon, [step][N][nx] / [step][N][ny] offset to k0 (loop_kernel_pxy), or nullptr
     double *lin;                                     // loop_kernel_pxy: slab of per-block stage data
+    double *SL, *soft_ws, *sl_keep;                  // loop_kernel_soft: log of the slacks [step][2 ny][Bs] offset to k0 (or nullptr), the arrowhead solver's workspace, the last accepted slacks [2 ny][Bs]
 };
 
 // x_p(t + h) (MPC_code.py:813-816).  Linear plant: Ap x + Bp u + pxp (Utilities.py:45-49).  User plant: MX classical RK4 steps of
@@ -488,6 +496,113 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
     MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
     MPC_UNROLL for (int i = 0; i < NU; i++) { a.u[i * Bs + b] = u[i]; a.us[i * Bs + b] = us[i]; }
     a.ws_valid[b] = ws_valid ? 1 : 0;
+}
+
+// The closed loop of a problem with SOFT output constraints (slacks = True; mpc_soft.hpp): loop_kernel's step - instance per lane, the same estimator, target and
+// plant code - with the arrowhead solver as its OCP, cold every step like ocp_kernel_soft: a fused run equals the three C-ABI calls per step bit for bit.  The optimal
+// slacks of every step go to the log SL (MPC_code.py:800).  One instantiation per dimension set.
+template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG>
+__global__ __launch_bounds__(64) void loop_kernel_soft(const DevProblem *__restrict__ Pp, LoopArgs a)
+{
+    constexpr int NS = NX + (DU ? NU : 0) + NG, NE = NX + ND;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const DevProblem &P = *Pp;
+    const size_t Bs = a.Bs;
+    double x[NXP], xh[NX], dh[ND > 0 ? ND : 1], u[NU], xs[NX], us[NU];
+    MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = a.x[i * Bs + b];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { xh[i] = a.xhat[i * Bs + b]; xs[i] = a.xs[i * Bs + b]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) dh[i] = a.dhat[i * Bs + b];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { u[i] = a.u[i * Bs + b]; us[i] = a.us[i * Bs + b]; }
+    using LY = SoftLayout<NS, NU, NY>;
+    double *const ws = a.soft_ws + (size_t)blockIdx.x * LY::FIELDS * P.N * 64 + threadIdx.x;
+    double slk[2 * NY];      // the slacks of the last accepted OCP (MPC_code.py:800, 808-809: Sl.append(sl_k))
+    for (int i = 0; i < 2 * NY; i++) slk[i] = a.sl_keep[i * Bs + b];
+    for (int k = 0; k < a.nsteps; k++) {
+        if (a.XP) { MPC_UNROLL for (int i = 0; i < NXP; i++) a.XP[((size_t)k * NXP + i) * Bs + b] = x[i]; }
+        if (a.XHAT) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XHAT[((size_t)k * NX + i) * Bs + b] = xh[i]; }
+        // ---- measure and estimate (MPC_code.py:524-534, 577-668) ---------------------------------
+        if (P.estimator != MPC_EST_NONE) {
+            double xi[NE], innov[NY];
+            MPC_UNROLL for (int i = 0; i < NX; i++) xi[i] = xh[i];
+            MPC_UNROLL for (int i = 0; i < ND; i++) xi[NX + i] = dh[i];
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double yh = P.fyc[i], yy = a.pyp[k * NY + i];
+                MPC_UNROLL for (int j = 0; j < NE; j++) yh += P.Ca[i][j] * xi[j];
+                MPC_UNROLL for (int j = 0; j < NXP; j++) yy += P.Cp[i][j] * x[j];
+                innov[i] = yy - yh;
+            }
+            if (P.estimator == MPC_EST_KALMAN) {
+                double Pk[NE][NE];
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) Pk[i][j] = a.Pk[(i * NE + j) * Bs + b]; }
+                kalman_lane<NE, NY>(P, xi, Pk, innov);
+                MPC_UNROLL for (int i = 0; i < NE; i++) { MPC_UNROLL for (int j = 0; j < NE; j++) a.Pk[(i * NE + j) * Bs + b] = Pk[i][j]; }
+            } else {
+                MPC_UNROLL for (int i = 0; i < NE; i++) { double s_ = 0.0; MPC_UNROLL for (int l = 0; l < NY; l++) s_ += P.Kfix[i][l] * innov[l]; xi[i] += s_; }
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xi[i];
+            MPC_UNROLL for (int i = 0; i < ND; i++) { double d = xi[NX + i]; if (P.has_dsat) d = dmin(dmax(d, P.dmin[i]), P.dmax[i]); dh[i] = d; }
+        }
+        if (a.DHAT) { MPC_UNROLL for (int i = 0; i < ND; i++) a.DHAT[((size_t)k * ND + i) * Bs + b] = dh[i]; }
+        // ---- target (MPC_code.py:693-718): keep the previous one when infeasible ------------------
+        double usp[NU], ysp[NY], xs_n[NX], us_n[NU], ys_n[NY];
+        MPC_UNROLL for (int i = 0; i < NU; i++) usp[i] = a.usp[k * NU + i];
+        MPC_UNROLL for (int i = 0; i < NY; i++) ysp[i] = a.ysp[k * NY + i];
+        int it_ss;
+        const int st_ss = target_lane<NX, NU, NY, ND>(P, usp, ysp, dh, us, xs_n, us_n, ys_n, it_ss, a.tw + b, Bs, a.tw_valid + b);
+        if (st_ss != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xs_n[i];
+            MPC_UNROLL for (int i = 0; i < NU; i++) us[i] = us_n[i];
+        }
+        if (a.XS) { MPC_UNROLL for (int i = 0; i < NX; i++) a.XS[((size_t)k * NX + i) * Bs + b] = xs[i]; }
+        if (a.US) { MPC_UNROLL for (int i = 0; i < NU; i++) a.US[((size_t)k * NU + i) * Bs + b] = us[i]; }
+        if (a.YS) {   // ys = Fy_model(xs, us, dhat), MPC_code.py:730
+            MPC_UNROLL for (int i = 0; i < NY; i++) {
+                double v = P.fyc[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Cm[i][j] * xs[j];
+                MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Cd[i][j] * dh[j];
+                a.YS[((size_t)k * NY + i) * Bs + b] = v;
+            }
+        }
+        // ---- OCP with the shared slack vector (MPC_code.py:733-805; Control_Calc.py:39-40,186-188,228-239) ---------------------------------------------
+        OcpInst<NS, NU> q;
+        build_inst<NX, NU, NY, ND, DU, NG>(P, xh, xs, us, dh, u, q);
+        SoftProb<NS, NU, NY> S;
+        soft_prob_fill<NX, NU, NY, ND, DU, NS>(P, q, dh, S);
+        double u0[NU], z1[NS], sl[2 * NY], res[3];
+        int it_dyn;
+        const int st_dyn = soft_solve<NS, NU, NY, 64>(S, ws, u0, z1, sl, res, it_dyn);
+        if (st_dyn != kInfeasible) {
+            MPC_UNROLL for (int i = 0; i < NU; i++) u[i] = (DU && P.in_is_du) ? z1[DU ? NX + i : 0] : u0[i];          // :798
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = z1[i];         // :799
+            for (int i = 0; i < 2 * NY; i++) slk[i] = sl[i];               // :800
+        } else {                                                           // :804-805 hold u, propagate the model
+            double xn[NX];
+            MPC_UNROLL for (int i = 0; i < NX; i++) {
+                double v = P.fxc[i];
+                MPC_UNROLL for (int j = 0; j < NX; j++) v += P.Am[i][j] * xh[j];
+                MPC_UNROLL for (int j = 0; j < NU; j++) v += P.Bm[i][j] * u[j];
+                MPC_UNROLL for (int j = 0; j < ND; j++) v += P.Bd[i][j] * dh[j];
+                xn[i] = v;
+            }
+            MPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = xn[i];
+        }
+        if (a.U) { MPC_UNROLL for (int i = 0; i < NU; i++) a.U[((size_t)k * NU + i) * Bs + b] = u[i]; }
+        if (a.SL) { for (int i = 0; i < 2 * NY; i++) a.SL[((size_t)k * 2 * NY + i) * Bs + b] = slk[i]; }
+        if (a.st_dyn) { a.st_dyn[(size_t)k * Bs + b] = st_dyn; a.st_ss[(size_t)k * Bs + b] = st_ss; a.it_dyn[(size_t)k * Bs + b] = it_dyn; a.it_ss[(size_t)k * Bs + b] = it_ss; }
+        // ---- plant (MPC_code.py:813-816) -----------------------------------------------------------
+        {
+            double xn[NXP];
+            plant_next<NXP, NU>(P, x, u, a.pxp + k * NXP, a.t0 + k * a.h, a.h, xn);
+            MPC_UNROLL for (int i = 0; i < NXP; i++) x[i] = xn[i];
+        }
+    }
+    MPC_UNROLL for (int i = 0; i < NXP; i++) a.x[i * Bs + b] = x[i];
+    MPC_UNROLL for (int i = 0; i < NX; i++) { a.xhat[i * Bs + b] = xh[i]; a.xs[i * Bs + b] = xs[i]; }
+    MPC_UNROLL for (int i = 0; i < ND; i++) a.dhat[i * Bs + b] = dh[i];
+    MPC_UNROLL for (int i = 0; i < NU; i++) { a.u[i * Bs + b] = u[i]; a.us[i * Bs + b] = us[i]; }
+    for (int i = 0; i < 2 * NY; i++) a.sl_keep[i * Bs + b] = slk[i];
+    a.ws_valid[b] = 0;
 }
 
 // The closed loop with model parameters that vary over the horizon (def_px / def_py, MPC_code.py:492-510): at step k the OCP sees
@@ -1275,6 +1390,7 @@ struct Launchers {
     void (*ocp_pxy)(const DevProblem *, OcpPxyArgs, hipStream_t);      // time-varying px / py: one variant (all bounds maskable)
     void (*ocp_soft)(const DevProblem *, OcpSoftArgs, hipStream_t);    // soft output constraints (mpc_soft.hpp)
     int soft_fields;                                                   // doubles per block and lane of its workspace
+    void (*loop_soft)(const DevProblem *, LoopArgs, hipStream_t);      // the closed loop with soft output constraints (instance per lane)
     void (*loop_pxy)(const DevProblem *, LoopArgs, hipStream_t);       // the closed loop with def_px / def_py schedules (instance per lane)
     int pxy_ws_rows, pxy_nc, pxy_lin;                                  // its workspace rows / bounded variables / slab entries per block
     void (*target)(const DevProblem *, TargetArgs, hipStream_t);
@@ -1321,6 +1437,7 @@ static Launchers make_launchers_mode()
         l.pxy_ws_rows = 2 * BlkLayout<NSZ, NU, NSZ + NU>::SLOTS; l.pxy_nc = NSZ + NU; l.pxy_lin = NSZ * (NSZ + NU + 1) + 2 * NSZ;
         l.ocp_soft = [](const DevProblem *p, OcpSoftArgs a, hipStream_t s) { hipLaunchKernelGGL((ocp_kernel_soft<NX, NU, NY, ND, DU, NG>), dim3((a.o.B + 63) / 64), dim3(64), 0, s, p, a); };
         l.soft_fields = SoftLayout<NSZ, NU, NY>::FIELDS;
+        l.loop_soft = [](const DevProblem *p, LoopArgs a, hipStream_t s) { hipLaunchKernelGGL((loop_kernel_soft<NX, NU, NY, ND, NXP, DU, NG>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     }
     l.target = [](const DevProblem *p, TargetArgs a, hipStream_t s) { hipLaunchKernelGGL((target_kernel<NX, NU, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
     l.kf = [](const DevProblem *p, KfArgs a, hipStream_t s) { hipLaunchKernelGGL((kf_kernel<NX, NY, ND>), dim3((a.B + 63) / 64), dim3(64), 0, s, p, a); };
@@ -1473,7 +1590,7 @@ struct mpc_handle {
     DevBuf pc_prev, pc_valid, pc_guess, pc_traj;
     // time-varying model parameters: horizon values of one mpc_ocp_solve call, its slab and workspace; this step's p_x_k / p_y_k for
     // mpc_target_solve / mpc_kf_update (mpc_set_model_offsets)
-    DevBuf soft_ws, soft_sl; int soft_B = 0;      // soft output constraints: the arrowhead solver's workspace, the last call's optimal slacks
+    DevBuf soft_ws, soft_sl, soft_keep; int soft_B = 0;      // soft output constraints: the arrowhead solver's workspace, the last call's optimal slacks
     DevBuf pxy_in, pxy_lin, pxy_ws, off_px, off_py; int off_B = 0; bool off_has_px = false, off_has_py = false;
     DevBuf msch; int msch_steps = 0; bool msch_px = false, msch_py = false;      // def_px / def_py over the horizon for every step of the fused loop
     DevBuf st_x, st_xhat, st_dhat, st_P, st_u, st_xs, st_us, st_flag, st_Kg, st_Pn, st_tw, sch, logs, logi;
@@ -1774,7 +1891,7 @@ extern "C" void mpc_destroy(mpc_handle *h)
     (void)mpc_comm_destroy(h);
     h->coll_send.release(); h->coll_recv.release();
     h->pc_prev.release(); h->pc_valid.release(); h->pc_guess.release(); h->pc_traj.release();
-    h->soft_ws.release(); h->soft_sl.release();
+    h->soft_ws.release(); h->soft_sl.release(); h->soft_keep.release();
     h->pxy_in.release(); h->pxy_lin.release(); h->pxy_ws.release(); h->off_px.release(); h->off_py.release(); h->msch.release();
     for (DevBuf *b : {&h->scratch, &h->ws, &h->st_x, &h->st_xhat, &h->st_dhat, &h->st_P, &h->st_u, &h->st_xs, &h->st_us, &h->st_flag, &h->st_Kg, &h->st_Pn, &h->st_tw, &h->sch, &h->logs, &h->logi}) b->release();
     if (h->dp) (void)hipFree(h->dp);
@@ -2177,7 +2294,6 @@ static const char *kLogI[] = {"STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"
 
 extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32_t log_level)
 {
-    if (h && h->hp.soft) return fail(-8, "soft output constraints (slacks) are solved call by call (mpc_kf_update, mpc_target_solve, mpc_ocp_solve): the fused closed loops do not carry the shared slack vector");
     if (!h || B < 1 || max_steps < 1) return fail(-1, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const DevProblem &P = h->hp;
@@ -2205,6 +2321,12 @@ extern "C" int mpc_loop_alloc(mpc_handle *h, int32_t B, int32_t max_steps, int32
     for (int i = 0; i < 7; i++) {
         const bool on = log_level >= MPC_LOG_ALL || (log_level >= MPC_LOG_U && i == 0);
         if (on && dims[i] > 0) { h->log_off[kLogD[i]] = {off, dims[i]}; off += (size_t)max_steps * dims[i] * Bs; }
+    }
+    if (P.soft) {      // soft output constraints: the optimal slack vector of every step (log "SL", with the inputs), and the arrowhead solver's workspace
+        if (log_level >= MPC_LOG_U) { h->log_off["SL"] = {off, 2 * P.ny}; off += (size_t)max_steps * 2 * P.ny * Bs; }
+        if (h->soft_ws.ensure((size_t)(Bs / 64) * h->L.soft_fields * P.N * 64 * sizeof(double)) || h->soft_keep.ensure((size_t)2 * P.ny * Bs * sizeof(double))) return -10;
+        HIP_TRY(hipMemsetAsync(h->soft_keep.p, 0, h->soft_keep.bytes, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
     }
     if (h->logs.ensure(off ? off * 8 : 8)) return -10;
     if (log_level >= MPC_LOG_U) {
@@ -2252,8 +2374,9 @@ extern "C" int mpc_loop_set_state(mpc_handle *h, const double *x_p, const double
     rc |= up_state(h, h->st_x, x_p, P.nxp); rc |= up_state(h, h->st_xhat, xhat, P.nx); rc |= up_state(h, h->st_dhat, dhat, P.nd);
     rc |= up_state(h, h->st_P, Pk, ne * ne); rc |= up_state(h, h->st_u, u, P.nu); rc |= up_state(h, h->st_xs, xs, P.nx);
     rc |= up_state(h, h->st_us, us, P.nu);
-    // a new state invalidates the warm start: the next OCP of every instance starts cold
+    // a new state invalidates the warm start: the next OCP of every instance starts cold (and no slack vector has been accepted yet)
     HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * h->Bs * 4, h->stream));
+    if (P.soft && h->soft_keep.p) HIP_TRY(hipMemsetAsync(h->soft_keep.p, 0, h->soft_keep.bytes, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (rc) return -10;
     h->state_set = true;
@@ -2344,7 +2467,8 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         const size_t N = P.N;
         if (h->pxy_lin.ensure(N * h->L.pxy_lin * Bs * sizeof(double)) || h->pxy_ws.ensure((size_t)h->L.pxy_ws_rows * (N + 2) * Bs * sizeof(double))) return -10;
     }
-    const int mode = pxy ? 5 : loop_mode(h);
+    if (pxy && P.soft) return fail(-8, "soft constraints with horizon parameters (def_px / def_py) are not carried");
+    const int mode = pxy ? 5 : (P.soft ? 6 : loop_mode(h));
     if (mode != h->ws_mode) {      // the workspace holds another layout (or a per-call solve used it): next OCPs start cold
         HIP_TRY(hipMemsetAsync(h->st_flag.p, 0, 3 * Bs * 4, h->stream));
         h->ws_mode = mode;
@@ -2372,8 +2496,9 @@ extern "C" int mpc_loop_run(mpc_handle *h, int32_t k0, int32_t nsteps)
         a.tw = (double *)h->st_tw.p; a.tw_valid = a.ws_valid + 2 * Bs;
         a.ws = (double *)h->ws.p; a.B = h->B; a.nsteps = n; a.Bs = Bs; a.N = P.N;
         a.h = h->h_sample; a.t0 = k * h->h_sample; a.wv_ni = h->wv_ni_opt;
-        a.px_h = a.py_h = nullptr; a.lin = nullptr;
-        if (pxy) {
+        a.px_h = a.py_h = nullptr; a.lin = nullptr; a.SL = dl("SL"); a.soft_ws = (double *)h->soft_ws.p; a.sl_keep = (double *)h->soft_keep.p;
+        if (P.soft) h->L.loop_soft(h->dp, a, h->stream);
+        else if (pxy) {
             const size_t npx = (size_t)h->msch_steps * P.N * P.nx;
             a.px_h = h->msch_px ? (const double *)h->msch.p + (size_t)k * P.N * P.nx : nullptr;
             a.py_h = h->msch_py ? (const double *)h->msch.p + npx + (size_t)k * P.N * P.ny : nullptr;

@@ -44,8 +44,6 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
     s = capi.Solver(p, device=device) if own else solver
     try:
         sched = p.schedules(nsteps)
-        if getattr(p, "slacks", False):
-            fused = False      # soft constraints: the shared slack vector is carried by mpc_ocp_solve (csrc/mpc_soft.hpp), the loop runs call by call
         if fused and not p.plant_is_linear and not getattr(s, "fused_plant", False):
             raise ValueError("this solver's library has no compiled plant function (User_fxp_Cont): the plant is simulated on the host, "
                              "call run_closed_loop(..., fused=False)")
@@ -65,6 +63,8 @@ def run_closed_loop(problem, x0_p=None, x0_m=None, nsteps: Optional[int] = None,
             s.loop_sync()
             out = {k: s.loop_get_log(k) for k in ("U", "X_HAT", "XS", "US", "YS", "Xp", "D_HAT", "STATUS_DYN",
                                                   "STATUS_SS", "ITERS_DYN", "ITERS_SS") if not (k == "D_HAT" and p.nd == 0)}
+            if getattr(p, "slacks", False):
+                out["Sl"] = s.loop_get_log("SL")                     # :800,808-809 (csrc/mpc_amd.hip:loop_kernel_soft)
             out["Yp"] = out["Xp"] @ p.Cp.T + sched["pyp"][:nsteps, None, :] + py0[:, None, :]                 # :531-534 (p_ymp = p_y_k, :505-507)
             d_prior = np.zeros((nsteps, B, p.nd))
             if p.nd:                                                 # dhat is carried unchanged between steps (:655-668)

@@ -125,8 +125,6 @@ def test_gpu_soft_ocp_matches_the_dense_statement(pkg, soft):
             o = _exact(soft, xhat[b], xs[b], us[b], dhat[b], up[b])
             tol = 1e-7 if o["exact"] else 2e-6      # (without a verified polish the oracle's own interior point answer is sqrt(mu) off on degenerate rows)
             assert np.abs(r["u0"][b] - o["u0"]).max() < tol and np.abs(r["x1"][b] - o["x1"]).max() < tol and np.abs(r["sl"][b] - o["sl"]).max() < 100 * tol, b
-        with pytest.raises(capi.MpcAmdError):
-            s.loop_alloc(B, 4, capi.LOG_ALL)      # the fused loops do not carry the slack vector: loud, not silent
     finally:
         s.close()
 
@@ -143,6 +141,26 @@ def test_gpu_soft_closed_loop_makes_the_shipped_start_feasible(pkg, soft, cstr):
     assert r["Sl"].shape == (ns, 1, 6) and r["Sl"][0].max() > 0.1 and r["Sl"].min() >= 0.0
     for k in ("U", "X_HAT", "XS", "US"):
         assert np.abs(r[k][:, 0] - np.array(o[k])).max() < 1e-5, k      # (the oracle's loop runs its interior point method at 1e-9 without the polish)
+
+
+@pytest.mark.gpu
+def test_gpu_soft_fused_loop_equals_the_three_calls_per_step(pkg, soft):
+    """the resident loop of a soft problem (csrc/mpc_amd.hip:loop_kernel_soft) against the reference's call sequence through the C-ABI (driver._stepwise): the same
+    numbers to the bit - inputs, estimates, targets, status words, iteration counts and the logged slack vector - over a batch of starts, several launches"""
+    from mpc_code_amd import capi, driver
+    rng = np.random.default_rng(5)
+    B, ns = 70, 7
+    x0 = np.vstack([soft.x0_p[None], soft.x0_p[None] + rng.uniform(-1.0, 1.0, size=(B - 1, soft.nxp))])
+    s = capi.Solver(soft)
+    try:
+        s.set_option("steps_per_launch", 3)
+        f = driver.run_closed_loop(soft, x0_p=x0, x0_m=x0[:, :soft.nx], nsteps=ns, solver=s, fused=True)
+        c = driver.run_closed_loop(soft, x0_p=x0, x0_m=x0[:, :soft.nx], nsteps=ns, solver=s, fused=False)
+    finally:
+        s.close()
+    assert f["Sl"].shape == (ns, B, 6) and f["Sl"].max() > 0.1
+    for k in ("U", "X_HAT", "XS", "US", "Xp", "D_HAT", "Sl", "STATUS_DYN", "STATUS_SS", "ITERS_DYN", "ITERS_SS"):
+        assert np.array_equal(f[k], c[k]), k
 
 
 @pytest.mark.gpu
