@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const DevProblem *__restrict__
 }
 
 // The closed loop of a problem with SOFT output constraints (slacks = True; mpc_soft.hpp): loop_kernel's step - instance per lane, the same estimator, target and
-// plant code - with the arrowhead solver as its OCP, cold every step like ocp_kernel_soft: a fused run equals the three C-ABI calls per step bit for bit.  The optimal
+// plant code - with the arrowhead solver as its OCP, cold every step like ocp_kernel_soft: a fused run is the loop of the three C-ABI calls per step.  The optimal
 // slacks of every step go to the log SL (MPC_code.py:800).  One instantiation per dimension set.
 template <int NX, int NU, int NY, int ND, int NXP, bool DU, int NG>
 __global__ __launch_bounds__(64) void loop_kernel_soft(const DevProblem *__restrict__ Pp, LoopArgs a)
