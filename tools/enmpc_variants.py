@@ -13,7 +13,11 @@ from mpc_code_amd import enmpc, econcodegen
 VARIANTS = [("base", []),
             ("broadcasts left in scalar registers", ["-DEC_BCAST_IN_SGPRS"]),
             ("OCP kernel compiled for one wave per SIMD (512 registers)", ["-DEC_OCP_WAVES=1"]),
-            ("both", ["-DEC_BCAST_IN_SGPRS", "-DEC_OCP_WAVES=1"])]
+            ("both", ["-DEC_BCAST_IN_SGPRS", "-DEC_OCP_WAVES=1"]),
+            # the OCP kernel's scratch frame (204 B per lane) holds loop invariants the compiler hoisted out of the iteration loop - the polynomial coefficients of exp / log among
+            # them - and then had no registers for: without machine LICM the frame is empty (tools/kernel_resources.py)
+            ("machine LICM off", ["-mllvm", "-disable-machine-licm"]),
+            ("loop invariants sunk back where they would spill", ["-mllvm", "-sink-insts-to-avoid-spills"])]
 WORK = [("enmpc N=40, 16384 instances", {"N": 40}, 16384), ("mhe N_mhe=20, 4096 instances", {"N_mhe": 20}, 4096)]
 
 if __name__ == "__main__":
