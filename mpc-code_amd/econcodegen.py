@@ -28,10 +28,15 @@ from . import symtrace as st
 
 CSRC = os.path.join(PKG_DIR, "csrc")
 # -amdgpu-spill-vgpr-to-agpr=0: a code-generator fault of this toolchain (AMD clang 22.0.0git, roc-7.2.0), found in round 5 in enmpc_mhe_kernel<64>: with that option on (the
-# default) a 128-bit register tuple was spilled as three dwords to scratch and the fourth into a spare accumulation register ("Reload Reuse" in the -S dump), and RELOADED as
-# the three dwords alone - the upper half of the tuple's second double came back as whatever its register held (the estimator's second disturbance estimate, 36 of 36
-# randomised models).  Without the option the same spill is four dwords to scratch and back; register and scratch sizes of every kernel are unchanged.
-ENMPC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+# default) a 128-bit register tuple was spilled as three dwords to scratch and the fourth into a spare accumulation register ("Reload Reuse" in the -S dump), and RELOADED into
+# an accumulation-register tuple as the three dwords alone - the upper half of the tuple's second double came back as whatever its register held (the estimator's second
+# disturbance estimate, 36 of 36 randomised models).  Without the option the same spill is four dwords to scratch and back; register and scratch sizes of
+# every kernel are unchanged.  (Not the fault of round 3's broadcasts-in-scalar-registers builds: those were wrong with this option off too, profiles/r03_enmpc_bcast_matrix.txt.)
+# -disable-machine-licm: the compiler hoists loop invariants out of the interior point iteration - the polynomial coefficients of exp and log as vector-register copies among them -
+# and, having no registers for them across the integration and the sweeps, spills them (204 B of scratch per lane in enmpc_ocp_kernel<64>, reloaded one dependent scratch load
+# after the other in every iteration).  Without machine LICM they are rebuilt where they are used: enmpc_ocp_kernel<64> has no scratch frame, the estimator kernels 520 B for 690 B,
+# and the two economic workloads run 4.6 % / 3.5 % faster with the same bits in every result (profiles/r05_enmpc_variants.json).
+ENMPC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ldl", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-mllvm", "-disable-machine-licm"]
 
 
 def _pp(j: int, k: int, NP: int) -> int:

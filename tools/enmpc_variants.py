@@ -16,7 +16,7 @@ VARIANTS = [("base", []),
             ("both", ["-DEC_BCAST_IN_SGPRS", "-DEC_OCP_WAVES=1"]),
             # the OCP kernel's scratch frame (204 B per lane) holds loop invariants the compiler hoisted out of the iteration loop - the polynomial coefficients of exp / log among
             # them - and then had no registers for: without machine LICM the frame is empty (tools/kernel_resources.py)
-            ("machine LICM off", ["-mllvm", "-disable-machine-licm"]),
+            ("machine LICM off", ["-mllvm", "-disable-machine-licm"]),      # (the product's build since this measurement: econcodegen.ENMPC_FLAGS)
             ("loop invariants sunk back where they would spill", ["-mllvm", "-sink-insts-to-avoid-spills"])]
 WORK = [("enmpc N=40, 16384 instances", {"N": 40}, 16384), ("mhe N_mhe=20, 4096 instances", {"N_mhe": 20}, 4096)]
 
