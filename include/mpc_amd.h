@@ -82,6 +82,12 @@ typedef struct mpc_lin_desc {
      * (mpc_loop_run) do not carry it: step by step through the three solver calls. */
     int32_t slacks;
     const double *Ws;
+    /* Affine user inequality rows of the OCP (User_g_ineq, Control_Calc.py:94-100,132-147; MPC_code.py:306-314): for k = 0..N-1
+     *     Gx x_k + Gu u_k + Gd dhat + g0 <= 0        (Gx [n][nx], Gu [n][nu], Gd [n][nd], g0 [n], row-major; y_k = C x_k + Cd dhat + fy_const substituted by the caller)
+     * Each row is carried as one more stage state w_{k+1} = Gx x_k + Gu u_k + const with the box (-inf, 0] at k = 1..N (the reference's solver gives such a row a slack
+     * variable of its own).  n_user_rows = 0: none.  Not together with slacks, term_cons or px / py. */
+    int32_t n_user_rows;
+    const double *Gx, *Gu, *Gd, *g0;
 } mpc_lin_desc;
 
 /* Replaces the construction nlpsol('solver','ipopt',...) of Control_Calc.py:256-258 and

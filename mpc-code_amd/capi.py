@@ -42,7 +42,8 @@ class _Desc(ct.Structure):
                                    "Q", "R", "P", "Qss", "Rss", "umin", "umax", "xmin", "xmax", "ymin", "ymax",
                                    "umin_ss", "umax_ss", "xmin_ss", "xmax_ss", "ymin_ss", "ymax_ss",
                                    "dmin", "dmax", "Q_kf", "R_kf", "K", "Dumin", "Dumax")] + [("term_cons", ct.c_int32), ("nl_plant", ct.c_int32), ("h_sample", ct.c_double),
-                                                                                             ("slacks", ct.c_int32), ("Ws", _dp)]
+                                                                                             ("slacks", ct.c_int32), ("Ws", _dp),
+                                                                                             ("n_user_rows", ct.c_int32), ("Gx", _dp), ("Gu", _dp), ("Gd", _dp), ("g0", _dp)]
 
 
 def jit_library_path(dims) -> str:
@@ -207,6 +208,11 @@ class Solver:
         d.slacks = int(bool(getattr(p, "slacks", False)))
         if d.slacks:
             self._keep["Ws"] = _c(p.Ws); d.Ws = _p(self._keep["Ws"])
+        d.n_user_rows = int(getattr(p, "n_user_rows", 0))
+        if d.n_user_rows:      # affine User_g_ineq rows (problem.py:_affine_user_rows)
+            for k in ("Gx", "Gu", "Gd", "g0"):
+                a = _c(getattr(p, k)); a = a if a.size else np.zeros(1)
+                self._keep[k] = a; setattr(d, k, _p(a))
         self.fused_plant = False
         if lib_path is None and not p.plant_is_linear and jit and not os.environ.get("MPC_AMD_NO_JIT"):
             # the Ex-file's plant function, traced and compiled into a library of this problem's own (cached under csrc/jit/)
@@ -217,6 +223,7 @@ class Solver:
                 hdr = None
             if hdr is not None:
                 ng = 0 if getattr(p, "slacks", False) else sum(1 for i in range(p.ny) if p.y_bounded and (np.isfinite(p.ymin[i]) or np.isfinite(p.ymax[i])) and np.count_nonzero(p.C[i]) != 1)
+                ng += int(getattr(p, "n_user_rows", 0))
                 dims = (p.nx, p.nu, p.ny, p.nd, p.nxp, int(p.DUForm or p.Dumin is not None or p.Dumax is not None), ng)
                 self.lib = load_library(build_library(dims=dims, plant_header=hdr))
                 d.nl_plant = 1

@@ -1619,16 +1619,19 @@ static void from_soa(const double *src, int B, int d, size_t Bs, double *dst)
     }
 }
 
-// bounded output rows that are not a multiple of one state; rows[] (optional) receives their indices
+// rows carried as stage states of their own: bounded output rows that are not a multiple of one state (rows[] (optional) receives their indices), then the user
+// inequality rows (rows[] = -1)
 static int general_output_rows(const mpc_lin_desc *d, int *rows)
 {
     int ng = 0;
-    if (!d->y_bounded || d->slacks) return 0;      // (soft output rows are rows of their own solver, not stage states)
-    for (int i = 0; i < d->ny; i++) {
-        int cnt = 0;
-        for (int j = 0; j < d->nx; j++) if (d->C[i * d->nx + j] != 0.0) cnt++;
-        if (cnt != 1 && (std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]))) { if (rows && ng < kMaxY) rows[ng] = i; ng++; }
+    if (d->y_bounded && !d->slacks) {      // (soft output rows are rows of their own solver, not stage states)
+        for (int i = 0; i < d->ny; i++) {
+            int cnt = 0;
+            for (int j = 0; j < d->nx; j++) if (d->C[i * d->nx + j] != 0.0) cnt++;
+            if (cnt != 1 && (std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]))) { if (rows && ng < kMaxY) rows[ng] = i; ng++; }
+        }
     }
+    for (int i = 0; i < d->n_user_rows; i++) { if (rows && ng < kMaxY) rows[ng] = -1; ng++; }
     return ng;
 }
 
@@ -1771,13 +1774,28 @@ static int build_problem(const mpc_lin_desc *d, DevProblem &P)
     // Any other row i gets a stage state of its own, w = C_i x, carried by w+ = C_i (A x + B u + c): the row becomes a box on w
     // at k = 1..N-1 (the terminal state has no output row); no cost on w.
     P.ng = general_output_rows(d, P.yg_row);
+    if (d->n_user_rows) {
+        // User inequality rows (Control_Calc.py:94-100,132-147): Gx x_k + Gu u_k + Gd dhat + g0 <= 0 at k = 0..N-1, each a stage state w+ = Gx x + Gu u + const with the box
+        // (-inf, 0] at k = 1..N (terminal state included: the row of stage N-1).  With the input-move form (stage state [x; u_prev], input v = u - u_prev) u = u_prev + v.
+        if (!d->Gx || !d->Gu || !d->g0 || (nd > 0 && !d->Gd)) return fail(-1, "n_user_rows = %d needs Gx, Gu, Gd, g0", d->n_user_rows);
+        if (d->slacks || d->term_cons) return fail(-8, "user inequality rows together with slacks or a terminal equality are not carried");
+        const int nb = n0 + (stage_has_uprev(d) ? m : 0);
+        for (int g = P.ng - d->n_user_rows, i = 0; g < P.ng; g++, i++) {
+            const int r = nb + g;
+            for (int j = 0; j < n0; j++) P.A[r][j] = d->Gx[i * n0 + j];
+            for (int j = 0; j < m; j++) { P.B[r][j] = d->Gu[i * m + j]; if (du_bounded(d)) P.A[r][n0 + j] = d->Gu[i * m + j]; }
+            for (int j = 0; j < nd; j++) P.Bd[r][j] = d->Gd[i * nd + j];
+            P.fxc[r] = d->g0[i];
+            P.zlo_m[r] = P.zlo_e[r] = -INFINITY; P.zhi_m[r] = P.zhi_e[r] = 0.0;
+        }
+    }
     if (d->y_bounded && !d->slacks) {
         const int nb = n0 + (stage_has_uprev(d) ? m : 0);
         for (int i = 0; i < q; i++) {
             P.ymap_idx[i] = -1;       // unbounded rows and rows that are identically zero: nothing to map
             for (int j = 0; j < n0; j++) if (d->C[i * n0 + j] != 0.0) { P.ymap_idx[i] = j; P.ymap_scale[i] = d->C[i * n0 + j]; }
         }
-        for (int g = 0; g < P.ng; g++) {
+        for (int g = 0; g < P.ng - d->n_user_rows; g++) {
             const int i = P.yg_row[g], r = nb + g;
             P.ymap_idx[i] = r; P.ymap_scale[i] = 1.0;
             for (int j = 0; j < n0; j++) { double acc = 0.0; for (int l = 0; l < n0; l++) acc += d->C[i * n0 + l] * d->A[l * n0 + j]; P.A[r][j] = acc; }
@@ -1823,7 +1841,7 @@ static int bound_mode(const mpc_lin_desc *d)
     }
     bool y_any = false;
     if (d->y_bounded && !d->slacks) for (int i = 0; i < d->ny; i++) y_any = y_any || std::isfinite(d->ymin[i]) || std::isfinite(d->ymax[i]);
-    if (du_bounded(d)) return kBoundsGeneric;
+    if (du_bounded(d) || d->n_user_rows) return kBoundsGeneric;      // (a user row's stage state is bounded from above only)
     if (u_all && x_all && !d->du_form) return kBoundsAllFinite;        // Delta-u form carries unbounded u_prev states
     if (u_all && x_none && !y_any) return kBoundsInputsOnly;
     return kBoundsGeneric;

@@ -196,7 +196,11 @@ __device__ __forceinline__ void build_inst(const PT &P, const double (&xhat)[NX]
     MPC_UNROLL for (int g = 0; g < NG; g++) {      // output-row states w = C_i x: initial value, reference, affine term
         const int r = P.yg_row[g];
         double w0 = 0.0, wr = 0.0, wc = 0.0;
-        MPC_UNROLL for (int j = 0; j < NX; j++) { const double cij = P.Cm[r][j]; w0 += cij * xhat[j]; wr += cij * xs[j]; wc += cij * q.c[j]; }
+        if (r >= 0) { MPC_UNROLL for (int j = 0; j < NX; j++) { const double cij = P.Cm[r < 0 ? 0 : r][j]; w0 += cij * xhat[j]; wr += cij * xs[j]; wc += cij * q.c[j]; } }
+        else {      // a user inequality row (yg_row = -1): w+ = Gx x + Gu u + (g0 + Gd dhat), its coefficients in row NB + g of A / B, its constant in that row of fxc / Bd; no cost on w
+            wc = P.fxc[NB + g];
+            MPC_UNROLL for (int j = 0; j < ND; j++) wc += P.Bd[NB + g][j] * dhat[j];
+        }
         q.z0[NB + g] = w0; q.zr[NB + g] = wr; q.c[NB + g] = wc;
     }
     MPC_UNROLL for (int i = 0; i < NS; i++) { q.zlo_m[i] = P.zlo_m[i]; q.zhi_m[i] = P.zhi_m[i]; }

@@ -127,6 +127,16 @@ class LinearMPCProblem:
     # soft output constraints (Control_Calc.py:39-40,186-192,228-239): one slack vector [sl_ub; sl_lb] >= 0 shared by all stages, Sl' Ws Sl in every stage's cost
     slacks: bool = False
     Ws: Optional[np.ndarray] = None
+    # affine user inequality rows of the OCP (User_g_ineq, Control_Calc.py:94-100,132-147): Gx x_k + Gu u_k + Gd dhat + g0 <= 0 for k = 0..N-1, with
+    # y_k = C x_k + Cd dhat + fy_const already substituted ([ng, nx], [ng, nu], [ng, nd], [ng]); None: no rows
+    Gx: Optional[np.ndarray] = None
+    Gu: Optional[np.ndarray] = None
+    Gd: Optional[np.ndarray] = None
+    g0: Optional[np.ndarray] = None
+
+    @property
+    def n_user_rows(self) -> int:
+        return 0 if self.Gx is None else int(self.Gx.shape[0])
 
     # ------------------------------------------------------------------ schedules
     def schedules(self, nsteps: int, k0: int = 0) -> Dict[str, np.ndarray]:
@@ -216,7 +226,7 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
     """Classify an Ex-file namespace and emit the numeric descriptor (or raise)."""
     for bad in ("User_fxm_Cont", "User_fxm_Dis", "User_fym", "User_fxp_Dis", "User_fyp",
                 "User_fobj_Cont", "User_fobj_Dis", "User_fobj_Coll", "User_fssobj", "User_vfin",
-                "User_g_ineq", "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y",
+                "User_h_eq", "User_g_ineq_SS", "User_h_eq_SS", "r_x", "rss_y",
                 "def_pxmp", "def_pymp", "R_wn", "G_wn"):
         if _has(ns, bad) and ns[bad] is not None:
             raise UnsupportedProblem(f"'{bad}' is outside the batched linear hot path (later scope row)")
@@ -336,6 +346,11 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         else:
             K = _mat(ns["K"], nxd, ny, "K")
 
+    Gx = Gu = Gd = g0 = None
+    if _has(ns, "User_g_ineq") and ns["User_g_ineq"] is not None:
+        Gx, Gu, Gd, g0 = _affine_user_rows(ns["User_g_ineq"], nx, nu, ny, nd, C, Cd, fy_const)
+        if slacks or ns.get("TermCons", False) or (_has(ns, "def_px") and ns["def_px"] is not None) or (_has(ns, "def_py") and ns["def_py"] is not None):
+            raise UnsupportedProblem("User_g_ineq together with slacks, a terminal equality or horizon parameters is not carried")
     prob = LinearMPCProblem(
         nx=nx, nu=nu, ny=ny, nd=nd, nxp=nxp, N=N, h=h, Nsim=Nsim,
         A=A, B=B, C=C, Bd=Bd, Cd=Cd, fx_const=fx_const, fy_const=fy_const,
@@ -357,6 +372,37 @@ def problem_from_namespace(ns: Dict[str, Any], name: str = "") -> LinearMPCProbl
         name=name or str(ns.get("__name__", "")),
         plant_fx_cont=ns["User_fxp_Cont"] if nl_plant else None, plant_Mx=int(ns.get("Mx", 10)),
         TermCons=bool(ns.get("TermCons", False)), def_px=ns.get("def_px"), def_py=ns.get("def_py"),
-        slacks=slacks, Ws=Ws,
+        slacks=slacks, Ws=Ws, Gx=Gx, Gu=Gu, Gd=Gd, g0=g0,
     )
     return prob
+
+
+def _affine_user_rows(fn, nx, nu, ny, nd, C, Cd, fy_const):
+    """User_g_ineq(x, u, y, d, t, px, py) <= 0 (Control_Calc.py:94-100; a row per stage k = 0..N-1 on (X[k], U[k], Y_k), :132-147) for the LINEAR hot path: the rows have
+    to be affine in (x, u, y, d) and independent of t, px, py (LinPar).  Traced once with symbols, then read off numerically - value at the origin, one unit vector per
+    argument - and checked at random points; y_k = C x_k + Cd d + fy_const is substituted.  Returns (Gx, Gu, Gd, g0)."""
+    from . import symtrace as st
+    vx, vu, vy, vd, vt = st.symvec("x", nx), st.symvec("u", nu), st.symvec("y", ny), st.symvec("d", nd), st.Sym.var("t")
+    col, zero = st.SymMat.col, (lambda n: st.SymMat.zeros(n))
+    try:
+        rows = st.flatten(fn(col(vx), col(vu), col(vy), col(vd), vt, zero(nx), zero(ny)))
+    except Exception as e:      # noqa: BLE001
+        raise UnsupportedProblem(f"User_g_ineq cannot be traced: {e}") from e
+    ng = len(rows)
+    if ng < 1 or ng > 4:
+        raise UnsupportedProblem("User_g_ineq: between one and four rows are carried")
+    nz = nx + nu + ny + nd
+    names = [f"x[{i}]" for i in range(nx)] + [f"u[{i}]" for i in range(nu)] + [f"y[{i}]" for i in range(ny)] + [f"d[{i}]" for i in range(nd)]
+
+    def ev(z, t=0.0):
+        vals = {n: float(v) for n, v in zip(names, z)}; vals["t"] = float(t)
+        return np.array([float(v) for v in st.evaluate(rows, vals)])
+    c0 = ev(np.zeros(nz))
+    J = np.stack([ev(np.eye(nz)[j]) - c0 for j in range(nz)], axis=1)
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        z = rng.normal(size=nz) * 3.0
+        if np.abs(ev(z, t=rng.normal()) - (c0 + J @ z)).max() > 1e-9 * (1.0 + np.abs(J).max() * 10.0):
+            raise UnsupportedProblem("User_g_ineq: only rows that are affine in (x, u, y, d) and independent of t are carried on the linear path")
+    Jx, Ju, Jy, Jd = J[:, :nx], J[:, nx:nx + nu], J[:, nx + nu:nx + nu + ny], J[:, nx + nu + ny:]
+    return Jx + Jy @ C, Ju, (Jd + Jy @ Cd if nd else np.zeros((ng, 0))), c0 + Jy @ fy_const

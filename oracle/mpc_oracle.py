@@ -183,6 +183,12 @@ def ocp_qp(p, xhat, xs, us, dhat, u_prev, drop_stage0_rows=False, px=None, py=No
                     if k > 0:
                         row[nxu * (k - 1) + n + i] = -1.0
                     rows.append(row); lo.append(dlo[i] + off); hi.append(dhi[i] + off)
+    if getattr(p, "Gx", None) is not None:      # g4 rows: G_ineq(X[k], U[k], Y_k, d, ...) <= 0, k = 0..N-1 (Control_Calc.py:132-147,245); affine on this path, Y_k substituted by the loader
+        gc = p.g0 + (p.Gd @ dhat if p.nd else 0.0)
+        for k in range(N):
+            for i in range(p.Gx.shape[0]):
+                row = np.zeros(nw); row[ix(k)] = p.Gx[i]; row[iu(k)] = p.Gu[i]
+                rows.append(row); lo.append(-np.inf); hi.append(-gc[i])
     for j in range(ns):                        # w_lb[nw-ns:nw] = 0 (Control_Calc.py:217)
         row = np.zeros(nw); row[nw - ns + j] = 1.0
         rows.append(row); lo.append(0.0); hi.append(np.inf)

@@ -67,7 +67,7 @@ if __name__ == "__main__":
             res.append(dict(library="non-linear", variant=name, flags=fl, error=str(e)[:300])); print(res[-1], flush=True); continue
         B = 16384
         rng = np.random.default_rng(20250614)
-        xp = np.tile(pn.x0_p, (B, 1)) * (1.0 + 0.05 * rng.uniform(-1, 1, size=(B, pn.nxp)))
+        xp = np.tile(pn.x0_p, (B, 1)) * (1.0 + 0.01 * rng.uniform(-1, 1, size=(B, pn.nxp)))
         best = None
         for _ in range(6):
             r = nmpc.run_nmpc_closed_loop(pn, xp, xp[:, :pn.nx], 20, solver=s)
