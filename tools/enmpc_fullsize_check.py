@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): every instance-step of a BASELINE-size batch on the HIP path against oracle/enmpc_oracle.c on the host cores.
-   tools/enmpc_fullsize_check.py [B] [steps] [N] [N_mhe]"""
+   tools/enmpc_fullsize_check.py [B] [steps] [N] [N_mhe] [threads of the C oracle, comma separated; default 64]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ ex = m.example_path("reactor_enmpc.py")
 x0 = np.random.default_rng(20250614).uniform([0.5, 0.0], [1.0, 0.5], size=(B, 2))
 g = enmpc.run_enmpc_closed_loop(m.load_problem(ex, overrides=over), x0, K)
 o = ec.OracleEC(eo.load_problem(ex, overrides=over), fast=True)
-for th in (0, 64):
+for th in [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else "64").split(",")]:
     t0 = time.time(); c = o.closed_loop(K, x0, nthreads=th); print(f"C oracle on {th or o.max_threads()} threads: {B * K / (time.time() - t0):.0f} steps/s")
 for k in ("U", "XS", "US", "X_ES", "Xp"):
     print(k, "max |gpu - c| =", float(np.abs(g[k] - c[k]).max()))
