@@ -138,6 +138,34 @@ def test_kernel_source_restoration_phase_of_the_ocp(emulated, pkg):
         s.close()
 
 
+def test_kernel_source_estimator_restoration_on_an_infeasible_window(emulated, pkg):
+    """An estimator NLP that cannot be met - state noise boxed to 1e-4 where the measurements need a hundred times that - takes the estimator's restoration phase
+    (enmpc_mhe_resto_kernel, the one-launch kernel's redo) to its end: the kernels report the failure (status 2: the loop keeps the predicted state) on every instance and step,
+    in both launch styles with the same numbers, as the C restatement does (status 1 or 2 - its restoration follows other iterates: the kernels eliminate the output noise through
+    its linear defining row, the restatements keep it as variables, so their infeasibility measures differ while that row is unmet); nothing non-finite leaves
+    either."""
+    import enmpc_oracle_c as ec
+    from mpc_code_amd import enmpc
+    over = {"wmin": [-1e-4] * 4, "wmax": [1e-4] * 4, "N_mhe": 8, "xmin": np.array([0.7, 0.1]), "xmax": np.array([1.0, 0.5]), "dmin": np.array([-0.01, -0.01]), "dmax": np.array([0.01, 0.01])}
+    x0 = np.array([[0.9, 0.2], [0.6, 0.4], [0.75, 0.05]])
+    p = pkg.load_problem(te.EX, overrides=over)
+    q = te.eo.load_problem(te.EX, overrides=over)
+    c = ec.OracleEC(q).closed_loop(3, x0, nthreads=3)
+    assert int(c["STATUS_MHE"].min()) >= 1 and np.isfinite(c["X_ES"]).all()
+    s = enmpc.EnmpcSolver(p)
+    try:
+        ref = None
+        for kernel in (2, 1):
+            r = enmpc.run_enmpc_closed_loop(p, x0, 3, solver=s, kernel=kernel)
+            assert int(r["STATUS_MHE"].min()) == 2 and int(r["ITERS_MHE"].max()) < 100 and np.isfinite(r["X_ES"]).all() and np.isfinite(r["U"]).all(), kernel
+            if ref is not None:
+                for k in ("U", "X_ES", "ITERS_MHE", "ITERS_DYN", "STATUS_DYN"):
+                    assert np.array_equal(r[k], ref[k]), k
+            ref = r
+    finally:
+        s.close()
+
+
 def test_kernel_source_user_inequality_rows(emulated, pkg):
     te.test_gpu_user_inequality_rows_follow_the_oracle(pkg, 3, 6)
 
