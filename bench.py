@@ -98,7 +98,7 @@ ISSUE_PEAK_WINST = 256 * 4 * 2.4e9 / 4.0      # wave-instructions per second the
                                                # takes four cycles on a 16-lane SIMD (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def issue_roofline(summary: str, launch_s: float, scale: float = 1.0):
+def issue_roofline(summary: str, launch_s: float, scale: float = 1.0, alg_flops_per_launch=None):
     """What 'bound: issue' is priced against: the vector instructions the priced kernel issues per launch (SQ_INSTS_VALU of the committed counter summary - the counters cannot be
     read from inside this process -, scaled to this run's launch size) over the LIVE launch time, against the rate at which the chip's SIMDs issue them."""
     try:
@@ -106,8 +106,11 @@ def issue_roofline(summary: str, launch_s: float, scale: float = 1.0):
         valu = float(d["SQ_INSTS_VALU"]["mean_per_launch"]) * scale
     except Exception:
         return None
-    return {"valu_insts_per_launch": valu, "achieved_winst_per_s": valu / launch_s, "peak_winst_per_s": ISSUE_PEAK_WINST, "frac": valu / launch_s / ISSUE_PEAK_WINST,
-            "wait_fraction": d.get("wait_fraction"), "source": os.path.relpath(summary, ROOT) + ": SQ_INSTS_VALU per launch of " + str(d.get("kernel"))}
+    out = {"valu_insts_per_launch": valu, "achieved_winst_per_s": valu / launch_s, "peak_winst_per_s": ISSUE_PEAK_WINST, "frac": valu / launch_s / ISSUE_PEAK_WINST,
+           "wait_fraction": d.get("wait_fraction"), "source": os.path.relpath(summary, ROOT) + ": SQ_INSTS_VALU per launch of " + str(d.get("kernel"))}
+    if alg_flops_per_launch:      # of the 64 lane-slots of every vector instruction issued, the share an algorithmic multiply-add occupies (2 flops each): what the mapping wastes in lanes
+        out["useful_lane_fraction"] = 0.5 * float(alg_flops_per_launch) / (valu * 64.0)
+    return out
 
 
 def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
@@ -360,7 +363,7 @@ def main_enmpc(args):
                           "timed_region_ms": {"median": dt * 1e3, "min": float(np.min(times)) * 1e3, "max": float(np.max(times)) * 1e3}},
                "roofline": {"bound": "issue", "priced_against": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": getattr(measured_traffic, "stale", None),
                             "kernel": kdesc, "launches": launches, "avg_launch_ms": per_launch_s * 1e3,
-                            "issue": issue_roofline(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PROFILE_ROUND, args.config)), per_launch_s, units / float(cfg["batch"])),
+                            "issue": issue_roofline(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PROFILE_ROUND, args.config)), per_launch_s, units / float(cfg["batch"]), alg_flops_per_launch=fl * units),
                             "launch_timing": ("HIP events around every launch of %d separate passes of the same %d steps on one stream (the timed regions run the batch in "
                                               "groups on streams of their own)" % (len(pms), K)) if kern == 2 else "HIP events around the timed regions' launches",
                             "alg_bytes_per_step": ab, "instance_steps_per_launch": units, "device_ms_per_run": float(np.mean(kms)),
@@ -631,7 +634,7 @@ def main():
                          "kernel": KERNEL_NAMES[loop_kernel], "launches": n_launch,
                          "avg_launch_ms": per_launch_s * 1e3, "alg_bytes_per_step": ab, "carried_bytes_per_step": carried_bytes_per_step(prob),
                          "issue_bound": True,
-                         "issue": issue_roofline(PMC_SUMMARY, per_launch_s, inst_steps_per_launch / 81920.0),
+                         "issue": issue_roofline(PMC_SUMMARY, per_launch_s, inst_steps_per_launch / 81920.0, alg_flops_per_launch=31.0e3 * float(it.mean()) * inst_steps_per_launch),
                          "fp64": (lambda fl: {"achieved_tflops": fl * inst_steps_per_launch / per_launch_s / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
                                               "frac": fl * inst_steps_per_launch / per_launch_s / 1e12 / FP64_PEAK_TFLOPS, "alg_flops_per_step": fl,
                                               "formula": "BASELINE.md section 3 / SURVEY.md 8d: 31 kflop per interior-point iteration x mean iterations per instance-step of this run"})(

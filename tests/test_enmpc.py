@@ -467,7 +467,7 @@ def test_gpu_filter_update_of_the_arrival_cost_follows_the_golden_loop(pkg, gold
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pre", ["ekf_", "sat_"])
-def test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restatement(pkg, pre):
+def test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restatement(pkg, pre, B=200):
     """The example with its estimator switch in the other position (Ex_ENMPC.py:109-123): the extended Kalman filter on [x; d] in the estimator's place
     (enmpc_ekf_kernel / phase_ekf; Estimator.py:313-386 through MPC_code.py:640-664), both launch styles against the golden loops, a larger batch against the C
     restatement, and the per-call seam (whose estimator call is then the filter) against the resident loop bit for bit."""
@@ -483,7 +483,7 @@ def test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restateme
             r = enmpc.run_enmpc_closed_loop(p, g[pre + "x0"], n, solver=s, kernel=kernel)
             _check(r, g, pre, n)
             assert int(r["STATUS_MHE"].max()) == 0 and int(r["ITERS_MHE"].max()) == 0
-        x0 = np.random.default_rng(3).uniform([0.5, 0.0], [1.0, 0.5], size=(200, 2))
+        x0 = np.random.default_rng(3).uniform([0.5, 0.0], [1.0, 0.5], size=(B, 2))      # (B: the kernel source on the CPU test suite's wave emulator takes a handful)
         c = ec.OracleEC(eo.load_problem(EX_EKF, overrides=over)).closed_loop(10, x0, nthreads=0)
         a = enmpc.run_enmpc_closed_loop(p, x0, 10, solver=s, kernel=2)
         for k in ("U", "XS", "US", "X_ES", "Xp"):
@@ -499,7 +499,7 @@ def test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restateme
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("more", [{}, {"mhe_up": "filter", "N_mhe": 18}])
-def test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, more):
+def test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, more, B=70):
     """wmin / wmax (Utilities.py:881-884,974-977): the library generated for such a problem (build info wb=1) carries the boxes of the noise in the estimator's
     solver - every launch style against the C restatement on 70 starts, the seam against the resident loop; a library generated without them refuses them."""
     import warnings
@@ -508,7 +508,7 @@ def test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, m
     from mpc_code_amd.capi import MpcAmdError
     over = dict(W_BOUNDS, **more)
     K = 24 if more else 12
-    x0 = np.random.default_rng(3).uniform([0.5, 0.0], [1.0, 0.5], size=(70, 2))
+    x0 = np.random.default_rng(3).uniform([0.5, 0.0], [1.0, 0.5], size=(B, 2))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         p = pkg.load_problem(EX, overrides=over)

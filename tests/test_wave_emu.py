@@ -73,11 +73,11 @@ def test_kernel_source_filter_update_of_the_arrival_cost(emulated, pkg, kernel):
 
 @pytest.mark.parametrize("pre", ["ekf_", "sat_"])
 def test_kernel_source_extended_kalman_filter(emulated, pkg, pre):
-    te.test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restatement(pkg, pre)
+    te.test_gpu_extended_kalman_filter_follows_the_golden_loops_and_the_c_restatement(pkg, pre, B=7)      # (the GPU takes 200 starts)
 
 
 def test_kernel_source_estimator_with_bounded_state_noise(emulated, pkg):
-    te.test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, {})
+    te.test_gpu_estimator_with_bounded_state_noise_follows_the_c_restatement(pkg, {}, B=7)      # (the GPU takes 70 starts)
 
 
 @pytest.mark.parametrize("over,what", [({"xmin": np.array([0.8, 0.8]), "N": 12}, "ocp"), ({"xmin_ss": np.array([0.8, 0.8]), "N": 12}, "target")])

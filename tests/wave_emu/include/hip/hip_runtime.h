@@ -26,7 +26,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
-extern "C" char __start_emu_lds[], __stop_emu_lds[];
+extern "C" char __start_emu_lds[] __attribute__((weak)), __stop_emu_lds[] __attribute__((weak));      // (absent from a translation unit without __shared__ arrays)
 inline int emu_poison() { static const int p = getenv("EMU_POISON") ? atoi(getenv("EMU_POISON")) : 0; return p; }      // 1: 0xFF bytes (NaN doubles, -1 integers); 2: finite random doubles
 inline void emu_fill(void *q, size_t n)
 {
@@ -104,7 +104,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()> &body)
     static const int wd = getenv("EMU_WATCHDOG") ? atoi(getenv("EMU_WATCHDOG")) : 0;
     if (wd > 0) { signal(SIGALRM, watchdog_fire); alarm(wd); }
     if (block.x > 64 || block.y != 1 || grid.y != 1) abort();
-    if (emu_poison()) emu_fill(__start_emu_lds, (size_t)(__stop_emu_lds - __start_emu_lds));
+    if (emu_poison() && __start_emu_lds) emu_fill(__start_emu_lds, (size_t)(__stop_emu_lds - __start_emu_lds));
     g_bdim.x = (int)block.x; g_gdim.x = (int)grid.x;
     for (unsigned b = 0; b < grid.x; b++) { g_bid.x = (int)b; run_block((int)block.x, body); }
     if (wd > 0) alarm(0);
