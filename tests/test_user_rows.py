@@ -55,14 +55,21 @@ def test_gpu_ocp_with_user_rows_matches_the_dense_statement(pkg, rows):
         n_active = 0
         for kern in (1, 3):      # the lane solver and the wave-autonomous one
             s.set_option("ocp_kernel", kern)
-            r = s.ocp_solve(xhat, xs, us, dhat, up)
+            r = s.ocp_solve(xhat, xs, us, dhat, up, want_w=True)
             for b in range(0, B, 5):
                 o = mo.ocp_solve_exact(rows, xhat[b], xs[b], us[b], dhat[b], up[b], tol=1e-9)
                 if o["status"] != 0:
                     assert r["status"][b] == 2, (kern, b); continue
                 assert r["status"][b] == 0, (kern, b)
-                assert np.abs(r["u0"][b] - o["u0"]).max() < 1e-6 and np.abs(r["x1"][b] - o["x1"]).max() < 3e-6, (kern, b, np.abs(r["u0"][b] - o["u0"]).max())      # BASELINE's bound on u*
-                n_active += int(np.abs(rows.Gx @ xhat[b] + rows.Gu @ o["u0"] + rows.Gd @ dhat[b] + rows.g0).min() < 1e-6)
+                if o["exact"]:      # a certified optimum (active set verified, KKT residual at rounding): BASELINE's bound on u*
+                    assert np.abs(r["u0"][b] - o["u0"]).max() < 1e-6 and np.abs(r["x1"][b] - o["x1"]).max() < 3e-6, (kern, b, np.abs(r["u0"][b] - o["u0"]).max())
+                else:               # the polish did not verify (a row active with a zero multiplier): the oracle's point is its interior point method's, some 1e-3 off along the
+                    H, g, E, e, G, lo, hi = mo.ocp_qp(rows, xhat[b], xs[b], us[b], dhat[b], up[b])      # flat direction - the kernel's point has to be feasible and at least as good
+                    w = r["w"][b]
+                    cost = lambda v: 0.5 * v @ H @ v + g @ v
+                    assert np.abs(E @ w - e).max() < 1e-9 and (G @ w - hi).max() < 1e-9 and (lo - G @ w).max() < 1e-9, (kern, b)
+                    assert cost(w) <= cost(o["w"]) + 1e-9 * abs(cost(o["w"])) and np.abs(r["u0"][b] - o["u0"]).max() < 5e-3, (kern, b, cost(w) - cost(o["w"]))
+                n_active += int(np.abs(rows.Gx @ xhat[b] + rows.Gu @ r["u0"][b] + rows.Gd @ dhat[b] + rows.g0).min() < 1e-6)
         assert n_active >= 2      # (rows that bind at stage 0 on some of the instances)
     finally:
         s.close()
@@ -73,7 +80,8 @@ def test_gpu_closed_loop_with_user_rows_follows_the_oracle_on_every_loop_kernel(
     """the shipped scenario with the rows (examples/cstr_lmpc_rows.py): both bind along the loop; lane, horizon-parallel and wave-autonomous kernels against the dense oracle's loop"""
     from mpc_code_amd import capi, driver
     ns = 9
-    o = mo.closed_loop(rows, ns, tol=1e-9)
+    o = mo.closed_loop(rows, ns, tol=1e-9, ocp=mo.ocp_solve_exact)      # (every OCP from the fourth step on to a certified optimum; the first three are infeasible, as the shipped scenario's)
+    assert all(o["EXACT_DYN"][3:])
     U = np.array(o["U"])
     assert np.abs(U[3:5, 0] + 0.5 * U[3:5, 1] - 5.0).max() < 1e-6      # the first row binds at steps 3 and 4
     s = capi.Solver(rows)
