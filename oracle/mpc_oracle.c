@@ -811,7 +811,12 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
         work_t *w = (work_t *)malloc(sizeof(work_t));
 #pragma omp for schedule(dynamic, 4)
         for (int b = 0; b < Bsz; b++) {
-            double *xb = x + b * nxp, *xh = xhat + b * n, *dh = dhat + b * nd, *ub = u + b * m, *xsb = xs + b * n, *usb = us + b * m;
+            /* the instance's state in this thread's own cache lines for the whole loop (rows of neighbouring instances share lines: 256 threads writing them every
+             * step was what kept this loop from scaling past 32 threads), written back once at the end */
+            double xb[MAXN], xh[MAXN], dh[MAXD + 1], ub[MAXM], xsb[MAXN], usb[MAXM], Pkb[MAXE * MAXE];
+            memcpy(xb, x + b * nxp, sizeof(double) * nxp); memcpy(xh, xhat + b * n, sizeof(double) * n); memcpy(dh, dhat + b * nd, sizeof(double) * nd);
+            memcpy(ub, u + b * m, sizeof(double) * m); memcpy(xsb, xs + b * n, sizeof(double) * n); memcpy(usb, us + b * m, sizeof(double) * m);
+            if (p->estimator == 1) memcpy(Pkb, Pk + (size_t)b * ne * ne, sizeof(double) * ne * ne);
             double pred[MAXN] = {0}, d_prev[MAXD] = {0}, xs_prev[MAXN] = {0}, us_prev[MAXM] = {0}; int ws_valid = 0;
             double tws[2 * MAXM + 3 * MAXC] = {0}; int tw_valid = 0;      /* warm start of the target solve */
             for (int k = 0; k < nsteps; k++) {
@@ -829,7 +834,7 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                 }
                 for (int i = 0; i < n; i++) xi[i] = xh[i];
                 for (int i = 0; i < nd; i++) xi[n + i] = dh[i];
-                if (p->estimator == 1) kalman_one(p, Aa, Ca, xi, Pk + (size_t)b * ne * ne, innov);
+                if (p->estimator == 1) kalman_one(p, Aa, Ca, xi, Pkb, innov);
                 else if (p->estimator == 2)
                     for (int i = 0; i < ne; i++) { double a = 0.0; for (int l = 0; l < q; l++) a += p->K[i * q + l] * innov[l]; xi[i] += a; }
                 for (int i = 0; i < n; i++) xh[i] = xi[i];
@@ -894,6 +899,9 @@ int orc_closed_loop(const orc_problem *p, int Bsz, int nsteps,
                 }
                 memcpy(xb, xn, sizeof(double) * nxp);
             }
+            memcpy(x + b * nxp, xb, sizeof(double) * nxp); memcpy(xhat + b * n, xh, sizeof(double) * n); memcpy(dhat + b * nd, dh, sizeof(double) * nd);
+            memcpy(u + b * m, ub, sizeof(double) * m); memcpy(xs + b * n, xsb, sizeof(double) * n); memcpy(us + b * m, usb, sizeof(double) * m);
+            if (p->estimator == 1) memcpy(Pk + (size_t)b * ne * ne, Pkb, sizeof(double) * ne * ne);
         }
         free(w);
     }
