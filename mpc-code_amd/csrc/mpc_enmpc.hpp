@@ -251,6 +251,183 @@ struct RicFac { double K[NU][NS], Qi[NU][NU], Pnx[NS][NS], P0i[NS][NS]; };
 template <int NS, int NU>
 struct RicVec { double kff[NU], pnx[NS], dx0[NS]; };
 
+template <int n>
+__device__ __forceinline__ bool gj_inverse(const double (&a_in)[n][n], double (&inv)[n][n])
+{
+    double a[n][n];
+    MPC_UNROLL for (int i = 0; i < n; i++) { MPC_UNROLL for (int j = 0; j < n; j++) { a[i][j] = a_in[i][j]; inv[i][j] = (i == j) ? 1.0 : 0.0; } }
+    bool ok = true;
+    MPC_UNROLL for (int cidx = 0; cidx < n; cidx++) {
+        MPC_UNROLL for (int r = cidx + 1; r < n; r++) {      // bring the largest entry of the column to the pivot row (conditional row swaps)
+            const bool sw = fabs(a[r][cidx]) > fabs(a[cidx][cidx]);
+            MPC_UNROLL for (int j = 0; j < n; j++) {
+                const double t1 = a[cidx][j], t2 = a[r][j]; a[cidx][j] = sw ? t2 : t1; a[r][j] = sw ? t1 : t2;
+                const double s1 = inv[cidx][j], s2 = inv[r][j]; inv[cidx][j] = sw ? s2 : s1; inv[r][j] = sw ? s1 : s2;
+            }
+        }
+        const double pv = a[cidx][cidx];
+        ok = ok && (fabs(pv) > 1e-300);
+        const double ip = 1.0 / pv;
+        MPC_UNROLL for (int j = 0; j < n; j++) { a[cidx][j] *= ip; inv[cidx][j] *= ip; }
+        MPC_UNROLL for (int r = 0; r < n; r++) {
+            if (r != cidx) {
+                const double f = a[r][cidx];
+                MPC_UNROLL for (int j = 0; j < n; j++) { a[r][j] -= f * a[cidx][j]; inv[r][j] -= f * inv[cidx][j]; }
+            }
+        }
+    }
+    return ok;
+}
+
+
+#ifdef EC_SWEEP_SCAN
+// ---- EXPERIMENT (build flag -DEC_SWEEP_SCAN, tools/enmpc_variants.py; not the product's build): the matrix pass of the backward sweep as a PARALLEL SCAN over the lanes.
+// A stage is the element (A~, b~, C, eta, J) of its conditional value function  V(x, x+) = max_lam [ 1/2 x'J x + eta'x + lam'(A~ x + b~ - x+) - 1/2 lam'C lam ]
+// (the stage's input eliminated: A~ = A - B Ri M', b~ = -c - B Ri gu, C = B Ri B', J = Qxx - M Ri M', eta = gx - M Ri gu with Ri = (R + Su)^-1); two neighbouring
+// elements combine associatively [Saerkkae, Garcia-Fernandez: Temporal parallelization of dynamic programming and linear quadratic control, 2023]:
+//     D = (I + C1 J2)^-1,  A = A2 D A1,  b = A2 D (b1 - C1 eta2) + b2,  C = A2 D C1 A2' + C2,  J = A1' J2 D A1 + J1,  eta = A1'(eta2 + J2 D (b1 - C1 eta2)) + eta1
+// and the combination of the stages k .. N-1 with the terminal element (0, 0, 0, pt, Pt) carries the cost-to-go (P_k, p_k) in its (J, eta).  A suffix scan over the lanes
+// (log2 SEG levels, the partner's element through ds_bpermute) gives every lane its P_{k+1}, from which it computes ITS gain and feed-forward by the recursion's own
+// formulas - so the factors (K, Qi, Pnx, kff, pnx) mean what they mean after the serial sweep and the vector passes and the forward sweep take them as they are.
+// Needs R_k + Su_k positive definite at EVERY stage (the recursion needs Lambda_k = R_k + Su_k + B'P_{k+1}B only): returns -1 where that fails and the caller runs
+// the recursion; and a free lane for the terminal element (N < SEG).  Values part from the recursion's by rounding.
+template <int NS> struct ScanEl { double A[NS][NS], b[NS], C[NS][NS], e[NS], J[NS][NS]; };
+
+template <int NS, int NU, bool FREE0, int SEG, class ST>
+__device__ __forceinline__ int ric_backward_scan(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const double (&Q)[NS][NS], const double (&Mx)[NS][NU], const double (&R)[NU][NU],
+                                                 const double (&Su)[NU], const double (&Sxk)[NS], const double (&Pt)[NS][NS], const double (&P0add)[NS][NS],
+                                                 const double (&gu)[NU], const double (&gxk)[NS], const double (&pt)[NS], const double (&p0add)[NS], const double (&c)[NS],
+                                                 RicFac<NS, NU> &Fc, RicVec<NS, NU> &Vc)
+{
+    using SG = Seg<SEG>;
+    const bool stage = k < N;
+    double Ad[NS][NS], Bd[NS][NU], Ri[NU][NU];
+    MPC_UNROLL for (int i = 0; i < NS; i++) {
+        MPC_UNROLL for (int j = 0; j < NS; j++) Ad[i][j] = ST::a_kind(i, j) == 0 ? 0.0 : (ST::a_kind(i, j) == 1 ? 1.0 : L.A[i][j]);
+        MPC_UNROLL for (int j = 0; j < NU; j++) Bd[i][j] = ST::b_kind(i, j) == 0 ? 0.0 : (ST::b_kind(i, j) == 1 ? 1.0 : L.B[i][j]);
+    }
+    MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Ri[i][j] = 0.5 * (R[i][j] + R[j][i]) + (i == j ? Su[i] : 0.0); }
+    const bool okr = sym_inverse<NU>(Ri);
+#if defined(EC_WAVE_EMU) && defined(EC_SCAN_STATS)      // (emulator only: how often the scan runs and how often it hands over to the recursion)
+    { static long n_scan = 0, n_fall = 0; static bool reg = false; if (lane == 0) { if (!reg) { reg = true; atexit([] { }); } (__any((stage && !okr) ? 1 : 0) ? n_fall : n_scan)++; if (((n_scan + n_fall) & 63) == 0) fprintf(stderr, "scan %ld fallback %ld\n", n_scan, n_fall); } else (void)__any((stage && !okr) ? 1 : 0); }
+#endif
+    if (__any((stage && !okr) ? 1 : 0)) return -1;      // (the whole wave: its segments stay in step)
+    ScanEl<NS> e;
+    {
+        double G[NU][NS], rg[NU], BR[NS][NU];
+        MPC_UNROLL for (int a = 0; a < NU; a++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double s_ = 0.0; MPC_UNROLL for (int b = 0; b < NU; b++) s_ += Ri[a][b] * Mx[j][b]; G[a][j] = s_; }
+            double s_ = 0.0; MPC_UNROLL for (int b = 0; b < NU; b++) s_ += Ri[a][b] * gu[b]; rg[a] = s_;
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int a = 0; a < NU; a++) { double s_ = 0.0; MPC_UNROLL for (int b = 0; b < NU; b++) s_ += Bd[i][b] * Ri[b][a]; BR[i][a] = s_; } }
+        double Ptb[NS][NS], ptb[NS];
+        bcast_sym<SEG, NS>(Pt, N - 1, lane, Ptb);
+        bcast_vec<SEG, NS>(pt, N - 1, lane, ptb);
+        const bool term = k == N;
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) {
+                double a_ = Ad[i][j], c_ = 0.0, j_ = Q[i][j] + (i == j ? Sxk[i] : 0.0);
+                MPC_UNROLL for (int a = 0; a < NU; a++) { a_ -= Bd[i][a] * G[a][j]; c_ += BR[i][a] * Bd[j][a]; j_ -= Mx[i][a] * G[a][j]; }
+                e.A[i][j] = stage ? a_ : (term ? 0.0 : (i == j ? 1.0 : 0.0));
+                e.C[i][j] = stage ? c_ : 0.0;
+                e.J[i][j] = stage ? j_ : (term ? Ptb[i][j] : 0.0);
+            }
+            double b_ = -c[i], e_ = gxk[i];
+            MPC_UNROLL for (int a = 0; a < NU; a++) { b_ -= Bd[i][a] * rg[a]; e_ -= Mx[i][a] * rg[a]; }
+            e.b[i] = stage ? b_ : 0.0;
+            e.e[i] = stage ? e_ : (term ? ptb[i] : 0.0);
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a_ = 0.5 * (e.J[i][j] + e.J[j][i]); e.J[i][j] = a_; e.J[j][i] = a_; const double c_ = 0.5 * (e.C[i][j] + e.C[j][i]); e.C[i][j] = c_; e.C[j][i] = c_; } }
+    }
+    const int base = lane & ~(SEG - 1);
+    auto from = [&](double v, int kk) { return __shfl(v, base + (kk < SEG ? kk : k)); };      // stage kk's value (this segment), own value beyond the segment
+    for (int d = 1; d < SEG; d <<= 1) {
+        const bool has = k + d < SEG;
+        ScanEl<NS> o;
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) {
+                const double a_ = from(e.A[i][j], k + d); o.A[i][j] = has ? a_ : (i == j ? 1.0 : 0.0);
+                if (j >= i) { const double c_ = from(e.C[i][j], k + d), j_ = from(e.J[i][j], k + d); o.C[i][j] = has ? c_ : 0.0; o.J[i][j] = has ? j_ : 0.0; }
+            }
+            const double b_ = from(e.b[i], k + d), e_ = from(e.e[i], k + d);
+            o.b[i] = has ? b_ : 0.0; o.e[i] = has ? e_ : 0.0;
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { o.C[i][j] = o.C[j][i]; o.J[i][j] = o.J[j][i]; } }
+        // e <- e (x) o
+        double Dm[NS][NS], Di[NS][NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double s_ = (i == j) ? 1.0 : 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) s_ += e.C[i][l] * o.J[l][j]; Dm[i][j] = s_; } }
+        gj_inverse<NS>(Dm, Di);
+        double y[NS][NS], DC[NS][NS], t[NS], Jy[NS][NS], w_[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double s1 = 0.0, s2 = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) { s1 += Di[i][l] * e.A[l][j]; s2 += Di[i][l] * e.C[l][j]; } y[i][j] = s1; DC[i][j] = s2; }
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double s_ = e.b[i]; MPC_UNROLL for (int l = 0; l < NS; l++) s_ -= e.C[i][l] * o.e[l]; w_[i] = s_; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double s_ = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) s_ += Di[i][l] * w_[l]; t[i] = s_; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double s_ = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) s_ += o.J[i][l] * y[l][j]; Jy[i][j] = s_; } }
+        ScanEl<NS> r;
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) {
+                double a_ = 0.0, j_ = e.J[i][j];
+                MPC_UNROLL for (int l = 0; l < NS; l++) { a_ += o.A[i][l] * y[l][j]; j_ += e.A[l][i] * Jy[l][j]; }
+                r.A[i][j] = a_; r.J[i][j] = j_;
+            }
+            double b_ = o.b[i], h_ = o.e[i];
+            MPC_UNROLL for (int l = 0; l < NS; l++) { b_ += o.A[i][l] * t[l]; h_ += o.J[i][l] * t[l]; }
+            r.b[i] = b_; w_[i] = h_;      // w_ <- eta2 + J2 t
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double s_ = e.e[i]; MPC_UNROLL for (int l = 0; l < NS; l++) s_ += e.A[l][i] * w_[l]; r.e[i] = s_; }
+        {
+            double ADC[NS][NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double s_ = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) s_ += o.A[i][l] * DC[l][j]; ADC[i][j] = s_; } }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double s_ = o.C[i][j]; MPC_UNROLL for (int l = 0; l < NS; l++) s_ += ADC[i][l] * o.A[j][l]; r.C[i][j] = s_; } }
+        }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a_ = 0.5 * (r.J[i][j] + r.J[j][i]); r.J[i][j] = a_; r.J[j][i] = a_; const double c_ = 0.5 * (r.C[i][j] + r.C[j][i]); r.C[i][j] = c_; r.C[j][i] = c_; } }
+        e = r;
+    }
+    // the cost-to-go behind this lane's stage, then its own factors by the recursion's formulas
+    double Pn[NS][NS], pn[NS];
+    MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = i; j < NS; j++) { const double a_ = from(e.J[i][j], k + 1); Pn[i][j] = a_; Pn[j][i] = a_; } pn[i] = from(e.e[i], k + 1); }
+    MPC_UNROLL for (int i = 0; i < NU; i++) Vc.kff[i] = 0.0;
+    MPC_UNROLL for (int i = 0; i < NS; i++) Vc.pnx[i] = 0.0;
+    double Kl[NU][NS], Qil[NU][NU];
+    bool ok = true;
+    {
+        double PA[NS][NS], PB[NS][NU];
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_A(a, Pn[i][l], l, j); PA[i][j] = a; }
+            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, Pn[i][l], l, j); PB[i][j] = a; }
+        }
+        double Qux[NU][NS];
+        MPC_UNROLL for (int i = 0; i < NU; i++) {
+            MPC_UNROLL for (int j = 0; j < NU; j++) { double a = R[i][j] + (i == j ? Su[i] : 0.0); MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PB[l][j], l, i); Qil[i][j] = a; }
+            MPC_UNROLL for (int j = 0; j < NS; j++) { double a = Mx[j][i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, PA[l][j], l, i); Qux[i][j] = a; }
+        }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) { const double a = 0.5 * (Qil[i][j] + Qil[j][i]); Qil[i][j] = a; Qil[j][i] = a; } }
+        ok = sym_inverse<NU>(Qil);
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < i; j++) Qil[i][j] = Qil[j][i]; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Qil[i][l] * Qux[l][j]; Kl[i][j] = a; } }
+    }
+    if (stage) {
+        MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.K[i][j] = Kl[i][j]; MPC_UNROLL for (int j = 0; j < NU; j++) Fc.Qi[i][j] = Qil[i][j]; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.Pnx[i][j] = Pn[i][j]; }
+        double pc[NS], qu[NU];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = pn[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a -= Pn[i][l] * c[l]; pc[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = gu[i]; MPC_UNROLL for (int l = 0; l < NS; l++) EC_B(a, pc[l], l, i); qu[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NU; l++) a -= Qil[i][l] * qu[l]; Vc.kff[i] = a; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) Vc.pnx[i] = pn[i];
+    }
+    bool bad = SG::any(stage && !ok, lane);
+    if (FREE0) {
+        double P0[NS][NS], p0[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = i; j < NS; j++) { const double a_ = from(e.J[i][j], 0) + P0add[i][j]; P0[i][j] = a_; P0[j][i] = a_; } p0[i] = from(e.e[i], 0); }
+        if (!sym_inverse<NS>(P0)) bad = true;
+        MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Fc.P0i[i][j] = j < i ? P0[j][i] : P0[i][j]; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = 0.0; MPC_UNROLL for (int j = 0; j < NS; j++) a -= Fc.P0i[i][j] * (p0[j] + p0add[j]); Vc.dx0[i] = a; }
+    } else { MPC_UNROLL for (int i = 0; i < NS; i++) Vc.dx0[i] = 0.0; }
+    return bad ? 0 : 1;
+}
+#endif
+
 // BACKWARD sweep of the Riccati recursion over the lanes: all lanes compute the stage update with the broadcast cost-to-go of the stage behind them, lane kk's
 // result is the valid one and is broadcast on.  MATRIX = true: gains and cost-to-go matrices from the Hessian blocks (Q, M, R) of this lane's stage, the
 // diagonal terms Su (inputs), Sxk (x_k, from the neighbour that holds it), the terminal block Pt of lane N-1, the initial state's own block P0add - and,
@@ -262,6 +439,15 @@ __device__ __forceinline__ bool ric_backward(const int N, const int lane, const 
                                              const double (&gu)[NU], const double (&gxk)[NS], const double (&pt)[NS], const double (&p0add)[NS], const double (&c)[NS],
                                              RicFac<NS, NU> &Fc, RicVec<NS, NU> &Vc)
 {
+#ifdef EC_SWEEP_SCAN
+#ifndef EC_SWEEP_SCAN_MAXNS
+#define EC_SWEEP_SCAN_MAXNS 2
+#endif
+    if (MATRIX && NS <= EC_SWEEP_SCAN_MAXNS && N < SEG) {
+        const int r_ = ric_backward_scan<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Q, Mx, R, Su, Sxk, Pt, P0add, gu, gxk, pt, p0add, c, Fc, Vc);
+        if (r_ >= 0) return r_ != 0;      // (-1: a stage without curvature of its own: the recursion below)
+    }
+#endif
     double Pn[NS][NS], pn[NS];
     if (MATRIX) bcast_sym<SEG, NS>(Pt, N - 1, lane, Pn);
     bcast_vec<SEG, NS>(pt, N - 1, lane, pn);
@@ -1073,34 +1259,6 @@ __device__ __forceinline__ int ipm_stage(const int N, const int lane, const bool
 
 // ---- small dense helpers (wave-uniform use) ---------------------------------------------------------------------------------------------
 // inverse of a general n x n matrix by Gauss-Jordan with partial pivoting; false when a pivot vanishes
-template <int n>
-__device__ __forceinline__ bool gj_inverse(const double (&a_in)[n][n], double (&inv)[n][n])
-{
-    double a[n][n];
-    MPC_UNROLL for (int i = 0; i < n; i++) { MPC_UNROLL for (int j = 0; j < n; j++) { a[i][j] = a_in[i][j]; inv[i][j] = (i == j) ? 1.0 : 0.0; } }
-    bool ok = true;
-    MPC_UNROLL for (int cidx = 0; cidx < n; cidx++) {
-        MPC_UNROLL for (int r = cidx + 1; r < n; r++) {      // bring the largest entry of the column to the pivot row (conditional row swaps)
-            const bool sw = fabs(a[r][cidx]) > fabs(a[cidx][cidx]);
-            MPC_UNROLL for (int j = 0; j < n; j++) {
-                const double t1 = a[cidx][j], t2 = a[r][j]; a[cidx][j] = sw ? t2 : t1; a[r][j] = sw ? t1 : t2;
-                const double s1 = inv[cidx][j], s2 = inv[r][j]; inv[cidx][j] = sw ? s2 : s1; inv[r][j] = sw ? s1 : s2;
-            }
-        }
-        const double pv = a[cidx][cidx];
-        ok = ok && (fabs(pv) > 1e-300);
-        const double ip = 1.0 / pv;
-        MPC_UNROLL for (int j = 0; j < n; j++) { a[cidx][j] *= ip; inv[cidx][j] *= ip; }
-        MPC_UNROLL for (int r = 0; r < n; r++) {
-            if (r != cidx) {
-                const double f = a[r][cidx];
-                MPC_UNROLL for (int j = 0; j < n; j++) { a[r][j] -= f * a[cidx][j]; inv[r][j] -= f * inv[cidx][j]; }
-            }
-        }
-    }
-    return ok;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // IPOPT's restoration phase for the target problem ([WB 3.3]): the same interior point iteration on
 //     min  rho sum(n + p) + sqrt(mu) / 2 |D_R (x - x_R)|^2   s.t.  c(x) + n - p = 0,  lo <= x <= hi,  n, p >= 0

@@ -18,6 +18,7 @@ def build(p, extra_flags=(), verbose=False) -> str:
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     from mpc_code_amd import econcodegen
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("EMU_EXTRA_FLAGS", "").split())      # (experiments: e.g. EMU_EXTRA_FLAGS=-DEC_SWEEP_SCAN python -m pytest tests/test_wave_emu.py)
     text = econcodegen.emit_econ_header(p)
     csrc = econcodegen.CSRC
     srcs = [os.path.join(csrc, f) for f in ("mpc_enmpc.hip", "mpc_enmpc.hpp", "mpc_rk4s2.hpp", "mpc_sym.hpp", "mpc_comm.hpp")] + \

@@ -17,7 +17,9 @@ VARIANTS = [("base", []),
             # the OCP kernel's scratch frame (204 B per lane) holds loop invariants the compiler hoisted out of the iteration loop - the polynomial coefficients of exp / log among
             # them - and then had no registers for: without machine LICM the frame is empty (tools/kernel_resources.py)
             ("machine LICM off", ["-mllvm", "-disable-machine-licm"]),      # (the product's build since this measurement: econcodegen.ENMPC_FLAGS)
-            ("loop invariants sunk back where they would spill", ["-mllvm", "-sink-insts-to-avoid-spills"])]
+            ("loop invariants sunk back where they would spill", ["-mllvm", "-sink-insts-to-avoid-spills"]),
+            # the matrix pass of the backward sweep as a parallel scan over the lanes (mpc_enmpc.hpp:ric_backward_scan; NS <= 2: the OCP): values part from the recursion's by rounding
+            ("backward sweep as a parallel scan", ["-DEC_SWEEP_SCAN"])]
 WORK = [("enmpc N=40, 16384 instances", {"N": 40}, 16384), ("mhe N_mhe=20, 4096 instances", {"N_mhe": 20}, 4096)]
 
 if __name__ == "__main__":
@@ -49,9 +51,12 @@ if __name__ == "__main__":
             for rep in range(3):
                 r2 = enmpc.run_enmpc_closed_loop(p, x0, 20, solver=s, kernel=2)
             same = True if ref is None else bool(all(np.array_equal(ref[k], r[k]) for k in ("U", "X_ES", "XS", "ITERS_DYN", "ITERS_MHE", "ITERS_SS", "STATUS_DYN")))
+            apart = None if ref is None or same else dict(max_abs_dU=float(np.abs(ref["U"] - r["U"]).max()), ocp_solves_with_other_iteration_count=int((ref["ITERS_DYN"] != r["ITERS_DYN"]).sum()),
+                                                          largest_iteration_difference=int(np.abs(ref["ITERS_DYN"].astype(int) - r["ITERS_DYN"]).max()), solves=int(r["ITERS_DYN"].size),
+                                                          status_words_that_differ=int((ref["STATUS_DYN"] != r["STATUS_DYN"]).sum()))
             ref = ref or r
             res.append(dict(workload=wname, variant=vname, flags=flags, one_stream_ms=best, msteps_per_s_one_stream=B * 20 / best / 1e3, stream_groups_ms=r2["kernel_ms"],
-                            msteps_per_s=B * 20 / r2["kernel_ms"] / 1e3, phase_ms_estimator_target_ocp=ph[0], launches=ph[1], same_as_base=same))
+                            msteps_per_s=B * 20 / r2["kernel_ms"] / 1e3, phase_ms_estimator_target_ocp=ph[0], launches=ph[1], same_as_base=same, apart_from_base=apart))
             print(res[-1], flush=True)
             s.close()
     if len(sys.argv) > 1:
