@@ -113,6 +113,28 @@ def issue_roofline(summary: str, launch_s: float, scale: float = 1.0, alg_flops_
     return out
 
 
+def cpu_quota():
+    """What the host gives this process: hardware threads it may run on (affinity) and the cgroup's CPU quota in cores (None: unlimited) - a thread curve that peaks far below the
+    hardware thread count is usually the quota, not the code."""
+    q = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(path).read().split()
+            if path.endswith("cpu.max"):
+                q = None if t[0] == "max" else float(t[0]) / float(t[1])
+            else:
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                q = None if float(t[0]) <= 0 else float(t[0]) / per
+            break
+        except Exception:
+            continue
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count()
+    return {"affinity_threads": aff, "cgroup_quota_cores": q}
+
+
 def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     """Time the oracle's C restatement on the host cores: the same closed loop (same instances, same steps, from
     t=0), on all cores and on one, each a bounded sample."""
@@ -148,7 +170,7 @@ def cpu_baseline(problem, x0, nsteps, target_seconds=8.0, max_seconds=25.0):
     nbn = tried[max(tried, key=lambda th: tried[th][0])][3]
     best = max(tried, key=lambda th: tried[th][0])
     vn, rn, sn = tried[best][:3]
-    return dict(value=vn, unit="steps/s", cores=best, kind="port", single_core_value=v1, threads_tried={str(th): tried[th][0] for th in tried},
+    return dict(value=vn, unit="steps/s", cores=best, kind="port", single_core_value=v1, threads_tried={str(th): tried[th][0] for th in tried}, host=cpu_quota(),
                 sample=f"{nbn} instances x {nsteps} closed-loop steps from t=0 of the same workload, {rn} repetitions, {sn:.1f} s wall on {best} threads, the fastest of "
                        f"{sorted(tried)} tried ({nthr} hardware threads) "
                        f"(single core: {nb1} instances, {r1} repetitions, {s1:.1f} s): oracle/mpc_oracle.c, a C port of the same Riccati-PDIP with the "
