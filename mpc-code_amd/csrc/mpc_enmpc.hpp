@@ -34,6 +34,9 @@
 #define EC_ANY_HINT(p) __any(p)
 #endif
 #define EC_UNI(x) mpc::uni(x)
+#ifndef EC_SWEEP_SCAN_MAXNS
+#define EC_SWEEP_SCAN_MAXNS 2      // stage states up to which the sweeps over the lanes run as parallel scans (ric_backward_scan, ric_forward)
+#endif
 #include "mpc_rk4s2.hpp"
 
 namespace enm {
@@ -280,8 +283,8 @@ __device__ __forceinline__ bool gj_inverse(const double (&a_in)[n][n], double (&
 }
 
 
-#ifdef EC_SWEEP_SCAN
-// ---- EXPERIMENT (build flag -DEC_SWEEP_SCAN, tools/enmpc_variants.py; not the product's build): the matrix pass of the backward sweep as a PARALLEL SCAN over the lanes.
+#ifndef EC_SWEEP_SERIAL
+// ---- The matrix pass of the backward sweep as a PARALLEL SCAN over the lanes (stage states up to EC_SWEEP_SCAN_MAXNS: the OCP; -DEC_SWEEP_SERIAL builds the recursion alone).
 // A stage is the element (A~, b~, C, eta, J) of its conditional value function  V(x, x+) = max_lam [ 1/2 x'J x + eta'x + lam'(A~ x + b~ - x+) - 1/2 lam'C lam ]
 // (the stage's input eliminated: A~ = A - B Ri M', b~ = -c - B Ri gu, C = B Ri B', J = Qxx - M Ri M', eta = gx - M Ri gu with Ri = (R + Su)^-1); two neighbouring
 // elements combine associatively [Saerkkae, Garcia-Fernandez: Temporal parallelization of dynamic programming and linear quadratic control, 2023]:
@@ -439,10 +442,7 @@ __device__ __forceinline__ bool ric_backward(const int N, const int lane, const 
                                              const double (&gu)[NU], const double (&gxk)[NS], const double (&pt)[NS], const double (&p0add)[NS], const double (&c)[NS],
                                              RicFac<NS, NU> &Fc, RicVec<NS, NU> &Vc)
 {
-#ifdef EC_SWEEP_SCAN
-#ifndef EC_SWEEP_SCAN_MAXNS
-#define EC_SWEEP_SCAN_MAXNS 2
-#endif
+#ifndef EC_SWEEP_SERIAL
     if (MATRIX && NS <= EC_SWEEP_SCAN_MAXNS && N < SEG) {
         const int r_ = ric_backward_scan<NS, NU, FREE0, SEG, ST>(N, lane, k, L, Q, Mx, R, Su, Sxk, Pt, P0add, gu, gxk, pt, p0add, c, Fc, Vc);
         if (r_ >= 0) return r_ != 0;      // (-1: a stage without curvature of its own: the recursion below)
@@ -515,6 +515,47 @@ template <int NS, int NU, int SEG, class ST>
 __device__ __forceinline__ void ric_forward(const int N, const int lane, const int k, const StageLin<NS, NU> &L, const RicFac<NS, NU> &Fc, const RicVec<NS, NU> &Vc, const double (&c)[NS],
                                             double (&du)[NU], double (&dxn)[NS], double (&pin)[NS])
 {
+#if !defined(EC_SWEEP_SERIAL) && !defined(EC_FWD_SERIAL)
+    if (NS <= EC_SWEEP_SCAN_MAXNS) {
+        // the forward sweep as a prefix scan: stage k is the affine map dx -> Acl_k dx + r_k (Acl = A + B K, r = B kff - c); the composition of the stages 0..k applied to
+        // dx_0 is this lane's dx_{k+1} (log2 SEG levels, the partner's map through ds_bpermute).  Values part from the recursion's by rounding.
+        using SG = Seg<SEG>;
+        const bool stage = k < N;
+        double Am[NS][NS], rm[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) {
+            MPC_UNROLL for (int j = 0; j < NS; j++) {
+                double a = ST::a_kind(i, j) == 0 ? 0.0 : (ST::a_kind(i, j) == 1 ? 1.0 : L.A[i][j]);
+                MPC_UNROLL for (int l = 0; l < NU; l++) EC_B(a, Fc.K[l][j], i, l);
+                Am[i][j] = stage ? a : (i == j ? 1.0 : 0.0);
+            }
+            double a = -c[i];
+            MPC_UNROLL for (int l = 0; l < NU; l++) EC_B(a, Vc.kff[l], i, l);
+            rm[i] = stage ? a : 0.0;
+        }
+        const int base = lane & ~(SEG - 1);
+        for (int d = 1; d < SEG; d <<= 1) {
+            const bool has = k >= d;
+            const int src = base + (has ? k - d : k);
+            double Ap[NS][NS], rp[NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NS; j++) { const double a = __shfl(Am[i][j], src); Ap[i][j] = has ? a : (i == j ? 1.0 : 0.0); }
+                const double a = __shfl(rm[i], src); rp[i] = has ? a : 0.0;
+            }
+            double An[NS][NS], rn[NS];
+            MPC_UNROLL for (int i = 0; i < NS; i++) {
+                MPC_UNROLL for (int j = 0; j < NS; j++) { double a = 0.0; MPC_UNROLL for (int l = 0; l < NS; l++) a += Am[i][l] * Ap[l][j]; An[i][j] = a; }
+                double a = rm[i]; MPC_UNROLL for (int l = 0; l < NS; l++) a += Am[i][l] * rp[l]; rn[i] = a;
+            }
+            MPC_UNROLL for (int i = 0; i < NS; i++) { MPC_UNROLL for (int j = 0; j < NS; j++) Am[i][j] = An[i][j]; rm[i] = rn[i]; }
+        }
+        double dxk[NS];
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = rm[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Am[i][j] * Vc.dx0[j]; dxn[i] = stage ? a : 0.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) dxk[i] = SG::up1(Vc.dx0[i], dxn[i], k);
+        MPC_UNROLL for (int i = 0; i < NU; i++) { double a = Vc.kff[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.K[i][j] * dxk[j]; du[i] = stage ? a : 0.0; }
+        MPC_UNROLL for (int i = 0; i < NS; i++) { double a = Vc.pnx[i]; MPC_UNROLL for (int j = 0; j < NS; j++) a += Fc.Pnx[i][j] * dxn[j]; pin[i] = a; }
+        return;
+    }
+#endif
     double dx[NS];
     MPC_UNROLL for (int i = 0; i < NS; i++) { dx[i] = Vc.dx0[i]; dxn[i] = 0.0; }
     MPC_UNROLL for (int i = 0; i < NU; i++) du[i] = 0.0;

