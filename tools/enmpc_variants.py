@@ -18,8 +18,10 @@ VARIANTS = [("base", []),
             # them - and then had no registers for: without machine LICM the frame is empty (tools/kernel_resources.py)
             ("machine LICM off", ["-mllvm", "-disable-machine-licm"]),      # (the product's build since this measurement: econcodegen.ENMPC_FLAGS)
             ("loop invariants sunk back where they would spill", ["-mllvm", "-sink-insts-to-avoid-spills"]),
-            # the matrix pass of the backward sweep as a parallel scan over the lanes (mpc_enmpc.hpp:ric_backward_scan; NS <= 2: the OCP): values part from the recursion's by rounding
-            ("backward sweep as a parallel scan", ["-DEC_SWEEP_SCAN"])]
+            # the OCP's sweeps over the lanes (mpc_enmpc.hpp:ric_backward_scan, ric_forward): parallel scans in the product's build since round 5 (third record: the backward
+            # scan as the variant, + 11 %); these build the recursions back in - values part by rounding
+            ("both sweeps as recursions (the build before the scans)", ["-DEC_SWEEP_SERIAL"]),
+            ("forward sweep as a recursion, backward matrix sweep as a scan", ["-DEC_FWD_SERIAL"])]
 WORK = [("enmpc N=40, 16384 instances", {"N": 40}, 16384), ("mhe N_mhe=20, 4096 instances", {"N_mhe": 20}, 4096)]
 
 if __name__ == "__main__":
