@@ -11,9 +11,11 @@
 // boundary, exact Hessian of the Lagrangian with inertia correction, scaled optimality error.  What is particular here:
 //   * OCP (opt_dyn with ContForm, Control_Calc.py:20-260): every lane integrates ITS shooting interval - state, cost quadrature and
 //     their first and second forward sensitivities with respect to (x_k, u_k) through the Runge-Kutta stages (generated code,
-//     econcodegen.py) - then the Newton system is factorised by a Riccati recursion over the lanes: the stage update is computed by
-//     all lanes at once, lane k's result is the valid one and is broadcast to the next iteration (v_readlane).  The recursion needs
-//     Lambda_k = R_k + B_k' P_{k+1} B_k > 0 at every stage, which is IPOPT's inertia condition on the reduced Hessian: when it fails
+//     econcodegen.py) - then the Newton system is factorised by a Riccati recursion over the lanes.  As a RECURSION (ric_backward: the estimator,
+//     stage states beyond two, and the fallback) the stage update is computed by all lanes at once, lane k's result is the valid one and is
+//     broadcast to the next iteration (v_readlane); since round 5 the OCP's matrix pass and its forward sweep are PARALLEL SCANS over the lanes
+//     (ric_backward_scan, ric_forward: log2 of the lanes levels, the partner's element through ds_bpermute).  Either way
+//     Lambda_k = R_k + B_k' P_{k+1} B_k > 0 is tested at every stage, which is IPOPT's inertia condition on the reduced Hessian: when it fails
 //     the Hessian is shifted by delta I exactly as there.
 //   * MHE (mhe_opt, Utilities.py:825-990): the same recursion with state [x; d], "input" w, a free initial state with the arrival
 //     cost, and the output noise v eliminated through its (linear) defining equation.
@@ -83,6 +85,7 @@ struct Seg {
             // to the problem constants) five of six builds of the estimator kernel computed garbage from the first step on - iteration
             // counts like 314141150, not reproducible from run to run - whatever else changed (-O2, scheduler and spill options, the dense
             // recursion); with the move, or with ds_bpermute broadcasts instead, all of them are right (round 3, tools/enmpc_bcast_matrix.py).
+            // (Not the partial-spill fault round 5 found and builds around - econcodegen.ENMPC_FLAGS -: round 3's builds were wrong with that option off too.)
             double r = lane_of(v, kk);
 #ifndef EC_BCAST_IN_SGPRS      // (the matrix's failing leg)
             EC_VGPR_PIN(r);
@@ -311,9 +314,6 @@ __device__ __forceinline__ int ric_backward_scan(const int N, const int lane, co
     }
     MPC_UNROLL for (int i = 0; i < NU; i++) { MPC_UNROLL for (int j = 0; j < NU; j++) Ri[i][j] = 0.5 * (R[i][j] + R[j][i]) + (i == j ? Su[i] : 0.0); }
     const bool okr = sym_inverse<NU>(Ri);
-#if defined(EC_WAVE_EMU) && defined(EC_SCAN_STATS)      // (emulator only: how often the scan runs and how often it hands over to the recursion)
-    { static long n_scan = 0, n_fall = 0; static bool reg = false; if (lane == 0) { if (!reg) { reg = true; atexit([] { }); } (__any((stage && !okr) ? 1 : 0) ? n_fall : n_scan)++; if (((n_scan + n_fall) & 63) == 0) fprintf(stderr, "scan %ld fallback %ld\n", n_scan, n_fall); } else (void)__any((stage && !okr) ? 1 : 0); }
-#endif
     if (__any((stage && !okr) ? 1 : 0)) return -1;      // (the whole wave: its segments stay in step)
     ScanEl<NS> e;
     {
