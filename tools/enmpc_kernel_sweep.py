@@ -20,7 +20,8 @@ for name, over in (("enmpc N=40", {"N": 40}), ("mhe N_mhe=20", {"N_mhe": 20})):
             ref = ref or r
             if kern == 64 and B <= 1024:
                 continue
-            res.append(dict(config=name, batch=B, kernel=kern, ms=r["kernel_ms"], msteps_per_s=B * 20 / r["kernel_ms"] / 1e3, same_as_kernel_1=same))
+            apart = None if same else dict(max_abs_dU=float(np.abs(ref["U"] - r["U"]).max()), iteration_counts_that_differ=int((ref["ITERS_DYN"] != r["ITERS_DYN"]).sum() + (ref["ITERS_MHE"] != r["ITERS_MHE"]).sum()))
+            res.append(dict(config=name, batch=B, kernel=kern, ms=r["kernel_ms"], msteps_per_s=B * 20 / r["kernel_ms"] / 1e3, same_as_kernel_1=same, apart_from_kernel_1=apart))
             print(res[-1], flush=True)
     s.close()
 if len(sys.argv) > 1:
