@@ -21,7 +21,8 @@ VARIANTS = [("base", []),
             # the OCP's sweeps over the lanes (mpc_enmpc.hpp:ric_backward_scan, ric_forward): parallel scans in the product's build since round 5 (third record: the backward
             # scan as the variant, + 11 %); these build the recursions back in - values part by rounding
             ("both sweeps as recursions (the build before the scans)", ["-DEC_SWEEP_SERIAL"]),
-            ("forward sweep as a recursion, backward matrix sweep as a scan", ["-DEC_FWD_SERIAL"])]
+            ("forward sweep as a recursion, backward matrix sweep as a scan", ["-DEC_FWD_SERIAL"]),
+            ("scans for stage states up to four too (the estimator, an OCP with user rows)", ["-DEC_SWEEP_SCAN_MAXNS=4"])]
 WORK = [("enmpc N=40, 16384 instances", {"N": 40}, 16384), ("mhe N_mhe=20, 4096 instances", {"N_mhe": 20}, 4096)]
 
 if __name__ == "__main__":
