@@ -78,8 +78,9 @@ typedef struct mpc_lin_desc {
     /* soft output constraints (`slacks = True`, Control_Calc.py:39-40,186-192,228-239; Default_Values.py:128): ONE slack vector Sl = [sl_ub (ny); sl_lb (ny)] >= 0
      * shared by all stages widens every stage's output rows, ymin - sl_lb <= y_k <= ymax + sl_ub (k = 0..N-1), and is penalised Sl' Ws Sl in every stage's cost;
      * Ws [2 ny][2 ny] (MPC_code.py:55-57).  Input and state bounds stay hard.  Solved by mpc_ocp_solve on the arrowhead solver (csrc/mpc_soft.hpp: one Riccati
-     * factorisation with 1 + 2 ny right-hand sides, a dense Schur complement for Sl); the optimal slacks of the last call: mpc_get_slacks.  The fused closed loops
-     * (mpc_loop_run) do not carry it: step by step through the three solver calls. */
+     * factorisation with 1 + 2 ny right-hand sides, a dense Schur complement for Sl); the optimal slacks of the last call: mpc_get_slacks.  The resident loop
+     * (mpc_loop_run) of such a problem is the instance-per-lane loop with this solver as its OCP; its log "SL" [step][B][2 ny] holds the last accepted slack vector
+     * of every step (MPC_code.py:800, 808-809). */
     int32_t slacks;
     const double *Ws;
     /* Affine user inequality rows of the OCP (User_g_ineq, Control_Calc.py:94-100,132-147; MPC_code.py:306-314): for k = 0..N-1
