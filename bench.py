@@ -255,7 +255,8 @@ def other_configs(args):
                      "roofline": {"bound": rf["bound"], "priced_against": rf.get("priced_against"), "kernel": rf["kernel"].split(" (")[0], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
                                   "frac": rf["frac"], "traffic": rf["traffic"], "avg_launch_ms": rf["avg_launch_ms"], "alg_bytes_per_step": rf["alg_bytes_per_step"],
                                   "instance_steps_per_launch": rf["instance_steps_per_launch"], "fp64_frac": (rf.get("fp64") or {}).get("frac"),
-                                  "issue_frac": (rf.get("issue") or {}).get("frac")},
+                                  "issue_frac": (rf.get("issue") or {}).get("frac"), "useful_lane_fraction": (rf.get("issue") or {}).get("useful_lane_fraction"),
+                                  "traffic_stale": rf.get("traffic_stale")},
                      "solver": d.get("solver"), "cpu_baseline": ({k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "single_core_value", "sample")} if "cpu_baseline" in d else None),
                      "command": " ".join(["python", "bench.py"] + cmd[2:]), "wall_s": time.perf_counter() - t0}
     return out
