@@ -410,11 +410,12 @@ def main_enmpc(args):
                 t0 = time.perf_counter(); oc.closed_loop(K, x0[:nb], nthreads=th, logs=False); tried[th] = (nb * K / (time.perf_counter() - t0), nb)
             best = max(tried, key=lambda th: tried[th][0])
             out["cpu_baseline"] = {"value": tried[best][0], "unit": "steps/s", "cores": best, "kind": "port", "single_core_value": r1,
-                                   "threads_tried": {str(th): tried[th][0] for th in tried},
+                                   "threads_tried": {str(th): tried[th][0] for th in tried}, "host": cpu_quota(),
                                    "sample": "%d instances x %d closed-loop steps from t=0 of the same workload on %d threads, the fastest of %s tried (%d hardware threads): "
                                              "oracle/enmpc_oracle.c - the same three NLPs per step solved by the same outer interior point method with complex-step "
                                              "derivatives and DENSE null-space (QR + Cholesky) Newton steps, gcc -O3 -march=native -fopenmp built on this host - the CHECKER, which makes no use of the "
-                                             "stage structure: a structure-exploiting host build would be one to two orders faster, the GPU / CPU ratio of this line is no statement about either; "
+                                             "stage structure: a structure-exploiting host build (analytic sensitivities in place of complex steps: a third of the flops; Riccati solves in place of the dense null-space "
+                                             "method: none of its n^3) is estimated five to ten times faster - the Runge-Kutta second-order sensitivities dominate either way; the GPU / CPU ratio of this line is no statement about either; "
                                              "the reference's CasADi/IPOPT/IDAS path is not installable here" % (tried[best][1], K, best, sorted(tried), nthr)}
         import ctypes
         sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
